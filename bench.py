@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-likelihoods/s of the RbSensor hot path on MI355X.
+
+A "step" is one RbSensor::loglikes(update=true) pass over one batch of particles:
+BASELINE.json config C1 per GPU = 2 000 particles, one 5 120-triangle mesh (M1), one 640x480
+synthetic frame, every child inheriting from a distinct random parent slot (permutation: no
+occlusion plane is read twice, the worst case for HBM traffic).  Inputs (frame, poses, parent
+indices, occlusion planes) are resident in HBM before the timed region.  With --gpus N each
+rank evaluates its own 2 000-particle shard (weak scaling) and the per-particle
+log-likelihoods are all-gathered over RCCL every step (the weight exchange before resampling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      algorithmic bytes (2*4*W*H per particle-likelihood) / live kernel time
+  cpu_baseline  the CPU oracle (reference CPU-path semantics) timed on this host, 1 thread
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--particles", type=int, default=2000, help="particles per GPU")
+    ap.add_argument("--cols", type=int, default=640)
+    ap.add_argument("--rows", type=int, default=480)
+    ap.add_argument("--mesh", default="m1")
+    ap.add_argument("--parents", default="permutation", choices=["permutation", "identity", "resampled"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(om, cam, P, truth, frame, seconds):
+    """The oracle in reference-CPU-semantics mode (LAZY), single thread as dbot's CPU model,
+    on a bounded sample of the same workload: config C0's 200 particles per call, repeated
+    frame after frame (update=true, multinomial-like parent shuffle) until `seconds` elapse."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    from dbot_ros_amd import synth
+    n = 200
+    orc = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
+    rng = np.random.default_rng(1)
+    poses = synth.particle_poses(truth, n, rng)
+    idx = np.zeros(n, dtype=np.int32)
+    orc.reset()
+    done, t0 = 0, time.perf_counter()
+    while True:
+        orc.set_observation(frame)
+        orc.loglikes_poses(poses, idx, update=True)
+        done += n
+        idx = rng.permutation(n).astype(np.int32)
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    orc.close()
+    return {"value": done / el, "unit": "particle-likelihoods/s", "cores": 1, "kind": "port",
+            "sample": f"{done} particle-likelihoods = {done // n} loglikes(update=true) calls x {n} "
+                      f"particles, {cam.cols}x{cam.rows}, {sum(len(t) for t in om.triangles)} triangles, "
+                      f"{el:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from dbot_ros_amd import CameraData, ObjectModel, RbSensor, RbSensorBuilder, synth
+    mesh_fn = {"m1": synth.mesh_m1, "m2": synth.mesh_m2, "m3": synth.mesh_m3, "m4": synth.mesh_m4}[a.mesh]
+    v, f = mesh_fn()
+    om = ObjectModel([v], [f], center=True)
+    cam = CameraData(synth.camera_matrix(a.cols, a.rows), a.rows, a.cols)
+    n = a.particles
+    P = RbSensorBuilder.Parameters(sample_count=n)
+    sensor = RbSensor(om, cam, P, device_id=local, max_particles=n)
+
+    # synthetic frame: the product's own render hook supplies the object's depth
+    rng = np.random.default_rng(0)
+    truth = synth.truth_pose(1)
+    frame = synth.make_frame(sensor.render_depth(truth), a.rows, a.cols, rng)
+    prng = np.random.default_rng(1 + rank)
+    poses = synth.particle_poses(truth, n, prng)
+    if a.parents == "permutation":
+        parents = synth.resample_like_indices(n, prng)
+    elif a.parents == "identity":
+        parents = np.arange(n, dtype=np.int32)
+    else:
+        parents = synth.resample_like_indices(n, prng, concentration=1.0)
+
+    dev = torch.device("cuda", local)
+    d_poses = torch.from_numpy(poses.reshape(n, -1)).to(dev)
+    d_idx = torch.from_numpy(parents).to(dev)
+    d_out = torch.empty(n, dtype=torch.float64, device=dev)
+    d_all = torch.empty(n * world, dtype=torch.float64, device=dev) if world > 1 else None
+    sensor.reset()
+    sensor.set_observation(frame)
+    sensor.synchronize()
+    stream = torch.cuda.current_stream()
+
+    def step():
+        sensor.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, True, d_out.data_ptr(),
+                               stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    k_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for s, e in k_ev:
+        s.record(stream)
+        sensor.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, True, d_out.data_ptr(),
+                               stream.cuda_stream)
+        e.record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in k_ev]))
+    ll = d_out.cpu().numpy()
+    if not np.isfinite(ll).all():
+        raise SystemExit("non-finite log-likelihoods in the timed run")
+
+    if rank == 0:
+        alg_bytes = 2.0 * 4.0 * a.rows * a.cols * n  # per launch, SURVEY 8d
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "particle-likelihoods/sec @640x480" if (a.cols, a.rows) == (640, 480)
+                      else f"particle-likelihoods/sec @{a.cols}x{a.rows}",
+            "value": n * world * a.steps / elapsed,
+            "unit": "particle-likelihoods/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C1: {n} particles/GPU x loglikes(update=true), {a.cols}x{a.rows} "
+                                   f"synthetic depth frame, mesh {a.mesh} ({len(f)} triangles), "
+                                   f"parents={a.parents}",
+                       "particles_per_gpu": n, "resolution": [a.cols, a.rows], "triangles": int(len(f)),
+                       "sharding": f"particles/{world}" + (" + RCCL all-gather of log-likelihoods" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "rbs_loglikes_kernel<update>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(om, cam, P, truth, frame, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    sensor.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

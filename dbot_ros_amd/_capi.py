@@ -1,0 +1,112 @@
+"""ctypes binding of librbsensor_mi355x.so (include/rbsensor_mi355x.h).
+
+The library is the product; this module only declares its prototypes.  Loading fails loudly
+when the shared object has not been built (``python -c 'import __graft_entry__ as g; g.build()'``
+or ``make -C dbot_ros_amd/csrc``) -- there is no Python or CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librbsensor_mi355x.so")
+
+RBS_ABI_VERSION = 1
+RBS_OK = 0
+RBS_ERR_INVALID_ARGUMENT = -1
+RBS_ERR_NO_DEVICE = -2
+RBS_ERR_OUT_OF_MEMORY = -3
+RBS_ERR_HIP = -4
+RBS_ERR_UNSUPPORTED = -5
+
+# every symbol include/rbsensor_mi355x.h declares
+EXPORTS = (
+    "rbs_abi_version", "rbs_device_count", "rbs_create", "rbs_destroy", "rbs_last_error",
+    "rbs_reset", "rbs_set_observation", "rbs_set_observation_f32", "rbs_loglikes",
+    "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
+    "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_render_depth",
+    "rbs_last_kernel_ms",
+)
+
+
+class RbsConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("device_id", C.c_int32),
+        ("rows", C.c_int32),
+        ("cols", C.c_int32),
+        ("K", C.c_double * 9),
+        ("max_particles", C.c_int32),
+        ("n_objects", C.c_int32),
+        ("vertices", C.POINTER(C.c_double)),
+        ("vertex_counts", C.POINTER(C.c_int32)),
+        ("triangles", C.POINTER(C.c_int32)),
+        ("triangle_counts", C.POINTER(C.c_int32)),
+        ("p_occluded_visible", C.c_double),
+        ("p_occluded_occluded", C.c_double),
+        ("initial_occlusion_prob", C.c_double),
+        ("tail_weight", C.c_double),
+        ("model_sigma", C.c_double),
+        ("sigma_factor", C.c_double),
+        ("delta_time", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Return the loaded library (cached). Raises OSError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(make -C dbot_ros_amd/csrc, or __graft_entry__.build()). "
+            "dbot_ros_amd has no CPU fallback.")
+    # When torch is in the process its bundled libamdhip64.so.7 must be the one HIP runtime;
+    # importing it first makes our DT_NEEDED resolve to the already-loaded copy.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing, not a requirement of the C-ABI
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    H = C.c_void_p
+    dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    lib.rbs_abi_version.restype = C.c_int32
+    lib.rbs_abi_version.argtypes = []
+    lib.rbs_device_count.restype = C.c_int32
+    lib.rbs_device_count.argtypes = []
+    lib.rbs_create.restype = C.c_int32
+    lib.rbs_create.argtypes = [C.POINTER(RbsConfig), C.POINTER(H)]
+    lib.rbs_destroy.restype = None
+    lib.rbs_destroy.argtypes = [H]
+    lib.rbs_last_error.restype = C.c_char_p
+    lib.rbs_last_error.argtypes = [H]
+    lib.rbs_reset.restype = C.c_int32
+    lib.rbs_reset.argtypes = [H]
+    lib.rbs_set_observation.restype = C.c_int32
+    lib.rbs_set_observation.argtypes = [H, dp, C.c_size_t]
+    lib.rbs_set_observation_f32.restype = C.c_int32
+    lib.rbs_set_observation_f32.argtypes = [H, fp, C.c_size_t]
+    lib.rbs_loglikes.restype = C.c_int32
+    lib.rbs_loglikes.argtypes = [H, dp, ip, C.c_int32, C.c_int32, dp]
+    lib.rbs_loglikes_device.restype = C.c_int32
+    lib.rbs_loglikes_device.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p]
+    lib.rbs_synchronize.restype = C.c_int32
+    lib.rbs_synchronize.argtypes = [H]
+    lib.rbs_get_occlusion.restype = C.c_int32
+    lib.rbs_get_occlusion.argtypes = [H, C.c_int32, fp]
+    lib.rbs_set_occlusion.restype = C.c_int32
+    lib.rbs_set_occlusion.argtypes = [H, C.c_int32, fp]
+    lib.rbs_occlusion_device_ptr.restype = C.c_int32
+    lib.rbs_occlusion_device_ptr.argtypes = [H, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.rbs_occlusion_next_device_ptr.restype = C.c_int32
+    lib.rbs_occlusion_next_device_ptr.argtypes = [H, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.rbs_render_depth.restype = C.c_int32
+    lib.rbs_render_depth.argtypes = [H, dp, fp]
+    lib.rbs_last_kernel_ms.restype = C.c_int32
+    lib.rbs_last_kernel_ms.argtypes = [H, C.POINTER(C.c_float)]
+    _lib = lib
+    return lib

@@ -1,0 +1,502 @@
+// rbsensor_capi.hip -- host side of librbsensor_mi355x.so: the C-ABI declared in
+// include/rbsensor_mi355x.h over the kernels in rbsensor_kernels.hip.
+//
+// Device-resident state per handle (sizes at 640x480, N slots):
+//   soup      9 * n_tri doubles, SoA triangle soup                     (368 KB @5 120 tris)
+//   frame     rows*cols float, current observation                     (1.2 MB)
+//   occ[2]    2 * N * rows*cols float, double-buffered occlusion planes (2.46 MB * N)
+//   poses / indices / out   per-call staging for the host-pointer API
+// There is no CPU path in this library.
+#include "rbsensor_kernels.hip"
+
+#include "../../include/rbsensor_mi355x.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using rbs::DevParams;
+
+struct rbs_handle {
+    int device = 0;
+    int rows = 0, cols = 0, npx = 0;
+    int max_particles = 0;
+    int n_bodies = 0;
+    DevParams base{};           // static part of the kernel parameters
+    double p_ov = 0, p_oo = 0, init_occ = 0, delta_time = 0;
+    double* d_soup = nullptr;
+    float* d_frame = nullptr;
+    float* d_occ[2] = {nullptr, nullptr};
+    int cur = 0;
+    int pending_frames = 0;     // set_observation calls since the last updating loglikes
+    double* d_poses = nullptr;
+    int* d_indices = nullptr;
+    double* d_out = nullptr;
+    float* d_render = nullptr;
+    float* h_frame = nullptr;   // pinned staging
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+std::string fmt(const char* f, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+
+#define RBS_HIP(h, call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (h)->err = fmt("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,   \
+                           __LINE__);                                                         \
+            return e_ == hipErrorOutOfMemory ? RBS_ERR_OUT_OF_MEMORY : RBS_ERR_HIP;           \
+        }                                                                                     \
+    } while (0)
+
+int32_t fail(rbs_handle* h, int32_t code, const std::string& msg)
+{
+    h->err = msg;
+    return code;
+}
+
+// alpha/beta of the occlusion process over n frames (affine form of SURVEY A.5), rounded
+// once to float -- the same rule as oracle orc_eager_coeffs().
+void occlusion_coeffs(const rbs_handle* h, int n_frames, float* alpha, float* beta)
+{
+    const double c = h->p_oo - h->p_ov;
+    const double a = std::exp(((double)n_frames * h->delta_time) * std::log(c));
+    const double g = (1.0 - h->p_oo) * (a - 1.0) / (c - 1.0);
+    *alpha = (float)a;
+    *beta = (float)((1.0 - a) - g);
+}
+
+int copy_bands_for(int rows, int cols)
+{
+    // ~3840 float4 (60 KB) per copy block; an EVEN band count keeps 1+bands odd so raster
+    // blocks (block index = particle*(1+bands)) rotate over all 8 XCDs.
+    const long n4 = ((long)rows * cols + 3) / 4;
+    long b = (n4 + 3839) / 3840;
+    if (b < 2) b = 2;
+    if (b & 1) ++b;
+    if (b > rows) b = (rows & 1) ? rows + 1 : rows;
+    return (int)b;
+}
+
+template <bool UPDATE>
+hipError_t launch_loglikes(const DevParams& P, hipStream_t s)
+{
+    const int G = UPDATE ? 1 + P.bands : 1;
+    const dim3 grid((unsigned)((size_t)P.n * G)), block(rbs::kBlock);
+    if ((P.cols & 3) == 0)
+        hipLaunchKernelGGL((rbs::rbs_loglikes_kernel<UPDATE, 4>), grid, block, rbs::kSmemBytes, s, P);
+    else
+        hipLaunchKernelGGL((rbs::rbs_loglikes_kernel<UPDATE, 1>), grid, block, rbs::kSmemBytes, s, P);
+    return hipGetLastError();
+}
+
+int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indices, int n,
+                         bool update, double* d_out, hipStream_t s)
+{
+    DevParams P = h->base;
+    occlusion_coeffs(h, h->pending_frames, &P.alpha, &P.beta);
+    P.frame = h->d_frame;
+    P.occ_src = h->d_occ[h->cur];
+    P.occ_dst = h->d_occ[1 - h->cur];
+    P.poses = d_poses;
+    P.indices = d_indices;
+    P.out = d_out;
+    P.n = n;
+    RBS_HIP(h, hipEventRecord(h->ev_start, s));
+    RBS_HIP(h, update ? launch_loglikes<true>(P, s) : launch_loglikes<false>(P, s));
+    RBS_HIP(h, hipEventRecord(h->ev_stop, s));
+    h->timed = true;
+    if (update) {
+        h->cur = 1 - h->cur;
+        h->pending_frames = 0;
+    }
+    return RBS_OK;
+}
+
+void release(rbs_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->d_soup);
+    (void)hipFree(h->d_frame);
+    (void)hipFree(h->d_occ[0]);
+    (void)hipFree(h->d_occ[1]);
+    (void)hipFree(h->d_poses);
+    (void)hipFree(h->d_indices);
+    (void)hipFree(h->d_out);
+    (void)hipFree(h->d_render);
+    if (h->h_frame) (void)hipHostFree(h->h_frame);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
+{
+    if (cfg->abi_version != RBS_ABI_VERSION)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT,
+                    fmt("abi_version %d, library is %d", cfg->abi_version, RBS_ABI_VERSION));
+    if (cfg->rows <= 0 || cfg->cols <= 0 || cfg->cols > 8192 || cfg->rows > 8192)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("bad resolution %dx%d", cfg->cols, cfg->rows));
+    if (cfg->max_particles <= 0)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "max_particles must be positive");
+    if (cfg->n_objects <= 0 || cfg->n_objects > rbs::kMaxBodies)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT,
+                    fmt("n_objects %d outside 1..%d", cfg->n_objects, rbs::kMaxBodies));
+    if (!cfg->vertices || !cfg->vertex_counts || !cfg->triangles || !cfg->triangle_counts)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "null mesh pointer");
+    const double* K = cfg->K;
+    if (!(K[0] > 0.0) || !(K[4] > 0.0) || K[1] != 0.0 || K[3] != 0.0 || K[6] != 0.0 ||
+        K[7] != 0.0 || K[8] != 1.0)
+        return fail(h, RBS_ERR_UNSUPPORTED,
+                    "camera matrix must be [fx 0 cx; 0 fy cy; 0 0 1] with fx, fy > 0");
+    const double c = cfg->p_occluded_occluded - cfg->p_occluded_visible;
+    if (!(c > 0.0) || !(c < 1.0))
+        return fail(h, RBS_ERR_INVALID_ARGUMENT,
+                    "need 0 < p_occluded_occluded - p_occluded_visible < 1");
+    if (!(cfg->delta_time > 0.0)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "delta_time must be > 0");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, RBS_ERR_NO_DEVICE,
+                    "no HIP device visible: librbsensor_mi355x has no CPU path");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(h, RBS_ERR_NO_DEVICE, fmt("device_id %d of %d", cfg->device_id, ndev));
+    h->device = cfg->device_id;
+    RBS_HIP(h, hipSetDevice(h->device));
+
+    h->rows = cfg->rows;
+    h->cols = cfg->cols;
+    h->npx = cfg->rows * cfg->cols;
+    h->max_particles = cfg->max_particles;
+    h->n_bodies = cfg->n_objects;
+    h->p_ov = cfg->p_occluded_visible;
+    h->p_oo = cfg->p_occluded_occluded;
+    h->init_occ = cfg->initial_occlusion_prob;
+    h->delta_time = cfg->delta_time;
+
+    DevParams& B = h->base;
+    B.rows = h->rows; B.cols = h->cols; B.npx = h->npx;
+    B.n_bodies = h->n_bodies;
+    B.fx = K[0]; B.fy = K[4]; B.cx = K[2]; B.cy = K[5];
+    B.tw = cfg->tail_weight; B.ms = cfg->model_sigma; B.sf = cfg->sigma_factor;
+    B.lambda = -std::log(0.5) / rbs::kHalfLifeDepth;
+    B.bands = copy_bands_for(h->rows, h->cols);
+    B.band_rows = (h->rows + B.bands - 1) / B.bands;
+
+    // triangle soup (SoA) + bounding spheres
+    long n_tri = 0;
+    B.tri_begin[0] = 0;
+    for (int b = 0; b < h->n_bodies; ++b) {
+        if (cfg->vertex_counts[b] <= 0 || cfg->triangle_counts[b] < 0)
+            return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("object %d: bad mesh counts", b));
+        n_tri += cfg->triangle_counts[b];
+        B.tri_begin[b + 1] = (int)n_tri;
+    }
+    for (int b = h->n_bodies; b < rbs::kMaxBodies; ++b) B.tri_begin[b + 1] = (int)n_tri;
+    B.n_tri = (int)n_tri;
+    std::vector<double> soup((size_t)9 * (n_tri > 0 ? n_tri : 1));
+    size_t voff = 0, toff = 0;
+    for (int b = 0; b < h->n_bodies; ++b) {
+        const int nv = cfg->vertex_counts[b], nt = cfg->triangle_counts[b];
+        const double* V = cfg->vertices + 3 * voff;
+        double lo[3] = {V[0], V[1], V[2]}, hi[3] = {V[0], V[1], V[2]};
+        for (int i = 0; i < nv; ++i)
+            for (int c3 = 0; c3 < 3; ++c3) {
+                const double x = V[3 * i + c3];
+                if (!std::isfinite(x))
+                    return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("object %d: non-finite vertex", b));
+                lo[c3] = std::fmin(lo[c3], x);
+                hi[c3] = std::fmax(hi[c3], x);
+            }
+        double ctr[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+        double r2 = 0.0;
+        for (int i = 0; i < nv; ++i) {
+            const double dx = V[3 * i] - ctr[0], dy = V[3 * i + 1] - ctr[1], dz = V[3 * i + 2] - ctr[2];
+            r2 = std::fmax(r2, dx * dx + dy * dy + dz * dz);
+        }
+        B.sphere[b][0] = ctr[0]; B.sphere[b][1] = ctr[1]; B.sphere[b][2] = ctr[2];
+        B.sphere[b][3] = std::sqrt(r2) * (1.0 + 1e-9) + 1e-12;
+        for (int t = 0; t < nt; ++t)
+            for (int k = 0; k < 3; ++k) {
+                const int vi = cfg->triangles[3 * (toff + t) + k];
+                if (vi < 0 || vi >= nv)
+                    return fail(h, RBS_ERR_INVALID_ARGUMENT,
+                                fmt("object %d triangle %d: vertex index %d out of range", b, t, vi));
+                for (int c3 = 0; c3 < 3; ++c3)
+                    soup[(size_t)(3 * k + c3) * n_tri + toff + t] = V[3 * vi + c3];
+            }
+        voff += nv;
+        toff += nt;
+    }
+
+    const size_t plane = (size_t)h->npx * sizeof(float);
+    RBS_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    RBS_HIP(h, hipEventCreate(&h->ev_start));
+    RBS_HIP(h, hipEventCreate(&h->ev_stop));
+    RBS_HIP(h, hipMalloc(&h->d_soup, soup.size() * sizeof(double)));
+    RBS_HIP(h, hipMemcpy(h->d_soup, soup.data(), soup.size() * sizeof(double), hipMemcpyHostToDevice));
+    B.soup = h->d_soup;
+    RBS_HIP(h, hipMalloc(&h->d_frame, plane));
+    RBS_HIP(h, hipMalloc(&h->d_render, plane));
+    RBS_HIP(h, hipMalloc(&h->d_occ[0], plane * h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_occ[1], plane * h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_poses, sizeof(double) * 12 * h->n_bodies * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_indices, sizeof(int) * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_out, sizeof(double) * (size_t)h->max_particles));
+    RBS_HIP(h, hipHostMalloc(&h->h_frame, plane, hipHostMallocDefault));
+
+    // raster blocks need the full dynamic LDS carve
+    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_loglikes_kernel<true, 4>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
+    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_loglikes_kernel<false, 4>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
+    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_loglikes_kernel<true, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
+    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_loglikes_kernel<false, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
+    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_render_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
+
+    // no observation yet: every pixel "no reading"
+    for (int p = 0; p < h->npx; ++p) h->h_frame[p] = NAN;
+    RBS_HIP(h, hipMemcpyAsync(h->d_frame, h->h_frame, plane, hipMemcpyHostToDevice, h->stream));
+    return rbs_reset(h);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rbs_abi_version(void) { return RBS_ABI_VERSION; }
+
+int32_t rbs_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* rbs_last_error(const rbs_handle* h)
+{
+    return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+int32_t rbs_create(const rbs_config* cfg, rbs_handle** out)
+{
+    if (!out) { g_create_error = "rbs_create: out is NULL"; return RBS_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (!cfg) { g_create_error = "rbs_create: cfg is NULL"; return RBS_ERR_INVALID_ARGUMENT; }
+    rbs_handle* h = new (std::nothrow) rbs_handle;
+    if (!h) { g_create_error = "rbs_create: out of host memory"; return RBS_ERR_OUT_OF_MEMORY; }
+    int32_t rc;
+    try {
+        rc = create_impl(cfg, h);
+    } catch (const std::exception& e) {
+        h->err = std::string("rbs_create: ") + e.what();
+        rc = RBS_ERR_OUT_OF_MEMORY;
+    }
+    if (rc != RBS_OK) {
+        g_create_error = h->err;
+        release(h);
+        return rc;
+    }
+    *out = h;
+    return RBS_OK;
+}
+
+void rbs_destroy(rbs_handle* h) { release(h); }
+
+int32_t rbs_reset(rbs_handle* h)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_HIP(h, hipSetDevice(h->device));
+    h->cur = 0;
+    h->pending_frames = 0;
+    const size_t n = (size_t)h->npx * h->max_particles;
+    hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(2048), dim3(256), 0, h->stream, h->d_occ[0], n,
+                       (float)h->init_occ);
+    RBS_HIP(h, hipGetLastError());
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    return RBS_OK;
+}
+
+int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!depth || n != (size_t)h->npx)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT,
+                    fmt("set_observation: expected %d pixels, got %zu", h->npx, n));
+    RBS_HIP(h, hipSetDevice(h->device));
+    RBS_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer reuse
+    for (size_t p = 0; p < n; ++p) h->h_frame[p] = (float)depth[p];
+    RBS_HIP(h, hipMemcpyAsync(h->d_frame, h->h_frame, n * sizeof(float), hipMemcpyHostToDevice,
+                              h->stream));
+    h->pending_frames += 1;
+    return RBS_OK;
+}
+
+int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!depth || n != (size_t)h->npx)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT,
+                    fmt("set_observation_f32: expected %d pixels, got %zu", h->npx, n));
+    RBS_HIP(h, hipSetDevice(h->device));
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    std::memcpy(h->h_frame, depth, n * sizeof(float));
+    RBS_HIP(h, hipMemcpyAsync(h->d_frame, h->h_frame, n * sizeof(float), hipMemcpyHostToDevice,
+                              h->stream));
+    h->pending_frames += 1;
+    return RBS_OK;
+}
+
+int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32_t n,
+                     int32_t update, double* out_loglik)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (n < 0 || n > h->max_particles)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT,
+                    fmt("loglikes: n = %d outside 0..max_particles = %d", n, h->max_particles));
+    if (n == 0) return RBS_OK;
+    if (!poses || !indices || !out_loglik)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "loglikes: null pointer");
+    for (int32_t i = 0; i < n; ++i)
+        if (indices[i] < 0 || indices[i] >= h->max_particles)
+            return fail(h, RBS_ERR_INVALID_ARGUMENT,
+                        fmt("loglikes: indices[%d] = %d outside 0..%d", i, indices[i],
+                            h->max_particles - 1));
+    RBS_HIP(h, hipSetDevice(h->device));
+    const size_t pose_bytes = sizeof(double) * 12 * h->n_bodies * (size_t)n;
+    RBS_HIP(h, hipMemcpyAsync(h->d_poses, poses, pose_bytes, hipMemcpyHostToDevice, h->stream));
+    RBS_HIP(h, hipMemcpyAsync(h->d_indices, indices, sizeof(int) * (size_t)n, hipMemcpyHostToDevice,
+                              h->stream));
+    const int32_t rc = enqueue_loglikes(h, h->d_poses, h->d_indices, n, update != 0, h->d_out, h->stream);
+    if (rc != RBS_OK) return rc;
+    RBS_HIP(h, hipMemcpyAsync(out_loglik, h->d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
+                              h->stream));
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    if (update)
+        for (int32_t i = 0; i < n; ++i) indices[i] = i;
+    return RBS_OK;
+}
+
+int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t* d_indices,
+                            int32_t n, int32_t update, double* d_out_loglik, void* stream)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (n < 0 || n > h->max_particles)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT,
+                    fmt("loglikes_device: n = %d outside 0..max_particles = %d", n, h->max_particles));
+    if (n == 0) return RBS_OK;
+    if (!d_poses || !d_indices || !d_out_loglik)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "loglikes_device: null pointer");
+    RBS_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    return enqueue_loglikes(h, d_poses, d_indices, n, update != 0, d_out_loglik, s);
+}
+
+int32_t rbs_synchronize(rbs_handle* h)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_HIP(h, hipSetDevice(h->device));
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    return RBS_OK;
+}
+
+int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (slot < 0 || slot >= h->max_particles || !out)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("get_occlusion: bad slot %d", slot));
+    RBS_HIP(h, hipSetDevice(h->device));
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    RBS_HIP(h, hipMemcpy(out, h->d_occ[h->cur] + (size_t)slot * h->npx, sizeof(float) * h->npx,
+                         hipMemcpyDeviceToHost));
+    return RBS_OK;
+}
+
+int32_t rbs_set_occlusion(rbs_handle* h, int32_t slot, const float* plane)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (slot < 0 || slot >= h->max_particles || !plane)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("set_occlusion: bad slot %d", slot));
+    RBS_HIP(h, hipSetDevice(h->device));
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    RBS_HIP(h, hipMemcpy(h->d_occ[h->cur] + (size_t)slot * h->npx, plane, sizeof(float) * h->npx,
+                         hipMemcpyHostToDevice));
+    return RBS_OK;
+}
+
+int32_t rbs_occlusion_device_ptr(rbs_handle* h, int32_t slot, void** out)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (slot < 0 || slot >= h->max_particles || !out)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("occlusion_device_ptr: bad slot %d", slot));
+    *out = h->d_occ[h->cur] + (size_t)slot * h->npx;
+    return RBS_OK;
+}
+
+int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (slot < 0 || slot >= h->max_particles || !out)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("occlusion_next_device_ptr: bad slot %d", slot));
+    *out = h->d_occ[1 - h->cur] + (size_t)slot * h->npx;
+    return RBS_OK;
+}
+
+int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!pose || !out) return fail(h, RBS_ERR_INVALID_ARGUMENT, "render_depth: null pointer");
+    RBS_HIP(h, hipSetDevice(h->device));
+    RBS_HIP(h, hipMemcpyAsync(h->d_poses, pose, sizeof(double) * 12 * h->n_bodies,
+                              hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(256), dim3(256), 0, h->stream, h->d_render,
+                       (size_t)h->npx, INFINITY);
+    DevParams P = h->base;
+    P.poses = h->d_poses;
+    P.n = 1;
+    hipLaunchKernelGGL(rbs::rbs_render_kernel, dim3(1), dim3(rbs::kBlock), rbs::kSmemBytes,
+                       h->stream, P, h->d_render);
+    RBS_HIP(h, hipGetLastError());
+    RBS_HIP(h, hipMemcpyAsync(out, h->d_render, sizeof(float) * h->npx, hipMemcpyDeviceToHost,
+                              h->stream));
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    return RBS_OK;
+}
+
+int32_t rbs_last_kernel_ms(rbs_handle* h, float* ms)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!ms) return fail(h, RBS_ERR_INVALID_ARGUMENT, "last_kernel_ms: null pointer");
+    if (!h->timed) return fail(h, RBS_ERR_INVALID_ARGUMENT, "last_kernel_ms: no loglikes launched yet");
+    RBS_HIP(h, hipSetDevice(h->device));
+    RBS_HIP(h, hipEventSynchronize(h->ev_stop));
+    RBS_HIP(h, hipEventElapsedTime(ms, h->ev_start, h->ev_stop));
+    return RBS_OK;
+}
+
+}  // extern "C"

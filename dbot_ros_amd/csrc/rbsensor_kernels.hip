@@ -1,0 +1,446 @@
+// rbsensor_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the RbSensor likelihood evaluator.
+//
+// One launch of rbs_loglikes_kernel evaluates RbSensor::loglikes(deltas, indices, update)
+// (the call made once per sampling block inside tracker_->track,
+// R:source/dbot_ros/object_tracker_ros.hpp:49) for n particles:
+//
+//   raster blocks (one per particle)      software depth rasterizer: triangles -> LDS depth
+//                                         tile (ds_min_u32 z-min), then the per-pixel Kinect
+//                                         likelihood + occlusion posterior over the particle's
+//                                         screen rectangle, wave64 shuffle reduce -> one double.
+//   copy blocks (`bands` per particle,    stream the parent's occlusion plane into the child's
+//   update only)                          slot outside that rectangle, advancing every pixel
+//                                         by the occlusion process: occ' = fma(alpha, occ, beta).
+//
+// Both kinds are interleaved in ONE grid (block = particle*(1+bands)+sub) so that the
+// FP64-heavy raster work of some particles overlaps the HBM streaming of others on every CU.
+// The kernel is HBM-bound: 2*4*rows*cols bytes per particle-likelihood.
+//
+// Arithmetic contract (tests/ compare against oracle/): the geometry is individually rounded
+// binary64 in a fixed operation order (compile with -ffp-contract=off), the stored depth is
+// one rounding to float, z-min is order independent, so coverage and depth are bit-exact.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace rbs {
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kTilePx = 12288;       // LDS depth tile: 48 KiB of u32
+constexpr int kBigCap = 1024;        // triangles deferred to the cooperative path per chunk
+constexpr int kBigThresh = 96;       // bbox pixels above which a triangle is "big"
+constexpr int kCopyUnroll = 8;       // float4 loads in flight per lane in copy blocks
+constexpr unsigned kInfBits = 0x7f800000u;
+constexpr int kMaxBodies = 16;
+constexpr double kMaxDepth = 6.0;    // KinectPixelModel max_depth
+constexpr double kHalfLifeDepth = 1.0;
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct DevParams {
+    int rows, cols, npx;
+    int n_bodies;
+    int n_tri;
+    int tri_begin[kMaxBodies + 1];
+    double fx, fy, cx, cy;
+    double sphere[kMaxBodies][4];  // model-space bounding sphere: centre xyz, radius
+    const double* soup;            // SoA [9][n_tri]: v0.xyz v1.xyz v2.xyz
+    const float* frame;            // observation, float metres
+    double tw, ms, sf, lambda;     // tail_weight, model_sigma, sigma_factor, ln2/half_life
+    float alpha, beta;             // occlusion process over the elapsed frames
+    const float* occ_src;          // [slots][npx]
+    float* occ_dst;                // [slots][npx]
+    const double* poses;           // [n][n_bodies][12]
+    const int* indices;            // [n] parent slot
+    double* out;                   // [n]
+    int n;
+    int bands, band_rows;          // copy blocks per particle, rows per band
+};
+
+struct Rect { int x0, y0, x1, y1; };
+
+// ------------------------------------------------------------------ screen rectangle
+// Conservative pixel rectangle containing every pixel the particle's bodies can cover, from
+// the bodies' bounding spheres; x-aligned to 32 pixels (128 B) so raster and copy blocks
+// never share a cache line.  Result only decides WHO writes a pixel, never its value.
+__device__ inline Rect particle_rect(const DevParams& P, const double* __restrict__ pose)
+{
+    double umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+    bool full = false;
+    for (int b = 0; b < P.n_bodies; ++b) {
+        const double* Rt = pose + 12 * b;
+        const double sx = P.sphere[b][0], sy = P.sphere[b][1], sz = P.sphere[b][2];
+        const double rho = P.sphere[b][3];
+        const double X = ((Rt[0] * sx + Rt[1] * sy) + Rt[2] * sz) + Rt[9];
+        const double Y = ((Rt[3] * sx + Rt[4] * sy) + Rt[5] * sz) + Rt[10];
+        const double Z = ((Rt[6] * sx + Rt[7] * sy) + Rt[8] * sz) + Rt[11];
+        const double zmin = Z - rho, zmax = Z + rho;
+        if (!(zmin > 1e-6)) { full = true; continue; }
+        const double xl = X - rho, xr = X + rho, yl = Y - rho, yr = Y + rho;
+        umax = fmax(umax, P.fx * (xr >= 0.0 ? xr / zmin : xr / zmax) + P.cx);
+        umin = fmin(umin, P.fx * (xl >= 0.0 ? xl / zmax : xl / zmin) + P.cx);
+        vmax = fmax(vmax, P.fy * (yr >= 0.0 ? yr / zmin : yr / zmax) + P.cy);
+        vmin = fmin(vmin, P.fy * (yl >= 0.0 ? yl / zmax : yl / zmin) + P.cy);
+    }
+    Rect r;
+    if (full) {
+        r.x0 = 0; r.y0 = 0; r.x1 = P.cols; r.y1 = P.rows;
+    } else {
+        const double W = (double)P.cols, H = (double)P.rows;
+        r.x0 = (int)fmin(fmax(floor(umin) - 1.0, 0.0), W);
+        r.x1 = (int)fmin(fmax(ceil(umax) + 2.0, 0.0), W);
+        r.y0 = (int)fmin(fmax(floor(vmin) - 1.0, 0.0), H);
+        r.y1 = (int)fmin(fmax(ceil(vmax) + 2.0, 0.0), H);
+    }
+    r.x0 &= ~31;
+    r.x1 = min(P.cols, (r.x1 + 31) & ~31);
+    if (r.x1 <= r.x0 || r.y1 <= r.y0) { r.x0 = r.x1 = r.y0 = r.y1 = 0; }
+    return r;
+}
+
+// ------------------------------------------------------------------ triangle setup
+struct Tri {
+    double u0, v0, u1, v1, u2, v2;
+    double e01u, e01v, e12u, e12v, e20u, e20v;
+    double pa, pb, pc, nv0;
+    int xlo, xhi, ylo, yhi;
+};
+
+// Same operations, same order as oracle/rbsensor_oracle.c raster_triangle().  The clip window
+// [wx0,wx1) x [wy0,wy1) is a sub-rectangle of the image, so clipping to it instead of to the
+// image changes nothing inside the window.
+__device__ inline bool tri_setup(const DevParams& P, int t, const double* __restrict__ Rt,
+                                 int wx0, int wy0, int wx1, int wy1, Tri& T)
+{
+    const double* __restrict__ s = P.soup;
+    const size_t n = (size_t)P.n_tri;
+    double X[3], Y[3], Z[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double vx = s[(3 * k + 0) * n + t], vy = s[(3 * k + 1) * n + t],
+                     vz = s[(3 * k + 2) * n + t];
+        X[k] = ((Rt[0] * vx + Rt[1] * vy) + Rt[2] * vz) + Rt[9];
+        Y[k] = ((Rt[3] * vx + Rt[4] * vy) + Rt[5] * vz) + Rt[10];
+        Z[k] = ((Rt[6] * vx + Rt[7] * vy) + Rt[8] * vz) + Rt[11];
+    }
+    if (!(Z[0] > 0.0 && Z[1] > 0.0 && Z[2] > 0.0)) return false;
+    double u[3], v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double iz = 1.0 / Z[k];
+        u[k] = P.fx * (X[k] * iz) + P.cx;
+        v[k] = P.fy * (Y[k] * iz) + P.cy;
+    }
+    T.u0 = u[0]; T.v0 = v[0]; T.u1 = u[1]; T.v1 = v[1]; T.u2 = u[2]; T.v2 = v[2];
+    T.e01u = u[1] - u[0]; T.e01v = v[1] - v[0];
+    T.e12u = u[2] - u[1]; T.e12v = v[2] - v[1];
+    T.e20u = u[0] - u[2]; T.e20v = v[0] - v[2];
+    const double area2 = T.e01u * (v[2] - v[0]) - T.e01v * (u[2] - u[0]);
+    if (!(area2 != 0.0) || !(fabs(area2) < INFINITY)) return false;
+
+    const double ax = X[1] - X[0], ay = Y[1] - Y[0], az = Z[1] - Z[0];
+    const double bx = X[2] - X[0], by = Y[2] - Y[0], bz = Z[2] - Z[0];
+    const double nx = ay * bz - az * by;
+    const double ny = az * bx - ax * bz;
+    const double nz = ax * by - ay * bx;
+    T.nv0 = (nx * X[0] + ny * Y[0]) + nz * Z[0];
+    T.pa = nx / P.fx;
+    T.pb = ny / P.fy;
+    T.pc = (nz - T.pa * P.cx) - T.pb * P.cy;
+
+    const double umin = fmin(fmin(u[0], u[1]), u[2]), umax = fmax(fmax(u[0], u[1]), u[2]);
+    const double vmin = fmin(fmin(v[0], v[1]), v[2]), vmax = fmax(fmax(v[0], v[1]), v[2]);
+    const double xlo_d = fmax(ceil(umin), (double)wx0), xhi_d = fmin(floor(umax), (double)(wx1 - 1));
+    const double ylo_d = fmax(ceil(vmin), (double)wy0), yhi_d = fmin(floor(vmax), (double)(wy1 - 1));
+    if (!(xlo_d <= xhi_d) || !(ylo_d <= yhi_d)) return false;
+    T.xlo = (int)xlo_d; T.xhi = (int)xhi_d; T.ylo = (int)ylo_d; T.yhi = (int)yhi_d;
+    return true;
+}
+
+// Coverage test + depth for one integer pixel; z-min into the LDS tile.
+__device__ inline void tri_pixel(const Tri& T, int col, int row, unsigned* tile, int tw, int wx0,
+                                 int wy0)
+{
+    const double px = (double)col, py = (double)row;
+    const double E0 = T.e01u * (py - T.v0) - T.e01v * (px - T.u0);
+    const double E1 = T.e12u * (py - T.v1) - T.e12v * (px - T.u1);
+    const double E2 = T.e20u * (py - T.v2) - T.e20v * (px - T.u2);
+    const bool in = (E0 >= 0.0 && E1 >= 0.0 && E2 >= 0.0) || (E0 <= 0.0 && E1 <= 0.0 && E2 <= 0.0);
+    if (!in) return;
+    const double den = (T.pa * px + T.pb * py) + T.pc;
+    const float zf = (float)(T.nv0 / den);
+    if (!(zf > 0.0f) || !(zf < INFINITY)) return;
+    atomicMin(&tile[(row - wy0) * tw + (col - wx0)], __float_as_uint(zf));
+}
+
+__device__ inline int body_of(const DevParams& P, int t)
+{
+    int b = 0;
+    while (b + 1 < P.n_bodies && t >= P.tri_begin[b + 1]) ++b;
+    return b;
+}
+
+// Rasterize every body of one particle into the LDS tile covering window
+// [wx0,wx1) x [wy0,wy1).  Small triangles: one lane each.  Triangles whose clipped bbox
+// exceeds kBigThresh pixels are queued in LDS and rasterized by the whole block, pixel-parallel.
+// Caller has cleared the tile and synchronised; on return the tile is complete and synchronised.
+__device__ inline void raster_window(const DevParams& P, const double* __restrict__ pose,
+                                     int wx0, int wy0, int wx1, int wy1, unsigned* tile,
+                                     int* big, int* nbig)
+{
+    const int tw = wx1 - wx0;
+    if (threadIdx.x == 0) *nbig = 0;
+    __syncthreads();
+    for (int b = 0; b < P.n_bodies; ++b) {
+        const double* Rt = pose + 12 * b;
+        for (int t = P.tri_begin[b] + (int)threadIdx.x; t < P.tri_begin[b + 1]; t += kBlock) {
+            Tri T;
+            if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, T)) continue;
+            const int bw = T.xhi - T.xlo + 1, bh = T.yhi - T.ylo + 1;
+            if (bw * bh > kBigThresh) {
+                const int slot = atomicAdd(nbig, 1);
+                if (slot < kBigCap) { big[slot] = t; continue; }
+            }
+            for (int row = T.ylo; row <= T.yhi; ++row)
+                for (int col = T.xlo; col <= T.xhi; ++col)
+                    tri_pixel(T, col, row, tile, tw, wx0, wy0);
+        }
+    }
+    __syncthreads();
+    const int nb = min(*nbig, kBigCap);
+    for (int e = 0; e < nb; ++e) {
+        const int t = big[e];
+        const double* Rt = pose + 12 * body_of(P, t);
+        Tri T;
+        if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, T)) continue;  // uniform across the block
+        const int bw = T.xhi - T.xlo + 1, bh = T.yhi - T.ylo + 1;
+        for (int k = threadIdx.x; k < bw * bh; k += kBlock) {
+            const int r = k / bw;
+            tri_pixel(T, T.xlo + (k - r * bw), T.ylo + r, tile, tw, wx0, wy0);
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ pixel model
+// KinectPixelModel / OcclusionModel restated; expression text kept identical to the
+// specification in oracle/rbsensor_oracle.c so both sides perform the same binary64
+// operations (transcendentals differ by <= a few ulp of double between libm and ocml).
+__device__ inline double prob_visible(const DevParams& P, double o, double r)
+{
+    const double tw = P.tw;
+    const double sigma = P.ms + P.sf * o * o;
+    const double d = r - o;
+    return tw / kMaxDepth +
+           (1.0 - tw) * exp(-(d * d) / (2.0 * sigma * sigma)) / (sqrt(2.0 * M_PI) * sigma);
+}
+
+__device__ inline double prob_occluded(const DevParams& P, double o, double r)
+{
+    const double tw = P.tw;
+    const double lam = P.lambda;
+    const double sigma = P.ms + P.sf * o * o;
+    return tw / kMaxDepth +
+           (1.0 - tw) * lam * exp(0.5 * lam * (2.0 * r - 2.0 * o + lam * sigma * sigma)) *
+               (1.0 + erf((r - o + lam * sigma * sigma) / (sqrt(2.0) * sigma))) /
+               (2.0 * (exp(r * lam) - 1.0));
+}
+
+__device__ inline double prob_background(const DevParams& P, double o)
+{
+    const double tw = P.tw;
+    const double lam = P.lambda;
+    const double sigma = P.ms + P.sf * o * o;
+    return tw / kMaxDepth + (1.0 - tw) * lam * exp(0.5 * lam * (-2.0 * o + lam * sigma * sigma));
+}
+
+// log-likelihood ratio of one covered, observed pixel + posterior occlusion.
+__device__ inline double pixel_loglik(const DevParams& P, float o, float r, float prior,
+                                      float& posterior)
+{
+    const float a = (float)(prob_visible(P, (double)o, (double)r) * (1.0 - (double)prior));
+    const float b = (float)(prob_occluded(P, (double)o, (double)r) * (double)prior);
+    const float pbg = (float)prob_background(P, (double)o);
+    const float sum = a + b;
+    posterior = b / sum;
+    return log((double)(sum / pbg));
+}
+
+__device__ inline double block_reduce_sum(double v, double* red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < kBlock / 64; ++w) s += red[w];
+    return s;
+}
+
+// ------------------------------------------------------------------ raster block
+template <bool UPDATE>
+__device__ inline void raster_eval(const DevParams& P, int particle, Rect r, unsigned char* smem)
+{
+    unsigned* tile = reinterpret_cast<unsigned*>(smem);
+    int* big = reinterpret_cast<int*>(smem + sizeof(unsigned) * kTilePx);
+    double* red = reinterpret_cast<double*>(smem + sizeof(unsigned) * kTilePx + sizeof(int) * kBigCap);
+    int* nbig = reinterpret_cast<int*>(red + kBlock / 64);
+
+    const double* pose = P.poses + (size_t)particle * 12 * P.n_bodies;
+    const int parent = P.indices[particle];
+    const float* __restrict__ src = P.occ_src + (size_t)parent * P.npx;
+    float* __restrict__ dst = UPDATE ? P.occ_dst + (size_t)particle * P.npx : nullptr;
+
+    double ll = 0.0;
+    const int rw = r.x1 - r.x0;
+    if (rw > 0) {
+        const int chunk_rows = kTilePx / rw;
+        for (int y = r.y0; y < r.y1; y += chunk_rows) {
+            const int ch = min(chunk_rows, r.y1 - y);
+            const int npx = rw * ch;
+            for (int p = threadIdx.x; p < npx; p += kBlock) tile[p] = kInfBits;
+            __syncthreads();
+            raster_window(P, pose, r.x0, y, r.x1, y + ch, tile, big, nbig);
+
+            for (int p = threadIdx.x; p < npx; p += kBlock) {
+                const int lr = p / rw;
+                const int gi = (y + lr) * P.cols + r.x0 + (p - lr * rw);
+                const unsigned dbits = tile[p];
+                if (UPDATE) {
+                    float occ = fmaf(P.alpha, src[gi], P.beta);
+                    if (dbits != kInfBits) {
+                        const float o = P.frame[gi];
+                        if (isfinite(o)) {
+                            float post;
+                            ll += pixel_loglik(P, o, __uint_as_float(dbits), occ, post);
+                            occ = post;
+                        }
+                    }
+                    dst[gi] = occ;
+                } else if (dbits != kInfBits) {
+                    const float o = P.frame[gi];
+                    if (isfinite(o)) {
+                        float post;
+                        ll += pixel_loglik(P, o, __uint_as_float(dbits),
+                                           fmaf(P.alpha, src[gi], P.beta), post);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const double total = block_reduce_sum(ll, red);
+    if (threadIdx.x == 0) P.out[particle] = total;
+}
+
+// ------------------------------------------------------------------ copy block
+// Rows [band*band_rows, ...) of the parent's plane -> the child's slot, skipping the raster
+// block's rectangle.  VEC == 4: float4 non-temporal stream; VEC == 1: any cols.
+template <int VEC>
+__device__ inline void copy_band(const DevParams& P, int particle, int band, Rect r)
+{
+    const int row0 = band * P.band_rows;
+    const int row1 = min(P.rows, row0 + P.band_rows);
+    if (row0 >= row1) return;
+    const int parent = P.indices[particle];
+    const float* __restrict__ src = P.occ_src + (size_t)parent * P.npx + (size_t)row0 * P.cols;
+    float* __restrict__ dst = P.occ_dst + (size_t)particle * P.npx + (size_t)row0 * P.cols;
+    const float alpha = P.alpha, beta = P.beta;
+
+    if (VEC == 4) {
+        const int W4 = P.cols >> 2;
+        const int n4 = (row1 - row0) * W4;
+        const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(src);
+        floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(dst);
+        const int qstep = kBlock / W4, rstep = kBlock - qstep * W4;
+        int row = row0 + (int)threadIdx.x / W4;
+        int c4 = (int)threadIdx.x - ((int)threadIdx.x / W4) * W4;
+        for (int base = threadIdx.x; base < n4; base += kBlock * kCopyUnroll) {
+            floatx4 v[kCopyUnroll];
+            bool ok[kCopyUnroll];
+#pragma unroll
+            for (int k = 0; k < kCopyUnroll; ++k) {
+                const int idx = base + k * kBlock;
+                const int col = c4 << 2;
+                ok[k] = idx < n4 && !(row >= r.y0 && row < r.y1 && col >= r.x0 && col < r.x1);
+                if (ok[k]) v[k] = __builtin_nontemporal_load(&s4[idx]);
+                c4 += rstep; row += qstep;
+                if (c4 >= W4) { c4 -= W4; ++row; }
+            }
+#pragma unroll
+            for (int k = 0; k < kCopyUnroll; ++k) {
+                if (!ok[k]) continue;
+                floatx4 w;
+                w.x = fmaf(alpha, v[k].x, beta);
+                w.y = fmaf(alpha, v[k].y, beta);
+                w.z = fmaf(alpha, v[k].z, beta);
+                w.w = fmaf(alpha, v[k].w, beta);
+                __builtin_nontemporal_store(w, &d4[base + k * kBlock]);
+            }
+        }
+    } else {
+        const int W = P.cols;
+        const int n1 = (row1 - row0) * W;
+        for (int idx = threadIdx.x; idx < n1; idx += kBlock) {
+            const int lr = idx / W;
+            const int row = row0 + lr, col = idx - lr * W;
+            if (row >= r.y0 && row < r.y1 && col >= r.x0 && col < r.x1) continue;
+            dst[idx] = fmaf(alpha, src[idx], beta);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ kernels
+template <bool UPDATE, int VEC>
+__global__ __launch_bounds__(kBlock) void rbs_loglikes_kernel(const DevParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int G = UPDATE ? 1 + P.bands : 1;
+    const int particle = (int)blockIdx.x / G;
+    const int sub = (int)blockIdx.x - particle * G;
+    const Rect r = particle_rect(P, P.poses + (size_t)particle * 12 * P.n_bodies);
+    if (UPDATE && sub > 0) {
+        copy_band<VEC>(P, particle, sub - 1, r);
+        return;
+    }
+    raster_eval<UPDATE>(P, particle, r, smem);
+}
+
+// Inspection hook: depth image of one pose through the same raster_window path.
+__global__ __launch_bounds__(kBlock) void rbs_render_kernel(const DevParams P, float* out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* tile = reinterpret_cast<unsigned*>(smem);
+    int* big = reinterpret_cast<int*>(smem + sizeof(unsigned) * kTilePx);
+    int* nbig = big + kBigCap;
+    const Rect r = particle_rect(P, P.poses);
+    const int rw = r.x1 - r.x0;
+    if (rw <= 0) return;
+    const int chunk_rows = kTilePx / rw;
+    for (int y = r.y0; y < r.y1; y += chunk_rows) {
+        const int ch = min(chunk_rows, r.y1 - y);
+        const int npx = rw * ch;
+        for (int p = threadIdx.x; p < npx; p += kBlock) tile[p] = kInfBits;
+        __syncthreads();
+        raster_window(P, P.poses, r.x0, y, r.x1, y + ch, tile, big, nbig);
+        for (int p = threadIdx.x; p < npx; p += kBlock) {
+            const int lr = p / rw;
+            out[(y + lr) * P.cols + r.x0 + (p - lr * rw)] = __uint_as_float(tile[p]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void rbs_fill_kernel(float* __restrict__ p, size_t n, float v)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+constexpr size_t kSmemBytes =
+    sizeof(unsigned) * kTilePx + sizeof(int) * kBigCap + sizeof(double) * (kBlock / 64) + 16;
+
+}  // namespace rbs

@@ -1,0 +1,270 @@
+"""Host-side mirror (Python flavour, used by tests and bench.py) of the plugin surface
+dbot_ros drives for this path -- same names and argument meaning as the reference's call sites:
+
+  ObjectModel, CameraData                R:source/dbot_ros/tracker/particle_tracker_node.cpp:89-121
+  RbSensorBuilder.Parameters             R:...particle_tracker_node.cpp:164-199
+  RbSensorBuilder(object_model, camera_data, params).build()   R:...particle_tracker_node.cpp:201-203
+  RbSensor.set_observation / loglikes / reset   driven from tracker_->track,
+                                         R:source/dbot_ros/object_tracker_ros.hpp:49
+
+Everything numeric happens in librbsensor_mi355x.so through the C-ABI; the C++ flavour of the
+same mirror is include/dbot_amd/rb_sensor_builder.hpp.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _capi
+from .pose import compose_with_default
+
+
+class RbSensorError(RuntimeError):
+    """Raised for any non-zero status of the C-ABI (the C++ shim throws std::runtime_error,
+    which the reference's service thread already catches,
+    R:source/dbot_ros/tracker/object_tracker_service_node.cpp:252-255)."""
+
+    def __init__(self, code, message):
+        super().__init__(f"[rbs {code}] {message}")
+        self.code = code
+
+
+class ObjectModel:
+    """Triangle meshes of the tracked rigid bodies (dbot::ObjectModel as constructed at
+    R:source/dbot_ros/tracker/particle_tracker_node.cpp:94-97).
+
+    center=True re-expresses every part around the mean of its vertices
+    (center_object_frame, R:config/particle_tracker.yaml:27-30)."""
+
+    def __init__(self, vertices, triangles, center=True):
+        self.vertices, self.triangles, self.centers = [], [], []
+        for v, t in zip(vertices, triangles):
+            v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1, 3)
+            t = np.ascontiguousarray(t, dtype=np.int32).reshape(-1, 3)
+            c = v.mean(axis=0) if center else np.zeros(3)
+            self.vertices.append(v - c)
+            self.triangles.append(t)
+            self.centers.append(c)
+
+    @property
+    def count_parts(self):
+        return len(self.vertices)
+
+
+@dataclass
+class CameraData:
+    """dbot::CameraData as the sensor sees it: intrinsics already divided by the
+    down-sampling factor (R:source/dbot_ros/util/ros_camera_data_provider.cpp:66-76) and the
+    evaluated resolution (R:config/camera.yaml:5-9)."""
+    camera_matrix: np.ndarray
+    rows: int
+    cols: int
+    downsampling_factor: int = 1
+
+    @classmethod
+    def from_native(cls, K, width, height, downsampling_factor):
+        K = np.array(K, dtype=np.float64).reshape(3, 3).copy()
+        K[:2, :] /= downsampling_factor
+        return cls(K, height // downsampling_factor, width // downsampling_factor,
+                   downsampling_factor)
+
+
+class RbSensorBuilder:
+    """dbot::RbSensorBuilder<State> mirror."""
+
+    @dataclass
+    class Occlusion:
+        p_occluded_visible: float = 0.1
+        p_occluded_occluded: float = 0.7
+        initial_occlusion_prob: float = 0.1
+
+    @dataclass
+    class Kinect:
+        tail_weight: float = 0.01
+        model_sigma: float = 0.003
+        sigma_factor: float = 0.0014247
+
+    @dataclass
+    class Parameters:
+        use_gpu: bool = True
+        sample_count: int = 2000
+        occlusion: "RbSensorBuilder.Occlusion" = field(default_factory=lambda: RbSensorBuilder.Occlusion())
+        kinect: "RbSensorBuilder.Kinect" = field(default_factory=lambda: RbSensorBuilder.Kinect())
+        delta_time: float = 1.0 / 30.0
+        # GL-only knobs of the CUDA/OpenGL model: accepted and ignored (no GL in this path)
+        use_custom_shaders: bool = False
+        vertex_shader_file: str = ""
+        fragment_shader_file: str = ""
+        geometry_shader_file: str = ""
+
+        @classmethod
+        def from_rosparam(cls, tree):
+            """Build from the dict loaded from R:config/particle_tracker.yaml (same keys the
+            node reads at R:source/dbot_ros/tracker/particle_tracker_node.cpp:165-199)."""
+            pf = tree["particle_filter"]
+            p = cls()
+            p.use_gpu = bool(pf["use_gpu"])
+            p.sample_count = int(pf["gpu" if p.use_gpu else "cpu"]["sample_count"])
+            o, k = pf["observation"]["occlusion"], pf["observation"]["kinect"]
+            p.occlusion = RbSensorBuilder.Occlusion(float(o["p_occluded_visible"]),
+                                                    float(o["p_occluded_occluded"]),
+                                                    float(o["initial_occlusion_prob"]))
+            p.kinect = RbSensorBuilder.Kinect(float(k["tail_weight"]), float(k["model_sigma"]),
+                                              float(k["sigma_factor"]))
+            g = pf.get("gpu", {})
+            p.use_custom_shaders = bool(g.get("use_custom_shaders", False))
+            p.vertex_shader_file = str(g.get("vertex_shader_file", ""))
+            p.fragment_shader_file = str(g.get("fragment_shader_file", ""))
+            p.geometry_shader_file = str(g.get("geometry_shader_file", ""))
+            return p
+
+    def __init__(self, object_model, camera_data, params, device_id=0):
+        self.object_model, self.camera_data, self.params = object_model, camera_data, params
+        self.device_id = device_id
+
+    def build(self):
+        if not self.params.use_gpu:
+            raise RbSensorError(_capi.RBS_ERR_UNSUPPORTED,
+                                "use_gpu:false selects dbot's CPU model; this package only "
+                                "provides the MI355X implementation (no CPU fallback)")
+        return RbSensor(self.object_model, self.camera_data, self.params, self.device_id)
+
+
+class RbSensor:
+    """dbot RbSensor mirror over the C-ABI handle."""
+
+    def __init__(self, object_model, camera_data, params, device_id=0, max_particles=None):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        self.n_bodies = object_model.count_parts
+        self.rows, self.cols = int(camera_data.rows), int(camera_data.cols)
+        self.max_particles = int(max_particles or params.sample_count)
+        self.integrated_poses = np.zeros(12 * self.n_bodies)  # default pose, SURVEY A.1
+
+        verts = np.ascontiguousarray(np.concatenate(object_model.vertices), dtype=np.float64)
+        tris = np.ascontiguousarray(np.concatenate(object_model.triangles), dtype=np.int32)
+        vcnt = np.array([len(v) for v in object_model.vertices], dtype=np.int32)
+        tcnt = np.array([len(t) for t in object_model.triangles], dtype=np.int32)
+        cfg = _capi.RbsConfig()
+        cfg.abi_version = _capi.RBS_ABI_VERSION
+        cfg.device_id = device_id
+        cfg.rows, cfg.cols = self.rows, self.cols
+        cfg.K = (C.c_double * 9)(*np.asarray(camera_data.camera_matrix, dtype=np.float64).ravel())
+        cfg.max_particles = self.max_particles
+        cfg.n_objects = self.n_bodies
+        cfg.vertices = verts.ctypes.data_as(C.POINTER(C.c_double))
+        cfg.vertex_counts = vcnt.ctypes.data_as(C.POINTER(C.c_int32))
+        cfg.triangles = tris.ctypes.data_as(C.POINTER(C.c_int32))
+        cfg.triangle_counts = tcnt.ctypes.data_as(C.POINTER(C.c_int32))
+        cfg.p_occluded_visible = params.occlusion.p_occluded_visible
+        cfg.p_occluded_occluded = params.occlusion.p_occluded_occluded
+        cfg.initial_occlusion_prob = params.occlusion.initial_occlusion_prob
+        cfg.tail_weight = params.kinect.tail_weight
+        cfg.model_sigma = params.kinect.model_sigma
+        cfg.sigma_factor = params.kinect.sigma_factor
+        cfg.delta_time = params.delta_time
+        rc = self._lib.rbs_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.rbs_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise RbSensorError(rc, msg)
+
+    # -- life cycle -----------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.rbs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RbSensorError(rc, self._lib.rbs_last_error(self._h).decode())
+
+    # -- RbSensor interface ---------------------------------------------------------
+    def reset(self):
+        self._check(self._lib.rbs_reset(self._h))
+
+    def set_observation(self, image):
+        """image: rows*cols depths in metres, row-major, NaN = no reading
+        (layout of ri::to_eigen_vector, R:source/dbot_ros/util/ros_interface.h:152-168)."""
+        img = np.asarray(image)
+        if img.dtype == np.float32:
+            a = np.ascontiguousarray(img).ravel()
+            self._check(self._lib.rbs_set_observation_f32(
+                self._h, a.ctypes.data_as(C.POINTER(C.c_float)), a.size))
+        else:
+            a = np.ascontiguousarray(img, dtype=np.float64).ravel()
+            self._check(self._lib.rbs_set_observation(
+                self._h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size))
+
+    def loglikes(self, deltas, indices, update=False):
+        """deltas: [n, n_bodies*12] state deltas around integrated_poses; indices: int32[n],
+        modified in place to identity when update is true. Returns float64[n]."""
+        poses = compose_with_default(deltas, self.integrated_poses, self.n_bodies)
+        return self.loglikes_poses(poses, indices, update)
+
+    def loglikes_poses(self, poses, indices, update=False):
+        """poses: absolute R|t, [n, n_bodies, 12]."""
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, self.n_bodies * 12)
+        n = poses.shape[0]
+        if not (isinstance(indices, np.ndarray) and indices.dtype == np.int32
+                and indices.flags.c_contiguous and indices.size == n):
+            raise RbSensorError(_capi.RBS_ERR_INVALID_ARGUMENT,
+                                "indices must be a contiguous int32 array of length n")
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.rbs_loglikes(
+            self._h, poses.ctypes.data_as(C.POINTER(C.c_double)),
+            indices.ctypes.data_as(C.POINTER(C.c_int32)), n, int(bool(update)),
+            out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def loglikes_device(self, d_poses_ptr, d_indices_ptr, n, update, d_out_ptr, stream=None):
+        """Asynchronous device-pointer variant (raw addresses, e.g. torch.Tensor.data_ptr())."""
+        self._check(self._lib.rbs_loglikes_device(self._h, d_poses_ptr, d_indices_ptr, int(n),
+                                                  int(bool(update)), d_out_ptr, stream))
+
+    def synchronize(self):
+        self._check(self._lib.rbs_synchronize(self._h))
+
+    # -- inspection -----------------------------------------------------------------
+    def get_occlusion(self, slot):
+        out = np.empty(self.rows * self.cols, dtype=np.float32)
+        self._check(self._lib.rbs_get_occlusion(self._h, int(slot),
+                                                out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def set_occlusion(self, slot, plane):
+        a = np.ascontiguousarray(plane, dtype=np.float32).ravel()
+        if a.size != self.rows * self.cols:
+            raise RbSensorError(_capi.RBS_ERR_INVALID_ARGUMENT, "plane has the wrong size")
+        self._check(self._lib.rbs_set_occlusion(self._h, int(slot),
+                                                a.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def occlusion_device_ptr(self, slot, next_buffer=False):
+        p = C.c_void_p()
+        fn = self._lib.rbs_occlusion_next_device_ptr if next_buffer else self._lib.rbs_occlusion_device_ptr
+        self._check(fn(self._h, int(slot), C.byref(p)))
+        return p.value
+
+    def render_depth(self, pose):
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(self.n_bodies * 12)
+        out = np.empty(self.rows * self.cols, dtype=np.float32)
+        self._check(self._lib.rbs_render_depth(self._h, pose.ctypes.data_as(C.POINTER(C.c_double)),
+                                               out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._check(self._lib.rbs_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)

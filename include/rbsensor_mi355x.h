@@ -1,0 +1,129 @@
+/*
+ * rbsensor_mi355x.h -- C-ABI of librbsensor_mi355x.so, the MI355X (gfx950) implementation of
+ * dbot's Rao-Blackwellised depth-image observation model (RbSensor), i.e. the likelihood
+ * evaluator that dbot_ros's particle tracker drives once per sampling block per frame.
+ *
+ * Drop-in boundary: each entry point replaces one virtual of the sensor object that
+ * dbot::RbSensorBuilder<State>::build() returns.  The reference only names that object
+ * through its builder, so the citations are the reference's own construction / call sites
+ * (R: = bayesian-object-tracking/dbot_ros):
+ *
+ *   rbs_create            <- RbSensorBuilder<State>(object_model, camera_data, params)
+ *                            R:source/dbot_ros/tracker/particle_tracker_node.cpp:164-203
+ *                            R:source/dbot_ros/tracker/object_tracker_service_node.cpp:136-175
+ *   rbs_reset             <- RbSensor::reset(), via tracker->initialize(...)
+ *                            R:source/dbot_ros/tracker/particle_tracker_node.cpp:252
+ *   rbs_set_observation   <- RbSensor::set_observation(image), via tracker_->track(image)
+ *                            R:source/dbot_ros/object_tracker_ros.hpp:44-49
+ *                            (layout R:source/dbot_ros/util/ros_interface.h:152-168)
+ *   rbs_loglikes          <- RbSensor::loglikes(deltas, indices, update), once per sampling
+ *                            block inside tracker_->track R:source/dbot_ros/object_tracker_ros.hpp:49
+ *   rbs_destroy           <- ~RbSensor (tracker torn down per service session,
+ *                            R:source/dbot_ros/tracker/object_tracker_service_node.cpp:233-238)
+ *
+ * Conventions: 0 = success, negative = error (message via rbs_last_error); the caller owns
+ * every pointer it passes, the library copies what it keeps; a handle is driven by one
+ * thread at a time but may be created/destroyed repeatedly from any thread; no exception
+ * crosses this boundary.  There is NO CPU fallback: without a usable gfx950 device
+ * rbs_create fails with RBS_ERR_NO_DEVICE.
+ */
+#ifndef RBSENSOR_MI355X_H
+#define RBSENSOR_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBS_ABI_VERSION 1
+
+enum {
+    RBS_OK = 0,
+    RBS_ERR_INVALID_ARGUMENT = -1,
+    RBS_ERR_NO_DEVICE = -2,
+    RBS_ERR_OUT_OF_MEMORY = -3,
+    RBS_ERR_HIP = -4,
+    RBS_ERR_UNSUPPORTED = -5
+};
+
+typedef struct rbs_handle rbs_handle;
+
+typedef struct rbs_config {
+    int32_t abi_version;            /* RBS_ABI_VERSION                                        */
+    int32_t device_id;              /* HIP device ordinal                                      */
+    int32_t rows, cols;             /* evaluated resolution (after down-sampling)             */
+    double K[9];                    /* row-major 3x3 intrinsics, top two rows already divided
+                                       by the down-sampling factor
+                                       (R:source/dbot_ros/util/ros_camera_data_provider.cpp:72);
+                                       zero skew, K[8] == 1                                    */
+    int32_t max_particles;          /* occlusion slots to allocate (>= any n passed later)    */
+    int32_t n_objects;              /* rigid bodies = meshes (object/meshes)                   */
+    const double* vertices;         /* concatenated xyz per object, sum(vertex_counts)*3      */
+    const int32_t* vertex_counts;   /* [n_objects]                                             */
+    const int32_t* triangles;       /* concatenated vertex-index triples, local to each object*/
+    const int32_t* triangle_counts; /* [n_objects]                                             */
+    /* RbSensorBuilder<State>::Parameters, R:...particle_tracker_node.cpp:176-189 */
+    double p_occluded_visible;
+    double p_occluded_occluded;
+    double initial_occlusion_prob;
+    double tail_weight;
+    double model_sigma;
+    double sigma_factor;
+    double delta_time;
+} rbs_config;
+
+int32_t rbs_abi_version(void);
+int32_t rbs_device_count(void);
+
+int32_t rbs_create(const rbs_config* cfg, rbs_handle** out);
+void rbs_destroy(rbs_handle* h);
+/* Message of the last error on this handle; h == NULL gives the calling thread's last
+ * rbs_create failure. Never NULL. */
+const char* rbs_last_error(const rbs_handle* h);
+
+int32_t rbs_reset(rbs_handle* h);
+
+/* depth[n], n == rows*cols, row-major (row*cols+col), metres, NaN/inf = no reading. */
+int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n);
+/* Same, from the float32 pixels the camera driver delivers (skips the double round trip). */
+int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n);
+
+/* poses:   [n][n_objects][12] doubles, R (row-major 3x3) then t: absolute camera-frame pose
+ *          of each body (delta composed with the default pose by the caller).
+ * indices: [n] in: occlusion slot each particle inherits from; out (update != 0): identity.
+ * update:  non-zero -> write the posterior occlusion of particle i into slot i.
+ * out_loglik: [n] doubles.  Host pointers; synchronous. */
+int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32_t n,
+                     int32_t update, double* out_loglik);
+
+/* Device-pointer variant: poses/indices/out_loglik are device memory on the handle's device,
+ * work is enqueued on `stream` (a hipStream_t, NULL = the handle's own stream) and the call
+ * returns without synchronising.  indices is read-only; with update != 0 the caller must
+ * treat the slot map as identity afterwards. */
+int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t* d_indices,
+                            int32_t n, int32_t update, double* d_out_loglik, void* stream);
+
+/* Block until everything enqueued on the handle's own stream has finished. */
+int32_t rbs_synchronize(rbs_handle* h);
+
+/* --- inspection hooks (tests, state migration between devices) --- */
+/* Stored occlusion plane of a slot -> host float[rows*cols]. */
+int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out);
+/* Overwrite a slot's plane from host float[rows*cols]. */
+int32_t rbs_set_occlusion(rbs_handle* h, int32_t slot, const float* plane);
+/* Device address of a slot's current plane (valid until the next updating call). */
+int32_t rbs_occlusion_device_ptr(rbs_handle* h, int32_t slot, void** out);
+/* Device address of slot's plane in the buffer the NEXT updating call will write. */
+int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out);
+/* Rasterize one pose [n_objects][12] -> host float[rows*cols], +inf where uncovered. */
+int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out);
+/* Duration in milliseconds of the most recent loglikes kernel launched by rbs_loglikes*
+ * (HIP events recorded on the launch stream around the kernel); blocks until it finished. */
+int32_t rbs_last_kernel_ms(rbs_handle* h, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,358 @@
+/*
+ * rbsensor_oracle.c -- see rbsensor_oracle.h.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED.
+ *
+ * Build with -ffp-contract=off (oracle/Makefile does): the geometry below is specified
+ * as individually rounded IEEE-754 binary64 operations and the HIP path reproduces the
+ * same operation order bit-for-bit.
+ *
+ * Each function cites the reference call site whose behaviour it restates
+ * (R: = /root/reference/) and the SURVEY.md appendix paragraph it follows.
+ */
+#include "rbsensor_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_MAX_DEPTH 6.0       /* hard-coded max_depth        */
+#define ORC_HALF_LIFE_DEPTH 1.0 /* hard-coded half_life_depth  */
+
+struct orc_sensor {
+    orc_config cfg;
+    int32_t n_tri_total;
+    double* soup;        /* [n_tri_total][9] model-space triangle soup      */
+    int32_t* tri_begin;  /* [n_objects+1] triangle range per body           */
+    size_t npx;
+    float* frame;        /* current observation, float metres               */
+    /* occlusion state, double-buffered over slots */
+    float* occ[2];       /* [max_particles][npx]                            */
+    int32_t* stamp[2];   /* LAZY only: frame index of last update per pixel */
+    int cur;
+    int32_t clock;       /* frame counter: t_now = clock * delta_time       */
+    int32_t last_update_clock; /* EAGER: clock at the last updating call    */
+    /* scratch */
+    float* depth;        /* [npx] */
+    int32_t* covered;    /* [npx] list of covered pixel ids */
+    double lambda;       /* ln 2 / half_life_depth */
+};
+
+/* ---------------------------------------------------------------- pixel model */
+
+/* KinectPixelModel::Probability, visible branch.
+ * Constants: R:source/dbot_ros/tracker/particle_tracker_node.cpp:183-188,
+ * defaults R:config/particle_tracker.yaml:47-49. */
+double orc_prob_visible(const orc_sensor* s, double o, double r)
+{
+    const double tw = s->cfg.tail_weight;
+    const double sigma = s->cfg.model_sigma + s->cfg.sigma_factor * o * o;
+    if (isinf(r)) return tw / ORC_MAX_DEPTH;
+    const double d = r - o;
+    return tw / ORC_MAX_DEPTH +
+           (1.0 - tw) * exp(-(d * d) / (2.0 * sigma * sigma)) / (sqrt(2.0 * M_PI) * sigma);
+}
+
+/* KinectPixelModel::Probability, occluded branch; r = +inf gives the
+ * background density p_bg(o) used as the denominator of the likelihood ratio. */
+double orc_prob_occluded(const orc_sensor* s, double o, double r)
+{
+    const double tw = s->cfg.tail_weight;
+    const double lam = s->lambda;
+    const double sigma = s->cfg.model_sigma + s->cfg.sigma_factor * o * o;
+    if (isinf(r))
+        return tw / ORC_MAX_DEPTH +
+               (1.0 - tw) * lam * exp(0.5 * lam * (-2.0 * o + lam * sigma * sigma));
+    return tw / ORC_MAX_DEPTH +
+           (1.0 - tw) * lam * exp(0.5 * lam * (2.0 * r - 2.0 * o + lam * sigma * sigma)) *
+               (1.0 + erf((r - o + lam * sigma * sigma) / (sqrt(2.0) * sigma))) /
+               (2.0 * (exp(r * lam) - 1.0));
+}
+
+/* OcclusionModel propagate.
+ * Constants: R:source/dbot_ros/tracker/particle_tracker_node.cpp:176-181,
+ * defaults R:config/particle_tracker.yaml:41-43; delta_time R:...particle_tracker_node.cpp:189. */
+double orc_propagate(const orc_sensor* s, double occ, double dt)
+{
+    const double p_oo = s->cfg.p_occluded_occluded;
+    const double c = p_oo - s->cfg.p_occluded_visible;
+    const double pow_c = exp(dt * log(c));
+    const double new_visible = pow_c * (1.0 - occ) + (1.0 - p_oo) * (pow_c - 1.0) / (c - 1.0);
+    return 1.0 - new_visible;
+}
+
+/* The device rule's affine form of orc_propagate over n frames:
+ * propagate(occ, n*dt) = alpha*occ + beta, coefficients rounded once to float. */
+void orc_eager_coeffs(const orc_sensor* s, int32_t n_frames, float* alpha, float* beta)
+{
+    const double p_oo = s->cfg.p_occluded_occluded;
+    const double c = p_oo - s->cfg.p_occluded_visible;
+    const double a = exp(((double)n_frames * s->cfg.delta_time) * log(c));
+    const double g = (1.0 - p_oo) * (a - 1.0) / (c - 1.0);
+    *alpha = (float)a;
+    *beta = (float)((1.0 - a) - g);
+}
+
+/* ---------------------------------------------------------------- renderer */
+
+/* RigidBodyRenderer::Render restated with this repo's written coverage rule:
+ *   - sample points are INTEGER pixel coordinates (col,row);
+ *   - a pixel is covered by a triangle iff all three edge functions are >= 0 or all
+ *     are <= 0 (closed triangle, either winding, no culling);
+ *   - triangles with a vertex at Z <= 0 or with zero projected area are skipped;
+ *   - depth = plane/ray intersection Z, rounded once to float, z-min across triangles.
+ * Mesh source R:source/dbot_ros/tracker/particle_tracker_node.cpp:89-97; K and resolution
+ * R:...particle_tracker_node.cpp:112-121. */
+static void raster_triangle(const orc_sensor* s, const double* tri, const double* Rt,
+                            float* depth, int32_t* covered, int32_t* n_covered)
+{
+    const double fx = s->cfg.fx, fy = s->cfg.fy, cx = s->cfg.cx, cy = s->cfg.cy;
+    double X[3], Y[3], Z[3], u[3], v[3];
+    for (int k = 0; k < 3; ++k) {
+        const double vx = tri[3 * k + 0], vy = tri[3 * k + 1], vz = tri[3 * k + 2];
+        X[k] = ((Rt[0] * vx + Rt[1] * vy) + Rt[2] * vz) + Rt[9];
+        Y[k] = ((Rt[3] * vx + Rt[4] * vy) + Rt[5] * vz) + Rt[10];
+        Z[k] = ((Rt[6] * vx + Rt[7] * vy) + Rt[8] * vz) + Rt[11];
+    }
+    if (!(Z[0] > 0.0 && Z[1] > 0.0 && Z[2] > 0.0)) return;
+    for (int k = 0; k < 3; ++k) {
+        const double iz = 1.0 / Z[k];
+        u[k] = fx * (X[k] * iz) + cx;
+        v[k] = fy * (Y[k] * iz) + cy;
+    }
+    const double e01u = u[1] - u[0], e01v = v[1] - v[0];
+    const double e12u = u[2] - u[1], e12v = v[2] - v[1];
+    const double e20u = u[0] - u[2], e20v = v[0] - v[2];
+    const double area2 = e01u * (v[2] - v[0]) - e01v * (u[2] - u[0]);
+    if (!(area2 != 0.0) || !(fabs(area2) < INFINITY)) return;
+
+    const double ax = X[1] - X[0], ay = Y[1] - Y[0], az = Z[1] - Z[0];
+    const double bx = X[2] - X[0], by = Y[2] - Y[0], bz = Z[2] - Z[0];
+    const double nx = ay * bz - az * by;
+    const double ny = az * bx - ax * bz;
+    const double nz = ax * by - ay * bx;
+    const double nv0 = (nx * X[0] + ny * Y[0]) + nz * Z[0];
+    const double pa = nx / fx;
+    const double pb = ny / fy;
+    const double pc = (nz - pa * cx) - pb * cy;
+
+    const double umin = fmin(fmin(u[0], u[1]), u[2]), umax = fmax(fmax(u[0], u[1]), u[2]);
+    const double vmin = fmin(fmin(v[0], v[1]), v[2]), vmax = fmax(fmax(v[0], v[1]), v[2]);
+    const double xlo_d = fmax(ceil(umin), 0.0), xhi_d = fmin(floor(umax), (double)(s->cfg.cols - 1));
+    const double ylo_d = fmax(ceil(vmin), 0.0), yhi_d = fmin(floor(vmax), (double)(s->cfg.rows - 1));
+    if (!(xlo_d <= xhi_d) || !(ylo_d <= yhi_d)) return;
+    const int xlo = (int)xlo_d, xhi = (int)xhi_d, ylo = (int)ylo_d, yhi = (int)yhi_d;
+
+    for (int row = ylo; row <= yhi; ++row) {
+        const double py = (double)row;
+        for (int col = xlo; col <= xhi; ++col) {
+            const double px = (double)col;
+            const double E0 = e01u * (py - v[0]) - e01v * (px - u[0]);
+            const double E1 = e12u * (py - v[1]) - e12v * (px - u[1]);
+            const double E2 = e20u * (py - v[2]) - e20v * (px - u[2]);
+            const int in = (E0 >= 0.0 && E1 >= 0.0 && E2 >= 0.0) ||
+                           (E0 <= 0.0 && E1 <= 0.0 && E2 <= 0.0);
+            if (!in) continue;
+            const double den = (pa * px + pb * py) + pc;
+            const float zf = (float)(nv0 / den);
+            if (!(zf > 0.0f) || !(zf < INFINITY)) continue;
+            const int32_t pid = row * s->cfg.cols + col;
+            float* d = &depth[pid];
+            if (zf < *d) {
+                if (!(*d < INFINITY)) covered[(*n_covered)++] = pid; /* first hit */
+                *d = zf;
+            }
+        }
+    }
+}
+
+/* depth must be all +inf on entry; returns the list of covered pixel ids (the upstream
+ * renderer's intersect_indices) in covered[0..n). */
+static int32_t render_into(const orc_sensor* s, const double* pose, float* depth,
+                           int32_t* covered)
+{
+    int32_t n = 0;
+    for (int b = 0; b < s->cfg.n_objects; ++b) {
+        const double* Rt = pose + 12 * b;
+        for (int32_t t = s->tri_begin[b]; t < s->tri_begin[b + 1]; ++t)
+            raster_triangle(s, s->soup + 9 * (size_t)t, Rt, depth, covered, &n);
+    }
+    return n;
+}
+
+int32_t orc_render(const orc_sensor* s, const double* pose, float* depth_out)
+{
+    for (size_t p = 0; p < s->npx; ++p) depth_out[p] = INFINITY;
+    return render_into(s, pose, depth_out, s->covered);
+}
+
+/* ---------------------------------------------------------------- life cycle */
+
+orc_sensor* orc_create(const orc_config* cfg)
+{
+    orc_sensor* s = (orc_sensor*)calloc(1, sizeof(*s));
+    if (!s) return NULL;
+    s->cfg = *cfg;
+    s->npx = (size_t)cfg->rows * cfg->cols;
+    s->lambda = -log(0.5) / ORC_HALF_LIFE_DEPTH;
+    s->tri_begin = (int32_t*)calloc((size_t)cfg->n_objects + 1, sizeof(int32_t));
+    for (int b = 0; b < cfg->n_objects; ++b)
+        s->tri_begin[b + 1] = s->tri_begin[b] + cfg->triangle_counts[b];
+    s->n_tri_total = s->tri_begin[cfg->n_objects];
+    s->soup = (double*)malloc(sizeof(double) * 9 * (size_t)(s->n_tri_total > 0 ? s->n_tri_total : 1));
+    size_t voff = 0, toff = 0;
+    for (int b = 0; b < cfg->n_objects; ++b) {
+        for (int32_t t = 0; t < cfg->triangle_counts[b]; ++t) {
+            for (int k = 0; k < 3; ++k) {
+                const int32_t vi = cfg->triangles[3 * (toff + t) + k];
+                for (int c = 0; c < 3; ++c)
+                    s->soup[9 * (toff + t) + 3 * k + c] = cfg->vertices[3 * (voff + vi) + c];
+            }
+        }
+        voff += (size_t)cfg->vertex_counts[b];
+        toff += (size_t)cfg->triangle_counts[b];
+    }
+    const size_t plane = s->npx * (size_t)cfg->max_particles;
+    s->frame = (float*)malloc(sizeof(float) * s->npx);
+    s->depth = (float*)malloc(sizeof(float) * s->npx);
+    s->covered = (int32_t*)malloc(sizeof(int32_t) * s->npx);
+    for (int k = 0; k < 2; ++k) {
+        s->occ[k] = (float*)malloc(sizeof(float) * plane);
+        s->stamp[k] = cfg->occlusion_mode == ORC_OCC_LAZY
+                          ? (int32_t*)malloc(sizeof(int32_t) * plane)
+                          : NULL;
+    }
+    /* copies of the caller's arrays are held in soup; drop the borrowed pointers */
+    s->cfg.vertices = NULL;
+    s->cfg.triangles = NULL;
+    s->cfg.vertex_counts = NULL;
+    s->cfg.triangle_counts = NULL;
+    for (size_t p = 0; p < s->npx; ++p) s->frame[p] = NAN;
+    for (size_t p = 0; p < s->npx; ++p) s->depth[p] = INFINITY;
+    orc_reset(s);
+    return s;
+}
+
+void orc_destroy(orc_sensor* s)
+{
+    if (!s) return;
+    free(s->soup);
+    free(s->tri_begin);
+    free(s->frame);
+    free(s->depth);
+    free(s->covered);
+    for (int k = 0; k < 2; ++k) {
+        free(s->occ[k]);
+        free(s->stamp[k]);
+    }
+    free(s);
+}
+
+/* RbSensor::reset(), triggered by tracker->initialize at
+ * R:source/dbot_ros/tracker/particle_tracker_node.cpp:252 (SURVEY A.4 last line). */
+void orc_reset(orc_sensor* s)
+{
+    const size_t plane = s->npx * (size_t)s->cfg.max_particles;
+    const float init = (float)s->cfg.initial_occlusion_prob;
+    s->cur = 0;
+    s->clock = 0;
+    s->last_update_clock = 0;
+    for (size_t p = 0; p < plane; ++p) s->occ[0][p] = init;
+    if (s->stamp[0]) memset(s->stamp[0], 0, sizeof(int32_t) * plane);
+}
+
+/* RbSensor::set_observation -- frame layout per R:source/dbot_ros/util/ros_interface.h:161-165;
+ * consumed through tracker_->track at R:source/dbot_ros/object_tracker_ros.hpp:49. */
+void orc_set_observation(orc_sensor* s, const double* depth)
+{
+    for (size_t p = 0; p < s->npx; ++p) s->frame[p] = (float)depth[p];
+    s->clock += 1;
+}
+
+/* ---------------------------------------------------------------- the hot function */
+
+/* KinectImageModel::loglikes restated; selected by use_gpu=false at
+ * R:source/dbot_ros/tracker/particle_tracker_node.cpp:165.  Rounding points:
+ *   prior occlusion    -> float
+ *   a = p_vis*(1-occ), b = p_occ*occ, p_bg -> float; a+b and (a+b)/p_bg in float
+ *   log(...) in double, accumulated in double
+ *   posterior occlusion b/(a+b) in float.
+ * Pixels whose observation is not finite contribute 0 and are left untouched. */
+void orc_loglikes(orc_sensor* s, const double* poses, int32_t* indices, int32_t n,
+                  int32_t update, double* out_loglik)
+{
+    const int lazy = s->cfg.occlusion_mode == ORC_OCC_LAZY;
+    const int src = s->cur, dst = 1 - s->cur;
+    float alpha = 1.0f, beta = 0.0f;
+    if (!lazy) orc_eager_coeffs(s, s->clock - s->last_update_clock, &alpha, &beta);
+
+    for (int32_t i = 0; i < n; ++i) {
+        const size_t poff = (size_t)indices[i] * s->npx;
+        const size_t coff = (size_t)i * s->npx;
+        const float* pocc = s->occ[src] + poff;
+        const int32_t* pstamp = lazy ? s->stamp[src] + poff : NULL;
+        float* cocc = s->occ[dst] + coff;
+        int32_t* cstamp = lazy ? s->stamp[dst] + coff : NULL;
+
+        if (update) {
+            if (lazy) {
+                memcpy(cocc, pocc, sizeof(float) * s->npx);
+                memcpy(cstamp, pstamp, sizeof(int32_t) * s->npx);
+            } else {
+                for (size_t p = 0; p < s->npx; ++p) cocc[p] = fmaf(alpha, pocc[p], beta);
+            }
+        }
+
+        const int32_t ncov =
+            render_into(s, poses + (size_t)i * 12 * s->cfg.n_objects, s->depth, s->covered);
+
+        double ll = 0.0;
+        for (int32_t k = 0; k < ncov; ++k) {
+            const size_t p = (size_t)s->covered[k];
+            const float r = s->depth[p];
+            s->depth[p] = INFINITY; /* leave the scratch buffer clean for the next particle */
+            const float o = s->frame[p];
+            if (!isfinite(o)) continue;
+            float occ;
+            if (lazy) {
+                const double dt = (double)(s->clock - pstamp[p]) * s->cfg.delta_time;
+                occ = (float)orc_propagate(s, (double)pocc[p], dt);
+            } else {
+                occ = fmaf(alpha, pocc[p], beta);
+            }
+            const float a = (float)(orc_prob_visible(s, (double)o, (double)r) * (1.0 - (double)occ));
+            const float b = (float)(orc_prob_occluded(s, (double)o, (double)r) * (double)occ);
+            const float pbg = (float)orc_prob_occluded(s, (double)o, INFINITY);
+            const float sum = a + b;
+            ll += log((double)(sum / pbg));
+            if (update) {
+                cocc[p] = b / sum;
+                if (lazy) cstamp[p] = s->clock;
+            }
+        }
+        out_loglik[i] = ll;
+    }
+    if (update) {
+        s->cur = dst;
+        s->last_update_clock = s->clock;
+        for (int32_t i = 0; i < n; ++i) indices[i] = i;
+    }
+}
+
+void orc_get_occlusion(const orc_sensor* s, int32_t slot, float* out)
+{
+    memcpy(out, s->occ[s->cur] + (size_t)slot * s->npx, sizeof(float) * s->npx);
+}
+
+void orc_get_occlusion_now(const orc_sensor* s, int32_t slot, float* out)
+{
+    const float* occ = s->occ[s->cur] + (size_t)slot * s->npx;
+    if (s->cfg.occlusion_mode == ORC_OCC_LAZY) {
+        const int32_t* st = s->stamp[s->cur] + (size_t)slot * s->npx;
+        for (size_t p = 0; p < s->npx; ++p)
+            out[p] = (float)orc_propagate(s, (double)occ[p],
+                                          (double)(s->clock - st[p]) * s->cfg.delta_time);
+    } else {
+        float alpha, beta;
+        orc_eager_coeffs(s, s->clock - s->last_update_clock, &alpha, &beta);
+        for (size_t p = 0; p < s->npx; ++p) out[p] = fmaf(alpha, occ[p], beta);
+    }
+}

@@ -1,0 +1,150 @@
+"""ctypes binding of oracle/librbsensor_oracle.so -- the CPU restatement used as the checker.
+Test infrastructure: importable only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(_ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "librbsensor_oracle.so")
+
+LAZY, EAGER = 0, 1
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int32), ("cols", C.c_int32),
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("max_particles", C.c_int32), ("n_objects", C.c_int32),
+        ("vertices", C.POINTER(C.c_double)), ("vertex_counts", C.POINTER(C.c_int32)),
+        ("triangles", C.POINTER(C.c_int32)), ("triangle_counts", C.POINTER(C.c_int32)),
+        ("p_occluded_visible", C.c_double), ("p_occluded_occluded", C.c_double),
+        ("initial_occlusion_prob", C.c_double),
+        ("tail_weight", C.c_double), ("model_sigma", C.c_double), ("sigma_factor", C.c_double),
+        ("delta_time", C.c_double),
+        ("occlusion_mode", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def build():
+    src = [os.path.join(ORACLE_DIR, f) for f in ("rbsensor_oracle.c", "rbsensor_oracle.h", "Makefile")]
+    if (not os.path.exists(ORACLE_LIB)
+            or os.path.getmtime(ORACLE_LIB) < max(os.path.getmtime(s) for s in src)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = C.CDLL(ORACLE_LIB)
+        H, dp, fp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        lib.orc_create.restype = H
+        lib.orc_create.argtypes = [C.POINTER(OrcConfig)]
+        lib.orc_destroy.argtypes = [H]
+        lib.orc_reset.argtypes = [H]
+        lib.orc_set_observation.argtypes = [H, dp]
+        lib.orc_loglikes.argtypes = [H, dp, ip, C.c_int32, C.c_int32, dp]
+        lib.orc_get_occlusion.argtypes = [H, C.c_int32, fp]
+        lib.orc_get_occlusion_now.argtypes = [H, C.c_int32, fp]
+        lib.orc_render.restype = C.c_int32
+        lib.orc_render.argtypes = [H, dp, fp]
+        for f in (lib.orc_prob_visible, lib.orc_prob_occluded, lib.orc_propagate):
+            f.restype = C.c_double
+            f.argtypes = [H, C.c_double, C.c_double]
+        lib.orc_eager_coeffs.argtypes = [H, C.c_int32, fp, fp]
+        _lib = lib
+    return _lib
+
+
+class Oracle:
+    """Same constructor arguments as dbot_ros_amd.RbSensor so parity tests read symmetrically."""
+
+    def __init__(self, object_model, camera_data, params, max_particles=None, mode=LAZY):
+        self._lib = load()
+        self.n_bodies = object_model.count_parts
+        self.rows, self.cols = int(camera_data.rows), int(camera_data.cols)
+        K = np.asarray(camera_data.camera_matrix, dtype=np.float64)
+        verts = np.ascontiguousarray(np.concatenate(object_model.vertices), dtype=np.float64)
+        tris = np.ascontiguousarray(np.concatenate(object_model.triangles), dtype=np.int32)
+        vcnt = np.array([len(v) for v in object_model.vertices], dtype=np.int32)
+        tcnt = np.array([len(t) for t in object_model.triangles], dtype=np.int32)
+        cfg = OrcConfig()
+        cfg.rows, cfg.cols = self.rows, self.cols
+        cfg.fx, cfg.fy, cfg.cx, cfg.cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+        cfg.max_particles = int(max_particles or params.sample_count)
+        cfg.n_objects = self.n_bodies
+        cfg.vertices = verts.ctypes.data_as(C.POINTER(C.c_double))
+        cfg.vertex_counts = vcnt.ctypes.data_as(C.POINTER(C.c_int32))
+        cfg.triangles = tris.ctypes.data_as(C.POINTER(C.c_int32))
+        cfg.triangle_counts = tcnt.ctypes.data_as(C.POINTER(C.c_int32))
+        cfg.p_occluded_visible = params.occlusion.p_occluded_visible
+        cfg.p_occluded_occluded = params.occlusion.p_occluded_occluded
+        cfg.initial_occlusion_prob = params.occlusion.initial_occlusion_prob
+        cfg.tail_weight = params.kinect.tail_weight
+        cfg.model_sigma = params.kinect.model_sigma
+        cfg.sigma_factor = params.kinect.sigma_factor
+        cfg.delta_time = params.delta_time
+        cfg.occlusion_mode = mode
+        self._h = C.c_void_p(self._lib.orc_create(C.byref(cfg)))
+        if not self._h.value:
+            raise MemoryError("orc_create failed")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.orc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+    def reset(self):
+        self._lib.orc_reset(self._h)
+
+    def set_observation(self, image):
+        a = np.ascontiguousarray(image, dtype=np.float64).ravel()
+        assert a.size == self.rows * self.cols
+        self._lib.orc_set_observation(self._h, a.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def loglikes_poses(self, poses, indices, update=False):
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, self.n_bodies * 12)
+        n = poses.shape[0]
+        assert indices.dtype == np.int32 and indices.size == n and indices.flags.c_contiguous
+        out = np.empty(n, dtype=np.float64)
+        self._lib.orc_loglikes(self._h, poses.ctypes.data_as(C.POINTER(C.c_double)),
+                               indices.ctypes.data_as(C.POINTER(C.c_int32)), n, int(bool(update)),
+                               out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def get_occlusion(self, slot, now=False):
+        out = np.empty(self.rows * self.cols, dtype=np.float32)
+        fn = self._lib.orc_get_occlusion_now if now else self._lib.orc_get_occlusion
+        fn(self._h, int(slot), out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def render_depth(self, pose):
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(self.n_bodies * 12)
+        out = np.empty(self.rows * self.cols, dtype=np.float32)
+        self._lib.orc_render(self._h, pose.ctypes.data_as(C.POINTER(C.c_double)),
+                             out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def prob_visible(self, o, r):
+        return self._lib.orc_prob_visible(self._h, float(o), float(r))
+
+    def prob_occluded(self, o, r):
+        return self._lib.orc_prob_occluded(self._h, float(o), float(r))
+
+    def propagate(self, occ, dt):
+        return self._lib.orc_propagate(self._h, float(occ), float(dt))
+
+    def eager_coeffs(self, n_frames):
+        a, b = C.c_float(), C.c_float()
+        self._lib.orc_eager_coeffs(self._h, int(n_frames), C.byref(a), C.byref(b))
+        return a.value, b.value

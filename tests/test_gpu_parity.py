@@ -1,0 +1,280 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs.
+
+Bars (written here, as DESIGN.md states them):
+  * coverage + rendered depth:            bit-exact (integer/compare work in binary64, one float rounding)
+  * log-likelihood vs the EAGER oracle    |d| <= 1e-9 * max(1,|ll|)   (same rule, only libm-vs-ocml ulps)
+    (the device's occlusion rule):
+  * occlusion planes vs the EAGER oracle: <= 1 float ulp on <= 1e-4 of the pixels, rest bit-exact
+  * log-likelihood vs the LAZY oracle     |d| <= 1e-5 * max(1,|ll|)   (north_star's tolerance)
+    (reference CPU semantics):
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scenarios as sc
+from dbot_ros_amd import RbSensor, RbSensorError, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_EAGER = 1e-9
+TOL_LAZY = 1e-5
+
+
+def rel_err(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+def assert_planes_match(g, o):
+    """bit-exact except a vanishing fraction of 1-ulp float differences (posterior b/(a+b)
+    rounded from doubles that differ in the last place between libm and ocml)."""
+    diff = g != o
+    # NaN never appears in an occlusion plane
+    assert not np.isnan(g).any() and not np.isnan(o).any()
+    frac = diff.mean()
+    assert frac <= 1e-4, f"{diff.sum()} of {diff.size} occlusion values differ"
+    if diff.any():
+        ulp = np.abs(g[diff].view(np.int32).astype(np.int64) - o[diff].view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1, f"max ulp distance {ulp.max()}"
+
+
+@pytest.mark.parametrize("mesh,cols,rows", [("m1", 640, 480), ("m3", 640, 480), ("m2", 640, 480),
+                                             ("box12", 640, 480), ("m1", 80, 60), ("m3", 80, 60),
+                                             ("m1_l2", 322, 241), ("m4", 1280, 960)])
+def test_render_depth_bit_exact(gpu_lib, mesh, cols, rows):
+    om, cam, P = sc.make_scene((mesh,), cols, rows, max_particles=2)
+    o = ob.Oracle(om, cam, P, max_particles=2)
+    with RbSensor(om, cam, P, max_particles=2) as g:
+        rng = np.random.default_rng(5)
+        for k in range(5):
+            pose = synth.particle_poses(synth.truth_pose(1, z=0.5 + 0.15 * k, frame=3 * k), 1, rng,
+                                        scale=4.0)[0]
+            dg, do = g.render_depth(pose), o.render_depth(pose)
+            assert np.isfinite(do).sum() > 0
+            assert np.array_equal(dg.view(np.uint32), do.view(np.uint32)), \
+                f"{(dg.view(np.uint32) != do.view(np.uint32)).sum()} depth pixels differ"
+
+
+@pytest.mark.parametrize("pose_case", ["near_fills_image", "behind_camera", "off_screen",
+                                       "straddles_image_edge", "crosses_camera_plane"])
+def test_render_edge_poses(gpu_lib, pose_case):
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=2)
+    o = ob.Oracle(om, cam, P, max_particles=2)
+    pose = synth.truth_pose(1).copy()
+    t = {"near_fills_image": (0.0, 0.0, 0.07), "behind_camera": (0.0, 0.0, -0.7),
+         "off_screen": (2.0, 0.0, 0.7), "straddles_image_edge": (0.38, 0.27, 0.7),
+         "crosses_camera_plane": (0.0, 0.0, 0.01)}[pose_case]
+    pose[0, 9:12] = t
+    with RbSensor(om, cam, P, max_particles=2) as g:
+        dg, do = g.render_depth(pose), o.render_depth(pose)
+    assert np.array_equal(dg.view(np.uint32), do.view(np.uint32))
+    if pose_case in ("behind_camera", "off_screen"):
+        assert not np.isfinite(do).any()
+    if pose_case == "near_fills_image":
+        assert np.isfinite(do).mean() > 0.5
+
+
+@pytest.mark.parametrize("meshes,cols,rows,n", [(("m1",), 640, 480, 24), (("m3",), 640, 480, 16),
+                                                 (("m1",), 80, 60, 64), (("box12",), 640, 480, 8),
+                                                 (("m1", "m2", "m3"), 640, 480, 12),
+                                                 (("m1_l2",), 322, 241, 16)])
+def test_sequence_matches_oracle(gpu_lib, meshes, cols, rows, n):
+    """set_observation -> loglikes(update) -> resample, 4 frames; eager and lazy oracles."""
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    nb = len(meshes)
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    lazy = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
+    frames = sc.make_frames(eager, nb, 4, seed=3)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        ll_g = sc.run_sequence(g, frames, n, n_bodies=nb)
+        ll_e = sc.run_sequence(eager, frames, n, n_bodies=nb)
+        ll_l = sc.run_sequence(lazy, frames, n, n_bodies=nb)
+        for k in range(len(frames)):
+            assert np.isfinite(ll_g[k]).all()
+            assert rel_err(ll_g[k], ll_e[k]).max() <= TOL_EAGER, (k, rel_err(ll_g[k], ll_e[k]).max())
+            assert rel_err(ll_g[k], ll_l[k]).max() <= TOL_LAZY, (k, rel_err(ll_g[k], ll_l[k]).max())
+        for slot in range(n):
+            assert_planes_match(g.get_occlusion(slot), eager.get_occlusion(slot))
+            # reference semantics: occlusion "as of now" of the lazy model
+            assert np.abs(g.get_occlusion(slot) - lazy.get_occlusion(slot, now=True)).max() <= 2e-6
+
+
+def test_update_false_leaves_state_untouched(gpu_lib):
+    """Non-final sampling blocks of a multi-object frame evaluate with update=false."""
+    n = 16
+    om, cam, P = sc.make_scene(("m1", "m3"), 640, 480, max_particles=n)
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    frames = sc.make_frames(eager, 2, 2, seed=9)
+    rng = np.random.default_rng(2)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        for s in (g, eager):
+            s.reset()
+        idx_g, idx_o = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for truth, frame in frames:
+            poses_a = synth.particle_poses(truth, n, rng)
+            poses_b = synth.particle_poses(truth, n, rng)
+            for s, idx in ((g, idx_g), (eager, idx_o)):
+                s.set_observation(frame)
+            before = g.get_occlusion(3)
+            la_g = g.loglikes_poses(poses_a, idx_g, update=False)
+            la_o = eager.loglikes_poses(poses_a, idx_o, update=False)
+            assert np.array_equal(before, g.get_occlusion(3))
+            lb_g = g.loglikes_poses(poses_b, idx_g, update=True)
+            lb_o = eager.loglikes_poses(poses_b, idx_o, update=True)
+            assert rel_err(la_g, la_o).max() <= TOL_EAGER
+            assert rel_err(lb_g, lb_o).max() <= TOL_EAGER
+            perm = rng.permutation(n).astype(np.int32)
+            idx_g, idx_o = perm.copy(), perm.copy()
+        for slot in range(n):
+            assert_planes_match(g.get_occlusion(slot), eager.get_occlusion(slot))
+
+
+def test_skipped_frames_advance_occlusion(gpu_lib):
+    """Two set_observation calls between updating evaluations: the occlusion process runs
+    over 2*delta_time."""
+    n = 8
+    om, cam, P = sc.make_scene(("m1",), 160, 120, max_particles=n)
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    lazy = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
+    frames = sc.make_frames(eager, 1, 3, seed=4)
+    rng = np.random.default_rng(8)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        sensors = (g, eager, lazy)
+        idx = [np.zeros(n, np.int32) for _ in sensors]
+        for s in sensors:
+            s.reset()
+        out = []
+        for k, (truth, frame) in enumerate(frames):
+            poses = synth.particle_poses(truth, n, rng)
+            res = []
+            for s, ix in zip(sensors, idx):
+                s.set_observation(frame)
+                if k == 1:
+                    s.set_observation(frame)  # a dropped evaluation
+                res.append(s.loglikes_poses(poses, ix, update=True))
+            out.append(res)
+        for lg, le, ll_ in out:
+            assert rel_err(lg, le).max() <= TOL_EAGER
+            assert rel_err(lg, ll_).max() <= TOL_LAZY
+
+
+def test_all_nan_frame_and_offscreen_particles(gpu_lib):
+    n = 8
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    rng = np.random.default_rng(0)
+    poses = synth.particle_poses(synth.truth_pose(1), n, rng)
+    poses[1, 0, 9:12] = (5.0, 0.0, 0.7)    # off screen
+    poses[2, 0, 9:12] = (0.0, 0.0, -1.0)   # behind the camera
+    frame = np.full(640 * 480, np.nan)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        for s in (g, eager):
+            s.reset()
+            s.set_observation(frame)
+        ig, io = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        lg = g.loglikes_poses(poses, ig, update=True)
+        lo = eager.loglikes_poses(poses, io, update=True)
+        assert np.array_equal(lg, np.zeros(n)) and np.array_equal(lo, np.zeros(n))
+        a, b = eager.eager_coeffs(1)
+        expect = np.float32(a) * np.float32(P.occlusion.initial_occlusion_prob) + np.float32(b)
+        for slot in range(n):
+            pl = g.get_occlusion(slot)
+            assert np.array_equal(pl, eager.get_occlusion(slot))
+            assert np.allclose(pl, expect, rtol=0, atol=1e-7)
+        # now a real frame: off-screen / behind-camera particles contribute exactly 0
+        d = eager.render_depth(synth.truth_pose(1))
+        fr = synth.make_frame(d, 480, 640, rng)
+        for s in (g, eager):
+            s.set_observation(fr)
+        lg = g.loglikes_poses(poses, ig, update=True)
+        lo = eager.loglikes_poses(poses, io, update=True)
+        assert lg[1] == 0.0 and lg[2] == 0.0
+        assert rel_err(lg, lo).max() <= TOL_EAGER
+
+
+def test_errors_through_the_c_abi(gpu_lib):
+    om, cam, P = sc.make_scene(("m1_l2",), 80, 60, max_particles=4)
+    with RbSensor(om, cam, P, max_particles=4) as g:
+        with pytest.raises(RbSensorError):
+            g.set_observation(np.zeros(10))
+        poses = synth.particle_poses(synth.truth_pose(1), 5, np.random.default_rng(0))
+        with pytest.raises(RbSensorError):  # n > max_particles
+            g.loglikes_poses(poses, np.zeros(5, np.int32))
+        with pytest.raises(RbSensorError):  # parent slot out of range
+            g.loglikes_poses(poses[:2], np.array([0, 9], np.int32))
+        assert g.loglikes_poses(poses[:0], np.zeros(0, np.int32)).size == 0
+    bad = sc.make_scene(("m1_l2",), 80, 60, max_particles=4)
+    bad[1].camera_matrix[0, 1] = 0.3  # skew is not supported
+    with pytest.raises(RbSensorError):
+        RbSensor(*bad, max_particles=4)
+
+
+def test_create_destroy_repeatedly_from_threads(gpu_lib):
+    """The service node builds and tears down a tracker per session on a worker thread
+    (R:source/dbot_ros/tracker/object_tracker_service_node.cpp:233-256)."""
+    import threading
+    om, cam, P = sc.make_scene(("m1_l2",), 80, 60, max_particles=8)
+    eager = ob.Oracle(om, cam, P, max_particles=8, mode=ob.EAGER)
+    frames = sc.make_frames(eager, 1, 2, seed=1)
+    ref = sc.run_sequence(eager, frames, 8)
+    errs = []
+
+    def session():
+        try:
+            with RbSensor(om, cam, P, max_particles=8) as g:
+                got = sc.run_sequence(g, frames, 8)
+            for a, b in zip(got, ref):
+                assert rel_err(a, b).max() <= TOL_EAGER
+        except Exception as e:  # surfaced below
+            errs.append(e)
+
+    for _ in range(3):
+        th = threading.Thread(target=session)
+        th.start()
+        th.join()
+    assert not errs, errs
+
+
+def test_full_size_properties(gpu_lib):
+    """BASELINE C1 size (2 000 particles, VGA, 5 120 triangles) through properties that do not
+    need the oracle at full size: determinism, slot-permutation equivariance, the first 32
+    particles against the oracle, untouched-pixel invariant."""
+    n = 2000
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
+    eager = ob.Oracle(om, cam, P, max_particles=32, mode=ob.EAGER)
+    rng = np.random.default_rng(11)
+    truth = synth.truth_pose(1)
+    frame = synth.make_frame(eager.render_depth(truth), 480, 640, rng)
+    poses = synth.particle_poses(truth, n, rng, scale=2.0)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        g.reset()
+        g.set_observation(frame)
+        idx = np.zeros(n, np.int32)
+        ll1 = g.loglikes_poses(poses, idx, update=True)
+        # determinism: same call again from a fresh state is bitwise identical
+        g.reset()
+        g.set_observation(frame)
+        idx = np.zeros(n, np.int32)
+        ll2 = g.loglikes_poses(poses, idx, update=True)
+        assert np.array_equal(ll1, ll2)
+        # oracle on the first 32 particles
+        eager.reset()
+        eager.set_observation(frame)
+        io = np.zeros(32, np.int32)
+        lo = eager.loglikes_poses(poses[:32], io, update=True)
+        assert rel_err(ll1[:32], lo).max() <= TOL_EAGER
+        for slot in (0, 7, 31):
+            assert_planes_match(g.get_occlusion(slot), eager.get_occlusion(slot))
+        # second frame with a permutation of parents: evaluating child j from parent p(j) must
+        # equal evaluating with the planes physically permuted
+        perm = rng.permutation(n).astype(np.int32)
+        g.set_observation(frame)
+        ll_perm = g.loglikes_poses(poses, perm.copy(), update=False)
+        ll_id = g.loglikes_poses(poses[np.argsort(perm)], np.arange(n, dtype=np.int32), update=False)
+        # particle j with parent perm[j]  ==  particle at position perm[j] holding pose j
+        assert np.array_equal(ll_perm[np.argsort(perm)], ll_id)
+        # untouched pixels: a corner pixel is never covered -> pure occlusion process
+        a, b = eager.eager_coeffs(1)
+        corner = g.get_occlusion(1999)[0]
+        assert corner == np.float32(np.float32(a) * np.float32(0.1) + np.float32(b)) or \
+            abs(corner - (a * 0.1 + b)) < 1e-7
