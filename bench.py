@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--mesh", default="m1")
     ap.add_argument("--parents", default="permutation", choices=["permutation", "identity", "resampled"])
+    ap.add_argument("--update", type=int, default=1, help="0: read-only evaluation (non-final blocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -118,10 +119,13 @@ def main():
     sensor.reset()
     sensor.set_observation(frame)
     sensor.synchronize()
-    stream = torch.cuda.current_stream()
+    # a non-default torch stream: the kernel, the timing events and the RCCL all-gather all
+    # live on it (a NULL stream would select the handle's private stream instead)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
 
     def step():
-        sensor.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, True, d_out.data_ptr(),
+        sensor.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, bool(a.update), d_out.data_ptr(),
                                stream.cuda_stream)
         if world > 1:
             dist.all_gather_into_tensor(d_all, d_out)
@@ -137,7 +141,7 @@ def main():
     t0 = time.perf_counter()
     for s, e in k_ev:
         s.record(stream)
-        sensor.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, True, d_out.data_ptr(),
+        sensor.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, bool(a.update), d_out.data_ptr(),
                                stream.cuda_stream)
         e.record(stream)
         if world > 1:
@@ -151,13 +155,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in k_ev]))
+    call_ms = float(np.mean([s.elapsed_time(e) for s, e in k_ev]))
+    # the dominant kernel (rbs_copy_kernel) runs on the library's second stream: its duration
+    # comes from the HIP events the library records on THAT stream, averaged over the timed steps
+    lib_call_ms, copy_ms, n_used = sensor.timing_summary(a.steps)
+    kernel_ms = copy_ms if a.update else lib_call_ms
     ll = d_out.cpu().numpy()
     if not np.isfinite(ll).all():
         raise SystemExit("non-finite log-likelihoods in the timed run")
 
     if rank == 0:
-        alg_bytes = 2.0 * 4.0 * a.rows * a.cols * n  # per launch, SURVEY 8d
+        alg_bytes = (2.0 if a.update else 1.0) * 4.0 * a.rows * a.cols * n  # per launch, SURVEY 8d
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -175,14 +183,16 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C1: {n} particles/GPU x loglikes(update=true), {a.cols}x{a.rows} "
+            "config": {"workload": f"C1: {n} particles/GPU x loglikes(update={'true' if a.update else 'false'}), {a.cols}x{a.rows} "
                                    f"synthetic depth frame, mesh {a.mesh} ({len(f)} triangles), "
                                    f"parents={a.parents}",
                        "particles_per_gpu": n, "resolution": [a.cols, a.rows], "triangles": int(len(f)),
                        "sharding": f"particles/{world}" + (" + RCCL all-gather of log-likelihoods" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rbs_loglikes_kernel<update>", "kernel_ms": kernel_ms,
+                         "kernel": "rbs_copy_kernel" if a.update else "rbs_raster_kernel",
+                         "kernel_ms": kernel_ms, "kernel_launches_averaged": n_used,
+                         "call_ms_launch_stream": call_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not a.no_cpu_baseline:

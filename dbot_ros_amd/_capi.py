@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librbsensor_mi355x.so")
+# RBS_LIB_PATH selects an alternative build of the SAME library (kernel tuning experiments)
+LIB_PATH = os.environ.get("RBS_LIB_PATH") or os.path.join(_HERE, "lib", "librbsensor_mi355x.so")
 
 RBS_ABI_VERSION = 1
 RBS_OK = 0
@@ -24,7 +25,7 @@ EXPORTS = (
     "rbs_reset", "rbs_set_observation", "rbs_set_observation_f32", "rbs_loglikes",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_render_depth",
-    "rbs_last_kernel_ms",
+    "rbs_last_kernel_ms", "rbs_timing_summary",
 )
 
 
@@ -108,5 +109,8 @@ def load():
     lib.rbs_render_depth.argtypes = [H, dp, fp]
     lib.rbs_last_kernel_ms.restype = C.c_int32
     lib.rbs_last_kernel_ms.argtypes = [H, C.POINTER(C.c_float)]
+    lib.rbs_timing_summary.restype = C.c_int32
+    lib.rbs_timing_summary.argtypes = [H, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_int32)]
     _lib = lib
     return lib

@@ -14,7 +14,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -30,17 +32,28 @@ struct rbs_handle {
     double p_ov = 0, p_oo = 0, init_occ = 0, delta_time = 0;
     double* d_soup = nullptr;
     float* d_frame = nullptr;
+    double* d_aux = nullptr;    // per-frame-pixel model terms, [4][npx]
+    float* d_pbg = nullptr;
     float* d_occ[2] = {nullptr, nullptr};
     int cur = 0;
     int pending_frames = 0;     // set_observation calls since the last updating loglikes
     double* d_poses = nullptr;
     int* d_indices = nullptr;
     double* d_out = nullptr;
+    int* d_rects = nullptr;     // [max_particles][4]
     float* d_render = nullptr;
     float* h_frame = nullptr;   // pinned staging
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool timed = false;
+    hipStream_t copy_stream = nullptr;   // the copy kernel runs here, beside the raster kernel
+    hipEvent_t ev_fork = nullptr;
+    int copy_blocks = 1 << 30;  // cap on the copy grid (one block per (particle, band) below it)
+    int raster_blocks = 512;    // persistent raster grid: 2 per CU
+    // timing ring: HIP events around the whole call (on the launch stream) and around the copy
+    // kernel (on the copy stream) for the last kRing loglikes calls
+    static constexpr int kRing = 64;
+    hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {}, ev_copy_start[kRing] = {}, ev_join[kRing] = {};
+    bool ring_update[kRing] = {};
+    long calls = 0;
     std::string err;
 };
 
@@ -97,34 +110,51 @@ int copy_bands_for(int rows, int cols)
     return (int)b;
 }
 
-template <bool UPDATE>
-hipError_t launch_loglikes(const DevParams& P, hipStream_t s)
-{
-    const int G = UPDATE ? 1 + P.bands : 1;
-    const dim3 grid((unsigned)((size_t)P.n * G)), block(rbs::kBlock);
-    if ((P.cols & 3) == 0)
-        hipLaunchKernelGGL((rbs::rbs_loglikes_kernel<UPDATE, 4>), grid, block, rbs::kSmemBytes, s, P);
-    else
-        hipLaunchKernelGGL((rbs::rbs_loglikes_kernel<UPDATE, 1>), grid, block, rbs::kSmemBytes, s, P);
-    return hipGetLastError();
-}
-
 int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indices, int n,
                          bool update, double* d_out, hipStream_t s)
 {
     DevParams P = h->base;
     occlusion_coeffs(h, h->pending_frames, &P.alpha, &P.beta);
     P.frame = h->d_frame;
+    P.aux = h->d_aux;
+    P.pbg = h->d_pbg;
     P.occ_src = h->d_occ[h->cur];
     P.occ_dst = h->d_occ[1 - h->cur];
     P.poses = d_poses;
     P.indices = d_indices;
     P.out = d_out;
     P.n = n;
-    RBS_HIP(h, hipEventRecord(h->ev_start, s));
-    RBS_HIP(h, update ? launch_loglikes<true>(P, s) : launch_loglikes<false>(P, s));
-    RBS_HIP(h, hipEventRecord(h->ev_stop, s));
-    h->timed = true;
+    const int slot = (int)(h->calls % rbs_handle::kRing);
+    h->ring_update[slot] = update;
+    RBS_HIP(h, hipEventRecord(h->ev_start[slot], s));
+    const dim3 block(rbs::kBlock);
+    P.rects = h->d_rects;
+    hipLaunchKernelGGL(rbs::rbs_rect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P,
+                       h->d_rects);
+    RBS_HIP(h, hipGetLastError());
+    const dim3 rgrid((unsigned)std::min(n, h->raster_blocks));
+    if (update) {
+        // fork: the copy kernel runs on the handle's second stream, concurrently with the
+        // persistent raster kernel; join before anything later on `s`
+        RBS_HIP(h, hipEventRecord(h->ev_fork, s));
+        RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
+        hipLaunchKernelGGL((rbs::rbs_raster_kernel<true>), rgrid, block, rbs::kSmemBytes, s, P);
+        RBS_HIP(h, hipGetLastError());
+        const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
+        RBS_HIP(h, hipEventRecord(h->ev_copy_start[slot], h->copy_stream));
+        if ((P.cols & 3) == 0)
+            hipLaunchKernelGGL((rbs::rbs_copy_kernel<4>), cgrid, block, 0, h->copy_stream, P);
+        else
+            hipLaunchKernelGGL((rbs::rbs_copy_kernel<1>), cgrid, block, 0, h->copy_stream, P);
+        RBS_HIP(h, hipGetLastError());
+        RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
+        RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[slot], 0));
+    } else {
+        hipLaunchKernelGGL((rbs::rbs_raster_kernel<false>), rgrid, block, rbs::kSmemBytes, s, P);
+        RBS_HIP(h, hipGetLastError());
+    }
+    RBS_HIP(h, hipEventRecord(h->ev_stop[slot], s));
+    h->calls += 1;
     if (update) {
         h->cur = 1 - h->cur;
         h->pending_frames = 0;
@@ -139,17 +169,39 @@ void release(rbs_handle* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_soup);
     (void)hipFree(h->d_frame);
+    (void)hipFree(h->d_aux);
+    (void)hipFree(h->d_pbg);
     (void)hipFree(h->d_occ[0]);
     (void)hipFree(h->d_occ[1]);
     (void)hipFree(h->d_poses);
     (void)hipFree(h->d_indices);
     (void)hipFree(h->d_out);
+    (void)hipFree(h->d_rects);
     (void)hipFree(h->d_render);
     if (h->h_frame) (void)hipHostFree(h->h_frame);
-    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
-    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int i = 0; i < rbs_handle::kRing; ++i) {
+        if (h->ev_start[i]) (void)hipEventDestroy(h->ev_start[i]);
+        if (h->ev_stop[i]) (void)hipEventDestroy(h->ev_stop[i]);
+        if (h->ev_copy_start[i]) (void)hipEventDestroy(h->ev_copy_start[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+// H2D of the staged frame + the per-frame model terms; stream ordered.
+int32_t upload_frame(rbs_handle* h)
+{
+    const size_t n = (size_t)h->npx;
+    RBS_HIP(h, hipMemcpyAsync(h->d_frame, h->h_frame, n * sizeof(float), hipMemcpyHostToDevice,
+                              h->stream));
+    hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       h->stream, h->d_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms,
+                       h->base.sf, h->base.lambda);
+    RBS_HIP(h, hipGetLastError());
+    return RBS_OK;
 }
 
 int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
@@ -253,35 +305,58 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
 
     const size_t plane = (size_t)h->npx * sizeof(float);
     RBS_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    RBS_HIP(h, hipEventCreate(&h->ev_start));
-    RBS_HIP(h, hipEventCreate(&h->ev_stop));
+    {
+        int lo = 0, hi = 0;  // numerically lower = higher priority
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char* pr = std::getenv("RBS_COPY_PRIO");
+        const int prio = pr ? std::atoi(pr) : 0;
+        RBS_HIP(h, hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking,
+                                               prio < 0 ? hi : (prio > 0 ? lo : 0)));
+    }
+    RBS_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < rbs_handle::kRing; ++i) {
+        RBS_HIP(h, hipEventCreate(&h->ev_start[i]));
+        RBS_HIP(h, hipEventCreate(&h->ev_stop[i]));
+        RBS_HIP(h, hipEventCreate(&h->ev_copy_start[i]));
+        RBS_HIP(h, hipEventCreate(&h->ev_join[i]));
+    }
+    if (const char* m = std::getenv("RBS_COPY_BLOCKS")) h->copy_blocks = std::max(1, std::atoi(m));
+    {
+        hipDeviceProp_t prop;
+        RBS_HIP(h, hipGetDeviceProperties(&prop, h->device));
+        h->raster_blocks = 2 * std::max(1, prop.multiProcessorCount);
+        if (const char* m = std::getenv("RBS_RASTER_BLOCKS")) h->raster_blocks = std::max(1, std::atoi(m));
+    }
+    if (const char* m = std::getenv("RBS_BANDS")) {
+        B.bands = std::max(1, std::atoi(m));
+        B.band_rows = (h->rows + B.bands - 1) / B.bands;
+    }
     RBS_HIP(h, hipMalloc(&h->d_soup, soup.size() * sizeof(double)));
     RBS_HIP(h, hipMemcpy(h->d_soup, soup.data(), soup.size() * sizeof(double), hipMemcpyHostToDevice));
     B.soup = h->d_soup;
     RBS_HIP(h, hipMalloc(&h->d_frame, plane));
+    RBS_HIP(h, hipMalloc(&h->d_aux, sizeof(double) * rbs::AUX_PLANES * (size_t)h->npx));
+    RBS_HIP(h, hipMalloc(&h->d_pbg, plane));
     RBS_HIP(h, hipMalloc(&h->d_render, plane));
     RBS_HIP(h, hipMalloc(&h->d_occ[0], plane * h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_occ[1], plane * h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_poses, sizeof(double) * 12 * h->n_bodies * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_indices, sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_out, sizeof(double) * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_rects, sizeof(int) * 4 * (size_t)h->max_particles));
     RBS_HIP(h, hipHostMalloc(&h->h_frame, plane, hipHostMallocDefault));
 
-    // raster blocks need the full dynamic LDS carve
-    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_loglikes_kernel<true, 4>),
+    // the raster / render kernels carve the LDS depth tile from dynamic shared memory
+    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
-    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_loglikes_kernel<false, 4>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
-    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_loglikes_kernel<true, 1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
-    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_loglikes_kernel<false, 1>),
+    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
     RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_render_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
 
     // no observation yet: every pixel "no reading"
     for (int p = 0; p < h->npx; ++p) h->h_frame[p] = NAN;
-    RBS_HIP(h, hipMemcpyAsync(h->d_frame, h->h_frame, plane, hipMemcpyHostToDevice, h->stream));
+    if (int32_t rc = upload_frame(h)) return rc;
     return rbs_reset(h);
 }
 
@@ -351,8 +426,7 @@ int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n)
     RBS_HIP(h, hipSetDevice(h->device));
     RBS_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer reuse
     for (size_t p = 0; p < n; ++p) h->h_frame[p] = (float)depth[p];
-    RBS_HIP(h, hipMemcpyAsync(h->d_frame, h->h_frame, n * sizeof(float), hipMemcpyHostToDevice,
-                              h->stream));
+    if (int32_t rc = upload_frame(h)) return rc;
     h->pending_frames += 1;
     return RBS_OK;
 }
@@ -366,8 +440,7 @@ int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n)
     RBS_HIP(h, hipSetDevice(h->device));
     RBS_HIP(h, hipStreamSynchronize(h->stream));
     std::memcpy(h->h_frame, depth, n * sizeof(float));
-    RBS_HIP(h, hipMemcpyAsync(h->d_frame, h->h_frame, n * sizeof(float), hipMemcpyHostToDevice,
-                              h->stream));
+    if (int32_t rc = upload_frame(h)) return rc;
     h->pending_frames += 1;
     return RBS_OK;
 }
@@ -490,12 +563,37 @@ int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out)
 
 int32_t rbs_last_kernel_ms(rbs_handle* h, float* ms)
 {
+    float copy_ms = 0.f;
+    int32_t used = 0;
+    return rbs_timing_summary(h, 1, ms, &copy_ms, &used);
+}
+
+int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float* copy_kernel_ms,
+                           int32_t* n_used)
+{
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
-    if (!ms) return fail(h, RBS_ERR_INVALID_ARGUMENT, "last_kernel_ms: null pointer");
-    if (!h->timed) return fail(h, RBS_ERR_INVALID_ARGUMENT, "last_kernel_ms: no loglikes launched yet");
+    if (!call_ms || !copy_kernel_ms || !n_used || last_n <= 0)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "timing_summary: bad argument");
+    if (h->calls == 0) return fail(h, RBS_ERR_INVALID_ARGUMENT, "timing_summary: no loglikes launched yet");
     RBS_HIP(h, hipSetDevice(h->device));
-    RBS_HIP(h, hipEventSynchronize(h->ev_stop));
-    RBS_HIP(h, hipEventElapsedTime(ms, h->ev_start, h->ev_stop));
+    const long n = std::min<long>({(long)last_n, h->calls, (long)rbs_handle::kRing});
+    double tot = 0.0, cpy = 0.0;
+    int n_copy = 0;
+    for (long k = 0; k < n; ++k) {
+        const int slot = (int)((h->calls - 1 - k) % rbs_handle::kRing);
+        float ms = 0.f;
+        RBS_HIP(h, hipEventSynchronize(h->ev_stop[slot]));
+        RBS_HIP(h, hipEventElapsedTime(&ms, h->ev_start[slot], h->ev_stop[slot]));
+        tot += ms;
+        if (h->ring_update[slot]) {
+            RBS_HIP(h, hipEventElapsedTime(&ms, h->ev_copy_start[slot], h->ev_join[slot]));
+            cpy += ms;
+            ++n_copy;
+        }
+    }
+    *call_ms = (float)(tot / (double)n);
+    *copy_kernel_ms = n_copy ? (float)(cpy / n_copy) : 0.f;
+    *n_used = (int32_t)n;
     return RBS_OK;
 }
 

@@ -1,20 +1,22 @@
 // rbsensor_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the RbSensor likelihood evaluator.
 //
-// One launch of rbs_loglikes_kernel evaluates RbSensor::loglikes(deltas, indices, update)
-// (the call made once per sampling block inside tracker_->track,
-// R:source/dbot_ros/object_tracker_ros.hpp:49) for n particles:
+// One RbSensor::loglikes(deltas, indices, update) call (made once per sampling block inside
+// tracker_->track, R:source/dbot_ros/object_tracker_ros.hpp:49) is three launches:
 //
-//   raster blocks (one per particle)      software depth rasterizer: triangles -> LDS depth
-//                                         tile (ds_min_u32 z-min), then the per-pixel Kinect
-//                                         likelihood + occlusion posterior over the particle's
-//                                         screen rectangle, wave64 shuffle reduce -> one double.
-//   copy blocks (`bands` per particle,    stream the parent's occlusion plane into the child's
-//   update only)                          slot outside that rectangle, advancing every pixel
-//                                         by the occlusion process: occ' = fma(alpha, occ, beta).
+//   rbs_rect_kernel     one thread per particle: conservative screen rectangle of the bodies
+//                       (bounding spheres), x-aligned to 128 B.
+//   rbs_raster_kernel   PERSISTENT, 2 blocks per CU, each walking particles: software depth
+//                       rasterizer (triangles -> LDS depth tile, ds_min_u32 z-min), then the
+//                       per-pixel Kinect likelihood + occlusion posterior over the rectangle,
+//                       wave64 shuffle reduce -> one double per particle.  FP64 VALU bound.
+//   rbs_copy_kernel     (update only, second stream, concurrent with the raster kernel) one
+//                       small block per (particle, row band): streams the parent's occlusion
+//                       plane into the child's slot outside the rectangle, advancing every
+//                       pixel by the occlusion process occ' = fma(alpha, occ, beta).
+//                       HBM bound: 2*4*rows*cols bytes per particle-likelihood.
 //
-// Both kinds are interleaved in ONE grid (block = particle*(1+bands)+sub) so that the
-// FP64-heavy raster work of some particles overlaps the HBM streaming of others on every CU.
-// The kernel is HBM-bound: 2*4*rows*cols bytes per particle-likelihood.
+// The raster kernel holds a fixed LDS/VGPR share of every CU for the whole call, the many
+// light copy blocks stream through the rest, so FP64 work and HBM streaming overlap.
 //
 // Arithmetic contract (tests/ compare against oracle/): the geometry is individually rounded
 // binary64 in a fixed operation order (compile with -ffp-contract=off), the stored depth is
@@ -26,11 +28,25 @@
 
 namespace rbs {
 
-constexpr int kBlock = 256;          // 4 waves
-constexpr int kTilePx = 12288;       // LDS depth tile: 48 KiB of u32
-constexpr int kBigCap = 1024;        // triangles deferred to the cooperative path per chunk
-constexpr int kBigThresh = 96;       // bbox pixels above which a triangle is "big"
-constexpr int kCopyUnroll = 8;       // float4 loads in flight per lane in copy blocks
+// tuning knobs (overridable with -D for A/B experiments; defaults are the measured best)
+#ifndef RBS_TILE_PX
+#define RBS_TILE_PX 16384
+#endif
+#ifndef RBS_COPY_UNROLL
+#define RBS_COPY_UNROLL 8
+#endif
+#ifndef RBS_NT
+#define RBS_NT 1
+#endif
+#ifndef RBS_BIG_THRESH
+#define RBS_BIG_THRESH 96
+#endif
+
+constexpr int kBlock = 256;                // 4 waves
+constexpr int kTilePx = RBS_TILE_PX;       // LDS depth tile (u32 per pixel)
+constexpr int kBigCap = 1024;              // triangles deferred to the cooperative path per chunk
+constexpr int kBigThresh = RBS_BIG_THRESH; // bbox pixels above which a triangle is "big"
+constexpr int kCopyUnroll = RBS_COPY_UNROLL; // float4 loads in flight per lane in copy blocks
 constexpr unsigned kInfBits = 0x7f800000u;
 constexpr int kMaxBodies = 16;
 constexpr double kMaxDepth = 6.0;    // KinectPixelModel max_depth
@@ -47,6 +63,8 @@ struct DevParams {
     double sphere[kMaxBodies][4];  // model-space bounding sphere: centre xyz, radius
     const double* soup;            // SoA [9][n_tri]: v0.xyz v1.xyz v2.xyz
     const float* frame;            // observation, float metres
+    const double* aux;             // per-frame-pixel terms, SoA [4][npx] (frame_aux_kernel)
+    const float* pbg;              // per-frame-pixel background density, rounded to float
     double tw, ms, sf, lambda;     // tail_weight, model_sigma, sigma_factor, ln2/half_life
     float alpha, beta;             // occlusion process over the elapsed frames
     const float* occ_src;          // [slots][npx]
@@ -56,6 +74,7 @@ struct DevParams {
     double* out;                   // [n]
     int n;
     int bands, band_rows;          // copy blocks per particle, rows per band
+    const int* rects;              // [n][4] screen rectangles written by rbs_rect_kernel
 };
 
 struct Rect { int x0, y0, x1, y1; };
@@ -132,6 +151,14 @@ __device__ inline bool tri_setup(const DevParams& P, int t, const double* __rest
         u[k] = P.fx * (X[k] * iz) + P.cx;
         v[k] = P.fy * (Y[k] * iz) + P.cy;
     }
+    // bbox first: most sub-pixel triangles contain no integer sample point and leave here
+    // (pure reordering of independent operations -- values are unchanged)
+    const double umin = fmin(fmin(u[0], u[1]), u[2]), umax = fmax(fmax(u[0], u[1]), u[2]);
+    const double vmin = fmin(fmin(v[0], v[1]), v[2]), vmax = fmax(fmax(v[0], v[1]), v[2]);
+    const double xlo_d = fmax(ceil(umin), (double)wx0), xhi_d = fmin(floor(umax), (double)(wx1 - 1));
+    const double ylo_d = fmax(ceil(vmin), (double)wy0), yhi_d = fmin(floor(vmax), (double)(wy1 - 1));
+    if (!(xlo_d <= xhi_d) || !(ylo_d <= yhi_d)) return false;
+
     T.u0 = u[0]; T.v0 = v[0]; T.u1 = u[1]; T.v1 = v[1]; T.u2 = u[2]; T.v2 = v[2];
     T.e01u = u[1] - u[0]; T.e01v = v[1] - v[0];
     T.e12u = u[2] - u[1]; T.e12v = v[2] - v[1];
@@ -148,12 +175,6 @@ __device__ inline bool tri_setup(const DevParams& P, int t, const double* __rest
     T.pa = nx / P.fx;
     T.pb = ny / P.fy;
     T.pc = (nz - T.pa * P.cx) - T.pb * P.cy;
-
-    const double umin = fmin(fmin(u[0], u[1]), u[2]), umax = fmax(fmax(u[0], u[1]), u[2]);
-    const double vmin = fmin(fmin(v[0], v[1]), v[2]), vmax = fmax(fmax(v[0], v[1]), v[2]);
-    const double xlo_d = fmax(ceil(umin), (double)wx0), xhi_d = fmin(floor(umax), (double)(wx1 - 1));
-    const double ylo_d = fmax(ceil(vmin), (double)wy0), yhi_d = fmin(floor(vmax), (double)(wy1 - 1));
-    if (!(xlo_d <= xhi_d) || !(ylo_d <= yhi_d)) return false;
     T.xlo = (int)xlo_d; T.xhi = (int)xhi_d; T.ylo = (int)ylo_d; T.yhi = (int)yhi_d;
     return true;
 }
@@ -227,44 +248,51 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
 // KinectPixelModel / OcclusionModel restated; expression text kept identical to the
 // specification in oracle/rbsensor_oracle.c so both sides perform the same binary64
 // operations (transcendentals differ by <= a few ulp of double between libm and ocml).
-__device__ inline double prob_visible(const DevParams& P, double o, double r)
-{
-    const double tw = P.tw;
-    const double sigma = P.ms + P.sf * o * o;
-    const double d = r - o;
-    return tw / kMaxDepth +
-           (1.0 - tw) * exp(-(d * d) / (2.0 * sigma * sigma)) / (sqrt(2.0 * M_PI) * sigma);
-}
+// Terms of the pixel model that depend on the observed depth only are computed once per
+// frame (frame_aux_kernel) instead of once per particle-pixel.  With sigma = ms + sf*o^2,
+// lam = ln2/half_life, d = r - o, w = d/(sqrt2 sigma):
+//   p_vis(o|r) = tw/D + c_v * exp(-w^2)                      c_v = (1-tw)/(sqrt(2pi) sigma)
+//   p_occ(o|r) = tw/D + e_o * E1/(E1-1) * (1 + erf(w + k))   E1 = exp(lam r), k = lam sigma/sqrt2,
+//                                                            e_o = (1-tw) lam/2 * exp(lam/2 (lam sigma^2 - 2o))
+//   p_bg(o)    = tw/D + (1-tw) lam exp(lam/2 (lam sigma^2 - 2o))        (rounded to float)
+// Algebraically identical to SURVEY A.3 / oracle orc_prob_*; binary64 results differ from the
+// oracle's expression order by a few ulp, far below the float rounding of a, b that follows.
+enum { AUX_INV_S2S = 0, AUX_K = 1, AUX_CV = 2, AUX_EO = 3, AUX_PLANES = 4 };
 
-__device__ inline double prob_occluded(const DevParams& P, double o, double r)
+__global__ void frame_aux_kernel(const float* __restrict__ frame, double* __restrict__ aux,
+                                 float* __restrict__ pbg, int npx, double tw, double ms, double sf,
+                                 double lam)
 {
-    const double tw = P.tw;
-    const double lam = P.lambda;
-    const double sigma = P.ms + P.sf * o * o;
-    return tw / kMaxDepth +
-           (1.0 - tw) * lam * exp(0.5 * lam * (2.0 * r - 2.0 * o + lam * sigma * sigma)) *
-               (1.0 + erf((r - o + lam * sigma * sigma) / (sqrt(2.0) * sigma))) /
-               (2.0 * (exp(r * lam) - 1.0));
-}
-
-__device__ inline double prob_background(const DevParams& P, double o)
-{
-    const double tw = P.tw;
-    const double lam = P.lambda;
-    const double sigma = P.ms + P.sf * o * o;
-    return tw / kMaxDepth + (1.0 - tw) * lam * exp(0.5 * lam * (-2.0 * o + lam * sigma * sigma));
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    const double o = (double)frame[i];
+    const double sigma = ms + sf * o * o;
+    const double eo = exp(0.5 * lam * (-2.0 * o + lam * sigma * sigma));
+    aux[(size_t)AUX_INV_S2S * npx + i] = 1.0 / (sqrt(2.0) * sigma);
+    aux[(size_t)AUX_K * npx + i] = lam * sigma / sqrt(2.0);
+    aux[(size_t)AUX_CV * npx + i] = (1.0 - tw) / (sqrt(2.0 * M_PI) * sigma);
+    aux[(size_t)AUX_EO * npx + i] = 0.5 * (1.0 - tw) * lam * eo;
+    pbg[i] = (float)(tw / kMaxDepth + (1.0 - tw) * lam * eo);
 }
 
 // log-likelihood ratio of one covered, observed pixel + posterior occlusion.
-__device__ inline double pixel_loglik(const DevParams& P, float o, float r, float prior,
+// Rounding points as in the oracle: a, b, p_bg -> float; a+b and the ratios in float; log in
+// double.
+__device__ inline double pixel_loglik(const DevParams& P, int gi, float o, float r, float prior,
                                       float& posterior)
 {
-    const float a = (float)(prob_visible(P, (double)o, (double)r) * (1.0 - (double)prior));
-    const float b = (float)(prob_occluded(P, (double)o, (double)r) * (double)prior);
-    const float pbg = (float)prob_background(P, (double)o);
+    const size_t n = (size_t)P.npx;
+    const double w = ((double)r - (double)o) * P.aux[(size_t)AUX_INV_S2S * n + gi];
+    const double twD = P.tw / kMaxDepth;
+    const double pv = twD + P.aux[(size_t)AUX_CV * n + gi] * exp(-(w * w));
+    const double E1 = exp((double)r * P.lambda);
+    const double po = twD + P.aux[(size_t)AUX_EO * n + gi] * (E1 / (E1 - 1.0)) *
+                                (1.0 + erf(w + P.aux[(size_t)AUX_K * n + gi]));
+    const float a = (float)(pv * (1.0 - (double)prior));
+    const float b = (float)(po * (double)prior);
     const float sum = a + b;
     posterior = b / sum;
-    return log((double)(sum / pbg));
+    return log((double)(sum / P.pbg[gi]));
 }
 
 __device__ inline double block_reduce_sum(double v, double* red)
@@ -315,7 +343,7 @@ __device__ inline void raster_eval(const DevParams& P, int particle, Rect r, uns
                         const float o = P.frame[gi];
                         if (isfinite(o)) {
                             float post;
-                            ll += pixel_loglik(P, o, __uint_as_float(dbits), occ, post);
+                            ll += pixel_loglik(P, gi, o, __uint_as_float(dbits), occ, post);
                             occ = post;
                         }
                     }
@@ -324,7 +352,7 @@ __device__ inline void raster_eval(const DevParams& P, int particle, Rect r, uns
                     const float o = P.frame[gi];
                     if (isfinite(o)) {
                         float post;
-                        ll += pixel_loglik(P, o, __uint_as_float(dbits),
+                        ll += pixel_loglik(P, gi, o, __uint_as_float(dbits),
                                            fmaf(P.alpha, src[gi], P.beta), post);
                     }
                 }
@@ -366,7 +394,11 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
                 const int idx = base + k * kBlock;
                 const int col = c4 << 2;
                 ok[k] = idx < n4 && !(row >= r.y0 && row < r.y1 && col >= r.x0 && col < r.x1);
+#if RBS_NT
                 if (ok[k]) v[k] = __builtin_nontemporal_load(&s4[idx]);
+#else
+                if (ok[k]) v[k] = s4[idx];
+#endif
                 c4 += rstep; row += qstep;
                 if (c4 >= W4) { c4 -= W4; ++row; }
             }
@@ -378,7 +410,11 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
                 w.y = fmaf(alpha, v[k].y, beta);
                 w.z = fmaf(alpha, v[k].z, beta);
                 w.w = fmaf(alpha, v[k].w, beta);
+#if RBS_NT
                 __builtin_nontemporal_store(w, &d4[base + k * kBlock]);
+#else
+                d4[base + k * kBlock] = w;
+#endif
             }
         }
     } else {
@@ -394,19 +430,43 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
 }
 
 // ------------------------------------------------------------------ kernels
-template <bool UPDATE, int VEC>
-__global__ __launch_bounds__(kBlock) void rbs_loglikes_kernel(const DevParams P)
+// One thread per particle: the screen rectangle both the raster and the copy kernel use.
+__global__ void rbs_rect_kernel(const DevParams P, int* __restrict__ rects)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const Rect r = particle_rect(P, P.poses + (size_t)i * 12 * P.n_bodies);
+    reinterpret_cast<int4*>(rects)[i] = make_int4(r.x0, r.y0, r.x1, r.y1);
+}
+
+#ifndef RBS_RASTER_MINWAVES
+#define RBS_RASTER_MINWAVES 1
+#endif
+template <bool UPDATE>
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel(const DevParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int G = UPDATE ? 1 + P.bands : 1;
-    const int particle = (int)blockIdx.x / G;
-    const int sub = (int)blockIdx.x - particle * G;
-    const Rect r = particle_rect(P, P.poses + (size_t)particle * 12 * P.n_bodies);
-    if (UPDATE && sub > 0) {
-        copy_band<VEC>(P, particle, sub - 1, r);
-        return;
+    // persistent: a fixed number of raster blocks per CU keeps its LDS/VGPR share for the
+    // whole launch (they are never starved by the many small copy blocks) and walks particles
+    for (int particle = (int)blockIdx.x; particle < P.n; particle += (int)gridDim.x) {
+        const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
+        const Rect r = {q.x, q.y, q.z, q.w};
+        raster_eval<UPDATE>(P, particle, r, smem);
+        __syncthreads();
     }
-    raster_eval<UPDATE>(P, particle, r, smem);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void rbs_copy_kernel(const DevParams P)
+{
+    const int items = P.n * P.bands;
+    for (int w = (int)blockIdx.x; w < items; w += (int)gridDim.x) {
+        const int particle = w / P.bands;
+        const int band = w - particle * P.bands;
+        const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
+        const Rect r = {q.x, q.y, q.z, q.w};
+        copy_band<VEC>(P, particle, band, r);
+    }
 }
 
 // Inspection hook: depth image of one pose through the same raster_window path.

@@ -268,3 +268,11 @@ class RbSensor:
         ms = C.c_float()
         self._check(self._lib.rbs_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def timing_summary(self, last_n):
+        """(call_ms, copy_kernel_ms, n_used) averaged over the last calls, from the library's
+        own HIP events on the streams its kernels run on."""
+        a, b, n = C.c_float(), C.c_float(), C.c_int32()
+        self._check(self._lib.rbs_timing_summary(self._h, int(last_n), C.byref(a), C.byref(b),
+                                                 C.byref(n)))
+        return float(a.value), float(b.value), int(n.value)

@@ -119,9 +119,15 @@ int32_t rbs_occlusion_device_ptr(rbs_handle* h, int32_t slot, void** out);
 int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out);
 /* Rasterize one pose [n_objects][12] -> host float[rows*cols], +inf where uncovered. */
 int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out);
-/* Duration in milliseconds of the most recent loglikes kernel launched by rbs_loglikes*
- * (HIP events recorded on the launch stream around the kernel); blocks until it finished. */
+/* Device time in milliseconds of the most recent rbs_loglikes* call (HIP events recorded on the
+ * launch stream around its kernels); blocks until it finished. */
 int32_t rbs_last_kernel_ms(rbs_handle* h, float* ms);
+/* Averages over the last min(last_n, 64) rbs_loglikes* calls, from HIP events the library
+ * records on the streams the kernels run on: call_ms = whole call on the launch stream
+ * (rect + raster kernels and the join with the copy stream); copy_kernel_ms = the copy kernel
+ * alone on its own stream (updating calls only, 0 if none).  Blocks until those calls finished. */
+int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float* copy_kernel_ms,
+                           int32_t* n_used);
 
 #ifdef __cplusplus
 }
