@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""tools/summarize_profile.py rNN -- condense gpurun_out/prof_rNN (written on the GPU box by
+tools/profile_round.sh) into the tracked files under profiles/:
+
+  profiles/rNN_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the bench command
+  profiles/rNN_pmc_hbm.json       FETCH_SIZE / WRITE_SIZE per dispatch (separate --pmc passes),
+                                  gfx950 correction and the calibration run it is based on
+  profiles/pmc_traffic.json       {"hbm_bytes_per_launch": ...} read by bench.py for roofline.traffic
+
+Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB;
+on gfx950 FETCH_SIZE reports exactly half the bytes of a wide (16 B/lane) coalesced streaming
+read, so it is doubled; both are cross-checked here against a plain float4 stream copy of a
+known byte count (tools/copybench.hip) profiled in the same session.
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def per_dispatch(path):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        k = (r["Kernel_Name"], r["Counter_Name"])
+        d[k][0] += 1
+        d[k][1] += float(r["Counter_Value"])
+    return {k: v[1] / v[0] for k, v in d.items()}, {k: v[0] for k, v in d.items()}
+
+
+shutil.copy(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+fetch, nf = per_dispatch(os.path.join(src, "fetch", "fetch_counter_collection.csv"))
+write, _ = per_dispatch(os.path.join(src, "write", "write_counter_collection.csv"))
+l2, _ = per_dispatch(os.path.join(src, "l2", "l2_counter_collection.csv"))
+
+out = {"tag": tag, "units": "FETCH_SIZE/WRITE_SIZE in KiB per dispatch (average over dispatches)",
+       "kernels": {}, "calibration": {}}
+KNOWN = 2000 * 640 * 480 * 4  # bytes read == bytes written by one copybench flat_copy launch
+cal_f = os.path.join(src, "cal_fetch", "cal_counter_collection.csv")
+fetch_scale, write_scale = 2.0, 1.0
+if os.path.exists(cal_f):
+    cf, _ = per_dispatch(cal_f)
+    cw, _ = per_dispatch(os.path.join(src, "cal_write", "cal_counter_collection.csv"))
+    f = [v for (k, c), v in cf.items() if k.startswith("void flat_copy<8, true>")]
+    w = [v for (k, c), v in cw.items() if k.startswith("void flat_copy<8, true>")]
+    if f and w:
+        fetch_scale = KNOWN / (f[0] * 1024.0)
+        write_scale = KNOWN / (w[0] * 1024.0)
+        out["calibration"] = {"kernel": "copybench flat_copy<8,nt>, 2.4576e9 B read + 2.4576e9 B written",
+                              "FETCH_SIZE_KiB": f[0], "WRITE_SIZE_KiB": w[0],
+                              "bytes_per_FETCH_KiB_unit": fetch_scale * 1024, "bytes_per_WRITE_KiB_unit": write_scale * 1024,
+                              "fetch_correction": fetch_scale, "write_correction": write_scale}
+total = 0.0
+for (k, c), v in sorted(fetch.items()):
+    if "rbs_copy_kernel" in k or "rbs_raster_kernel" in k or "rbs_rect_kernel" in k:
+        wv = write.get((k, "WRITE_SIZE"), 0.0)
+        # the x2 fetch correction is calibrated for 16 B/lane streams (the copy kernel); the raster
+        # kernel's narrow reads are uncalibrated and reported with the same factor as an upper bound
+        b = v * 1024 * fetch_scale + wv * 1024 * write_scale
+        hit, miss = l2.get((k, "TCC_HIT_sum")), l2.get((k, "TCC_MISS_sum"))
+        out["kernels"][k] = {"dispatches": nf[(k, c)], "FETCH_SIZE_KiB": v, "WRITE_SIZE_KiB": wv,
+                             "hbm_bytes_per_dispatch_corrected": b,
+                             "l2_hit_rate": (hit / (hit + miss)) if hit is not None and (hit + miss) > 0 else None}
+        total += b
+out["hbm_bytes_per_loglikes_call"] = total
+out["algorithmic_bytes_per_loglikes_call"] = 2.0 * KNOWN
+out["traffic_over_algorithmic"] = total / (2.0 * KNOWN)
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
+json.dump({"hbm_bytes_per_launch": total, "source": f"profiles/{tag}_pmc_hbm.json",
+           "workload": "bench.py default (C1: 2000 particles, 640x480, update=true)"},
+          open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:3000])
