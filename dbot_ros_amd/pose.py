@@ -44,20 +44,21 @@ def quat_to_matrix(q):
 
 
 def matrix_to_rotvec(R):
-    """Rotation matrix [3,3] -> rotation vector [3]."""
+    """Rotation matrix [3,3] -> rotation vector [3] (atan2 form: accurate for tiny angles)."""
     R = np.asarray(R, dtype=np.float64)
-    cos = np.clip((np.trace(R) - 1.0) * 0.5, -1.0, 1.0)
-    angle = np.arccos(cos)
-    if angle < 1e-12:
-        return np.zeros(3)
-    axis = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
-    n = np.linalg.norm(axis)
-    if n < 1e-12:  # angle ~ pi
-        d = np.sqrt(np.maximum((np.diag(R) + 1.0) * 0.5, 0.0))
-        i = int(np.argmax(d))
-        axis = (R[:, i] + np.eye(3)[i]) / (2.0 * d[i])
-        return axis / np.linalg.norm(axis) * angle
-    return axis / n * angle
+    s = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])  # sin(a) * axis
+    sn = np.linalg.norm(s)
+    cs = 0.5 * (np.trace(R) - 1.0)
+    angle = np.arctan2(sn, cs)
+    if sn > 1e-8:
+        return s * (angle / sn)
+    if cs > 0.0:  # angle ~ 0: sin(a)/a -> 1
+        return s
+    # angle ~ pi: axis from the symmetric part
+    d = np.sqrt(np.maximum((np.diag(R) + 1.0) * 0.5, 0.0))
+    i = int(np.argmax(d))
+    axis = (R[:, i] + np.eye(3)[i]) / (2.0 * d[i])
+    return axis / np.linalg.norm(axis) * angle
 
 
 def pack_Rt(R, t):

@@ -1,0 +1,110 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol
+include/rbsensor_mi355x.h declares, rejects bad arguments, and -- with no GPU -- fails loudly
+instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from dbot_ros_amd import RbSensor, RbSensorBuilder, RbSensorError, _capi
+import scenarios as sc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "rbsensor_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rbs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(_capi.LIB_PATH)
+    declared = header_symbols()
+    assert len(declared) >= 15
+    for s in declared:
+        assert hasattr(lib, s), f"{s} declared in include/rbsensor_mi355x.h but not exported"
+    assert sorted(_capi.EXPORTS) == declared
+
+
+def test_abi_version_and_struct_layout():
+    lib = _capi.load()
+    assert lib.rbs_abi_version() == _capi.RBS_ABI_VERSION
+    # rbs_config layout the ctypes mirror must match (LP64): 4 ints, 9 doubles, 2 ints, 4 ptrs, 7 doubles
+    assert C.sizeof(_capi.RbsConfig) == 16 + 72 + 8 + 32 + 56
+
+
+def test_bad_arguments_are_rejected_before_touching_a_device():
+    lib = _capi.load()
+    h = C.c_void_p()
+    assert lib.rbs_create(None, C.byref(h)) == _capi.RBS_ERR_INVALID_ARGUMENT
+    assert b"NULL" in lib.rbs_last_error(None)
+    cfg = _capi.RbsConfig()
+    cfg.abi_version = 999
+    assert lib.rbs_create(C.byref(cfg), C.byref(h)) == _capi.RBS_ERR_INVALID_ARGUMENT
+    assert b"abi_version" in lib.rbs_last_error(None)
+    assert lib.rbs_reset(None) == _capi.RBS_ERR_INVALID_ARGUMENT
+    assert lib.rbs_loglikes(None, None, None, 0, 0, None) == _capi.RBS_ERR_INVALID_ARGUMENT
+    lib.rbs_destroy(None)  # no-op
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    lib = _capi.load()
+    if lib.rbs_device_count() > 0:
+        pytest.skip("a GPU is visible here; the no-device path is covered on the CPU container")
+    om, cam, P = sc.make_scene(("m1_l2",), 80, 60, max_particles=4)
+    with pytest.raises(RbSensorError) as e:
+        RbSensor(om, cam, P, max_particles=4)
+    assert e.value.code == _capi.RBS_ERR_NO_DEVICE
+    assert "no CPU path" in str(e.value)
+    P.use_gpu = False
+    with pytest.raises(RbSensorError) as e:
+        RbSensorBuilder(om, cam, P).build()
+    assert e.value.code == _capi.RBS_ERR_UNSUPPORTED
+
+
+def test_invalid_models_rejected():
+    lib = _capi.load()
+    om, cam, P = sc.make_scene(("m1_l2",), 80, 60, max_particles=4)
+    bad_cam = sc.make_scene(("m1_l2",), 80, 60, max_particles=4)[1]
+    bad_cam.camera_matrix[0, 1] = 0.5
+    with pytest.raises(RbSensorError) as e:
+        RbSensor(om, bad_cam, P, max_particles=4)
+    assert e.value.code == _capi.RBS_ERR_UNSUPPORTED
+    P2 = RbSensorBuilder.Parameters(sample_count=4)
+    P2.occlusion.p_occluded_occluded = 0.05  # c = p_oo - p_ov < 0: log(c) undefined
+    with pytest.raises(RbSensorError) as e:
+        RbSensor(om, cam, P2, max_particles=4)
+    assert e.value.code == _capi.RBS_ERR_INVALID_ARGUMENT
+    om.triangles[0][0, 0] = 10 ** 6
+    with pytest.raises(RbSensorError) as e:
+        RbSensor(om, cam, P, max_particles=4)
+    assert e.value.code in (_capi.RBS_ERR_INVALID_ARGUMENT, _capi.RBS_ERR_NO_DEVICE)
+
+
+def _strip_comments(txt, path):
+    if path.endswith(".py"):
+        txt = re.sub(r'"""[\s\S]*?"""', "", txt)
+        return re.sub(r"#.*", "", txt)
+    txt = re.sub(r"/\*[\s\S]*?\*/", "", txt)
+    return re.sub(r"//.*", "", txt)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path must never include, import, link or call anything under oracle/
+    (comments may cite it as the specification)."""
+    for sub in ("dbot_ros_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                    path = os.path.join(dp, f)
+                    code = _strip_comments(open(path, errors="ignore").read(), path)
+                    assert "oracle" not in code, path
+                    assert not re.search(r"\borc_[a-z_]+", code), path
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in needed
+    syms = subprocess.run(["nm", "-D", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert " orc_" not in syms

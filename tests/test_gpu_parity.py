@@ -278,3 +278,31 @@ def test_full_size_properties(gpu_lib):
         corner = g.get_occlusion(1999)[0]
         assert corner == np.float32(np.float32(a) * np.float32(0.1) + np.float32(b)) or \
             abs(corner - (a * 0.1 + b)) < 1e-7
+
+
+@pytest.mark.parametrize("name,meshes,cols,rows", [("single", ("m1_l2",), 80, 60),
+                                                    ("multi", ("m1_l2", "box12"), 160, 120)])
+def test_golden_sequences(gpu_lib, name, meshes, cols, rows):
+    """The committed golden vectors (tests/golden/sequences.npz, tests/golden/coverage.npz)."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "sequences.npz"))
+    n = 16
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    frames = list(zip(g[f"{name}_truth"], g[f"{name}_frames"]))
+    with RbSensor(om, cam, P, max_particles=n) as s:
+        lls = np.array(sc.run_sequence(s, frames, n, n_bodies=len(meshes)))
+        assert rel_err(lls, g[f"{name}_eager_loglik"]).max() <= TOL_EAGER
+        assert rel_err(lls, g[f"{name}_lazy_loglik"]).max() <= TOL_LAZY
+        assert_planes_match(s.get_occlusion(0), g[f"{name}_eager_occ_slot0"])
+        assert_planes_match(s.get_occlusion(5), g[f"{name}_eager_occ_slot5"])
+
+
+@pytest.mark.parametrize("mesh,cols,rows", [("m1_l2", 80, 60), ("m3", 160, 120), ("box12", 160, 120)])
+def test_golden_coverage(gpu_lib, mesh, cols, rows):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "coverage.npz"))
+    om, cam, P = sc.make_scene((mesh,), cols, rows, max_particles=1)
+    with RbSensor(om, cam, P, max_particles=1) as s:
+        for pose, ref in zip(g[f"{mesh}_{cols}x{rows}_poses"], g[f"{mesh}_{cols}x{rows}_depth"]):
+            assert np.array_equal(s.render_depth(pose).view(np.uint32), ref.view(np.uint32))
