@@ -1,0 +1,152 @@
+"""Particle sharding across the GPUs of one node: one process per GPU, contiguous
+particle ranges, occlusion planes resident on the owning rank, one collective per sampling
+block -- an all-gather of per-particle log-likelihoods (RCCL over xGMI with backend "nccl";
+gloo in the CPU tests) -- and, after resampling, migration of only those parent planes whose
+children could not be placed on the parent's own rank.
+
+Everything here is host logic over torch.distributed; the evaluator is any object with
+loglikes_poses / get_occlusion / set_occlusion (the product's RbSensor on GPUs; the CPU tests
+plug the oracle in).  Each rank's sensor is created with 2 x shard slots: [0, shard) own
+planes, [shard, 2*shard) staging for planes received from other ranks.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world):
+    """Contiguous ranges: rank r owns [b[r], b[r+1])."""
+    base, rem = divmod(n, world)
+    sizes = [base + (1 if r < rem else 0) for r in range(world)]
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+def gather_loglikes(local_ll, bounds, group=None, device=None):
+    """All-gather of the ranks' log-likelihood shards -> the full [N] vector on every rank."""
+    world = dist.get_world_size(group)
+    sizes = np.diff(bounds)
+    m = int(sizes.max())
+    t = torch.zeros(m, dtype=torch.float64, device=device)
+    t[: len(local_ll)] = torch.as_tensor(local_ll, dtype=torch.float64, device=device)
+    out = [torch.empty(m, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return np.concatenate([out[r][: sizes[r]].cpu().numpy() for r in range(world)])
+
+
+def place_children(parents, bounds):
+    """Deterministic child placement (identical on every rank).
+
+    parents: global parent index of each of the N children (any order).
+    Returns (child_rank[N], child_slot[N]): children are placed on their parent's rank while
+    that rank has free slots (parent-affine), the surplus fills the remaining free slots of
+    the other ranks in rank order."""
+    parents = np.asarray(parents, dtype=np.int64)
+    world = len(bounds) - 1
+    cap = np.diff(bounds).astype(np.int64)
+    owner = np.searchsorted(bounds, parents, side="right") - 1
+    child_rank = np.full(len(parents), -1, dtype=np.int64)
+    child_slot = np.full(len(parents), -1, dtype=np.int64)
+    used = np.zeros(world, dtype=np.int64)
+    order = np.argsort(parents, kind="stable")
+    surplus = []
+    for j in order:
+        r = owner[j]
+        if used[r] < cap[r]:
+            child_rank[j], child_slot[j] = r, used[r]
+            used[r] += 1
+        else:
+            surplus.append(j)
+    r = 0
+    for j in surplus:
+        while used[r] >= cap[r]:
+            r += 1
+        child_rank[j], child_slot[j] = r, used[r]
+        used[r] += 1
+    return child_rank, child_slot
+
+
+class ShardedSensor:
+    """Drives one rank's sensor inside a particle-sharded filter.
+
+    Particles keep their GLOBAL ids (0..N-1: the row of the pose / weight arrays every rank
+    holds identically).  `layout[g]` is the particle id stored at global slot g (rank-major:
+    rank r owns global slots bounds[r]..bounds[r+1]); it is recomputed identically on every
+    rank after each resampling, so no rank ever needs to ask where a plane lives."""
+
+    def __init__(self, sensor, n_total, group=None, device=None):
+        self.sensor, self.group, self.device = sensor, group, device
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_total = n_total
+        self.bounds = shard_bounds(n_total, self.world)
+        self.lo, self.hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+        self.shard = self.hi - self.lo
+        self.stage0 = int(np.diff(self.bounds).max())        # first staging slot
+        self.layout = np.arange(n_total, dtype=np.int64)
+        self.local_parent_slots = np.zeros(self.shard, dtype=np.int32)
+
+    @property
+    def owned(self):
+        """Global particle ids this rank evaluates, in local slot order."""
+        return self.layout[self.lo:self.hi]
+
+    def reset(self):
+        self.sensor.reset()
+        self.layout = np.arange(self.n_total, dtype=np.int64)
+        self.local_parent_slots[:] = 0
+
+    def set_observation(self, image):
+        self.sensor.set_observation(image)
+
+    def loglikes(self, poses_all, update):
+        """poses_all: [N, ...] poses of ALL particles by global id (identical on every rank).
+        Evaluates this rank's particles and returns the full [N] log-likelihood vector in
+        global-id order (one all-gather)."""
+        idx = self.local_parent_slots.copy()
+        ll = self.sensor.loglikes_poses(np.asarray(poses_all)[self.owned], idx, update=update)
+        if update:
+            self.local_parent_slots = idx  # identity: slot k now holds particle owned[k]
+        by_slot = gather_loglikes(ll, self.bounds, self.group, self.device)
+        out = np.empty(self.n_total)
+        out[self.layout] = by_slot
+        return out
+
+    def resample(self, parents):
+        """parents[j] = global id of the particle child j inherits from (identical on all
+        ranks).  Places the children parent-affine, migrates the planes of parents whose
+        children landed on another rank into that rank's staging slots, and updates the
+        layout: afterwards particle j is evaluated where its plane is."""
+        parents = np.asarray(parents, dtype=np.int64)
+        slot_of = np.empty(self.n_total, dtype=np.int64)
+        slot_of[self.layout] = np.arange(self.n_total)
+        pslot = slot_of[parents]                      # global slot holding each child's parent plane
+        child_rank, child_slot = place_children(pslot, self.bounds)
+        owner = np.searchsorted(self.bounds, pslot, side="right") - 1
+        moves = sorted({(int(owner[j]), int(child_rank[j]), int(pslot[j]))
+                        for j in range(len(parents)) if owner[j] != child_rank[j]})
+        staging, ops, keep = {}, [], []
+        npx = self.sensor.rows * self.sensor.cols
+        for src, dst, g in moves:
+            if src == self.rank:
+                t = torch.from_numpy(np.ascontiguousarray(self.sensor.get_occlusion(g - self.lo)))
+                t = t.to(self.device) if self.device is not None else t
+                ops.append(dist.P2POp(dist.isend, t, dst, group=self.group))
+                keep.append(t)
+            elif dst == self.rank:
+                t = torch.empty(npx, dtype=torch.float32, device=self.device)
+                ops.append(dist.P2POp(dist.irecv, t, src, group=self.group))
+                staging[g] = (self.stage0 + len(staging), t)
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for g, (slot, t) in staging.items():
+            self.sensor.set_occlusion(slot, t.cpu().numpy())
+        new_layout = np.empty(self.n_total, dtype=np.int64)
+        new_layout[self.bounds[child_rank] + child_slot] = np.arange(self.n_total)
+        self.layout = new_layout
+        slots = np.empty(self.shard, dtype=np.int32)
+        for k, j in enumerate(self.owned):
+            g = int(pslot[j])
+            slots[k] = g - self.lo if owner[j] == self.rank else staging[g][0]
+        self.local_parent_slots = slots
+        return moves

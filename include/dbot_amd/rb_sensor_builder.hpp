@@ -1,0 +1,276 @@
+// rb_sensor_builder.hpp -- C++ host-side mirror of the plugin surface dbot_ros drives for the
+// observation model, implemented over the C-ABI of librbsensor_mi355x.so.
+//
+// It keeps the names, argument meaning and error behaviour of the types the reference
+// constructs in R:source/dbot_ros/tracker/particle_tracker_node.cpp:
+//     dbot::ObjectModel / dbot::CameraData                         :94-97, :112-121
+//     dbot::RbSensorBuilder<State>::Parameters (field names)       :164-199
+//     dbot::RbSensorBuilder<State>(object_model, camera_data, p)   :201-203   -> build()
+// and of the sensor the filter drives inside tracker_->track(image)
+// (R:source/dbot_ros/object_tracker_ros.hpp:49):
+//     set_observation(image), loglikes(deltas, indices, update), reset()
+//
+// The upstream types are Eigen based; Eigen is not part of this repository, so the mirror
+// uses plain std::vector<double> storage with the same layout (an Eigen::Map over .data()
+// is the one-line adapter).  Errors of the C-ABI are rethrown as
+// std::runtime_error, which the reference's service thread already catches
+// (R:source/dbot_ros/tracker/object_tracker_service_node.cpp:252-255).
+//
+// Header-only; link with -lrbsensor_mi355x.  No CPU fallback: use_gpu == false throws.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../rbsensor_mi355x.h"
+
+namespace dbot_amd
+{
+typedef double Real;  // fl::Real
+
+/// dbot::FreeFloatingRigidBodiesState<>: per body 12 reals = position(3), orientation as a
+/// rotation ("Euler") vector(3), linear velocity(3), angular velocity(3).
+class FreeFloatingRigidBodiesState
+{
+public:
+    static constexpr int BODY_SIZE = 12;
+    explicit FreeFloatingRigidBodiesState(int body_count = 1)
+        : data_(static_cast<size_t>(body_count) * BODY_SIZE, 0.0)
+    {
+    }
+    int count() const { return static_cast<int>(data_.size()) / BODY_SIZE; }
+    Real* component(int i) { return data_.data() + static_cast<size_t>(i) * BODY_SIZE; }
+    const Real* component(int i) const { return data_.data() + static_cast<size_t>(i) * BODY_SIZE; }
+    Real* position(int i) { return component(i); }
+    Real* euler_vector(int i) { return component(i) + 3; }
+    const Real* position(int i) const { return component(i); }
+    const Real* euler_vector(int i) const { return component(i) + 3; }
+    std::vector<Real>& data() { return data_; }
+    const std::vector<Real>& data() const { return data_; }
+
+    /// rotation vector -> row-major rotation matrix (angle-axis through the unit quaternion)
+    static void rotation_matrix(const Real* rv, Real* R)
+    {
+        const Real angle = std::sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+        const Real half = 0.5 * angle;
+        const Real k = angle < 1e-9 ? 0.5 - angle * angle / 48.0 : std::sin(half) / angle;
+        const Real w = std::cos(half), x = rv[0] * k, y = rv[1] * k, z = rv[2] * k;
+        R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - w * z); R[2] = 2.0 * (x * z + w * y);
+        R[3] = 2.0 * (x * y + w * z); R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - w * x);
+        R[6] = 2.0 * (x * z - w * y); R[7] = 2.0 * (y * z + w * x); R[8] = 1.0 - 2.0 * (x * x + y * y);
+    }
+
+private:
+    std::vector<Real> data_;
+};
+
+/// dbot::ObjectModel: triangle meshes of the tracked parts; center == true re-expresses each
+/// part around the mean of its vertices (center_object_frame, R:config/particle_tracker.yaml:27-30).
+class ObjectModel
+{
+public:
+    ObjectModel(const std::vector<std::vector<Real>>& vertices_xyz,
+                const std::vector<std::vector<int32_t>>& triangle_indices, bool center)
+        : vertices_(vertices_xyz), triangles_(triangle_indices)
+    {
+        if (vertices_.size() != triangles_.size() || vertices_.empty())
+            throw std::runtime_error("ObjectModel: need one triangle list per vertex list");
+        centers_.assign(vertices_.size() * 3, 0.0);
+        for (size_t p = 0; p < vertices_.size(); ++p) {
+            std::vector<Real>& v = vertices_[p];
+            if (v.empty() || v.size() % 3 || triangles_[p].size() % 3)
+                throw std::runtime_error("ObjectModel: malformed mesh");
+            if (!center) continue;
+            const size_t n = v.size() / 3;
+            Real c[3] = {0, 0, 0};
+            for (size_t i = 0; i < n; ++i)
+                for (int k = 0; k < 3; ++k) c[k] += v[3 * i + k];
+            for (int k = 0; k < 3; ++k) centers_[3 * p + k] = c[k] /= static_cast<Real>(n);
+            for (size_t i = 0; i < n; ++i)
+                for (int k = 0; k < 3; ++k) v[3 * i + k] -= c[k];
+        }
+    }
+    int count_parts() const { return static_cast<int>(vertices_.size()); }
+    const std::vector<std::vector<Real>>& vertices() const { return vertices_; }
+    const std::vector<std::vector<int32_t>>& triangle_indices() const { return triangles_; }
+    const std::vector<Real>& centers() const { return centers_; }
+
+private:
+    std::vector<std::vector<Real>> vertices_;
+    std::vector<std::vector<int32_t>> triangles_;
+    std::vector<Real> centers_;
+};
+
+/// dbot::CameraData as the sensor needs it: intrinsics already divided by the down-sampling
+/// factor (R:source/dbot_ros/util/ros_camera_data_provider.cpp:66-76) and the evaluated resolution.
+struct CameraData {
+    struct Resolution { int width = 0; int height = 0; };
+    Real camera_matrix[9] = {0};  // row-major
+    Resolution resolution;        // after down-sampling
+    int downsampling_factor = 1;
+
+    static CameraData from_native(const Real K[9], int width, int height, int downsampling)
+    {
+        CameraData c;
+        for (int i = 0; i < 9; ++i) c.camera_matrix[i] = K[i];
+        for (int i = 0; i < 6; ++i) c.camera_matrix[i] /= static_cast<Real>(downsampling);
+        c.resolution.width = width / downsampling;
+        c.resolution.height = height / downsampling;
+        c.downsampling_factor = downsampling;
+        return c;
+    }
+};
+
+template <typename State> class RbSensor;
+
+/// dbot::RbSensorBuilder<State>
+template <typename State = FreeFloatingRigidBodiesState>
+class RbSensorBuilder
+{
+public:
+    struct Parameters {
+        bool use_gpu = true;
+        int sample_count = 2000;
+        struct Occlusion {
+            Real p_occluded_visible = 0.1;
+            Real p_occluded_occluded = 0.7;
+            Real initial_occlusion_prob = 0.1;
+        } occlusion;
+        struct Kinect {
+            Real tail_weight = 0.01;
+            Real model_sigma = 0.003;
+            Real sigma_factor = 0.0014247;
+        } kinect;
+        Real delta_time = 1.0 / 30.0;
+        // OpenGL-only knobs of the CUDA/GL model: accepted, never used (no GL in this path)
+        bool use_custom_shaders = false;
+        std::string vertex_shader_file;
+        std::string fragment_shader_file;
+        std::string geometry_shader_file;
+    };
+
+    RbSensorBuilder(const std::shared_ptr<ObjectModel>& object_model,
+                    const std::shared_ptr<CameraData>& camera_data, const Parameters& params,
+                    int device_id = 0)
+        : object_model_(object_model), camera_data_(camera_data), params_(params), device_id_(device_id)
+    {
+    }
+
+    std::shared_ptr<RbSensor<State>> build() const
+    {
+        if (!params_.use_gpu)
+            throw std::runtime_error(
+                "RbSensorBuilder: use_gpu == false selects dbot's CPU model; librbsensor_mi355x "
+                "only provides the MI355X implementation (no CPU fallback)");
+        return std::make_shared<RbSensor<State>>(*object_model_, *camera_data_, params_, device_id_);
+    }
+
+private:
+    std::shared_ptr<ObjectModel> object_model_;
+    std::shared_ptr<CameraData> camera_data_;
+    Parameters params_;
+    int device_id_;
+};
+
+/// The sensor object the filter drives (dbot RbSensor<State> interface).
+template <typename State = FreeFloatingRigidBodiesState>
+class RbSensor
+{
+public:
+    typedef std::vector<State> StateArray;
+    typedef std::vector<Real> RealArray;
+    typedef std::vector<int32_t> IntArray;
+    typedef std::vector<Real> Observation;  // rows*cols, row-major, metres, NaN = no reading
+
+    RbSensor(const ObjectModel& om, const CameraData& cam,
+             const typename RbSensorBuilder<State>::Parameters& p, int device_id = 0)
+        : n_bodies_(om.count_parts()), integrated_poses_(om.count_parts())
+    {
+        std::vector<Real> verts;
+        std::vector<int32_t> tris, vcnt, tcnt;
+        for (int b = 0; b < n_bodies_; ++b) {
+            verts.insert(verts.end(), om.vertices()[b].begin(), om.vertices()[b].end());
+            tris.insert(tris.end(), om.triangle_indices()[b].begin(), om.triangle_indices()[b].end());
+            vcnt.push_back(static_cast<int32_t>(om.vertices()[b].size() / 3));
+            tcnt.push_back(static_cast<int32_t>(om.triangle_indices()[b].size() / 3));
+        }
+        rbs_config cfg{};
+        cfg.abi_version = RBS_ABI_VERSION;
+        cfg.device_id = device_id;
+        cfg.rows = cam.resolution.height;
+        cfg.cols = cam.resolution.width;
+        for (int i = 0; i < 9; ++i) cfg.K[i] = cam.camera_matrix[i];
+        cfg.max_particles = p.sample_count;
+        cfg.n_objects = n_bodies_;
+        cfg.vertices = verts.data();
+        cfg.vertex_counts = vcnt.data();
+        cfg.triangles = tris.data();
+        cfg.triangle_counts = tcnt.data();
+        cfg.p_occluded_visible = p.occlusion.p_occluded_visible;
+        cfg.p_occluded_occluded = p.occlusion.p_occluded_occluded;
+        cfg.initial_occlusion_prob = p.occlusion.initial_occlusion_prob;
+        cfg.tail_weight = p.kinect.tail_weight;
+        cfg.model_sigma = p.kinect.model_sigma;
+        cfg.sigma_factor = p.kinect.sigma_factor;
+        cfg.delta_time = p.delta_time;
+        const int32_t rc = rbs_create(&cfg, &handle_);
+        if (rc != RBS_OK)
+            throw std::runtime_error(std::string("RbSensor: ") + rbs_last_error(nullptr));
+    }
+    ~RbSensor() { rbs_destroy(handle_); }
+    RbSensor(const RbSensor&) = delete;
+    RbSensor& operator=(const RbSensor&) = delete;
+
+    void reset() { check(rbs_reset(handle_)); }
+
+    void set_observation(const Observation& image)
+    {
+        check(rbs_set_observation(handle_, image.data(), image.size()));
+    }
+
+    /// deltas: state deltas around integrated_poses(); indices: occlusion slot each particle
+    /// inherits from, set to identity when update is true.  Returns log-likelihoods.
+    RealArray loglikes(const StateArray& deltas, IntArray& indices, const bool& update = false)
+    {
+        const size_t n = deltas.size();
+        if (indices.size() != n) throw std::runtime_error("RbSensor::loglikes: indices.size() != deltas.size()");
+        poses_.resize(n * static_cast<size_t>(n_bodies_) * 12);
+        Real Rd[9], R0[9];
+        for (size_t i = 0; i < n; ++i)
+            for (int b = 0; b < n_bodies_; ++b) {
+                // absolute pose = delta (+) default: R = R(delta) R(default), t = t(delta) + t(default)
+                State::rotation_matrix(deltas[i].euler_vector(b), Rd);
+                State::rotation_matrix(integrated_poses_.euler_vector(b), R0);
+                Real* out = poses_.data() + (i * n_bodies_ + b) * 12;
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c)
+                        out[3 * r + c] = Rd[3 * r] * R0[c] + Rd[3 * r + 1] * R0[3 + c] + Rd[3 * r + 2] * R0[6 + c];
+                for (int k = 0; k < 3; ++k)
+                    out[9 + k] = deltas[i].position(b)[k] + integrated_poses_.position(b)[k];
+            }
+        RealArray ll(n);
+        check(rbs_loglikes(handle_, poses_.data(), indices.data(), static_cast<int32_t>(n), update ? 1 : 0,
+                           ll.data()));
+        return ll;
+    }
+
+    State& integrated_poses() { return integrated_poses_; }
+    const State& integrated_poses() const { return integrated_poses_; }
+    rbs_handle* handle() { return handle_; }
+
+private:
+    void check(int32_t rc) const
+    {
+        if (rc != RBS_OK) throw std::runtime_error(std::string("RbSensor: ") + rbs_last_error(handle_));
+    }
+    rbs_handle* handle_ = nullptr;
+    int n_bodies_;
+    State integrated_poses_;
+    std::vector<Real> poses_;
+};
+
+}  // namespace dbot_amd

@@ -342,6 +342,15 @@ void orc_get_occlusion(const orc_sensor* s, int32_t slot, float* out)
     memcpy(out, s->occ[s->cur] + (size_t)slot * s->npx, sizeof(float) * s->npx);
 }
 
+void orc_set_occlusion(orc_sensor* s, int32_t slot, const float* plane)
+{
+    memcpy(s->occ[s->cur] + (size_t)slot * s->npx, plane, sizeof(float) * s->npx);
+    if (s->stamp[s->cur]) {
+        int32_t* st = s->stamp[s->cur] + (size_t)slot * s->npx;
+        for (size_t p = 0; p < s->npx; ++p) st[p] = s->clock;
+    }
+}
+
 void orc_get_occlusion_now(const orc_sensor* s, int32_t slot, float* out)
 {
     const float* occ = s->occ[s->cur] + (size_t)slot * s->npx;

@@ -75,6 +75,9 @@ void orc_loglikes(orc_sensor* s, const double* poses, int32_t* indices, int32_t 
 
 /* Stored occlusion plane of a slot (float[rows*cols]). */
 void orc_get_occlusion(const orc_sensor* s, int32_t slot, float* out);
+/* Overwrite a slot's stored plane (LAZY: stamps := current clock, i.e. the plane is taken to
+ * be "as of now", which is what orc_get_occlusion_now of the sending side delivers). */
+void orc_set_occlusion(orc_sensor* s, int32_t slot, const float* plane);
 /* Occlusion plane of a slot advanced to the current clock (what the next evaluation
  * would use as its prior if set_observation were not called again). */
 void orc_get_occlusion_now(const orc_sensor* s, int32_t slot, float* out);

@@ -1,0 +1,100 @@
+// shim_check.cpp -- exercises include/dbot_amd/rb_sensor_builder.hpp the way
+// R:source/dbot_ros/tracker/particle_tracker_node.cpp:164-203 builds the sensor and the filter
+// drives it.  Reads a scene from a text file (written by tests/test_cpp_shim.py), prints the
+// log-likelihoods of two calls; the pytest side compares them with the oracle.
+//   shim_check <scene.txt>        -> "LL1 ..." / "LL2 ..." lines, or "NO_DEVICE <message>"
+#include <dbot_amd/rb_sensor_builder.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <limits>
+
+typedef dbot_amd::FreeFloatingRigidBodiesState State;
+typedef dbot_amd::RbSensorBuilder<State> SensorBuilder;
+
+static double read_real(std::istream& in)
+{
+    std::string tok;
+    in >> tok;
+    if (tok == "nan") return std::numeric_limits<double>::quiet_NaN();
+    return std::strtod(tok.c_str(), nullptr);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { std::fprintf(stderr, "usage: shim_check scene.txt\n"); return 2; }
+    std::ifstream in(argv[1]);
+    int rows, cols, parts, n;
+    in >> rows >> cols;
+    double K[9];
+    for (double& k : K) k = read_real(in);
+    in >> parts;
+    std::vector<std::vector<double>> verts(parts);
+    std::vector<std::vector<int32_t>> tris(parts);
+    for (int p = 0; p < parts; ++p) {
+        int nv, nt;
+        in >> nv >> nt;
+        verts[p].resize(3 * nv);
+        tris[p].resize(3 * nt);
+        for (double& v : verts[p]) v = read_real(in);
+        for (int32_t& t : tris[p]) in >> t;
+    }
+    in >> n;
+    State def(parts);
+    for (double& v : def.data()) v = read_real(in);
+    std::vector<State> deltas(n, State(parts));
+    for (State& s : deltas)
+        for (double& v : s.data()) v = read_real(in);
+    std::vector<double> frame(static_cast<size_t>(rows) * cols);
+    for (double& v : frame) v = read_real(in);
+
+    // ---- same construction order as the node ----
+    auto object_model = std::make_shared<dbot_amd::ObjectModel>(verts, tris, /*center_object_frame=*/true);
+    auto camera_data = std::make_shared<dbot_amd::CameraData>(dbot_amd::CameraData::from_native(K, cols, rows, 1));
+    SensorBuilder::Parameters params_obsrv;
+    params_obsrv.use_gpu = true;
+    params_obsrv.sample_count = n;
+    params_obsrv.occlusion.p_occluded_visible = 0.1;
+    params_obsrv.occlusion.p_occluded_occluded = 0.7;
+    params_obsrv.occlusion.initial_occlusion_prob = 0.1;
+    params_obsrv.kinect.tail_weight = 0.01;
+    params_obsrv.kinect.model_sigma = 0.003;
+    params_obsrv.kinect.sigma_factor = 0.0014247;
+    params_obsrv.delta_time = 1. / 30.;
+    params_obsrv.use_custom_shaders = false;
+    params_obsrv.geometry_shader_file = "none";
+    auto sensor_builder = std::shared_ptr<SensorBuilder>(new SensorBuilder(object_model, camera_data, params_obsrv));
+
+    std::shared_ptr<dbot_amd::RbSensor<State>> sensor;
+    try {
+        sensor = sensor_builder->build();
+    } catch (const std::exception& e) {  // what the service node's catch sees
+        std::printf("NO_DEVICE %s\n", e.what());
+        return 0;
+    }
+    sensor->integrated_poses() = def;
+    sensor->reset();
+    sensor->set_observation(frame);
+    std::vector<int32_t> indices(n, 0);
+    auto ll1 = sensor->loglikes(deltas, indices, true);
+    std::printf("LL1");
+    for (double v : ll1) std::printf(" %.17g", v);
+    std::printf("\nIDX");
+    for (int32_t v : indices) std::printf(" %d", v);
+    for (int i = 0; i < n; ++i) indices[i] = n - 1 - i;
+    sensor->set_observation(frame);
+    auto ll2 = sensor->loglikes(deltas, indices, false);
+    std::printf("\nLL2");
+    for (double v : ll2) std::printf(" %.17g", v);
+    std::printf("\n");
+    // error path: wrong observation size must surface as std::runtime_error
+    try {
+        sensor->set_observation(std::vector<double>(3));
+        std::printf("ERR missing\n");
+    } catch (const std::runtime_error& e) {
+        std::printf("ERR ok\n");
+    }
+    return 0;
+}

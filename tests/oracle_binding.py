@@ -53,6 +53,7 @@ def load():
         lib.orc_loglikes.argtypes = [H, dp, ip, C.c_int32, C.c_int32, dp]
         lib.orc_get_occlusion.argtypes = [H, C.c_int32, fp]
         lib.orc_get_occlusion_now.argtypes = [H, C.c_int32, fp]
+        lib.orc_set_occlusion.argtypes = [H, C.c_int32, fp]
         lib.orc_render.restype = C.c_int32
         lib.orc_render.argtypes = [H, dp, fp]
         for f in (lib.orc_prob_visible, lib.orc_prob_occluded, lib.orc_propagate):

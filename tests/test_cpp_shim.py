@@ -1,0 +1,82 @@
+"""The C++ flavour of the plugin-surface mirror (include/dbot_amd/rb_sensor_builder.hpp),
+driven the way the reference's node builds and uses the sensor."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scenarios as sc
+from dbot_ros_amd import CameraData, ObjectModel, RbSensorBuilder, pose, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BIN = os.path.join(HERE, "cpp", "shim_check")
+
+
+def _build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "cpp")])
+
+
+def _scene(tmp_path):
+    rows, cols, n = 60, 80, 6
+    v1, f1 = synth.mesh_m1(level=2)
+    v2, f2 = synth.mesh_box12()
+    K = synth.camera_matrix(cols, rows)
+    rng = np.random.default_rng(3)
+    default = np.zeros(24)
+    default[0:3], default[3:6] = (-0.05, 0.0, 0.6), (0.2, -0.4, 0.1)
+    default[12:15], default[15:18] = (0.06, 0.01, 0.65), (0.5, 0.1, -0.3)
+    deltas = np.zeros((n, 24))
+    for b in range(2):
+        deltas[:, 12 * b:12 * b + 3] = rng.normal(0, 0.004, (n, 3))
+        deltas[:, 12 * b + 3:12 * b + 6] = rng.normal(0, 0.03, (n, 3))
+    # frame from the oracle's renderer at the default pose
+    om = ObjectModel([v1, v2], [f1, f2], center=True)
+    cam = CameraData(K, rows, cols)
+    P = RbSensorBuilder.Parameters(sample_count=n)
+    o = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    frame = synth.make_frame(o.render_depth(pose.compose_with_default(np.zeros((1, 24)), default, 2)[0]),
+                             rows, cols, rng).astype(np.float64)
+    path = tmp_path / "scene.txt"
+    with open(path, "w") as f:
+        f.write(f"{rows} {cols}\n" + " ".join(repr(float(x)) for x in K.ravel()) + "\n2\n")
+        for v, t in ((v1, f1), (v2, f2)):
+            f.write(f"{len(v)} {len(t)}\n" + " ".join(repr(float(x)) for x in v.ravel()) + "\n")
+            f.write(" ".join(str(int(x)) for x in t.ravel()) + "\n")
+        f.write(f"{n}\n" + " ".join(repr(float(x)) for x in default) + "\n")
+        for d in deltas:
+            f.write(" ".join(repr(float(x)) for x in d) + "\n")
+        f.write(" ".join("nan" if np.isnan(x) else repr(float(x)) for x in frame) + "\n")
+    return path, o, default, deltas, frame, n
+
+
+def test_cpp_shim_builds_and_fails_loudly_without_gpu(tmp_path):
+    _build()
+    from dbot_ros_amd import _capi
+    if _capi.load().rbs_device_count() > 0:
+        pytest.skip("GPU visible: covered by the gpu test")
+    path, *_ = _scene(tmp_path)
+    out = subprocess.run([BIN, str(path)], capture_output=True, text=True, check=True).stdout
+    assert out.startswith("NO_DEVICE") and "no CPU path" in out
+
+
+@pytest.mark.gpu
+def test_cpp_shim_matches_oracle(tmp_path, gpu_lib):
+    _build()
+    path, o, default, deltas, frame, n = _scene(tmp_path)
+    out = subprocess.run([BIN, str(path)], capture_output=True, text=True, check=True).stdout
+    lines = {l.split()[0]: l.split()[1:] for l in out.strip().splitlines()}
+    ll1 = np.array(lines["LL1"], dtype=np.float64)
+    ll2 = np.array(lines["LL2"], dtype=np.float64)
+    assert [int(x) for x in lines["IDX"]] == list(range(n))
+    assert lines["ERR"] == ["ok"]
+    poses = pose.compose_with_default(deltas, default, 2)
+    o.reset()
+    o.set_observation(frame)
+    idx = np.zeros(n, np.int32)
+    r1 = o.loglikes_poses(poses, idx, update=True)
+    o.set_observation(frame)
+    r2 = o.loglikes_poses(poses, np.arange(n - 1, -1, -1, dtype=np.int32), update=False)
+    for got, ref in ((ll1, r1), (ll2, r2)):
+        assert (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max() <= 1e-9
