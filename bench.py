@@ -90,9 +90,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from dbot_ros_amd import CameraData, ObjectModel, RbSensor, RbSensorBuilder, synth
-    mesh_fn = {"m1": synth.mesh_m1, "m2": synth.mesh_m2, "m3": synth.mesh_m3, "m4": synth.mesh_m4}[a.mesh]
-    v, f = mesh_fn()
-    om = ObjectModel([v], [f], center=True)
+    mesh_fns = {"m1": synth.mesh_m1, "m2": synth.mesh_m2, "m3": synth.mesh_m3, "m4": synth.mesh_m4,
+                "box12": synth.mesh_box12}
+    meshes = [mesh_fns[m]() for m in a.mesh.split(",")]
+    nb = len(meshes)
+    f = np.concatenate([t for _, t in meshes])
+    om = ObjectModel([v for v, _ in meshes], [t for _, t in meshes], center=True)
     cam = CameraData(synth.camera_matrix(a.cols, a.rows), a.rows, a.cols)
     n = a.particles
     P = RbSensorBuilder.Parameters(sample_count=n)
@@ -100,7 +103,7 @@ def main():
 
     # synthetic frame: the product's own render hook supplies the object's depth
     rng = np.random.default_rng(0)
-    truth = synth.truth_pose(1)
+    truth = synth.truth_pose(nb)
     frame = synth.make_frame(sensor.render_depth(truth), a.rows, a.cols, rng)
     prng = np.random.default_rng(1 + rank)
     poses = synth.particle_poses(truth, n, prng)

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 using rbs::DevParams;
@@ -41,6 +42,12 @@ struct rbs_handle {
     int* d_indices = nullptr;
     double* d_out = nullptr;
     int* d_rects = nullptr;     // [max_particles][4]
+    int* d_tiles = nullptr;     // [max_particles] tiles per particle
+    int* d_item_offset = nullptr; // [max_particles+1]
+    int* d_work_counter = nullptr;
+    double* d_partial = nullptr; // [partial_cap] per-item partial sums
+    size_t partial_cap = 0;
+    float* d_cluster_sphere = nullptr;
     float* d_render = nullptr;
     float* h_frame = nullptr;   // pinned staging
     hipStream_t stream = nullptr;
@@ -48,6 +55,7 @@ struct rbs_handle {
     hipEvent_t ev_fork = nullptr;
     int copy_blocks = 1 << 30;  // cap on the copy grid (one block per (particle, band) below it)
     int raster_blocks = 512;    // persistent raster grid: 2 per CU
+    const char* tile_override = nullptr;  // RBS_TILE env (tuning)
     // timing ring: HIP events around the whole call (on the launch stream) and around the copy
     // kernel (on the copy stream) for the last kRing loglikes calls
     static constexpr int kRing = 64;
@@ -126,13 +134,36 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.n = n;
     const int slot = (int)(h->calls % rbs_handle::kRing);
     h->ring_update[slot] = update;
+    // tile size: full 128x128 tiles when there are enough particles to fill the persistent
+    // grid, smaller tiles (more work items per particle) when there are few
+    const int tile = n >= 2 * h->raster_blocks ? 128 : 64;
+    P.tile_w = tile < 32 ? 32 : tile;
+    P.tile_h = tile;
+    if (const char* m = h->tile_override) { P.tile_w = std::max(32, std::atoi(m) / 32 * 32); P.tile_h = std::max(1, std::atoi(m)); }
+    const size_t tiles_max = (size_t)((h->cols + P.tile_w - 1) / P.tile_w + 1) * ((h->rows + P.tile_h - 1) / P.tile_h + 1);
+    const size_t need = (size_t)n * tiles_max;
+    if (need > h->partial_cap) {
+        RBS_HIP(h, hipStreamSynchronize(s));
+        RBS_HIP(h, hipStreamSynchronize(h->copy_stream));
+        (void)hipFree(h->d_partial);
+        h->d_partial = nullptr;
+        h->partial_cap = 0;
+        RBS_HIP(h, hipMalloc(&h->d_partial, sizeof(double) * need));
+        h->partial_cap = need;
+    }
+    P.rects = h->d_rects;
+    P.item_offset = h->d_item_offset;
+    P.work_counter = h->d_work_counter;
+    P.partial = h->d_partial;
     RBS_HIP(h, hipEventRecord(h->ev_start[slot], s));
     const dim3 block(rbs::kBlock);
-    P.rects = h->d_rects;
-    hipLaunchKernelGGL(rbs::rbs_rect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P,
-                       h->d_rects);
+    const dim3 pgrid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(256), 0, s, P, h->d_rects, h->d_tiles);
     RBS_HIP(h, hipGetLastError());
-    const dim3 rgrid((unsigned)std::min(n, h->raster_blocks));
+    hipLaunchKernelGGL(rbs::rbs_scan_kernel, dim3(1), dim3(1024), 0, s, h->d_tiles, h->d_item_offset, n,
+                       h->d_work_counter);
+    RBS_HIP(h, hipGetLastError());
+    const dim3 rgrid((unsigned)h->raster_blocks);
     if (update) {
         // fork: the copy kernel runs on the handle's second stream, concurrently with the
         // persistent raster kernel; join before anything later on `s`
@@ -148,11 +179,13 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             hipLaunchKernelGGL((rbs::rbs_copy_kernel<1>), cgrid, block, 0, h->copy_stream, P);
         RBS_HIP(h, hipGetLastError());
         RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
-        RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[slot], 0));
     } else {
         hipLaunchKernelGGL((rbs::rbs_raster_kernel<false>), rgrid, block, rbs::kSmemBytes, s, P);
         RBS_HIP(h, hipGetLastError());
     }
+    hipLaunchKernelGGL(rbs::rbs_reduce_kernel, pgrid, dim3(256), 0, s, P);
+    RBS_HIP(h, hipGetLastError());
+    if (update) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[slot], 0));
     RBS_HIP(h, hipEventRecord(h->ev_stop[slot], s));
     h->calls += 1;
     if (update) {
@@ -177,6 +210,11 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_indices);
     (void)hipFree(h->d_out);
     (void)hipFree(h->d_rects);
+    (void)hipFree(h->d_tiles);
+    (void)hipFree(h->d_item_offset);
+    (void)hipFree(h->d_work_counter);
+    (void)hipFree(h->d_partial);
+    (void)hipFree(h->d_cluster_sphere);
     (void)hipFree(h->d_render);
     if (h->h_frame) (void)hipHostFree(h->h_frame);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -257,22 +295,28 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     B.bands = copy_bands_for(h->rows, h->cols);
     B.band_rows = (h->rows + B.bands - 1) / B.bands;
 
-    // triangle soup (SoA) + bounding spheres
+    // triangle soup (SoA) + bounding spheres.  Per body the triangles are ordered along a
+    // Morton curve of their centroids and padded to a multiple of 64 with NaN triangles, so
+    // that every aligned run of 64 is a compact surface patch ("cluster") one wave rasterizes.
     long n_tri = 0;
     B.tri_begin[0] = 0;
     for (int b = 0; b < h->n_bodies; ++b) {
         if (cfg->vertex_counts[b] <= 0 || cfg->triangle_counts[b] < 0)
             return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("object %d: bad mesh counts", b));
-        n_tri += cfg->triangle_counts[b];
+        n_tri += ((long)cfg->triangle_counts[b] + 63) / 64 * 64;
         B.tri_begin[b + 1] = (int)n_tri;
     }
     for (int b = h->n_bodies; b < rbs::kMaxBodies; ++b) B.tri_begin[b + 1] = (int)n_tri;
+    if (n_tri > (1L << 30)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "too many triangles");
     B.n_tri = (int)n_tri;
-    std::vector<double> soup((size_t)9 * (n_tri > 0 ? n_tri : 1));
+    const size_t n_alloc = (size_t)(n_tri > 0 ? n_tri : 64);
+    std::vector<double> soup((size_t)9 * n_alloc, std::nan(""));
+    std::vector<float> cluster_sphere(4 * (n_alloc / 64), 0.f);
     size_t voff = 0, toff = 0;
     for (int b = 0; b < h->n_bodies; ++b) {
         const int nv = cfg->vertex_counts[b], nt = cfg->triangle_counts[b];
         const double* V = cfg->vertices + 3 * voff;
+        const int32_t* T = cfg->triangles + 3 * toff;
         double lo[3] = {V[0], V[1], V[2]}, hi[3] = {V[0], V[1], V[2]};
         for (int i = 0; i < nv; ++i)
             for (int c3 = 0; c3 < 3; ++c3) {
@@ -291,17 +335,62 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         B.sphere[b][0] = ctr[0]; B.sphere[b][1] = ctr[1]; B.sphere[b][2] = ctr[2];
         B.sphere[b][3] = std::sqrt(r2) * (1.0 + 1e-9) + 1e-12;
         for (int t = 0; t < nt; ++t)
-            for (int k = 0; k < 3; ++k) {
-                const int vi = cfg->triangles[3 * (toff + t) + k];
-                if (vi < 0 || vi >= nv)
+            for (int k = 0; k < 3; ++k)
+                if (T[3 * t + k] < 0 || T[3 * t + k] >= nv)
                     return fail(h, RBS_ERR_INVALID_ARGUMENT,
-                                fmt("object %d triangle %d: vertex index %d out of range", b, t, vi));
-                for (int c3 = 0; c3 < 3; ++c3)
-                    soup[(size_t)(3 * k + c3) * n_tri + toff + t] = V[3 * vi + c3];
+                                fmt("object %d triangle %d: vertex index %d out of range", b, t, T[3 * t + k]));
+        // Morton order of the triangle centroids (10 bits per axis over the body's bbox)
+        std::vector<std::pair<uint32_t, int>> order(nt);
+        const double ext[3] = {std::fmax(hi[0] - lo[0], 1e-300), std::fmax(hi[1] - lo[1], 1e-300),
+                               std::fmax(hi[2] - lo[2], 1e-300)};
+        auto spread = [](uint32_t v) {
+            v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu;
+            v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u; return v;
+        };
+        for (int t = 0; t < nt; ++t) {
+            uint32_t code = 0;
+            for (int c3 = 0; c3 < 3; ++c3) {
+                const double m = (V[3 * T[3 * t] + c3] + V[3 * T[3 * t + 1] + c3] + V[3 * T[3 * t + 2] + c3]) / 3.0;
+                const uint32_t q = (uint32_t)std::fmin(1023.0, std::fmax(0.0, (m - lo[c3]) / ext[c3] * 1023.0));
+                code |= spread(q) << c3;
             }
+            order[t] = {code, t};
+        }
+        std::stable_sort(order.begin(), order.end());
+        const size_t base = (size_t)B.tri_begin[b];
+        for (int j = 0; j < nt; ++j) {
+            const int t = order[j].second;
+            for (int k = 0; k < 3; ++k)
+                for (int c3 = 0; c3 < 3; ++c3)
+                    soup[(size_t)(3 * k + c3) * n_alloc + base + j] = V[3 * T[3 * t + k] + c3];
+        }
+        // bounding sphere of each cluster of 64 (centre = bbox centre of its vertices)
+        for (size_t c = base / 64; c < (size_t)B.tri_begin[b + 1] / 64; ++c) {
+            double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+            const size_t j0 = c * 64 - base, j1 = std::min<size_t>(j0 + 64, (size_t)nt);
+            for (size_t j = j0; j < j1; ++j)
+                for (int k = 0; k < 3; ++k)
+                    for (int c3 = 0; c3 < 3; ++c3) {
+                        const double x = soup[(size_t)(3 * k + c3) * n_alloc + base + j];
+                        clo[c3] = std::fmin(clo[c3], x); chi[c3] = std::fmax(chi[c3], x);
+                    }
+            double cc[3] = {0.5 * (clo[0] + chi[0]), 0.5 * (clo[1] + chi[1]), 0.5 * (clo[2] + chi[2])}, cr2 = 0.0;
+            for (size_t j = j0; j < j1; ++j)
+                for (int k = 0; k < 3; ++k) {
+                    double d2 = 0.0;
+                    for (int c3 = 0; c3 < 3; ++c3) {
+                        const double d = soup[(size_t)(3 * k + c3) * n_alloc + base + j] - cc[c3];
+                        d2 += d * d;
+                    }
+                    cr2 = std::fmax(cr2, d2);
+                }
+            for (int c3 = 0; c3 < 3; ++c3) cluster_sphere[4 * c + c3] = (float)cc[c3];
+            cluster_sphere[4 * c + 3] = (float)(std::sqrt(cr2) * 1.0001 + 1e-6);
+        }
         voff += nv;
         toff += nt;
     }
+    B.n_tri = (int)n_alloc;
 
     const size_t plane = (size_t)h->npx * sizeof(float);
     RBS_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -326,6 +415,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         RBS_HIP(h, hipGetDeviceProperties(&prop, h->device));
         h->raster_blocks = 2 * std::max(1, prop.multiProcessorCount);
         if (const char* m = std::getenv("RBS_RASTER_BLOCKS")) h->raster_blocks = std::max(1, std::atoi(m));
+        h->tile_override = std::getenv("RBS_TILE");
     }
     if (const char* m = std::getenv("RBS_BANDS")) {
         B.bands = std::max(1, std::atoi(m));
@@ -344,6 +434,13 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMalloc(&h->d_indices, sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_out, sizeof(double) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_rects, sizeof(int) * 4 * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_tiles, sizeof(int) * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_item_offset, sizeof(int) * ((size_t)h->max_particles + 1)));
+    RBS_HIP(h, hipMalloc(&h->d_work_counter, sizeof(int)));
+    RBS_HIP(h, hipMalloc(&h->d_cluster_sphere, sizeof(float) * cluster_sphere.size()));
+    RBS_HIP(h, hipMemcpy(h->d_cluster_sphere, cluster_sphere.data(), sizeof(float) * cluster_sphere.size(),
+                         hipMemcpyHostToDevice));
+    B.cluster_sphere = h->d_cluster_sphere;
     RBS_HIP(h, hipHostMalloc(&h->h_frame, plane, hipHostMallocDefault));
 
     // the raster / render kernels carve the LDS depth tile from dynamic shared memory
@@ -552,6 +649,8 @@ int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out)
     DevParams P = h->base;
     P.poses = h->d_poses;
     P.n = 1;
+    P.tile_w = 128;
+    P.tile_h = 128;
     hipLaunchKernelGGL(rbs::rbs_render_kernel, dim3(1), dim3(rbs::kBlock), rbs::kSmemBytes,
                        h->stream, P, h->d_render);
     RBS_HIP(h, hipGetLastError());

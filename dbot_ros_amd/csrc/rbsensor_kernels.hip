@@ -1,14 +1,18 @@
 // rbsensor_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the RbSensor likelihood evaluator.
 //
 // One RbSensor::loglikes(deltas, indices, update) call (made once per sampling block inside
-// tracker_->track, R:source/dbot_ros/object_tracker_ros.hpp:49) is three launches:
+// tracker_->track, R:source/dbot_ros/object_tracker_ros.hpp:49) is:
 //
-//   rbs_rect_kernel     one thread per particle: conservative screen rectangle of the bodies
-//                       (bounding spheres), x-aligned to 128 B.
-//   rbs_raster_kernel   PERSISTENT, 2 blocks per CU, each walking particles: software depth
-//                       rasterizer (triangles -> LDS depth tile, ds_min_u32 z-min), then the
-//                       per-pixel Kinect likelihood + occlusion posterior over the rectangle,
-//                       wave64 shuffle reduce -> one double per particle.  FP64 VALU bound.
+//   rbs_prep_kernel     per particle: conservative screen rectangle of the bodies (bounding
+//                       spheres, x-aligned to 128 B) and its split into <=128x128-px tiles;
+//                       exclusive scan of the tile counts -> (particle, tile) work items.
+//   rbs_raster_kernel   PERSISTENT, 2 blocks per CU, pulling work items from an atomic queue:
+//                       software depth rasterizer (wave64 = one 64-triangle cluster, culled
+//                       against the tile frustum; triangles -> LDS depth tile, ds_min_u32
+//                       z-min), then the per-pixel Kinect likelihood + occlusion posterior
+//                       over the tile, wave64 shuffle reduce -> one partial sum per item.
+//                       FP64 VALU bound.
+//   rbs_reduce_kernel   per particle: ordered sum of its tiles' partial sums -> out[i].
 //   rbs_copy_kernel     (update only, second stream, concurrent with the raster kernel) one
 //                       small block per (particle, row band): streams the parent's occlusion
 //                       plane into the child's slot outside the rectangle, advancing every
@@ -57,8 +61,10 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 struct DevParams {
     int rows, cols, npx;
     int n_bodies;
-    int n_tri;
-    int tri_begin[kMaxBodies + 1];
+    int n_tri;                     // soup length: every body padded to a multiple of 64
+    int tri_begin[kMaxBodies + 1]; // triangle range per body (multiples of 64)
+    const float* cluster_sphere;   // [n_tri/64][4] model-space bounding sphere of each cluster
+    int tile_w, tile_h;            // work-item tile: tile_w % 32 == 0, tile_w*tile_h <= kTilePx
     double fx, fy, cx, cy;
     double sphere[kMaxBodies][4];  // model-space bounding sphere: centre xyz, radius
     const double* soup;            // SoA [9][n_tri]: v0.xyz v1.xyz v2.xyz
@@ -74,7 +80,10 @@ struct DevParams {
     double* out;                   // [n]
     int n;
     int bands, band_rows;          // copy blocks per particle, rows per band
-    const int* rects;              // [n][4] screen rectangles written by rbs_rect_kernel
+    const int* rects;              // [n][4] screen rectangles (rbs_prep_kernel)
+    const int* item_offset;        // [n+1] exclusive scan of tiles per particle
+    int* work_counter;             // atomic queue head over the (particle, tile) items
+    double* partial;               // [items] partial log-likelihood per work item
 };
 
 struct Rect { int x0, y0, x1, y1; };
@@ -202,30 +211,73 @@ __device__ inline int body_of(const DevParams& P, int t)
     return b;
 }
 
+// Conservative float32 test: can any triangle of the cluster (model-space bounding sphere
+// c, rho) touch the pixel window [wx0,wx1) x [wy0,wy1)?  The window's four frustum planes
+// pass through the camera centre; the sphere is culled only if it lies entirely outside one
+// of them, with the window widened by 2 px and the radius by 1 mm + 0.1 % so float rounding
+// can never cull a cluster the binary64 rasterizer would have touched.  Wave-uniform.
+__device__ inline bool cluster_may_touch(const DevParams& P, const double* __restrict__ Rt,
+                                         const float* __restrict__ sph, int wx0, int wy0, int wx1,
+                                         int wy1)
+{
+    const float sx = sph[0], sy = sph[1], sz = sph[2];
+    const float rho = sph[3] * 1.001f + 1e-3f;
+    const float X = (float)Rt[0] * sx + (float)Rt[1] * sy + (float)Rt[2] * sz + (float)Rt[9];
+    const float Y = (float)Rt[3] * sx + (float)Rt[4] * sy + (float)Rt[5] * sz + (float)Rt[10];
+    const float Z = (float)Rt[6] * sx + (float)Rt[7] * sy + (float)Rt[8] * sz + (float)Rt[11];
+    if (!(Z - rho > 1e-3f)) return Z + rho > 0.0f;  // straddles the camera plane: keep unless fully behind
+    const float fx = (float)P.fx, fy = (float)P.fy, cx = (float)P.cx, cy = (float)P.cy;
+    // u >= a  <=>  fx*X + (cx-a)*Z >= 0  (Z > 0); signed distance to that plane = (.)/|n|
+    const float al = cx - ((float)wx0 - 2.0f), ar = cx - ((float)wx1 + 1.0f);
+    const float at = cy - ((float)wy0 - 2.0f), ab = cy - ((float)wy1 + 1.0f);
+    if (fx * X + al * Z < -rho * sqrtf(fx * fx + al * al)) return false;   // left of the window
+    if (fx * X + ar * Z > rho * sqrtf(fx * fx + ar * ar)) return false;    // right
+    if (fy * Y + at * Z < -rho * sqrtf(fy * fy + at * at)) return false;   // above
+    if (fy * Y + ab * Z > rho * sqrtf(fy * fy + ab * ab)) return false;    // below
+    return true;
+}
+
 // Rasterize every body of one particle into the LDS tile covering window
-// [wx0,wx1) x [wy0,wy1).  Small triangles: one lane each.  Triangles whose clipped bbox
-// exceeds kBigThresh pixels are queued in LDS and rasterized by the whole block, pixel-parallel.
+// [wx0,wx1) x [wy0,wy1).  One wave takes one 64-triangle cluster at a time (triangles were
+// ordered along a space-filling curve at create time, so a cluster is a compact surface
+// patch): wave-uniform frustum cull, then one lane per triangle.  Small triangles are
+// rasterized by their lane; triangles whose clipped bbox exceeds kBigThresh pixels are queued
+// in LDS and rasterized by the whole block, pixel-parallel.
 // Caller has cleared the tile and synchronised; on return the tile is complete and synchronised.
 __device__ inline void raster_window(const DevParams& P, const double* __restrict__ pose,
-                                     int wx0, int wy0, int wx1, int wy1, unsigned* tile,
+                                     int wx0, int wy0, int wx1, int wy1, bool cull, unsigned* tile,
                                      int* big, int* nbig)
 {
     const int tw = wx1 - wx0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x == 0) *nbig = 0;
     __syncthreads();
+    int taken = 0;  // surviving clusters so far: dealt round-robin to the block's waves
     for (int b = 0; b < P.n_bodies; ++b) {
         const double* Rt = pose + 12 * b;
-        for (int t = P.tri_begin[b] + (int)threadIdx.x; t < P.tri_begin[b + 1]; t += kBlock) {
-            Tri T;
-            if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, T)) continue;
-            const int bw = T.xhi - T.xlo + 1, bh = T.yhi - T.ylo + 1;
-            if (bw * bh > kBigThresh) {
-                const int slot = atomicAdd(nbig, 1);
-                if (slot < kBigCap) { big[slot] = t; continue; }
+        const int c0 = P.tri_begin[b] >> 6, c1 = P.tri_begin[b + 1] >> 6;
+        for (int base = c0; base < c1; base += 64) {
+            // 64 clusters culled at once, one per lane (every wave computes the same mask)
+            const int ci = base + lane;
+            const bool hit = ci < c1 && (!cull || cluster_may_touch(P, Rt, P.cluster_sphere + 4 * ci,
+                                                                    wx0, wy0, wx1, wy1));
+            unsigned long long mask = __ballot(hit);
+            while (mask) {
+                const int bit = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                if (((taken++) & (kBlock / 64 - 1)) != wave) continue;
+                const int t = ((base + bit) << 6) + lane;
+                Tri T;
+                if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, T)) continue;
+                const int bw = T.xhi - T.xlo + 1, bh = T.yhi - T.ylo + 1;
+                if (bw * bh > kBigThresh) {
+                    const int slot = atomicAdd(nbig, 1);
+                    if (slot < kBigCap) { big[slot] = t; continue; }
+                }
+                for (int row = T.ylo; row <= T.yhi; ++row)
+                    for (int col = T.xlo; col <= T.xhi; ++col)
+                        tri_pixel(T, col, row, tile, tw, wx0, wy0);
             }
-            for (int row = T.ylo; row <= T.yhi; ++row)
-                for (int col = T.xlo; col <= T.xhi; ++col)
-                    tri_pixel(T, col, row, tile, tw, wx0, wy0);
         }
     }
     __syncthreads();
@@ -308,60 +360,69 @@ __device__ inline double block_reduce_sum(double v, double* red)
     return s;
 }
 
-// ------------------------------------------------------------------ raster block
-template <bool UPDATE>
-__device__ inline void raster_eval(const DevParams& P, int particle, Rect r, unsigned char* smem)
+// ------------------------------------------------------------------ raster work item
+struct Smem {
+    unsigned* tile; int* big; double* red; int* nbig; int* item;
+};
+__device__ inline Smem carve(unsigned char* smem)
 {
-    unsigned* tile = reinterpret_cast<unsigned*>(smem);
-    int* big = reinterpret_cast<int*>(smem + sizeof(unsigned) * kTilePx);
-    double* red = reinterpret_cast<double*>(smem + sizeof(unsigned) * kTilePx + sizeof(int) * kBigCap);
-    int* nbig = reinterpret_cast<int*>(red + kBlock / 64);
+    Smem m;
+    m.tile = reinterpret_cast<unsigned*>(smem);
+    m.big = reinterpret_cast<int*>(smem + sizeof(unsigned) * kTilePx);
+    m.red = reinterpret_cast<double*>(smem + sizeof(unsigned) * kTilePx + sizeof(int) * kBigCap);
+    m.nbig = reinterpret_cast<int*>(m.red + kBlock / 64);
+    m.item = m.nbig + 1;
+    return m;
+}
+
+// One (particle, tile) work item: rasterize the tile window, evaluate its pixels, return the
+// block-reduced partial log-likelihood (valid in thread 0).
+template <bool UPDATE>
+__device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect r, int tile_id,
+                                          const Smem& m)
+{
+    const int tiles_x = (r.x1 - r.x0 + P.tile_w - 1) / P.tile_w;
+    const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
+    const int wx0 = r.x0 + tx * P.tile_w, wy0 = r.y0 + ty * P.tile_h;
+    const int wx1 = min(r.x1, wx0 + P.tile_w), wy1 = min(r.y1, wy0 + P.tile_h);
+    const int tw = wx1 - wx0, npx = tw * (wy1 - wy0);
+    const bool whole = (wx0 == r.x0 && wy0 == r.y0 && wx1 == r.x1 && wy1 == r.y1);
 
     const double* pose = P.poses + (size_t)particle * 12 * P.n_bodies;
     const int parent = P.indices[particle];
     const float* __restrict__ src = P.occ_src + (size_t)parent * P.npx;
     float* __restrict__ dst = UPDATE ? P.occ_dst + (size_t)particle * P.npx : nullptr;
 
-    double ll = 0.0;
-    const int rw = r.x1 - r.x0;
-    if (rw > 0) {
-        const int chunk_rows = kTilePx / rw;
-        for (int y = r.y0; y < r.y1; y += chunk_rows) {
-            const int ch = min(chunk_rows, r.y1 - y);
-            const int npx = rw * ch;
-            for (int p = threadIdx.x; p < npx; p += kBlock) tile[p] = kInfBits;
-            __syncthreads();
-            raster_window(P, pose, r.x0, y, r.x1, y + ch, tile, big, nbig);
+    for (int p = threadIdx.x; p < npx; p += kBlock) m.tile[p] = kInfBits;
+    __syncthreads();
+    // a rectangle that is a single tile was sized from the same spheres: nothing to cull
+    raster_window(P, pose, wx0, wy0, wx1, wy1, !whole || P.n_bodies > 1, m.tile, m.big, m.nbig);
 
-            for (int p = threadIdx.x; p < npx; p += kBlock) {
-                const int lr = p / rw;
-                const int gi = (y + lr) * P.cols + r.x0 + (p - lr * rw);
-                const unsigned dbits = tile[p];
-                if (UPDATE) {
-                    float occ = fmaf(P.alpha, src[gi], P.beta);
-                    if (dbits != kInfBits) {
-                        const float o = P.frame[gi];
-                        if (isfinite(o)) {
-                            float post;
-                            ll += pixel_loglik(P, gi, o, __uint_as_float(dbits), occ, post);
-                            occ = post;
-                        }
-                    }
-                    dst[gi] = occ;
-                } else if (dbits != kInfBits) {
-                    const float o = P.frame[gi];
-                    if (isfinite(o)) {
-                        float post;
-                        ll += pixel_loglik(P, gi, o, __uint_as_float(dbits),
-                                           fmaf(P.alpha, src[gi], P.beta), post);
-                    }
+    double ll = 0.0;
+    for (int p = threadIdx.x; p < npx; p += kBlock) {
+        const int lr = p / tw;
+        const int gi = (wy0 + lr) * P.cols + wx0 + (p - lr * tw);
+        const unsigned dbits = m.tile[p];
+        if (UPDATE) {
+            float occ = fmaf(P.alpha, src[gi], P.beta);
+            if (dbits != kInfBits) {
+                const float o = P.frame[gi];
+                if (isfinite(o)) {
+                    float post;
+                    ll += pixel_loglik(P, gi, o, __uint_as_float(dbits), occ, post);
+                    occ = post;
                 }
             }
-            __syncthreads();
+            dst[gi] = occ;
+        } else if (dbits != kInfBits) {
+            const float o = P.frame[gi];
+            if (isfinite(o)) {
+                float post;
+                ll += pixel_loglik(P, gi, o, __uint_as_float(dbits), fmaf(P.alpha, src[gi], P.beta), post);
+            }
         }
     }
-    const double total = block_reduce_sum(ll, red);
-    if (threadIdx.x == 0) P.out[particle] = total;
+    return block_reduce_sum(ll, m.red);
 }
 
 // ------------------------------------------------------------------ copy block
@@ -430,30 +491,88 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
 }
 
 // ------------------------------------------------------------------ kernels
-// One thread per particle: the screen rectangle both the raster and the copy kernel use.
-__global__ void rbs_rect_kernel(const DevParams P, int* __restrict__ rects)
+// One thread per particle: the screen rectangle both the raster and the copy kernel use, and
+// the number of tiles it splits into.
+__global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int* __restrict__ tiles)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
     const Rect r = particle_rect(P, P.poses + (size_t)i * 12 * P.n_bodies);
     reinterpret_cast<int4*>(rects)[i] = make_int4(r.x0, r.y0, r.x1, r.y1);
+    const int tx = (r.x1 - r.x0 + P.tile_w - 1) / P.tile_w, ty = (r.y1 - r.y0 + P.tile_h - 1) / P.tile_h;
+    tiles[i] = max(1, tx * ty);   // an empty rectangle still owns one (empty) item
+}
+
+// Single block: exclusive scan tiles[0..n) -> offset[0..n]; resets the work queue.
+__global__ __launch_bounds__(1024) void rbs_scan_kernel(const int* __restrict__ tiles,
+                                                         int* __restrict__ offset, int n,
+                                                         int* __restrict__ work_counter)
+{
+    __shared__ int part[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += tiles[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+        const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (int i = lo; i < hi; ++i) { offset[i] = run; run += tiles[i]; }
+    if (threadIdx.x == 1023) offset[n] = part[1023];
+    if (threadIdx.x == 0) *work_counter = 0;
 }
 
 #ifndef RBS_RASTER_MINWAVES
 #define RBS_RASTER_MINWAVES 1
 #endif
+// Persistent: a fixed number of raster blocks per CU keeps its LDS/VGPR share for the whole
+// launch (never starved by the many small copy blocks) and pulls (particle, tile) items from
+// an atomic queue.
 template <bool UPDATE>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel(const DevParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // persistent: a fixed number of raster blocks per CU keeps its LDS/VGPR share for the
-    // whole launch (they are never starved by the many small copy blocks) and walks particles
-    for (int particle = (int)blockIdx.x; particle < P.n; particle += (int)gridDim.x) {
+    const Smem m = carve(smem);
+    const int total = P.item_offset[P.n];
+    for (;;) {
+        if (threadIdx.x == 0) *m.item = atomicAdd(P.work_counter, 1);
+        __syncthreads();
+        const int item = *m.item;
+        if (item >= total) break;
+        // particle owning this item: largest i with item_offset[i] <= item (64-ary search, wave-parallel)
+        int lo = 0, hi = P.n;
+        const int lane = threadIdx.x & 63;
+        while (hi - lo > 1) {
+            const int step = (hi - lo + 63) >> 6;
+            const int idx = lo + lane * step;
+            const bool le = idx < hi && P.item_offset[idx] <= item;
+            const int k = __popcll(__ballot(le));   // probes are sorted: the first k lanes are true
+            lo = lo + (k - 1) * step;
+            hi = min(hi, lo + step);
+        }
+        const int particle = lo;
         const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
         const Rect r = {q.x, q.y, q.z, q.w};
-        raster_eval<UPDATE>(P, particle, r, smem);
+        double part = 0.0;
+        if (r.x1 > r.x0) part = raster_eval_tile<UPDATE>(P, particle, r, item - P.item_offset[particle], m);
+        if (threadIdx.x == 0) P.partial[item] = part;
         __syncthreads();
     }
+}
+
+// One thread per particle: ordered (deterministic) sum of its work items' partial sums.
+__global__ void rbs_reduce_kernel(const DevParams P)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    double s = 0.0;
+    for (int k = P.item_offset[i]; k < P.item_offset[i + 1]; ++k) s += P.partial[k];
+    P.out[i] = s;
 }
 
 template <int VEC>
@@ -473,25 +592,22 @@ __global__ __launch_bounds__(kBlock) void rbs_copy_kernel(const DevParams P)
 __global__ __launch_bounds__(kBlock) void rbs_render_kernel(const DevParams P, float* out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned* tile = reinterpret_cast<unsigned*>(smem);
-    int* big = reinterpret_cast<int*>(smem + sizeof(unsigned) * kTilePx);
-    int* nbig = big + kBigCap;
+    const Smem m = carve(smem);
     const Rect r = particle_rect(P, P.poses);
-    const int rw = r.x1 - r.x0;
-    if (rw <= 0) return;
-    const int chunk_rows = kTilePx / rw;
-    for (int y = r.y0; y < r.y1; y += chunk_rows) {
-        const int ch = min(chunk_rows, r.y1 - y);
-        const int npx = rw * ch;
-        for (int p = threadIdx.x; p < npx; p += kBlock) tile[p] = kInfBits;
-        __syncthreads();
-        raster_window(P, P.poses, r.x0, y, r.x1, y + ch, tile, big, nbig);
-        for (int p = threadIdx.x; p < npx; p += kBlock) {
-            const int lr = p / rw;
-            out[(y + lr) * P.cols + r.x0 + (p - lr * rw)] = __uint_as_float(tile[p]);
+    if (r.x1 <= r.x0) return;
+    for (int wy0 = r.y0; wy0 < r.y1; wy0 += P.tile_h)
+        for (int wx0 = r.x0; wx0 < r.x1; wx0 += P.tile_w) {
+            const int wx1 = min(r.x1, wx0 + P.tile_w), wy1 = min(r.y1, wy0 + P.tile_h);
+            const int tw = wx1 - wx0, npx = tw * (wy1 - wy0);
+            for (int p = threadIdx.x; p < npx; p += kBlock) m.tile[p] = kInfBits;
+            __syncthreads();
+            raster_window(P, P.poses, wx0, wy0, wx1, wy1, true, m.tile, m.big, m.nbig);
+            for (int p = threadIdx.x; p < npx; p += kBlock) {
+                const int lr = p / tw;
+                out[(wy0 + lr) * P.cols + wx0 + (p - lr * tw)] = __uint_as_float(m.tile[p]);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
 }
 
 __global__ void rbs_fill_kernel(float* __restrict__ p, size_t n, float v)
