@@ -1,0 +1,69 @@
+"""End-to-end tracker loop (transition -> loglikes -> weights -> KL -> resample -> mean) around
+the sensor: tracks a synthetic object moving 2 mm and 1 degree per frame."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scenarios as sc
+from dbot_ros_amd import RbSensor, pose, synth
+from dbot_ros_amd.tracker import (ObjectTransitionBuilder, ParticleTracker, ParticleTrackerBuilder)
+
+
+def _truth_state(frame, centers):
+    """State (camera-frame pose of the ORIGINAL mesh frame) of the synthetic truth."""
+    Rt = synth.truth_pose(1, frame=frame)[0]
+    R, t = Rt[:9].reshape(3, 3), Rt[9:]
+    s = np.zeros(12)
+    s[3:6] = pose.matrix_to_rotvec(R)
+    s[0:3] = t - R @ centers[0]   # truth_pose places the CENTRED mesh
+    return s
+
+
+def _run(sensor, om, cam, n, frames_n, renderer, seed=0):
+    tp = ParticleTrackerBuilder.Parameters(evaluation_count=n, max_kl_divergence=2.0)
+    tr = ParticleTracker(ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters()).build(), sensor, om, tp,
+                         np.random.default_rng(seed))
+    init = _truth_state(0, om.centers)
+    init[0:3] += [0.004, -0.003, 0.005]      # start a few mm off
+    tr.initialize([init])
+    rng = np.random.default_rng(100 + seed)
+    errs = []
+    for k in range(1, frames_n + 1):
+        truth = synth.truth_pose(1, frame=k)
+        frame = synth.make_frame(renderer(truth), cam.rows, cam.cols, rng, occluder=False)
+        est = tr.track(frame)
+        ref = _truth_state(k, om.centers)
+        dR = pose.rotvec_to_matrix(est[3:6]).T @ pose.rotvec_to_matrix(ref[3:6])
+        errs.append((np.linalg.norm(est[0:3] - ref[0:3]), np.linalg.norm(pose.matrix_to_rotvec(dR))))
+    return np.array(errs), tr
+
+
+def test_transition_is_a_velocity_random_walk():
+    p = ObjectTransitionBuilder.Parameters(part_count=2)
+    t = ObjectTransitionBuilder(p).build()
+    s = np.zeros((3, 24))
+    s[:, 6:9] = 0.01
+    n = np.ones((3, 6))
+    out = t.apply(s, n, 0)
+    assert np.allclose(out[:, 6:9], 0.8 * 0.01 + 0.0025) and np.allclose(out[:, 0:3], 0.8 * 0.01 + 0.0025)
+    assert np.allclose(out[:, 9:12], 0.02) and np.allclose(out[:, 3:6], 0.02)
+    assert np.array_equal(out[:, 12:], s[:, 12:]) and np.array_equal(s[:, 0:3], np.zeros((3, 3)))
+
+
+def test_tracker_follows_the_object_cpu_oracle():
+    n = 96
+    om, cam, P = sc.make_scene(("m1_l2",), 80, 60, max_particles=n)
+    o = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
+    errs, tr = _run(o, om, cam, n, 8, o.render_depth)
+    assert errs[-3:, 0].max() < 0.012 and errs[-3:, 1].max() < 0.2, errs
+    assert np.isfinite(errs).all()
+
+
+@pytest.mark.gpu
+def test_tracker_follows_the_object_gpu(gpu_lib):
+    n = 2000
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        errs, tr = _run(g, om, cam, n, 20, g.render_depth)
+    assert errs[-5:, 0].max() < 0.004 and errs[-5:, 1].max() < 0.06, errs
+    assert tr.n_resamplings >= 1
