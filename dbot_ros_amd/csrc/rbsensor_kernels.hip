@@ -51,6 +51,7 @@ constexpr int kTilePx = RBS_TILE_PX;       // LDS depth tile (u32 per pixel)
 constexpr int kBigCap = 1024;              // triangles deferred to the cooperative path per chunk
 constexpr int kBigThresh = RBS_BIG_THRESH; // bbox pixels above which a triangle is "big"
 constexpr int kCopyUnroll = RBS_COPY_UNROLL; // float4 loads in flight per lane in copy blocks
+constexpr int kEvalQueue = 128;             // per-wave queue of covered pixels awaiting evaluation
 constexpr unsigned kInfBits = 0x7f800000u;
 constexpr int kMaxBodies = 16;
 constexpr double kMaxDepth = 6.0;    // KinectPixelModel max_depth
@@ -362,7 +363,7 @@ __device__ inline double block_reduce_sum(double v, double* red)
 
 // ------------------------------------------------------------------ raster work item
 struct Smem {
-    unsigned* tile; int* big; double* red; int* nbig; int* item;
+    unsigned* tile; int* big; double* red; int* nbig; int* item; int4* evalq;
 };
 __device__ inline Smem carve(unsigned char* smem)
 {
@@ -372,6 +373,7 @@ __device__ inline Smem carve(unsigned char* smem)
     m.red = reinterpret_cast<double*>(smem + sizeof(unsigned) * kTilePx + sizeof(int) * kBigCap);
     m.nbig = reinterpret_cast<int*>(m.red + kBlock / 64);
     m.item = m.nbig + 1;
+    m.evalq = reinterpret_cast<int4*>(m.nbig + 4);   // 16 B aligned: all carve sizes are multiples of 16
     return m;
 }
 
@@ -398,29 +400,58 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     // a rectangle that is a single tile was sized from the same spheres: nothing to cull
     raster_window(P, pose, wx0, wy0, wx1, wy1, !whole || P.n_bodies > 1, m.tile, m.big, m.nbig);
 
+    // Pixel pass.  Only ~1/3 of a tile's pixels are covered by the object, in runs that leave
+    // most lanes of a wave idle in the expensive likelihood code, so each wave compacts its
+    // covered+observed pixels into an LDS queue and evaluates them 64 at a time with full lanes.
+    // Everything else (the occlusion process on uncovered pixels) is finished in the scan.
     double ll = 0.0;
-    for (int p = threadIdx.x; p < npx; p += kBlock) {
-        const int lr = p / tw;
-        const int gi = (wy0 + lr) * P.cols + wx0 + (p - lr * tw);
-        const unsigned dbits = m.tile[p];
-        if (UPDATE) {
-            float occ = fmaf(P.alpha, src[gi], P.beta);
-            if (dbits != kInfBits) {
-                const float o = P.frame[gi];
-                if (isfinite(o)) {
-                    float post;
-                    ll += pixel_loglik(P, gi, o, __uint_as_float(dbits), occ, post);
-                    occ = post;
-                }
-            }
-            dst[gi] = occ;
-        } else if (dbits != kInfBits) {
-            const float o = P.frame[gi];
-            if (isfinite(o)) {
-                float post;
-                ll += pixel_loglik(P, gi, o, __uint_as_float(dbits), fmaf(P.alpha, src[gi], P.beta), post);
-            }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int4* q = m.evalq + wave * kEvalQueue;
+    int qn = 0;
+    for (int p0 = wave * 64; p0 < npx; p0 += kBlock) {
+        const int p = p0 + lane;
+        const bool valid = p < npx;
+        int gi = 0;
+        unsigned dbits = kInfBits;
+        float prior = 0.f, o = 0.f;
+        if (valid) {
+            const int lr = p / tw;
+            gi = (wy0 + lr) * P.cols + wx0 + (p - lr * tw);
+            dbits = m.tile[p];
         }
+        const bool covered = dbits != kInfBits;
+        if (valid && (UPDATE || covered)) prior = fmaf(P.alpha, src[gi], P.beta);
+        if (covered) o = P.frame[gi];
+        const bool active = covered && isfinite(o);
+        if (UPDATE && valid && !active) dst[gi] = prior;
+        const unsigned long long mask = __ballot(active);
+        if (active) {
+            const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            q[pos] = make_int4(gi, (int)dbits, __float_as_int(prior), __float_as_int(o));
+        }
+        qn += __popcll(mask);
+        if (qn >= 64) {
+            __builtin_amdgcn_wave_barrier();
+            const int4 e = q[lane];
+            float post;
+            ll += pixel_loglik(P, e.x, __int_as_float(e.w), __uint_as_float((unsigned)e.y),
+                               __int_as_float(e.z), post);
+            if (UPDATE) dst[e.x] = post;
+            qn -= 64;
+            int4 carry = make_int4(0, 0, 0, 0);
+            if (lane < qn) carry = q[64 + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < qn) q[lane] = carry;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < qn) {
+        const int4 e = q[lane];
+        float post;
+        ll += pixel_loglik(P, e.x, __int_as_float(e.w), __uint_as_float((unsigned)e.y),
+                           __int_as_float(e.z), post);
+        if (UPDATE) dst[e.x] = post;
     }
     return block_reduce_sum(ll, m.red);
 }
@@ -657,7 +688,8 @@ __global__ void rbs_fill_kernel(float* __restrict__ p, size_t n, float v)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
-constexpr size_t kSmemBytes =
-    sizeof(unsigned) * kTilePx + sizeof(int) * kBigCap + sizeof(double) * (kBlock / 64) + 16;
+constexpr size_t kSmemBytes = sizeof(unsigned) * kTilePx + sizeof(int) * kBigCap +
+                              sizeof(double) * (kBlock / 64) + 16 +
+                              sizeof(int4) * (kBlock / 64) * kEvalQueue;
 
 }  // namespace rbs
