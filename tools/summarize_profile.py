@@ -59,7 +59,7 @@ if os.path.exists(cal_f):
                               "fetch_correction": fetch_scale, "write_correction": write_scale}
 total = 0.0
 for (k, c), v in sorted(fetch.items()):
-    if "rbs_copy_kernel" in k or "rbs_raster_kernel" in k or "rbs_rect_kernel" in k:
+    if any(t in k for t in ("rbs_copy_kernel", "rbs_copy_rows_kernel", "rbs_raster_kernel", "rbs_prep_kernel", "rbs_scan_kernel", "rbs_reduce_kernel")):
         wv = write.get((k, "WRITE_SIZE"), 0.0)
         # the x2 fetch correction is calibrated for 16 B/lane streams (the copy kernel); the raster
         # kernel's narrow reads are uncalibrated and reported with the same factor as an upper bound
