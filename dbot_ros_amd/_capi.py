@@ -22,7 +22,8 @@ RBS_ERR_UNSUPPORTED = -5
 # every symbol include/rbsensor_mi355x.h declares
 EXPORTS = (
     "rbs_abi_version", "rbs_device_count", "rbs_create", "rbs_destroy", "rbs_last_error",
-    "rbs_reset", "rbs_set_observation", "rbs_set_observation_f32", "rbs_loglikes",
+    "rbs_reset", "rbs_set_observation", "rbs_set_observation_f32",
+    "rbs_set_observation_native_f32", "rbs_get_observation", "rbs_loglikes",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_render_depth",
     "rbs_last_kernel_ms", "rbs_timing_summary",
@@ -90,6 +91,10 @@ def load():
     lib.rbs_set_observation.argtypes = [H, dp, C.c_size_t]
     lib.rbs_set_observation_f32.restype = C.c_int32
     lib.rbs_set_observation_f32.argtypes = [H, fp, C.c_size_t]
+    lib.rbs_set_observation_native_f32.restype = C.c_int32
+    lib.rbs_set_observation_native_f32.argtypes = [H, fp, C.c_int32, C.c_int32, C.c_int32]
+    lib.rbs_get_observation.restype = C.c_int32
+    lib.rbs_get_observation.argtypes = [H, fp]
     lib.rbs_loglikes.restype = C.c_int32
     lib.rbs_loglikes.argtypes = [H, dp, ip, C.c_int32, C.c_int32, dp]
     lib.rbs_loglikes_device.restype = C.c_int32

@@ -50,6 +50,9 @@ struct rbs_handle {
     float* d_cluster_sphere = nullptr;
     float* d_render = nullptr;
     float* h_frame = nullptr;   // pinned staging
+    float* h_native = nullptr;  // pinned staging for full-resolution frames
+    float* d_native = nullptr;
+    size_t native_cap = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // the copy kernel runs here, beside the raster kernel
     hipEvent_t ev_fork = nullptr;
@@ -230,6 +233,8 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_cluster_sphere);
     (void)hipFree(h->d_render);
     if (h->h_frame) (void)hipHostFree(h->h_frame);
+    if (h->h_native) (void)hipHostFree(h->h_native);
+    (void)hipFree(h->d_native);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int i = 0; i < rbs_handle::kRing; ++i) {
         if (h->ev_start[i]) (void)hipEventDestroy(h->ev_start[i]);
@@ -553,6 +558,48 @@ int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n)
     std::memcpy(h->h_frame, depth, n * sizeof(float));
     if (int32_t rc = upload_frame(h)) return rc;
     h->pending_frames += 1;
+    return RBS_OK;
+}
+
+int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32_t width,
+                                       int32_t height, int32_t f)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!native || f <= 0 || width <= 0 || height <= 0 || height / f != h->rows || width / f != h->cols)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT,
+                    fmt("set_observation_native: %dx%d / %d does not give the evaluated %dx%d", width,
+                        height, f, h->cols, h->rows));
+    RBS_HIP(h, hipSetDevice(h->device));
+    RBS_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer reuse
+    const size_t n = (size_t)width * height;
+    if (n > h->native_cap) {
+        if (h->h_native) (void)hipHostFree(h->h_native);
+        (void)hipFree(h->d_native);
+        h->h_native = nullptr; h->d_native = nullptr; h->native_cap = 0;
+        RBS_HIP(h, hipHostMalloc(&h->h_native, n * sizeof(float), hipHostMallocDefault));
+        RBS_HIP(h, hipMalloc(&h->d_native, n * sizeof(float)));
+        h->native_cap = n;
+    }
+    std::memcpy(h->h_native, native, n * sizeof(float));
+    RBS_HIP(h, hipMemcpyAsync(h->d_native, h->h_native, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(rbs::rbs_subsample_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0,
+                       h->stream, h->d_native, width, f, h->d_frame, h->rows, h->cols);
+    RBS_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0,
+                       h->stream, h->d_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms,
+                       h->base.sf, h->base.lambda);
+    RBS_HIP(h, hipGetLastError());
+    h->pending_frames += 1;
+    return RBS_OK;
+}
+
+int32_t rbs_get_observation(rbs_handle* h, float* out)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!out) return fail(h, RBS_ERR_INVALID_ARGUMENT, "get_observation: null pointer");
+    RBS_HIP(h, hipSetDevice(h->device));
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    RBS_HIP(h, hipMemcpy(out, h->d_frame, sizeof(float) * h->npx, hipMemcpyDeviceToHost));
     return RBS_OK;
 }
 

@@ -208,6 +208,21 @@ class RbSensor:
             self._check(self._lib.rbs_set_observation(
                 self._h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size))
 
+    def set_observation_native(self, image, downsampling_factor):
+        """image: the driver's full-resolution float32 frame [height, width]; sub-sampled on the
+        device by the reference's rule eval(r, c) = native(r*f, c*f)."""
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        if img.ndim != 2:
+            raise RbSensorError(_capi.RBS_ERR_INVALID_ARGUMENT, "native frame must be 2-D [height, width]")
+        self._check(self._lib.rbs_set_observation_native_f32(
+            self._h, img.ctypes.data_as(C.POINTER(C.c_float)), img.shape[1], img.shape[0],
+            int(downsampling_factor)))
+
+    def get_observation(self):
+        out = np.empty(self.rows * self.cols, dtype=np.float32)
+        self._check(self._lib.rbs_get_observation(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     def loglikes(self, deltas, indices, update=False):
         """deltas: [n, n_bodies*12] state deltas around integrated_poses; indices: int32[n],
         modified in place to identity when update is true. Returns float64[n]."""

@@ -90,6 +90,17 @@ int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n);
 /* Same, from the float32 pixels the camera driver delivers (skips the double round trip). */
 int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n);
 
+/* Frame ingest straight from the camera driver: `native` is the full-resolution
+ * float32 image (width x height, metres, NaN = no reading); the evaluated image is its
+ * sub-sampling by the reference's rule, eval(row, col) = native(row*f, col*f) with
+ * rows = height/f, cols = width/f (ri::to_eigen_vector, R:source/dbot_ros/util/ros_interface.h:152-168),
+ * done on the device after one H2D copy -- replaces the reference's three host copies per frame
+ * (R:source/dbot_ros/object_tracker_ros.hpp:82,119, ros_interface.h:156-165). */
+int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32_t width,
+                                       int32_t height, int32_t downsampling_factor);
+/* Current evaluated observation -> host float[rows*cols] (inspection). */
+int32_t rbs_get_observation(rbs_handle* h, float* out);
+
 /* poses:   [n][n_objects][12] doubles, R (row-major 3x3) then t: absolute camera-frame pose
  *          of each body (delta composed with the default pose by the caller).
  * indices: [n] in: occlusion slot each particle inherits from; out (update != 0): identity.

@@ -353,3 +353,35 @@ def test_two_rank_sharding_on_one_gpu(gpu_lib, tmp_path):
     r = subprocess.run([sys.executable, script, str(port)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SHARDED_OK" in r.stdout
+
+
+@pytest.mark.parametrize("factor,width,height", [(8, 640, 480), (1, 160, 120), (3, 322, 241)])
+def test_native_frame_ingest_subsampling(gpu_lib, factor, width, height):
+    """SURVEY f3: eval(row, col) = native(row*f, col*f), rows = height//f, cols = width//f
+    (ri::to_eigen_vector, R:source/dbot_ros/util/ros_interface.h:152-168); bit-exact."""
+    from dbot_ros_amd import CameraData
+    rows, cols = height // factor, width // factor
+    om, _, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=4)
+    K = synth.camera_matrix(width, height)
+    cam = CameraData.from_native(K, width, height, factor)
+    assert (cam.rows, cam.cols) == (rows, cols)
+    rng = np.random.default_rng(1)
+    native = rng.uniform(0.4, 2.0, size=(height, width)).astype(np.float32)
+    native[rng.random(native.shape) < 0.05] = np.nan
+    ref = native[: rows * factor: factor, : cols * factor: factor]
+    assert ref.shape == (rows, cols)
+    with RbSensor(om, cam, P, max_particles=4) as g:
+        g.reset()
+        g.set_observation_native(native, factor)
+        got = g.get_observation().reshape(rows, cols)
+        assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(ref).view(np.uint32))
+        with pytest.raises(RbSensorError):
+            g.set_observation_native(native[:-factor * 2], factor)
+        # the same frame through the double-precision entry point gives the same likelihoods
+        poses = synth.particle_poses(synth.truth_pose(1), 4, rng)
+        i1, i2 = np.zeros(4, np.int32), np.zeros(4, np.int32)
+        a = g.loglikes_poses(poses, i1, update=False)
+        g.reset()  # same elapsed time (one frame) for the second evaluation
+        g.set_observation(ref.astype(np.float64).ravel())
+        b = g.loglikes_poses(poses, i2, update=False)
+        assert np.array_equal(a, b)
