@@ -27,7 +27,19 @@ EXPORTS = (
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_render_depth",
     "rbs_last_kernel_ms", "rbs_timing_summary",
+    "rbs_tracker_create", "rbs_tracker_destroy", "rbs_tracker_initialize", "rbs_tracker_track",
+    "rbs_tracker_get",
 )
+
+
+class RbsTrackerParams(C.Structure):
+    _fields_ = [
+        ("linear_sigma", C.c_double * 3),
+        ("angular_sigma", C.c_double * 3),
+        ("velocity_factor", C.c_double),
+        ("max_kl_divergence", C.c_double),
+        ("n_particles", C.c_int32),
+    ]
 
 
 class RbsConfig(C.Structure):
@@ -117,5 +129,15 @@ def load():
     lib.rbs_timing_summary.restype = C.c_int32
     lib.rbs_timing_summary.argtypes = [H, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                        C.POINTER(C.c_int32)]
+    lib.rbs_tracker_create.restype = C.c_int32
+    lib.rbs_tracker_create.argtypes = [H, C.POINTER(RbsTrackerParams), C.POINTER(H)]
+    lib.rbs_tracker_destroy.restype = None
+    lib.rbs_tracker_destroy.argtypes = [H]
+    lib.rbs_tracker_initialize.restype = C.c_int32
+    lib.rbs_tracker_initialize.argtypes = [H, dp]
+    lib.rbs_tracker_track.restype = C.c_int32
+    lib.rbs_tracker_track.argtypes = [H, fp, dp, dp, C.c_uint64, dp, ip]
+    lib.rbs_tracker_get.restype = C.c_int32
+    lib.rbs_tracker_get.argtypes = [H, dp, dp, ip]
     _lib = lib
     return lib

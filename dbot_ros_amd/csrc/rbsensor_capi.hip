@@ -8,6 +8,7 @@
 //   poses / indices / out   per-call staging for the host-pointer API
 // There is no CPU path in this library.
 #include "rbsensor_kernels.hip"
+#include "rbsensor_tracker.hip"
 
 #include "../../include/rbsensor_mi355x.h"
 
@@ -754,6 +755,166 @@ int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float*
     *call_ms = (float)(tot / (double)n);
     *copy_kernel_ms = n_copy ? (float)(cpy / n_copy) : 0.f;
     *n_used = (int32_t)n;
+    return RBS_OK;
+}
+
+// ---------------------------------------------------------------------------- device tracker
+}  // extern "C"
+
+struct rbs_tracker {
+    rbs_handle* s = nullptr;
+    rbt::TrackerDev T{};
+    std::vector<void*> allocs;
+    double* d_normals = nullptr;   // staging for host-supplied randomness
+    double* d_uniforms = nullptr;
+    std::string err;
+};
+
+namespace {
+int32_t tfail(rbs_tracker* t, int32_t code, const std::string& msg) { t->err = msg; t->s->err = msg; return code; }
+
+#define RBT_HIP(t, call)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return tfail(t, e_ == hipErrorOutOfMemory ? RBS_ERR_OUT_OF_MEMORY : RBS_ERR_HIP,   \
+                         fmt("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); \
+    } while (0)
+
+template <typename X>
+int32_t talloc(rbs_tracker* t, X** p, size_t count)
+{
+    RBT_HIP(t, hipMalloc(p, sizeof(X) * (count ? count : 1)));
+    t->allocs.push_back(*p);
+    return RBS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t rbs_tracker_create(rbs_handle* sensor, const rbs_tracker_params* p, rbs_tracker** out)
+{
+    if (!sensor || !out) return RBS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!p || p->n_particles <= 0 || p->n_particles > sensor->max_particles)
+        return fail(sensor, RBS_ERR_INVALID_ARGUMENT, "tracker_create: n_particles outside 1..max_particles");
+    RBS_HIP(sensor, hipSetDevice(sensor->device));
+    rbs_tracker* t = new (std::nothrow) rbs_tracker;
+    if (!t) return fail(sensor, RBS_ERR_OUT_OF_MEMORY, "tracker_create: out of host memory");
+    t->s = sensor;
+    rbt::TrackerDev& T = t->T;
+    T.n = p->n_particles;
+    T.parts = sensor->n_bodies;
+    T.D = T.parts * rbt::kBody;
+    for (int k = 0; k < 3; ++k) { T.sigma[k] = p->linear_sigma[k]; T.sigma[3 + k] = p->angular_sigma[k]; }
+    T.vf = p->velocity_factor;
+    T.max_kl = p->max_kl_divergence;
+    const size_t n = (size_t)T.n, D = (size_t)T.D, P6 = (size_t)T.parts * 6;
+    int32_t rc = RBS_OK;
+    if ((rc = talloc(t, &T.part_old, n * D)) || (rc = talloc(t, &T.part_new, n * D)) ||
+        (rc = talloc(t, &T.part_old2, n * D)) || (rc = talloc(t, &T.part_new2, n * D)) ||
+        (rc = talloc(t, &T.noise, n * P6)) || (rc = talloc(t, &T.noise2, n * P6)) ||
+        (rc = talloc(t, &T.logw, n)) || (rc = talloc(t, &T.ll, n)) || (rc = talloc(t, &T.ll2, n)) ||
+        (rc = talloc(t, &T.ll_new, n)) || (rc = talloc(t, &T.idx, n)) || (rc = talloc(t, &T.idx2, n)) ||
+        (rc = talloc(t, &T.parents, n)) || (rc = talloc(t, &T.cdf, n)) || (rc = talloc(t, &T.deflt, D)) ||
+        (rc = talloc(t, &T.mean, D + (size_t)T.parts * 9)) || (rc = talloc(t, &T.poses, n * (size_t)T.parts * 12)) ||
+        (rc = talloc(t, &T.flag, 2)) || (rc = talloc(t, &t->d_normals, n * P6)) ||
+        (rc = talloc(t, &t->d_uniforms, n * (size_t)T.parts))) {
+        rbs_tracker_destroy(t);
+        return rc;
+    }
+    RBS_HIP(sensor, hipMemsetAsync(T.deflt, 0, sizeof(double) * D, sensor->stream));
+    *out = t;
+    return RBS_OK;
+}
+
+void rbs_tracker_destroy(rbs_tracker* t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->s->device);
+    (void)hipStreamSynchronize(t->s->stream);
+    for (void* p : t->allocs) (void)hipFree(p);
+    delete t;
+}
+
+int32_t rbs_tracker_initialize(rbs_tracker* t, const double* default_state)
+{
+    if (!t) return RBS_ERR_INVALID_ARGUMENT;
+    if (!default_state) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_initialize: null state");
+    rbt::TrackerDev& T = t->T;
+    RBT_HIP(t, hipSetDevice(t->s->device));
+    if (int32_t rc = rbs_reset(t->s)) return rc;
+    hipStream_t s = t->s->stream;
+    RBT_HIP(t, hipMemcpyAsync(T.deflt, default_state, sizeof(double) * T.D, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(rbt::init_kernel, dim3((unsigned)((T.n + 255) / 256)), dim3(256), 0, s, T);
+    RBT_HIP(t, hipGetLastError());
+    RBT_HIP(t, hipStreamSynchronize(s));
+    T.frame = 0;
+    return RBS_OK;
+}
+
+int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* normals,
+                          const double* uniforms, uint64_t seed, double* out_state,
+                          int32_t* out_resamplings)
+{
+    if (!t) return RBS_ERR_INVALID_ARGUMENT;
+    if (!out_state) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_track: null output");
+    rbt::TrackerDev& T = t->T;
+    rbs_handle* h = t->s;
+    RBT_HIP(t, hipSetDevice(h->device));
+    if (frame)
+        if (int32_t rc = rbs_set_observation_f32(h, frame, (size_t)h->npx)) return rc;
+    hipStream_t s = h->stream;
+    const size_t n = (size_t)T.n;
+    T.normals = nullptr;
+    T.uniforms = nullptr;
+    if (normals) {
+        RBT_HIP(t, hipMemcpyAsync(t->d_normals, normals, sizeof(double) * n * T.parts * 6, hipMemcpyHostToDevice, s));
+        T.normals = t->d_normals;
+    }
+    if (uniforms) {
+        RBT_HIP(t, hipMemcpyAsync(t->d_uniforms, uniforms, sizeof(double) * n * T.parts, hipMemcpyHostToDevice, s));
+        T.uniforms = t->d_uniforms;
+    }
+    T.seed = seed;
+    const dim3 g256((unsigned)((T.n + 255) / 256)), b256(256);
+    for (int b = 0; b < T.parts; ++b) {
+        const bool last = b == T.parts - 1;
+        hipLaunchKernelGGL(rbt::propagate_kernel, g256, b256, 0, s, T, b);
+        RBT_HIP(t, hipGetLastError());
+        if (int32_t rc = enqueue_loglikes(h, T.poses, T.idx, T.n, last, T.ll_new, s)) return rc;
+        hipLaunchKernelGGL(rbt::weights_kernel, dim3(1), dim3(1024), 0, s, T, last ? 1 : 0);
+        hipLaunchKernelGGL(rbt::resample_kernel, g256, b256, 0, s, T, b);
+        hipLaunchKernelGGL(rbt::gather_kernel, dim3((unsigned)T.n), dim3(64), 0, s, T);
+        RBT_HIP(t, hipGetLastError());
+        std::swap(T.part_old, T.part_old2);
+        std::swap(T.part_new, T.part_new2);
+        std::swap(T.noise, T.noise2);
+        std::swap(T.ll, T.ll2);
+        std::swap(T.idx, T.idx2);
+    }
+    hipLaunchKernelGGL(rbt::mean_kernel, dim3(1), dim3(1024), 0, s, T);
+    hipLaunchKernelGGL(rbt::recentre_kernel, g256, b256, 0, s, T);
+    RBT_HIP(t, hipGetLastError());
+    std::swap(T.part_old, T.part_new);   // this frame's particles are the next frame's old ones
+    RBT_HIP(t, hipMemcpyAsync(out_state, T.deflt, sizeof(double) * T.D, hipMemcpyDeviceToHost, s));
+    int flags[2] = {0, 0};
+    RBT_HIP(t, hipMemcpyAsync(flags, T.flag, sizeof(flags), hipMemcpyDeviceToHost, s));
+    RBT_HIP(t, hipStreamSynchronize(s));
+    if (out_resamplings) *out_resamplings = flags[1];
+    T.frame += 1;
+    return RBS_OK;
+}
+
+int32_t rbs_tracker_get(rbs_tracker* t, double* particles, double* log_weights, int32_t* indices)
+{
+    if (!t) return RBS_ERR_INVALID_ARGUMENT;
+    rbt::TrackerDev& T = t->T;
+    RBT_HIP(t, hipSetDevice(t->s->device));
+    RBT_HIP(t, hipStreamSynchronize(t->s->stream));
+    if (particles) RBT_HIP(t, hipMemcpy(particles, T.part_old, sizeof(double) * (size_t)T.n * T.D, hipMemcpyDeviceToHost));
+    if (log_weights) RBT_HIP(t, hipMemcpy(log_weights, T.logw, sizeof(double) * (size_t)T.n, hipMemcpyDeviceToHost));
+    if (indices) RBT_HIP(t, hipMemcpy(indices, T.idx, sizeof(int) * (size_t)T.n, hipMemcpyDeviceToHost));
     return RBS_OK;
 }
 

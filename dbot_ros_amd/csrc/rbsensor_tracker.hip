@@ -1,0 +1,324 @@
+// rbsensor_tracker.hip -- device-side callers of the hot path ("next" rows): the
+// object state transition, the Rao-Blackwellised coordinate particle filter step (log-weight
+// update, KL test, multinomial resampling, gather) and the tracker's weighted mean + re-centring,
+// as the reference's filter drives them once per sampling block inside tracker_->track(image)
+// (R:source/dbot_ros/object_tracker_ros.hpp:49; parameters
+// R:source/dbot_ros/tracker/particle_tracker_node.cpp:138-159,208-218).  Semantics follow
+// SURVEY.md Appendix A.1/A.6 and are mirrored on the host by dbot_ros_amd/tracker.py, which the
+// parity tests compare against.  Everything is stream-ordered: one host synchronisation per frame.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace rbt {
+
+constexpr int kBody = 12;   // position(3) rotation-vector(3) linear-velocity(3) angular-velocity(3)
+
+struct TrackerDev {
+    int n, parts, D;              // particles, bodies, state length = parts*12
+    double sigma[6];              // linear xyz, angular xyz
+    double vf;                    // velocity_factor
+    double max_kl;
+    double* part_old; double* part_new; double* noise;      // [n][D], [n][D], [n][parts][6]
+    double* part_old2; double* part_new2; double* noise2;   // gather targets (ping-pong)
+    double* logw; double* ll; double* ll2; double* ll_new;  // [n]
+    int* idx; int* idx2; int* parents;                       // [n]
+    double* cdf;                  // [n]
+    double* deflt;                // [D] integrated (default) pose the deltas live around
+    double* mean;                 // [D] + [parts][9] transposed mean rotations
+    double* poses;                // [n][parts][12] absolute R|t handed to the sensor
+    int* flag;                    // [0] resample decision of the last block, [1] resampling count
+    const double* normals;        // host-supplied [parts][n][6] or nullptr (device RNG)
+    const double* uniforms;       // host-supplied [parts][n] or nullptr
+    unsigned long long seed, frame;
+};
+
+// ------------------------------------------------------------------ rotations
+// rotation vector -> row-major matrix through the unit quaternion; same formula as
+// dbot_ros_amd/pose.py rotvec_to_matrix.
+__device__ inline void rotvec_to_matrix(const double* rv, double* R)
+{
+    const double angle = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    const double half = 0.5 * angle;
+    const double k = angle < 1e-9 ? 0.5 - angle * angle / 48.0 : sin(half) / angle;
+    const double w = cos(half), x = rv[0] * k, y = rv[1] * k, z = rv[2] * k;
+    R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - w * z); R[2] = 2.0 * (x * z + w * y);
+    R[3] = 2.0 * (x * y + w * z); R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - w * x);
+    R[6] = 2.0 * (x * z - w * y); R[7] = 2.0 * (y * z + w * x); R[8] = 1.0 - 2.0 * (x * x + y * y);
+}
+
+// matrix -> rotation vector, atan2 form (dbot_ros_amd/tracker.py _rotvecs / pose.py matrix_to_rotvec)
+__device__ inline void matrix_to_rotvec(const double* R, double* rv)
+{
+    const double sx = 0.5 * (R[7] - R[5]), sy = 0.5 * (R[2] - R[6]), sz = 0.5 * (R[3] - R[1]);
+    const double sn = sqrt(sx * sx + sy * sy + sz * sz);
+    const double cs = 0.5 * ((R[0] + R[4] + R[8]) - 1.0);
+    const double ang = atan2(sn, cs);
+    const double k = sn > 1e-8 ? ang / sn : 1.0;
+    rv[0] = sx * k; rv[1] = sy * k; rv[2] = sz * k;
+}
+
+__device__ inline void matmul3(const double* A, const double* B, double* C)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+
+// ------------------------------------------------------------------ random numbers
+// Philox4x32-10 counter-based generator: (seed, frame, stream, index) -> 4 x 32 random bits.
+__device__ inline uint4 philox(unsigned long long seed, unsigned long long ctr_hi, unsigned long long ctr_lo)
+{
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    unsigned c0 = (unsigned)ctr_lo, c1 = (unsigned)(ctr_lo >> 32), c2 = (unsigned)ctr_hi, c3 = (unsigned)(ctr_hi >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+__device__ inline double u01(unsigned hi, unsigned lo)   // 53-bit uniform in [0,1)
+{
+    return (double)((((unsigned long long)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------------ f2: transition + pose composition
+// One thread per particle, sampling block b: restart from the OLD particle, apply the
+// transition of bodies 0..b with their accumulated noise (vel' = vf vel + sigma o n,
+// pose' = pose + vel'), write the new particle and its absolute poses
+// R = R(delta) R(default), t = t(delta) + t(default)   (SURVEY A.1).
+__global__ void propagate_kernel(const TrackerDev T, int b)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T.n) return;
+    for (int bb = 0; bb < T.parts; ++bb) {
+        double s[kBody];
+#pragma unroll
+        for (int k = 0; k < kBody; ++k) s[k] = T.part_old[(size_t)i * T.D + bb * kBody + k];
+        if (bb <= b) {
+            double nz[6];
+            if (bb == b) {
+                if (T.normals) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) nz[k] = T.normals[((size_t)b * T.n + i) * 6 + k];
+                } else {  // Box-Muller on Philox uniforms: 3 pairs
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {
+                        const uint4 r = philox(T.seed, (T.frame << 8) | (unsigned)b, ((unsigned long long)i << 2) | pr);
+                        const double u1 = 1.0 - u01(r.x, r.y), u2 = u01(r.z, r.w);
+                        const double rad = sqrt(-2.0 * log(u1));
+                        nz[2 * pr] = rad * cos(6.283185307179586 * u2);
+                        nz[2 * pr + 1] = rad * sin(6.283185307179586 * u2);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) T.noise[((size_t)i * T.parts + bb) * 6 + k] = nz[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nz[k] = T.noise[((size_t)i * T.parts + bb) * 6 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                s[6 + k] = T.vf * s[6 + k] + T.sigma[k] * nz[k];
+                s[k] = s[k] + s[6 + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kBody; ++k) T.part_new[(size_t)i * T.D + bb * kBody + k] = s[k];
+        double Rd[9], R0[9], R[9];
+        rotvec_to_matrix(s + 3, Rd);
+        rotvec_to_matrix(T.deflt + bb * kBody + 3, R0);
+        matmul3(Rd, R0, R);
+        double* out = T.poses + ((size_t)i * T.parts + bb) * 12;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out[k] = R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[9 + k] = s[k] + T.deflt[bb * kBody + k];
+    }
+}
+
+// ------------------------------------------------------------------ f1: weights, KL, resampling
+__device__ inline double block_sum(double v, double* sh)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += sh[k];
+    return s;
+}
+__device__ inline double block_max(double v, double* sh)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double s = -INFINITY;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s = fmax(s, sh[k]);
+    return s;
+}
+
+// Single block (1024 threads): log_w += new_ll - ll; ll = new_ll; w = softmax(log_w);
+// KL(w || uniform) = log n + sum w log w; if KL > max_kl: cdf = cumsum(w)/sum, flag = 1.
+// `updated`: the sensor call wrote slot i for particle i, so the slot map becomes identity.
+__global__ __launch_bounds__(1024) void weights_kernel(const TrackerDev T, int updated)
+{
+    __shared__ double sh[1024];
+    const int n = T.n;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    double m = -INFINITY;
+    for (int i = lo; i < hi; ++i) {
+        const double nl = T.ll_new[i];
+        const double lw = T.logw[i] + (nl - T.ll[i]);
+        T.logw[i] = lw;
+        T.ll[i] = nl;
+        if (updated) T.idx[i] = i;
+        m = fmax(m, lw);
+    }
+    m = block_max(m, sh);
+    double s = 0.0;
+    for (int i = lo; i < hi; ++i) s += exp(T.logw[i] - m);
+    const double local = s;
+    const double S = block_sum(s, sh);
+    double e = 0.0;
+    for (int i = lo; i < hi; ++i) {
+        const double w = exp(T.logw[i] - m) / S;
+        if (w > 0.0) e += w * log(w);
+    }
+    const double kl = log((double)n) + block_sum(e, sh);
+    const bool resample = kl > T.max_kl;
+    if (threadIdx.x == 0) {
+        T.flag[0] = resample ? 1 : 0;
+        if (resample) T.flag[1] += 1;
+    }
+    if (!resample) return;
+    // inclusive scan of the per-thread sums -> exclusive offsets, then the running cdf
+    __syncthreads();
+    sh[threadIdx.x] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const double v = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    double run = threadIdx.x ? sh[threadIdx.x - 1] : 0.0;
+    const double total = sh[1023];
+    for (int i = lo; i < hi; ++i) {
+        run += exp(T.logw[i] - m);
+        T.cdf[i] = run / total;
+    }
+}
+
+// parents[j] = flag ? upper_bound(cdf, u_j) : j   (multinomial resampling)
+__global__ void resample_kernel(const TrackerDev T, int b)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T.n) return;
+    int p = j;
+    if (T.flag[0]) {
+        double u;
+        if (T.uniforms) u = T.uniforms[(size_t)b * T.n + j];
+        else {
+            const uint4 r = philox(T.seed ^ 0x5bd1e995ull, (T.frame << 8) | (unsigned)b, (unsigned long long)j);
+            u = u01(r.x, r.y);
+        }
+        int lo = 0, hi = T.n;   // first index with cdf > u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (T.cdf[mid] > u) hi = mid; else lo = mid + 1;
+        }
+        p = min(lo, T.n - 1);
+    }
+    T.parents[j] = p;
+}
+
+// children inherit particle, noise, likelihood and occlusion slot of their parent; weights reset
+__global__ void gather_kernel(const TrackerDev T)
+{
+    const int j = blockIdx.x;
+    const int p = T.parents[j];
+    for (int k = threadIdx.x; k < T.D; k += blockDim.x) {
+        T.part_old2[(size_t)j * T.D + k] = T.part_old[(size_t)p * T.D + k];
+        T.part_new2[(size_t)j * T.D + k] = T.part_new[(size_t)p * T.D + k];
+    }
+    for (int k = threadIdx.x; k < T.parts * 6; k += blockDim.x)
+        T.noise2[(size_t)j * T.parts * 6 + k] = T.noise[(size_t)p * T.parts * 6 + k];
+    if (threadIdx.x == 0) {
+        T.ll2[j] = T.ll[p];
+        T.idx2[j] = T.idx[p];
+        if (T.flag[0]) T.logw[j] = 0.0;   // every child writes its own weight slot only
+    }
+}
+
+// ------------------------------------------------------------------ tracker: mean + re-centring
+// Single block: mean = sum_i softmax(log_w)_i * particle_i; fold it into the default pose.
+__global__ __launch_bounds__(1024) void mean_kernel(const TrackerDev T)
+{
+    __shared__ double sh[1024];
+    const int n = T.n;
+    double m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 1024) m = fmax(m, T.logw[i]);
+    m = block_max(m, sh);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) s += exp(T.logw[i] - m);
+    const double S = block_sum(s, sh);
+    for (int d = 0; d < T.D; ++d) {
+        double a = 0.0;
+        for (int i = threadIdx.x; i < n; i += 1024) a += (exp(T.logw[i] - m) / S) * T.part_new[(size_t)i * T.D + d];
+        a = block_sum(a, sh);
+        if (threadIdx.x == 0) T.mean[d] = a;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < T.parts) {
+        const int b = threadIdx.x;
+        double* z = T.deflt + b * kBody;
+        const double* mu = T.mean + b * kBody;
+        double Rm[9], Rz[9], R[9];
+        rotvec_to_matrix(mu + 3, Rm);
+        rotvec_to_matrix(z + 3, Rz);
+        matmul3(Rm, Rz, R);
+        for (int k = 0; k < 3; ++k) z[k] += mu[k];
+        matrix_to_rotvec(R, z + 3);
+        for (int k = 6; k < 12; ++k) z[k] = mu[k];
+        double* RmT = T.mean + T.D + b * 9;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) RmT[3 * r + c] = Rm[3 * c + r];
+    }
+}
+
+// delta_i <- delta_i (-) mean:  t -= t_mean,  R(delta_i) <- R(delta_i) R(mean)^T
+__global__ void recentre_kernel(const TrackerDev T)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T.n) return;
+    for (int b = 0; b < T.parts; ++b) {
+        double* p = T.part_new + (size_t)i * T.D + b * kBody;
+        for (int k = 0; k < 3; ++k) p[k] -= T.mean[b * kBody + k];
+        double Rd[9], R[9];
+        rotvec_to_matrix(p + 3, Rd);
+        matmul3(Rd, T.mean + T.D + b * 9, R);
+        matrix_to_rotvec(R, p + 3);
+    }
+}
+
+__global__ void init_kernel(const TrackerDev T)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T.n) { T.logw[i] = 0.0; T.ll[i] = 0.0; T.idx[i] = 0; }
+    if (i < 2) T.flag[i] = 0;
+    for (size_t k = i; k < (size_t)T.n * T.D; k += (size_t)gridDim.x * blockDim.x) T.part_old[k] = 0.0;
+    for (size_t k = i; k < (size_t)T.n * T.parts * 6; k += (size_t)gridDim.x * blockDim.x) T.noise[k] = 0.0;
+}
+
+}  // namespace rbt

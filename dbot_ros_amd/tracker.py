@@ -146,14 +146,21 @@ class ParticleTracker:
         R = rotvec_to_matrix(d[..., 3:6]) @ rotvec_to_matrix(z[:, 3:6])[None]
         return pack_Rt(R, d[..., 0:3] + z[None, :, 0:3])
 
-    def track(self, image):
+    def draw_randomness(self):
+        """Per frame: standard normals [parts, n, 6] and uniforms [parts, n], drawn
+        unconditionally so host and device trackers consume identical streams."""
+        return (self.rng.standard_normal((self.parts, self.n, 6)), self.rng.random((self.parts, self.n)))
+
+    def track(self, image, normals=None, uniforms=None):
         """One depth frame -> estimated State (camera-frame poses + velocities per object)."""
+        if normals is None or uniforms is None:
+            normals, uniforms = self.draw_randomness()
         self.sensor.set_observation(image)
         old = self.particles
         noises = np.zeros((self.n, self.parts, 6))
         new = old
         for b in range(self.parts):
-            noises[:, b] = self.rng.standard_normal((self.n, 6))
+            noises[:, b] = normals[b]
             # every block restarts from the SAME old particles; noise accumulates over blocks
             new = old
             for bb in range(b + 1):
@@ -167,7 +174,7 @@ class ParticleTracker:
             self.loglikes = new_ll
             w = flt.normalized_weights(self.log_weights)
             if flt.kl_to_uniform(w) > self.params.max_kl_divergence:
-                parents = flt.multinomial_resample(w, self.rng.random(self.n))
+                parents = flt.multinomial_resample(w, uniforms[b])
                 self.n_resamplings += 1
                 self.indices = self.indices[parents].copy()
                 old, new, noises = old[parents], new[parents], noises[parents]
@@ -201,3 +208,83 @@ def _rotvecs(R):
     ang = np.arctan2(sn, cs)
     k = np.where(sn > 1e-8, ang / np.where(sn > 1e-8, sn, 1.0), 1.0)
     return s * k[:, None]
+
+
+class DeviceParticleTracker(ParticleTracker):
+    """Same interface, but the transition, filter step and mean run on the sensor's device
+    (rbs_tracker_* in librbsensor_mi355x.so): one host synchronisation per frame.  With
+    device_rng=True the normals/uniforms are drawn on the device (Philox), otherwise they come
+    from this object's numpy Generator exactly as in the host tracker."""
+
+    def __init__(self, transition, sensor, object_model, params, rng=None, device_rng=False, seed=0):
+        import ctypes as C
+        from . import _capi
+        super().__init__(transition, sensor, object_model, params, rng)
+        self._C, self._capi = C, _capi
+        self._lib = _capi.load()
+        self.device_rng, self.seed = device_rng, seed
+        tp = _capi.RbsTrackerParams()
+        tp.linear_sigma = (C.c_double * 3)(*transition.sigma[:3])
+        tp.angular_sigma = (C.c_double * 3)(*transition.sigma[3:])
+        tp.velocity_factor = transition.vf
+        tp.max_kl_divergence = params.max_kl_divergence
+        tp.n_particles = self.n
+        self._t = C.c_void_p()
+        rc = self._lib.rbs_tracker_create(sensor._h, C.byref(tp), C.byref(self._t))
+        if rc != 0:
+            sensor._check(rc)
+
+    def close(self):
+        if getattr(self, "_t", None) is not None and self._t.value:
+            self._lib.rbs_tracker_destroy(self._t)
+            self._t = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def initialize(self, initial_states):
+        self.default = self._to_model(initial_states[0])
+        self.default.reshape(self.parts, BODY)[:, 6:12] = 0.0
+        d = np.ascontiguousarray(self.default, dtype=np.float64)
+        self.sensor._check(self._lib.rbs_tracker_initialize(self._t, d.ctypes.data_as(self._C.POINTER(self._C.c_double))))
+        self.moving_average = None
+        self.n_resamplings = 0
+
+    def track(self, image, normals=None, uniforms=None):
+        C = self._C
+        dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
+        if not self.device_rng and (normals is None or uniforms is None):
+            normals, uniforms = self.draw_randomness()
+        img = np.ascontiguousarray(image, dtype=np.float32).ravel()
+        nptr = uptr = None
+        if normals is not None:
+            normals = np.ascontiguousarray(normals, dtype=np.float64)
+            nptr = normals.ctypes.data_as(dp)
+        if uniforms is not None:
+            uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
+            uptr = uniforms.ctypes.data_as(dp)
+        out = np.empty(self.parts * BODY)
+        nres = C.c_int32()
+        self.sensor._check(self._lib.rbs_tracker_track(self._t, img.ctypes.data_as(fp), nptr, uptr,
+                                                       C.c_uint64(self.seed), out.ctypes.data_as(dp),
+                                                       C.byref(nres)))
+        self.default = out
+        self.n_resamplings = int(nres.value)
+        est = self._from_model(self.default)
+        rate = self.params.moving_average_update_rate
+        self.moving_average = est if self.moving_average is None else rate * est + (1 - rate) * self.moving_average
+        return self.moving_average.copy()
+
+    def get_state(self):
+        """(particle deltas [n, parts*12], log-weights [n], occlusion slot map [n]) from the device."""
+        C = self._C
+        p = np.empty((self.n, self.parts * BODY))
+        w = np.empty(self.n)
+        i = np.empty(self.n, dtype=np.int32)
+        self.sensor._check(self._lib.rbs_tracker_get(self._t, p.ctypes.data_as(C.POINTER(C.c_double)),
+                                                     w.ctypes.data_as(C.POINTER(C.c_double)),
+                                                     i.ctypes.data_as(C.POINTER(C.c_int32))))
+        return p, w, i

@@ -140,6 +140,46 @@ int32_t rbs_last_kernel_ms(rbs_handle* h, float* ms);
 int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float* copy_kernel_ms,
                            int32_t* n_used);
 
+/* ------------------------------------------------------------------------------------------
+ * Device-side tracker (the callers either side of the hot path): the object
+ * state transition, the RBC particle-filter step (weights, KL test, multinomial resampling)
+ * and the tracker's weighted mean, run on the sensor's device around rbs_loglikes_device with
+ * one host synchronisation per frame.  Replaces, for use_gpu trackers,
+ *   dbot::ObjectTransitionBuilder<State>  R:source/dbot_ros/tracker/particle_tracker_node.cpp:138-159
+ *   dbot::ParticleTrackerBuilder<Tracker> R:source/dbot_ros/tracker/particle_tracker_node.cpp:208-218
+ *   tracker->initialize / tracker_->track R:...particle_tracker_node.cpp:252,
+ *                                         R:source/dbot_ros/object_tracker_ros.hpp:49
+ * States are in MODEL coordinates (pose of the centred mesh frame); the host mirrors do the
+ * center_object_frame conversion and the moving average. */
+typedef struct rbs_tracker rbs_tracker;
+
+typedef struct rbs_tracker_params {
+    double linear_sigma[3];      /* object_transition/linear_sigma_{x,y,z}  */
+    double angular_sigma[3];     /* object_transition/angular_sigma_{x,y,z} */
+    double velocity_factor;      /* object_transition/velocity_factor       */
+    double max_kl_divergence;    /* particle_filter/max_kl_divergence       */
+    int32_t n_particles;         /* evaluation_count / #objects; <= the sensor's max_particles */
+} rbs_tracker_params;
+
+/* The tracker borrows `sensor` (must outlive it) and drives it on the sensor's own stream. */
+int32_t rbs_tracker_create(rbs_handle* sensor, const rbs_tracker_params* params, rbs_tracker** out);
+void rbs_tracker_destroy(rbs_tracker* t);
+/* default_state: [n_objects*12] = per body position, rotation vector, linear + angular velocity.
+ * Particles := zero deltas, weights := uniform, sensor reset. */
+int32_t rbs_tracker_initialize(rbs_tracker* t, const double* default_state);
+/* One frame.  frame: float32[rows*cols] evaluated-resolution depth (NULL: the caller has
+ * already called an rbs_set_observation* variant for this frame).  normals: [n_objects][n][6]
+ * standard normals, uniforms: [n_objects][n] in [0,1) -- host-supplied randomness (reproducible,
+ * used by the parity tests); either may be NULL to draw on the device (Philox4x32-10 keyed by
+ * `seed` and the frame counter).  Outputs: the updated default state [n_objects*12] and the
+ * number of resamplings so far. */
+int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* normals,
+                          const double* uniforms, uint64_t seed, double* out_state,
+                          int32_t* out_resamplings);
+/* Inspection: particle deltas [n][n_objects*12], log-weights [n], occlusion slot map [n]
+ * (any pointer may be NULL). */
+int32_t rbs_tracker_get(rbs_tracker* t, double* particles, double* log_weights, int32_t* indices);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,3 +67,68 @@ def test_tracker_follows_the_object_gpu(gpu_lib):
         errs, tr = _run(g, om, cam, n, 20, g.render_depth)
     assert errs[-5:, 0].max() < 0.004 and errs[-5:, 1].max() < 0.06, errs
     assert tr.n_resamplings >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("meshes,n,cols,rows", [(("m1_l2",), 64, 160, 120), (("m1_l2", "box12"), 96, 160, 120),
+                                                 (("m1",), 500, 640, 480)])
+def test_device_tracker_matches_host_tracker(gpu_lib, meshes, n, cols, rows):
+    """f1/f2 on the device (rbs_tracker_*) against the host mirror (dbot_ros_amd.tracker) driving
+    the same product sensor, with identical host-supplied normals/uniforms: estimated state,
+    particle cloud, weights, slot map and resampling decisions agree frame after frame."""
+    from dbot_ros_amd.tracker import DeviceParticleTracker
+    nb = len(meshes)
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    tp = ParticleTrackerBuilder.Parameters(evaluation_count=n, max_kl_divergence=2.0)
+    with RbSensor(om, cam, P, max_particles=n) as s_host, RbSensor(om, cam, P, max_particles=n) as s_dev:
+        tr = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=nb)).build()
+        host = ParticleTracker(tr, s_host, om, tp, np.random.default_rng(5))
+        dev = DeviceParticleTracker(tr, s_dev, om, tp, np.random.default_rng(5))
+        assert host.n == dev.n == n // nb
+        init = np.zeros(12 * nb)
+        for b in range(nb):
+            Rt = synth.truth_pose(nb, frame=0)[b]
+            init[12 * b + 3:12 * b + 6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+            init[12 * b:12 * b + 3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[b]
+        host.initialize([init])
+        dev.initialize([init])
+        rng = np.random.default_rng(77)
+        resampled = 0
+        for k in range(1, 7):
+            frame = synth.make_frame(s_host.render_depth(synth.truth_pose(nb, frame=k)), rows, cols, rng,
+                                     occluder=False)
+            normals, uniforms = host.draw_randomness()
+            eh = host.track(frame, normals, uniforms)
+            ed = dev.track(frame, normals, uniforms)
+            assert np.abs(eh - ed).max() <= 1e-9, (k, np.abs(eh - ed).max())
+            p, w, idx = dev.get_state()
+            assert np.abs(p - host.particles).max() <= 1e-9
+            assert np.abs(w - host.log_weights).max() <= 1e-6 * max(1.0, np.abs(host.log_weights).max())
+            assert np.array_equal(idx, host.indices)
+            assert dev.n_resamplings == host.n_resamplings
+        assert host.n_resamplings >= 1
+        dev.close()
+
+
+@pytest.mark.gpu
+def test_device_tracker_with_device_rng_tracks(gpu_lib):
+    from dbot_ros_amd.tracker import DeviceParticleTracker
+    n = 2000
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        tp = ParticleTrackerBuilder.Parameters(evaluation_count=n)
+        tr = DeviceParticleTracker(ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters()).build(), g, om, tp,
+                                   device_rng=True, seed=1234)
+        init = _truth_state(0, om.centers)
+        init[0:3] += [0.004, -0.003, 0.005]
+        tr.initialize([init])
+        rng = np.random.default_rng(3)
+        errs = []
+        for k in range(1, 21):
+            frame = synth.make_frame(g.render_depth(synth.truth_pose(1, frame=k)), 480, 640, rng, occluder=False)
+            est = tr.track(frame)
+            ref = _truth_state(k, om.centers)
+            errs.append(np.linalg.norm(est[0:3] - ref[0:3]))
+        assert max(errs[-5:]) < 0.004, errs
+        assert tr.n_resamplings >= 1
+        tr.close()

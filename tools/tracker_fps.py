@@ -2,8 +2,8 @@
 """Tracker FPS (the second half of BASELINE.json's metric): frames/s of the full per-frame step
 -- set_observation + transition + loglikes(update) + weights + KL + resample + mean -- on a
 30-frame synthetic sequence (object translating 2 mm and rotating 1 degree per frame), for
-{200, 2 000, 20 000} particles on one MI355X.  Host-side filter logic is numpy (SURVEY f1/f2
-"next" rows); the sensor is librbsensor_mi355x.so.  Prints one JSON line per particle count."""
+{200, 2 000, 20 000} particles on one MI355X.  Two variants per count: filter='device' (rbs_tracker_*: transition, weights, KL,
+resampling, mean on the GPU, one host sync per frame) and filter='host' (numpy mirror).  Prints one JSON line per particle count."""
 import json
 import os
 import sys
@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from dbot_ros_amd import CameraData, ObjectModel, RbSensor, RbSensorBuilder, pose, synth  # noqa: E402
-from dbot_ros_amd.tracker import ObjectTransitionBuilder, ParticleTracker, ParticleTrackerBuilder  # noqa: E402
+from dbot_ros_amd.tracker import (DeviceParticleTracker, ObjectTransitionBuilder, ParticleTracker,  # noqa: E402
+                                  ParticleTrackerBuilder)
 
 
 def main():
@@ -24,14 +25,18 @@ def main():
     v, f = synth.mesh_m1()
     om = ObjectModel([v], [f], center=True)
     cam = CameraData(synth.camera_matrix(cols, rows), rows, cols)
-    for n in counts:
+    for n, mode in [(n, m) for n in counts for m in ("device", "host")]:
         P = RbSensorBuilder.Parameters(sample_count=n)
         with RbSensor(om, cam, P, max_particles=n) as s:
             rng = np.random.default_rng(0)
             frames = [synth.make_frame(s.render_depth(synth.truth_pose(1, frame=k)), rows, cols, rng,
                                        occluder=False) for k in range(n_frames + 1)]
-            tr = ParticleTracker(ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters()).build(), s, om,
-                                 ParticleTrackerBuilder.Parameters(evaluation_count=n), np.random.default_rng(1))
+            trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters()).build()
+            tp = ParticleTrackerBuilder.Parameters(evaluation_count=n)
+            if mode == "device":   # transition + filter step + mean on the GPU, device RNG
+                tr = DeviceParticleTracker(trans, s, om, tp, device_rng=True, seed=1)
+            else:                  # host mirror (numpy)
+                tr = ParticleTracker(trans, s, om, tp, np.random.default_rng(1))
             Rt = synth.truth_pose(1, frame=0)[0]
             init = np.zeros(12)
             init[3:6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
@@ -46,7 +51,7 @@ def main():
             dt = time.perf_counter() - t0
             Rt = synth.truth_pose(1, frame=n_frames)[0]
             err = np.linalg.norm(est[0:3] - (Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0]))
-            print(json.dumps({"metric": "tracker FPS", "particles": n, "value": n_frames / dt, "unit": "frames/s",
+            print(json.dumps({"metric": "tracker FPS", "filter": mode, "particles": n, "value": n_frames / dt, "unit": "frames/s",
                               "ms_per_frame": dt / n_frames * 1e3, "sensor_device_ms_per_frame": sensor_ms / n_frames,
                               "resamplings": tr.n_resamplings, "final_position_error_m": float(err),
                               "resolution": [cols, rows], "triangles": int(len(f)), "n_gpus": 1}), flush=True)
