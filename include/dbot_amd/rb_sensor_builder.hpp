@@ -273,4 +273,153 @@ private:
     std::vector<Real> poses_;
 };
 
+/// dbot::ObjectTransitionBuilder<State>: parameters of the velocity random walk
+/// (R:source/dbot_ros/tracker/particle_tracker_node.cpp:138-159, R:config/particle_tracker.yaml:51-63).
+template <typename State = FreeFloatingRigidBodiesState>
+class ObjectTransitionBuilder
+{
+public:
+    struct Parameters {
+        Real linear_sigma_x = 0.0025, linear_sigma_y = 0.0025, linear_sigma_z = 0.0025;
+        Real angular_sigma_x = 0.02, angular_sigma_y = 0.02, angular_sigma_z = 0.02;
+        Real velocity_factor = 0.8;
+        int part_count = 1;
+    };
+    explicit ObjectTransitionBuilder(const Parameters& p) : params_(p) {}
+    const Parameters& parameters() const { return params_; }
+
+private:
+    Parameters params_;
+};
+
+/// dbot::ParticleTracker: initialize(initial_states), track(image) -> State.  The transition,
+/// the RBC filter step and the weighted mean run on the sensor's device (rbs_tracker_*).
+class ParticleTracker
+{
+public:
+    typedef FreeFloatingRigidBodiesState State;
+    typedef std::vector<Real> Obsrv;  // rows*cols depth image, Obsrv::value_type == fl::Real
+
+    ParticleTracker(const std::shared_ptr<RbSensor<State>>& sensor, const std::shared_ptr<ObjectModel>& om,
+                    const rbs_tracker_params& tp, bool center_object_frame, Real moving_average_update_rate,
+                    uint64_t seed)
+        : sensor_(sensor), om_(om), center_(center_object_frame), rate_(moving_average_update_rate), seed_(seed),
+          parts_(om->count_parts())
+    {
+        if (rbs_tracker_create(sensor_->handle(), &tp, &t_) != RBS_OK)
+            throw std::runtime_error(std::string("ParticleTracker: ") + rbs_last_error(sensor_->handle()));
+    }
+    ~ParticleTracker() { rbs_tracker_destroy(t_); }
+    ParticleTracker(const ParticleTracker&) = delete;
+    ParticleTracker& operator=(const ParticleTracker&) = delete;
+
+    /// R:source/dbot_ros/tracker/particle_tracker_node.cpp:242-252: the first initial state
+    /// becomes the default pose the particle deltas live around.
+    void initialize(const std::vector<State>& initial_states)
+    {
+        if (initial_states.empty()) throw std::runtime_error("ParticleTracker::initialize: no initial state");
+        State m = to_model(initial_states[0]);
+        for (int b = 0; b < parts_; ++b)
+            for (int k = 6; k < 12; ++k) m.component(b)[k] = 0.0;
+        check(rbs_tracker_initialize(t_, m.data().data()));
+        have_average_ = false;
+    }
+
+    /// R:source/dbot_ros/object_tracker_ros.hpp:49  current_state_ = tracker_->track(image)
+    State track(const Obsrv& image)
+    {
+        frame_.resize(image.size());
+        for (size_t i = 0; i < image.size(); ++i) frame_[i] = static_cast<float>(image[i]);
+        State model(parts_);
+        int32_t nres = 0;
+        check(rbs_tracker_track(t_, frame_.data(), nullptr, nullptr, seed_, model.data().data(), &nres));
+        resamplings_ = nres;
+        State est = from_model(model);
+        if (!have_average_) { average_ = est; have_average_ = true; }
+        else
+            for (size_t k = 0; k < est.data().size(); ++k)
+                average_.data()[k] = rate_ * est.data()[k] + (1.0 - rate_) * average_.data()[k];
+        return average_;
+    }
+    int resamplings() const { return resamplings_; }
+
+private:
+    void check(int32_t rc) const
+    {
+        if (rc != RBS_OK) throw std::runtime_error(std::string("ParticleTracker: ") + rbs_last_error(sensor_->handle()));
+    }
+    // camera-frame pose of the ORIGINAL mesh frame <-> pose of the centred mesh frame
+    State to_model(const State& s) const { return shift(s, +1.0); }
+    State from_model(const State& s) const { return shift(s, -1.0); }
+    State shift(const State& s, Real sign) const
+    {
+        State o = s;
+        if (!center_) return o;
+        Real R[9];
+        for (int b = 0; b < parts_; ++b) {
+            State::rotation_matrix(o.euler_vector(b), R);
+            const Real* c = om_->centers().data() + 3 * b;
+            for (int r = 0; r < 3; ++r) o.position(b)[r] += sign * (R[3 * r] * c[0] + R[3 * r + 1] * c[1] + R[3 * r + 2] * c[2]);
+        }
+        return o;
+    }
+    std::shared_ptr<RbSensor<State>> sensor_;
+    std::shared_ptr<ObjectModel> om_;
+    bool center_;
+    Real rate_;
+    uint64_t seed_;
+    int parts_;
+    rbs_tracker* t_ = nullptr;
+    std::vector<float> frame_;
+    State average_{1};
+    bool have_average_ = false;
+    int resamplings_ = 0;
+};
+
+/// dbot::ParticleTrackerBuilder<Tracker>(transition_builder, sensor_builder, object_model, params).build()
+/// (R:source/dbot_ros/tracker/particle_tracker_node.cpp:208-218).
+template <typename Tracker = ParticleTracker>
+class ParticleTrackerBuilder
+{
+public:
+    typedef typename Tracker::State State;
+    typedef ObjectTransitionBuilder<State> TransitionBuilder;
+    typedef RbSensorBuilder<State> SensorBuilder;
+    struct Parameters {
+        int evaluation_count = 2000;
+        Real moving_average_update_rate = 1.0;
+        Real max_kl_divergence = 2.0;
+        bool center_object_frame = true;
+        uint64_t seed = 0;  // device RNG key (fl's fixed mt19937 seed has no equivalent here)
+    };
+
+    ParticleTrackerBuilder(const std::shared_ptr<TransitionBuilder>& transition_builder,
+                           const std::shared_ptr<SensorBuilder>& sensor_builder,
+                           const std::shared_ptr<ObjectModel>& object_model, const Parameters& params)
+        : tb_(transition_builder), sb_(sensor_builder), om_(object_model), params_(params)
+    {
+    }
+
+    std::shared_ptr<Tracker> build() const
+    {
+        auto sensor = sb_->build();
+        const auto& tp = tb_->parameters();
+        rbs_tracker_params p{};
+        p.linear_sigma[0] = tp.linear_sigma_x; p.linear_sigma[1] = tp.linear_sigma_y; p.linear_sigma[2] = tp.linear_sigma_z;
+        p.angular_sigma[0] = tp.angular_sigma_x; p.angular_sigma[1] = tp.angular_sigma_y; p.angular_sigma[2] = tp.angular_sigma_z;
+        p.velocity_factor = tp.velocity_factor;
+        p.max_kl_divergence = params_.max_kl_divergence;
+        p.n_particles = params_.evaluation_count / om_->count_parts();
+        if (p.n_particles < 1) p.n_particles = 1;
+        return std::make_shared<Tracker>(sensor, om_, p, params_.center_object_frame,
+                                         params_.moving_average_update_rate, params_.seed);
+    }
+
+private:
+    std::shared_ptr<TransitionBuilder> tb_;
+    std::shared_ptr<SensorBuilder> sb_;
+    std::shared_ptr<ObjectModel> om_;
+    Parameters params_;
+};
+
 }  // namespace dbot_amd

@@ -89,6 +89,43 @@ int main(int argc, char** argv)
     std::printf("\nLL2");
     for (double v : ll2) std::printf(" %.17g", v);
     std::printf("\n");
+    // ---- the tracker, built exactly as R:source/dbot_ros/tracker/particle_tracker_node.cpp:138-252 ----
+    {
+        typedef dbot_amd::ParticleTracker Tracker;
+        typedef dbot_amd::ParticleTrackerBuilder<Tracker> TrackerBuilder;
+        typedef TrackerBuilder::TransitionBuilder TransitionBuilder;
+        dbot_amd::ObjectTransitionBuilder<State>::Parameters params_state;
+        params_state.linear_sigma_x = params_state.linear_sigma_y = params_state.linear_sigma_z = 0.0025;
+        params_state.angular_sigma_x = params_state.angular_sigma_y = params_state.angular_sigma_z = 0.02;
+        params_state.velocity_factor = 0.8;
+        params_state.part_count = parts;
+        auto state_trans_builder = std::shared_ptr<TransitionBuilder>(new TransitionBuilder(params_state));
+        TrackerBuilder::Parameters params_tracker;
+        params_tracker.evaluation_count = params_obsrv.sample_count;
+        params_tracker.moving_average_update_rate = 1.0;
+        params_tracker.max_kl_divergence = 2.0;
+        params_tracker.center_object_frame = true;
+        params_tracker.seed = 42;
+        auto tracker_builder = TrackerBuilder(state_trans_builder, sensor_builder, object_model, params_tracker);
+        auto tracker = tracker_builder.build();
+        // initial state in ORIGINAL mesh coordinates = default pose of the centred frame shifted back
+        std::vector<State> initial_poses;
+        initial_poses.push_back(def);
+        double R[9];
+        for (int b = 0; b < parts; ++b) {
+            State::rotation_matrix(def.euler_vector(b), R);
+            const double* c = object_model->centers().data() + 3 * b;
+            for (int r = 0; r < 3; ++r)
+                initial_poses[0].position(b)[r] -= R[3 * r] * c[0] + R[3 * r + 1] * c[1] + R[3 * r + 2] * c[2];
+        }
+        tracker->initialize(initial_poses);
+        for (int k = 0; k < 3; ++k) {
+            State est = tracker->track(frame);
+            std::printf("TRK%d", k);
+            for (double v : est.data()) std::printf(" %.17g", v);
+            std::printf("\n");
+        }
+    }
     // error path: wrong observation size must surface as std::runtime_error
     try {
         sensor->set_observation(std::vector<double>(3));

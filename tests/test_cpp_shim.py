@@ -80,3 +80,22 @@ def test_cpp_shim_matches_oracle(tmp_path, gpu_lib):
     r2 = o.loglikes_poses(poses, np.arange(n - 1, -1, -1, dtype=np.int32), update=False)
     for got, ref in ((ll1, r1), (ll2, r2)):
         assert (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max() <= 1e-9
+    # the C++ tracker mirror against the Python device tracker: same device RNG key -> same states
+    from dbot_ros_amd import RbSensor
+    from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
+    om = ObjectModel([synth.mesh_m1(level=2)[0], synth.mesh_box12()[0]],
+                     [synth.mesh_m1(level=2)[1], synth.mesh_box12()[1]], center=True)
+    cam = CameraData(synth.camera_matrix(80, 60), 60, 80)
+    P = RbSensorBuilder.Parameters(sample_count=n)
+    with RbSensor(om, cam, P, max_particles=n) as s:
+        tr = DeviceParticleTracker(ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=2)).build(),
+                                   s, om, ParticleTrackerBuilder.Parameters(evaluation_count=n), device_rng=True, seed=42)
+        init = default.copy().reshape(2, 12)
+        for b in range(2):
+            init[b, 0:3] -= pose.rotvec_to_matrix(init[b, 3:6]) @ om.centers[b]
+        tr.initialize([init.ravel()])
+        for k in range(3):
+            est = tr.track(frame)
+            got = np.array(lines[f"TRK{k}"], dtype=np.float64)
+            assert np.abs(got - est).max() <= 1e-12, (k, np.abs(got - est).max())
+        tr.close()
