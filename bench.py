@@ -45,32 +45,43 @@ def parse():
 
 
 def cpu_baseline(om, cam, P, truth, frame, seconds):
-    """The oracle in reference-CPU-semantics mode (LAZY), single thread as dbot's CPU model,
-    on a bounded sample of the same workload: config C0's 200 particles per call, repeated
-    frame after frame (update=true, multinomial-like parent shuffle) until `seconds` elapse."""
+    """The oracle in reference-CPU-semantics mode (LAZY) on a bounded sample of the same
+    workload: config C0's 200 particles per call, repeated frame after frame (update=true,
+    permuted parents) until `seconds` elapse.  Headline = single thread, as dbot's CPU model
+    runs; `all_cores` = the same loop with OpenMP over particles on every host core."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     from dbot_ros_amd import synth
     n = 200
-    orc = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
-    rng = np.random.default_rng(1)
-    poses = synth.particle_poses(truth, n, rng)
-    idx = np.zeros(n, dtype=np.int32)
-    orc.reset()
-    done, t0 = 0, time.perf_counter()
-    while True:
-        orc.set_observation(frame)
-        orc.loglikes_poses(poses, idx, update=True)
-        done += n
-        idx = rng.permutation(n).astype(np.int32)
-        el = time.perf_counter() - t0
-        if el >= seconds:
-            break
-    orc.close()
+    tris = sum(len(t) for t in om.triangles)
+
+    def run(threads, budget):
+        orc = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
+        rng = np.random.default_rng(1)
+        poses = synth.particle_poses(truth, n, rng)
+        idx = np.zeros(n, dtype=np.int32)
+        orc.reset()
+        done, t0 = 0, time.perf_counter()
+        while True:
+            orc.set_observation(frame)
+            orc.loglikes_poses(poses, idx, update=True, threads=threads)
+            done += n
+            idx = rng.permutation(n).astype(np.int32)
+            el = time.perf_counter() - t0
+            if el >= budget:
+                break
+        orc.close()
+        return done, el
+
+    done, el = run(1, seconds)
+    cores = os.cpu_count() or 1
+    threads = min(cores, n)
+    done_mt, el_mt = run(threads, max(3.0, seconds / 3))
     return {"value": done / el, "unit": "particle-likelihoods/s", "cores": 1, "kind": "port",
             "sample": f"{done} particle-likelihoods = {done // n} loglikes(update=true) calls x {n} "
-                      f"particles, {cam.cols}x{cam.rows}, {sum(len(t) for t in om.triangles)} triangles, "
-                      f"{el:.1f} s on 1 of {os.cpu_count()} host cores"}
+                      f"particles, {cam.cols}x{cam.rows}, {tris} triangles, {el:.1f} s on 1 of {cores} host cores",
+            "all_cores": {"value": done_mt / el_mt, "cores": threads,
+                          "sample": f"{done_mt} particle-likelihoods in {el_mt:.1f} s, OpenMP over particles"}}
 
 
 def main():

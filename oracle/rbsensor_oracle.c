@@ -269,72 +269,109 @@ void orc_set_observation(orc_sensor* s, const double* depth)
 
 /* ---------------------------------------------------------------- the hot function */
 
+/* One particle of orc_loglikes; depth/covered are per-thread scratch (depth all +inf on entry
+ * and on exit). */
+static double loglik_one(orc_sensor* s, const double* pose, int32_t parent, int32_t child,
+                         int32_t update, float alpha, float beta, float* depth, int32_t* covered)
+{
+    const int lazy = s->cfg.occlusion_mode == ORC_OCC_LAZY;
+    const int src = s->cur, dst = 1 - s->cur;
+    const size_t poff = (size_t)parent * s->npx;
+    const size_t coff = (size_t)child * s->npx;
+    const float* pocc = s->occ[src] + poff;
+    const int32_t* pstamp = lazy ? s->stamp[src] + poff : NULL;
+    float* cocc = s->occ[dst] + coff;
+    int32_t* cstamp = lazy ? s->stamp[dst] + coff : NULL;
+
+    if (update) {
+        if (lazy) {
+            memcpy(cocc, pocc, sizeof(float) * s->npx);
+            memcpy(cstamp, pstamp, sizeof(int32_t) * s->npx);
+        } else {
+            for (size_t p = 0; p < s->npx; ++p) cocc[p] = fmaf(alpha, pocc[p], beta);
+        }
+    }
+
+    const int32_t ncov = render_into(s, pose, depth, covered);
+
+    double ll = 0.0;
+    for (int32_t k = 0; k < ncov; ++k) {
+        const size_t p = (size_t)covered[k];
+        const float r = depth[p];
+        depth[p] = INFINITY; /* leave the scratch buffer clean for the next particle */
+        const float o = s->frame[p];
+        if (!isfinite(o)) continue;
+        float occ;
+        if (lazy) {
+            const double dt = (double)(s->clock - pstamp[p]) * s->cfg.delta_time;
+            occ = (float)orc_propagate(s, (double)pocc[p], dt);
+        } else {
+            occ = fmaf(alpha, pocc[p], beta);
+        }
+        const float a = (float)(orc_prob_visible(s, (double)o, (double)r) * (1.0 - (double)occ));
+        const float b = (float)(orc_prob_occluded(s, (double)o, (double)r) * (double)occ);
+        const float pbg = (float)orc_prob_occluded(s, (double)o, INFINITY);
+        const float sum = a + b;
+        ll += log((double)(sum / pbg));
+        if (update) {
+            cocc[p] = b / sum;
+            if (lazy) cstamp[p] = s->clock;
+        }
+    }
+    return ll;
+}
+
 /* KinectImageModel::loglikes restated; selected by use_gpu=false at
  * R:source/dbot_ros/tracker/particle_tracker_node.cpp:165.  Rounding points:
  *   prior occlusion    -> float
  *   a = p_vis*(1-occ), b = p_occ*occ, p_bg -> float; a+b and (a+b)/p_bg in float
  *   log(...) in double, accumulated in double
  *   posterior occlusion b/(a+b) in float.
- * Pixels whose observation is not finite contribute 0 and are left untouched. */
-void orc_loglikes(orc_sensor* s, const double* poses, int32_t* indices, int32_t n,
-                  int32_t update, double* out_loglik)
+ * Pixels whose observation is not finite contribute 0 and are left untouched.
+ * n_threads <= 1: the reference's single-threaded loop; > 1: the same per-particle work
+ * spread over OpenMP threads (particles are independent; results are identical). */
+void orc_loglikes_mt(orc_sensor* s, const double* poses, int32_t* indices, int32_t n,
+                     int32_t update, double* out_loglik, int32_t n_threads)
 {
-    const int lazy = s->cfg.occlusion_mode == ORC_OCC_LAZY;
-    const int src = s->cur, dst = 1 - s->cur;
     float alpha = 1.0f, beta = 0.0f;
-    if (!lazy) orc_eager_coeffs(s, s->clock - s->last_update_clock, &alpha, &beta);
-
-    for (int32_t i = 0; i < n; ++i) {
-        const size_t poff = (size_t)indices[i] * s->npx;
-        const size_t coff = (size_t)i * s->npx;
-        const float* pocc = s->occ[src] + poff;
-        const int32_t* pstamp = lazy ? s->stamp[src] + poff : NULL;
-        float* cocc = s->occ[dst] + coff;
-        int32_t* cstamp = lazy ? s->stamp[dst] + coff : NULL;
-
-        if (update) {
-            if (lazy) {
-                memcpy(cocc, pocc, sizeof(float) * s->npx);
-                memcpy(cstamp, pstamp, sizeof(int32_t) * s->npx);
-            } else {
-                for (size_t p = 0; p < s->npx; ++p) cocc[p] = fmaf(alpha, pocc[p], beta);
-            }
+    if (s->cfg.occlusion_mode != ORC_OCC_LAZY)
+        orc_eager_coeffs(s, s->clock - s->last_update_clock, &alpha, &beta);
+    const size_t pstride = (size_t)12 * s->cfg.n_objects;
+    if (n_threads <= 1) {
+        for (int32_t i = 0; i < n; ++i)
+            out_loglik[i] = loglik_one(s, poses + (size_t)i * pstride, indices[i], i, update, alpha, beta,
+                                       s->depth, s->covered);
+    } else {
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads)
+        {
+            float* depth = (float*)malloc(sizeof(float) * s->npx);
+            int32_t* covered = (int32_t*)malloc(sizeof(int32_t) * s->npx);
+            for (size_t p = 0; p < s->npx; ++p) depth[p] = INFINITY;
+#pragma omp for schedule(dynamic, 1)
+            for (int32_t i = 0; i < n; ++i)
+                out_loglik[i] = loglik_one(s, poses + (size_t)i * pstride, indices[i], i, update, alpha,
+                                           beta, depth, covered);
+            free(depth);
+            free(covered);
         }
-
-        const int32_t ncov =
-            render_into(s, poses + (size_t)i * 12 * s->cfg.n_objects, s->depth, s->covered);
-
-        double ll = 0.0;
-        for (int32_t k = 0; k < ncov; ++k) {
-            const size_t p = (size_t)s->covered[k];
-            const float r = s->depth[p];
-            s->depth[p] = INFINITY; /* leave the scratch buffer clean for the next particle */
-            const float o = s->frame[p];
-            if (!isfinite(o)) continue;
-            float occ;
-            if (lazy) {
-                const double dt = (double)(s->clock - pstamp[p]) * s->cfg.delta_time;
-                occ = (float)orc_propagate(s, (double)pocc[p], dt);
-            } else {
-                occ = fmaf(alpha, pocc[p], beta);
-            }
-            const float a = (float)(orc_prob_visible(s, (double)o, (double)r) * (1.0 - (double)occ));
-            const float b = (float)(orc_prob_occluded(s, (double)o, (double)r) * (double)occ);
-            const float pbg = (float)orc_prob_occluded(s, (double)o, INFINITY);
-            const float sum = a + b;
-            ll += log((double)(sum / pbg));
-            if (update) {
-                cocc[p] = b / sum;
-                if (lazy) cstamp[p] = s->clock;
-            }
-        }
-        out_loglik[i] = ll;
+#else
+        for (int32_t i = 0; i < n; ++i)
+            out_loglik[i] = loglik_one(s, poses + (size_t)i * pstride, indices[i], i, update, alpha, beta,
+                                       s->depth, s->covered);
+#endif
     }
     if (update) {
-        s->cur = dst;
+        s->cur = 1 - s->cur;
         s->last_update_clock = s->clock;
         for (int32_t i = 0; i < n; ++i) indices[i] = i;
     }
+}
+
+void orc_loglikes(orc_sensor* s, const double* poses, int32_t* indices, int32_t n,
+                  int32_t update, double* out_loglik)
+{
+    orc_loglikes_mt(s, poses, indices, n, update, out_loglik, 1);
 }
 
 void orc_get_occlusion(const orc_sensor* s, int32_t slot, float* out)

@@ -73,6 +73,11 @@ void orc_set_observation(orc_sensor* s, const double* depth);
 void orc_loglikes(orc_sensor* s, const double* poses, int32_t* indices, int32_t n,
                   int32_t update, double* out_loglik);
 
+/* Same, with the per-particle loop spread over n_threads OpenMP threads (the reference's CPU
+ * model is single-threaded; this is the "all host cores" baseline of BASELINE.md section 2). */
+void orc_loglikes_mt(orc_sensor* s, const double* poses, int32_t* indices, int32_t n,
+                     int32_t update, double* out_loglik, int32_t n_threads);
+
 /* Stored occlusion plane of a slot (float[rows*cols]). */
 void orc_get_occlusion(const orc_sensor* s, int32_t slot, float* out);
 /* Overwrite a slot's stored plane (LAZY: stamps := current clock, i.e. the plane is taken to

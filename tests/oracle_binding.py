@@ -51,6 +51,7 @@ def load():
         lib.orc_reset.argtypes = [H]
         lib.orc_set_observation.argtypes = [H, dp]
         lib.orc_loglikes.argtypes = [H, dp, ip, C.c_int32, C.c_int32, dp]
+        lib.orc_loglikes_mt.argtypes = [H, dp, ip, C.c_int32, C.c_int32, dp, C.c_int32]
         lib.orc_get_occlusion.argtypes = [H, C.c_int32, fp]
         lib.orc_get_occlusion_now.argtypes = [H, C.c_int32, fp]
         lib.orc_set_occlusion.argtypes = [H, C.c_int32, fp]
@@ -113,14 +114,14 @@ class Oracle:
         assert a.size == self.rows * self.cols
         self._lib.orc_set_observation(self._h, a.ctypes.data_as(C.POINTER(C.c_double)))
 
-    def loglikes_poses(self, poses, indices, update=False):
+    def loglikes_poses(self, poses, indices, update=False, threads=1):
         poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, self.n_bodies * 12)
         n = poses.shape[0]
         assert indices.dtype == np.int32 and indices.size == n and indices.flags.c_contiguous
         out = np.empty(n, dtype=np.float64)
-        self._lib.orc_loglikes(self._h, poses.ctypes.data_as(C.POINTER(C.c_double)),
-                               indices.ctypes.data_as(C.POINTER(C.c_int32)), n, int(bool(update)),
-                               out.ctypes.data_as(C.POINTER(C.c_double)))
+        self._lib.orc_loglikes_mt(self._h, poses.ctypes.data_as(C.POINTER(C.c_double)),
+                                  indices.ctypes.data_as(C.POINTER(C.c_int32)), n, int(bool(update)),
+                                  out.ctypes.data_as(C.POINTER(C.c_double)), int(threads))
         return out
 
     def get_occlusion(self, slot, now=False):
