@@ -558,8 +558,10 @@ __global__ __launch_bounds__(1024) void rbs_scan_kernel(const int* __restrict__ 
     if (threadIdx.x == 0) *work_counter = 0;
 }
 
+// 3 waves/SIMD caps the raster kernel at 168 VGPRs (a 44-byte spill): leaves the copy kernel's
+// waves more of the register file; measured +1.5 % on the C1 call.
 #ifndef RBS_RASTER_MINWAVES
-#define RBS_RASTER_MINWAVES 1
+#define RBS_RASTER_MINWAVES 3
 #endif
 // Persistent: a fixed number of raster blocks per CU keeps its LDS/VGPR share for the whole
 // launch (never starved by the many small copy blocks) and pulls (particle, tile) items from
