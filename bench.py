@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--mesh", default="m1")
-    ap.add_argument("--parents", default="permutation", choices=["permutation", "identity", "resampled"])
+    ap.add_argument("--parents", default="permutation",
+                    choices=["permutation", "identity", "resampled", "peaked", "peaked_unsorted"])
     ap.add_argument("--update", type=int, default=1, help="0: read-only evaluation (non-final blocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -122,8 +123,14 @@ def main():
         parents = synth.resample_like_indices(n, prng)
     elif a.parents == "identity":
         parents = np.arange(n, dtype=np.int32)
-    else:
+    elif a.parents == "resampled":
         parents = synth.resample_like_indices(n, prng, concentration=1.0)
+    else:  # a tracker's usual regime: few survivors, many siblings
+        parents = synth.resample_like_indices(n, prng, concentration=0.02)
+        if a.parents == "peaked_unsorted":
+            parents = prng.permutation(parents).astype(np.int32)
+    if rank == 0:
+        print(f"# parents={a.parents}: {len(np.unique(parents))} distinct of {n}", file=sys.stderr)
 
     dev = torch.device("cuda", local)
     d_poses = torch.from_numpy(poses.reshape(n, -1)).to(dev)

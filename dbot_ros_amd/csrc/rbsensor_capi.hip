@@ -413,14 +413,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
 
     const size_t plane = (size_t)h->npx * sizeof(float);
     RBS_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    {
-        int lo = 0, hi = 0;  // numerically lower = higher priority
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const char* pr = std::getenv("RBS_COPY_PRIO");
-        const int prio = pr ? std::atoi(pr) : 0;
-        RBS_HIP(h, hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking,
-                                               prio < 0 ? hi : (prio > 0 ? lo : 0)));
-    }
+    RBS_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     RBS_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < rbs_handle::kRing; ++i) {
         RBS_HIP(h, hipEventCreate(&h->ev_start[i]));
@@ -428,18 +421,14 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         RBS_HIP(h, hipEventCreate(&h->ev_copy_start[i]));
         RBS_HIP(h, hipEventCreate(&h->ev_join[i]));
     }
-    if (const char* m = std::getenv("RBS_COPY_BLOCKS")) h->copy_blocks = std::max(1, std::atoi(m));
     {
         hipDeviceProp_t prop;
         RBS_HIP(h, hipGetDeviceProperties(&prop, h->device));
         h->raster_blocks = 2 * std::max(1, prop.multiProcessorCount);
+        // tuning overrides (defaults are the measured best on MI355X)
         if (const char* m = std::getenv("RBS_RASTER_BLOCKS")) h->raster_blocks = std::max(1, std::atoi(m));
         h->tile_override = std::getenv("RBS_TILE");
         if (const char* m = std::getenv("RBS_COPY_ROWS")) h->copy_rows = std::atoi(m);
-    }
-    if (const char* m = std::getenv("RBS_BANDS")) {
-        B.bands = std::max(1, std::atoi(m));
-        B.band_rows = (h->rows + B.bands - 1) / B.bands;
     }
     RBS_HIP(h, hipMalloc(&h->d_soup, soup.size() * sizeof(double)));
     RBS_HIP(h, hipMemcpy(h->d_soup, soup.data(), soup.size() * sizeof(double), hipMemcpyHostToDevice));
