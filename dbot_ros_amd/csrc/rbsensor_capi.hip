@@ -47,6 +47,7 @@ struct rbs_handle {
     int* d_item_offset = nullptr; // [max_particles+1]
     int* d_work_counter = nullptr;
     double* d_partial = nullptr; // [partial_cap] per-item partial sums
+    unsigned long long* d_phase = nullptr;  // RBS_PHASE_TIMING builds
     size_t partial_cap = 0;
     float* d_cluster_sphere = nullptr;
     float* d_render = nullptr;
@@ -160,6 +161,10 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.item_offset = h->d_item_offset;
     P.work_counter = h->d_work_counter;
     P.partial = h->d_partial;
+#ifdef RBS_PHASE_TIMING
+    if (!h->d_phase) { RBS_HIP(h, hipMalloc(&h->d_phase, 64)); RBS_HIP(h, hipMemset(h->d_phase, 0, 64)); }
+    P.phase = h->d_phase;
+#endif
     RBS_HIP(h, hipEventRecord(h->ev_start[slot], s));
     const dim3 block(rbs::kBlock);
     const dim3 pgrid((unsigned)((n + 255) / 256));
@@ -710,6 +715,17 @@ int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out)
     RBS_HIP(h, hipStreamSynchronize(h->stream));
     return RBS_OK;
 }
+
+#ifdef RBS_PHASE_TIMING
+int32_t rbs_debug_phase_cycles(rbs_handle* h, unsigned long long* out8)
+{
+    if (!h || !h->d_phase) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_HIP(h, hipDeviceSynchronize());
+    RBS_HIP(h, hipMemcpy(out8, h->d_phase, 64, hipMemcpyDeviceToHost));
+    RBS_HIP(h, hipMemset(h->d_phase, 0, 64));
+    return RBS_OK;
+}
+#endif
 
 int32_t rbs_last_kernel_ms(rbs_handle* h, float* ms)
 {

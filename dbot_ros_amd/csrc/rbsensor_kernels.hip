@@ -85,7 +85,17 @@ struct DevParams {
     const int* item_offset;        // [n+1] exclusive scan of tiles per particle
     int* work_counter;             // atomic queue head over the (particle, tile) items
     double* partial;               // [items] partial log-likelihood per work item
+#ifdef RBS_PHASE_TIMING
+    unsigned long long* phase;     // [8] accumulated wave-0 cycles per phase (profiling builds only)
+#endif
 };
+#ifdef RBS_PHASE_TIMING
+#define RBS_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); atomicAdd(&P.phase[k], t_ - tick_); tick_ = t_; } } while (0)
+#define RBS_TICK_DECL unsigned long long tick_ = clock64()
+#else
+#define RBS_TICK(k) do {} while (0)
+#define RBS_TICK_DECL do {} while (0)
+#endif
 
 struct Rect { int x0, y0, x1, y1; };
 
@@ -144,11 +154,15 @@ __device__ inline bool tri_setup(const DevParams& P, int t, const double* __rest
 {
     const double* __restrict__ s = P.soup;
     const size_t n = (size_t)P.n_tri;
+    // all nine coalesced loads in flight together (one memory round trip per triangle, not three)
+    double vv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) vv[k] = s[k * n + t];
+    __builtin_amdgcn_sched_barrier(0);
     double X[3], Y[3], Z[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double vx = s[(3 * k + 0) * n + t], vy = s[(3 * k + 1) * n + t],
-                     vz = s[(3 * k + 2) * n + t];
+        const double vx = vv[3 * k + 0], vy = vv[3 * k + 1], vz = vv[3 * k + 2];
         X[k] = ((Rt[0] * vx + Rt[1] * vy) + Rt[2] * vz) + Rt[9];
         Y[k] = ((Rt[3] * vx + Rt[4] * vy) + Rt[5] * vz) + Rt[10];
         Z[k] = ((Rt[6] * vx + Rt[7] * vy) + Rt[8] * vz) + Rt[11];
@@ -335,17 +349,23 @@ __device__ inline double pixel_loglik(const DevParams& P, int gi, float o, float
                                       float& posterior)
 {
     const size_t n = (size_t)P.npx;
-    const double w = ((double)r - (double)o) * P.aux[(size_t)AUX_INV_S2S * n + gi];
+    // the five per-frame terms of this pixel: one memory round trip
+    const double inv_s2s = P.aux[(size_t)AUX_INV_S2S * n + gi];
+    const double kk = P.aux[(size_t)AUX_K * n + gi];
+    const double cv = P.aux[(size_t)AUX_CV * n + gi];
+    const double eo = P.aux[(size_t)AUX_EO * n + gi];
+    const float pbg = P.pbg[gi];
+    __builtin_amdgcn_sched_barrier(0);
+    const double w = ((double)r - (double)o) * inv_s2s;
     const double twD = P.tw / kMaxDepth;
-    const double pv = twD + P.aux[(size_t)AUX_CV * n + gi] * exp(-(w * w));
+    const double pv = twD + cv * exp(-(w * w));
     const double E1 = exp((double)r * P.lambda);
-    const double po = twD + P.aux[(size_t)AUX_EO * n + gi] * (E1 / (E1 - 1.0)) *
-                                (1.0 + erf(w + P.aux[(size_t)AUX_K * n + gi]));
+    const double po = twD + eo * (E1 / (E1 - 1.0)) * (1.0 + erf(w + kk));
     const float a = (float)(pv * (1.0 - (double)prior));
     const float b = (float)(po * (double)prior);
     const float sum = a + b;
     posterior = b / sum;
-    return log((double)(sum / P.pbg[gi]));
+    return log((double)(sum / pbg));
 }
 
 __device__ inline double block_reduce_sum(double v, double* red)
@@ -395,10 +415,13 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     const float* __restrict__ src = P.occ_src + (size_t)parent * P.npx;
     float* __restrict__ dst = UPDATE ? P.occ_dst + (size_t)particle * P.npx : nullptr;
 
+    RBS_TICK_DECL;
     for (int p = threadIdx.x; p < npx; p += kBlock) m.tile[p] = kInfBits;
     __syncthreads();
+    RBS_TICK(1);
     // a rectangle that is a single tile was sized from the same spheres: nothing to cull
     raster_window(P, pose, wx0, wy0, wx1, wy1, !whole || P.n_bodies > 1, m.tile, m.big, m.nbig);
+    RBS_TICK(2);
 
     // Pixel pass.  Only ~1/3 of a tile's pixels are covered by the object, in runs that leave
     // most lanes of a wave idle in the expensive likelihood code, so each wave compacts its
@@ -408,41 +431,56 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int4* q = m.evalq + wave * kEvalQueue;
     int qn = 0;
-    for (int p0 = wave * 64; p0 < npx; p0 += kBlock) {
-        const int p = p0 + lane;
-        const bool valid = p < npx;
-        int gi = 0;
-        unsigned dbits = kInfBits;
-        float prior = 0.f, o = 0.f;
-        if (valid) {
-            const int lr = p / tw;
-            gi = (wy0 + lr) * P.cols + wx0 + (p - lr * tw);
-            dbits = m.tile[p];
+    constexpr int kScanUnroll = 4;   // chunks whose loads are in flight together (latency, not VALU, bounds the scan)
+    for (int p0 = wave * 64; p0 < npx; p0 += kBlock * kScanUnroll) {
+        int gi[kScanUnroll];
+        unsigned dbits[kScanUnroll];
+        float sv[kScanUnroll], ov[kScanUnroll];
+        bool valid[kScanUnroll];
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            const int p = p0 + u * kBlock + lane;
+            valid[u] = p < npx;
+            gi[u] = 0;
+            dbits[u] = kInfBits;
+            sv[u] = 0.f;
+            ov[u] = 0.f;
+            if (valid[u]) {
+                const int lr = p / tw;
+                gi[u] = (wy0 + lr) * P.cols + wx0 + (p - lr * tw);
+                dbits[u] = m.tile[p];
+            }
+            const bool covered = dbits[u] != kInfBits;
+            if (valid[u] && (UPDATE || covered)) sv[u] = src[gi[u]];
+            if (covered) ov[u] = P.frame[gi[u]];
         }
-        const bool covered = dbits != kInfBits;
-        if (valid && (UPDATE || covered)) prior = fmaf(P.alpha, src[gi], P.beta);
-        if (covered) o = P.frame[gi];
-        const bool active = covered && isfinite(o);
-        if (UPDATE && valid && !active) dst[gi] = prior;
-        const unsigned long long mask = __ballot(active);
-        if (active) {
-            const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-            q[pos] = make_int4(gi, (int)dbits, __float_as_int(prior), __float_as_int(o));
-        }
-        qn += __popcll(mask);
-        if (qn >= 64) {
-            __builtin_amdgcn_wave_barrier();
-            const int4 e = q[lane];
-            float post;
-            ll += pixel_loglik(P, e.x, __int_as_float(e.w), __uint_as_float((unsigned)e.y),
-                               __int_as_float(e.z), post);
-            if (UPDATE) dst[e.x] = post;
-            qn -= 64;
-            int4 carry = make_int4(0, 0, 0, 0);
-            if (lane < qn) carry = q[64 + lane];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < qn) q[lane] = carry;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            if (p0 + u * kBlock >= npx) break;   // wave-uniform
+            const float prior = fmaf(P.alpha, sv[u], P.beta);
+            const bool active = dbits[u] != kInfBits && isfinite(ov[u]);
+            if (UPDATE && valid[u] && !active) dst[gi[u]] = prior;
+            const unsigned long long mask = __ballot(active);
+            if (active) {
+                const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                q[pos] = make_int4(gi[u], (int)dbits[u], __float_as_int(prior), __float_as_int(ov[u]));
+            }
+            qn += __popcll(mask);
+            if (qn >= 64) {
+                __builtin_amdgcn_wave_barrier();
+                const int4 e = q[lane];
+                float post;
+                ll += pixel_loglik(P, e.x, __int_as_float(e.w), __uint_as_float((unsigned)e.y),
+                                   __int_as_float(e.z), post);
+                if (UPDATE) dst[e.x] = post;
+                qn -= 64;
+                int4 carry = make_int4(0, 0, 0, 0);
+                if (lane < qn) carry = q[64 + lane];
+                __builtin_amdgcn_wave_barrier();
+                if (lane < qn) q[lane] = carry;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -453,7 +491,10 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                            __int_as_float(e.z), post);
         if (UPDATE) dst[e.x] = post;
     }
-    return block_reduce_sum(ll, m.red);
+    RBS_TICK(3);
+    const double total = block_reduce_sum(ll, m.red);
+    RBS_TICK(4);
+    return total;
 }
 
 // ------------------------------------------------------------------ copy block
@@ -575,7 +616,7 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
     for (;;) {
         if (threadIdx.x == 0) *m.item = atomicAdd(P.work_counter, 1);
         __syncthreads();
-        const int item = *m.item;
+        const int item = __builtin_amdgcn_readfirstlane(*m.item);
         if (item >= total) break;
         // particle owning this item: largest i with item_offset[i] <= item (64-ary search, wave-parallel)
         int lo = 0, hi = P.n;
@@ -588,7 +629,9 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
             lo = lo + (k - 1) * step;
             hi = min(hi, lo + step);
         }
-        const int particle = lo;
+        // wave-uniform by construction: tell the compiler, so the pose / rectangle / parent index
+        // become scalar loads held in SGPRs instead of per-lane vector loads in every loop
+        const int particle = __builtin_amdgcn_readfirstlane(lo);
         const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
         const Rect r = {q.x, q.y, q.z, q.w};
         double part = 0.0;

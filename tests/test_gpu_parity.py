@@ -77,7 +77,8 @@ def test_render_edge_poses(gpu_lib, pose_case):
 @pytest.mark.parametrize("meshes,cols,rows,n", [(("m1",), 640, 480, 24), (("m3",), 640, 480, 16),
                                                  (("m1",), 80, 60, 64), (("box12",), 640, 480, 8),
                                                  (("m1", "m2", "m3"), 640, 480, 12),
-                                                 (("m1_l2",), 322, 241, 16)])
+                                                 (("m1_l2",), 322, 241, 16),
+                                                 (("m4",), 1280, 960, 4)])
 def test_sequence_matches_oracle(gpu_lib, meshes, cols, rows, n):
     """set_observation -> loglikes(update) -> resample, 4 frames; eager and lazy oracles."""
     om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)

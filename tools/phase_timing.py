@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the raster kernel (needs a -DRBS_PHASE_TIMING build:
+RBS_LIB_PATH=build_variants/phase.so python tools/phase_timing.py [--update 0|1])."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dbot_ros_amd import CameraData, ObjectModel, RbSensor, RbSensorBuilder, synth, _capi
+upd = int(sys.argv[sys.argv.index("--update") + 1]) if "--update" in sys.argv else 0
+n = 2000
+v, f = synth.mesh_m1()
+om = ObjectModel([v], [f]); cam = CameraData(synth.camera_matrix(), 480, 640)
+P = RbSensorBuilder.Parameters(sample_count=n)
+with RbSensor(om, cam, P, max_particles=n) as s:
+    lib = _capi.load()
+    rng = np.random.default_rng(0)
+    truth = synth.truth_pose(1)
+    s.set_observation(synth.make_frame(s.render_depth(truth), 480, 640, rng))
+    poses = synth.particle_poses(truth, n, rng)
+    idx = rng.permutation(n).astype(np.int32)
+    out = (C.c_ulonglong * 8)()
+    for rep in range(3):
+        s.loglikes_poses(poses, idx.copy(), update=bool(upd))
+        lib.rbs_debug_phase_cycles(s._h, out)
+        c = np.array(list(out), dtype=np.float64)
+        names = ["-", "clear", "raster(+barriers)", "pixel pass", "reduce"]
+        tot = c[1:5].sum()
+        print("rep", rep, "ms", "%.3f" % s.last_kernel_ms(), {names[k]: "%.1f%%" % (100 * c[k] / tot) for k in range(1, 5)},
+              "wave0 cycles per item: %.0f" % (tot / n))

@@ -76,4 +76,23 @@ json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 json.dump({"hbm_bytes_per_launch": total, "source": f"profiles/{tag}_pmc_hbm.json",
            "workload": "bench.py default (C1: 2000 particles, 640x480, update=true)"},
           open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+sq_path = os.path.join(src, "sq", "sq_counter_collection.csv")
+if os.path.exists(sq_path):
+    sq, nd = per_dispatch(sq_path)
+    k = [kk for (kk, c) in sq if "rbs_raster_kernel" in kk]
+    if k:
+        k = k[0]
+        g = lambda c: sq.get((k, c), 0.0)
+        # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves
+        summary = {"kernel": k, "workload": "bench.py --update 0 (raster kernel alone, 2000 particles)",
+                   "per_dispatch": {c: g(c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+                                                      "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                                                      "SQ_BUSY_CYCLES")},
+                   "valu_instructions_per_particle": g("SQ_INSTS_VALU") / 2000.0,
+                   "cycles_per_valu_instruction": 4.0 * g("SQ_ACTIVE_INST_VALU") / max(g("SQ_INSTS_VALU"), 1.0),
+                   "fraction_of_wave_time_issuing_valu": g("SQ_ACTIVE_INST_VALU") / max(g("SQ_WAVE_CYCLES"), 1.0),
+                   "fraction_waiting": g("SQ_WAIT_ANY") / max(g("SQ_WAVE_CYCLES"), 1.0),
+                   "fraction_issue_stalled": g("SQ_WAIT_INST_ANY") / max(g("SQ_WAVE_CYCLES"), 1.0)}
+        json.dump(summary, open(os.path.join(dst, f"{tag}_raster_sq.json"), "w"), indent=1)
+        print(json.dumps(summary, indent=1))
+print(json.dumps(out, indent=1)[:1500])
