@@ -94,12 +94,20 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
+    # RBS_BENCH_BACKEND=gloo: functional test of the multi-rank path on a box with fewer GPUs than
+    # ranks (ranks share devices, the all-gather goes through host tensors); never used for numbers
+    backend = os.environ.get("RBS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from dbot_ros_amd import CameraData, ObjectModel, RbSensor, RbSensorBuilder, synth
     mesh_fns = {"m1": synth.mesh_m1, "m2": synth.mesh_m2, "m3": synth.mesh_m3, "m4": synth.mesh_m4,
@@ -145,11 +153,20 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
 
+    def exchange():
+        # the weight exchange before resampling: every rank gets all N*world log-likelihoods
+        if backend == "nccl":
+            dist.all_gather_into_tensor(d_all, d_out)      # RCCL over xGMI, on `stream`
+        else:
+            host = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(host, d_out.cpu())
+            d_all.copy_(torch.cat(host))
+
     def step():
         sensor.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, bool(a.update), d_out.data_ptr(),
                                stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_out)
+            exchange()
 
     for _ in range(a.warmup):
         step()
@@ -166,16 +183,20 @@ def main():
                                stream.cuda_stream)
         e.record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_out)
+            exchange()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank must hold every rank's log-likelihoods after the exchange
+        ref = d_all.view(world, n)[rank].cpu().numpy()
+        if not np.array_equal(ref, d_out.cpu().numpy()):
+            raise SystemExit("all-gather returned the wrong shard")
     call_ms = float(np.mean([s.elapsed_time(e) for s, e in k_ev]))
     # the dominant kernel (rbs_copy_kernel) runs on the library's second stream: its duration
     # comes from the HIP events the library records on THAT stream, averaged over the timed steps
@@ -211,7 +232,7 @@ def main():
                        "sharding": f"particles/{world}" + (" + RCCL all-gather of log-likelihoods" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rbs_copy_kernel" if a.update else "rbs_raster_kernel",
+                         "kernel": "rbs_copy_rows_kernel" if a.update else "rbs_raster_kernel",
                          "kernel_ms": kernel_ms, "kernel_launches_averaged": n_used,
                          "call_ms_launch_stream": call_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
