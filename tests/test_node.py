@@ -1,0 +1,105 @@
+"""The ROS-free node assembly: the reference's own YAML key tree -> tracker, driven on a
+synthetic sequence at the reference's default operating point (640x480 / 8 = 80x60)."""
+import numpy as np
+import pytest
+import yaml
+
+from dbot_ros_amd import node, objloader, pose, synth
+
+# verbatim key structure of R:config/particle_tracker.yaml, R:config/camera.yaml, R:config/object.yaml
+FILTER_YAML = """
+particle_filter:
+  use_gpu: true
+  cpu: {sample_count: 100}
+  gpu:
+    sample_count: 400
+    use_custom_shaders: false
+    vertex_shader_file: /path/to/custom/vertex_shader.vertexshader
+    fragment_shader_file: /path/to/custom/fragment_shader.fragmentshader
+    geometry_shader_file: none
+  moving_average_update_rate: 1.0
+  center_object_frame: true
+  max_kl_divergence: 2.0
+  observation:
+    occlusion: {initial_occlusion_prob: 0.1, p_occluded_visible: 0.1, p_occluded_occluded: 0.7}
+    kinect: {tail_weight: 0.01, model_sigma: 0.003, sigma_factor: 0.0014247}
+  object_transition:
+    linear_sigma_x: 0.0025
+    linear_sigma_y: 0.0025
+    linear_sigma_z: 0.0025
+    angular_sigma_x: 0.02
+    angular_sigma_y: 0.02
+    angular_sigma_z: 0.02
+    velocity_factor: 0.8
+  object_color: {R: 10, G: 200, B: 50}
+"""
+CAMERA_YAML = """
+depth_image_topic: /XTION/depth/image
+camera_info_topic: /XTION/depth/camera_info
+downsampling_factor: 8
+resolution: {width: 640, height: 480}
+"""
+OBJECT_YAML = """
+object:
+  package: object_meshes
+  directory: object_models
+  meshes: [ part.obj ]
+"""
+
+
+def _write(tmp_path):
+    paths = []
+    for name, txt in (("particle_tracker.yaml", FILTER_YAML), ("camera.yaml", CAMERA_YAML), ("object.yaml", OBJECT_YAML)):
+        p = tmp_path / name
+        p.write_text(txt)
+        paths.append(str(p))
+    (tmp_path / "object_models").mkdir()
+    v, t = synth.mesh_m1(level=3)
+    objloader.write_obj(tmp_path / "object_models" / "part.obj", v + np.array([0.2, 0.1, -0.05]), t)
+    return paths
+
+
+def test_rosparam_tree_and_subsampling(tmp_path):
+    paths = _write(tmp_path)
+    tree = node.load_rosparams(*paths)
+    assert tree["particle_filter"]["gpu"]["sample_count"] == 400 and tree["downsampling_factor"] == 8
+    assert tree["object"]["meshes"] == ["part.obj"]
+    img = np.arange(480 * 640, dtype=np.float32).reshape(480, 640)
+    sub = node.to_eigen_vector(img, 8)
+    assert sub.shape == (60 * 80,) and sub[1] == img[0, 8] and sub[80] == img[8, 0]
+
+
+@pytest.mark.gpu
+def test_node_assembly_tracks_at_the_reference_operating_point(tmp_path, gpu_lib):
+    paths = _write(tmp_path)
+    tree = node.load_rosparams(*paths)
+    K = synth.camera_matrix(640, 480)
+    tracker, om, cam, ori = node.build_particle_tracker(tree, K, str(tmp_path), seed=3)
+    assert (cam.rows, cam.cols) == (60, 80) and tracker.n == 400 and ori.count_meshes() == 1
+    v0 = synth.mesh_m1(level=3)[0] + np.array([0.2, 0.1, -0.05])   # mesh was written off-centre
+    assert np.allclose(om.centers[0], v0.mean(axis=0), atol=1e-12)
+    sensor = tracker.sensor
+    # native-resolution frames from a full-resolution twin of the sensor, ingested with the reference's sub-sampling
+    from dbot_ros_amd import CameraData, RbSensor, RbSensorBuilder
+    full = RbSensor(om, CameraData(K, 480, 640), RbSensorBuilder.Parameters(sample_count=1), max_particles=1)
+    rng = np.random.default_rng(0)
+
+    def truth_state(k):
+        Rt = synth.truth_pose(1, frame=k)[0]
+        s = np.zeros(12)
+        s[3:6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+        s[0:3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0]
+        return s
+
+    tracker.initialize([truth_state(0)])
+    errs = []
+    for k in range(1, 16):
+        native = synth.make_frame(full.render_depth(synth.truth_pose(1, frame=k)), 480, 640, rng, occluder=False)
+        sensor.set_observation_native(native.reshape(480, 640), tree["downsampling_factor"])
+        assert np.array_equal(sensor.get_observation(), node.to_eigen_vector(native.reshape(480, 640), 8), equal_nan=True)
+        est = tracker.track(sensor.get_observation())
+        errs.append(np.linalg.norm(est[0:3] - truth_state(k)[0:3]))
+    full.close()
+    assert max(errs[-5:]) < 0.025, errs   # 80x60: one pixel is 8.8 mm at 0.7 m -> a few pixels
+    tracker.close()
+    sensor.close()
