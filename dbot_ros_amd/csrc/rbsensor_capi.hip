@@ -358,6 +358,11 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         }
         B.sphere[b][0] = ctr[0]; B.sphere[b][1] = ctr[1]; B.sphere[b][2] = ctr[2];
         B.sphere[b][3] = std::sqrt(r2) * (1.0 + 1e-9) + 1e-12;
+        for (int c3 = 0; c3 < 3; ++c3) {   // bounding box, padded so rounding can never shave a vertex off
+            const double pad = 1e-9 * (hi[c3] - lo[c3]) + 1e-12;
+            B.aabb[b][c3] = lo[c3] - pad;
+            B.aabb[b][3 + c3] = hi[c3] + pad;
+        }
         for (int t = 0; t < nt; ++t)
             for (int k = 0; k < 3; ++k)
                 if (T[3 * t + k] < 0 || T[3 * t + k] >= nv)

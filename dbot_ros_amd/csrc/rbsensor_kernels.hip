@@ -52,6 +52,7 @@ constexpr int kBigCap = 1024;              // triangles deferred to the cooperat
 constexpr int kBigThresh = RBS_BIG_THRESH; // bbox pixels above which a triangle is "big"
 constexpr int kCopyUnroll = RBS_COPY_UNROLL; // float4 loads in flight per lane in copy blocks
 constexpr int kEvalQueue = 128;             // per-wave queue of covered pixels awaiting evaluation
+constexpr int kRectAlign = 16;              // rectangle x-alignment in pixels (64 B)
 constexpr unsigned kInfBits = 0x7f800000u;
 constexpr int kMaxBodies = 16;
 constexpr double kMaxDepth = 6.0;    // KinectPixelModel max_depth
@@ -68,6 +69,7 @@ struct DevParams {
     int tile_w, tile_h;            // work-item tile: tile_w % 32 == 0, tile_w*tile_h <= kTilePx
     double fx, fy, cx, cy;
     double sphere[kMaxBodies][4];  // model-space bounding sphere: centre xyz, radius
+    double aabb[kMaxBodies][6];    // model-space bounding box: lo xyz, hi xyz
     const double* soup;            // SoA [9][n_tri]: v0.xyz v1.xyz v2.xyz
     const float* frame;            // observation, float metres
     const double* aux;             // per-frame-pixel terms, SoA [4][npx] (frame_aux_kernel)
@@ -101,8 +103,10 @@ struct Rect { int x0, y0, x1, y1; };
 
 // ------------------------------------------------------------------ screen rectangle
 // Conservative pixel rectangle containing every pixel the particle's bodies can cover, from
-// the bodies' bounding spheres; x-aligned to 32 pixels (128 B) so raster and copy blocks
-// never share a cache line.  Result only decides WHO writes a pixel, never its value.
+// the bodies' bounding spheres intersected with the projection of their model-space bounding
+// boxes (8 corners; a convex hull projects inside the hull of its projected corners when it is
+// entirely in front of the camera); x-aligned to kRectAlign pixels so raster and copy blocks
+// split rows at 64-byte boundaries.  Result only decides WHO writes a pixel, never its value.
 __device__ inline Rect particle_rect(const DevParams& P, const double* __restrict__ pose)
 {
     double umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
@@ -122,6 +126,30 @@ __device__ inline Rect particle_rect(const DevParams& P, const double* __restric
         vmax = fmax(vmax, P.fy * (yr >= 0.0 ? yr / zmin : yr / zmax) + P.cy);
         vmin = fmin(vmin, P.fy * (yl >= 0.0 ? yl / zmax : yl / zmin) + P.cy);
     }
+    if (!full) {
+        // tighter bound: the 8 corners of every body's bounding box (all are in front of the
+        // camera here because the enclosing sphere is)
+        double bumin = INFINITY, bumax = -INFINITY, bvmin = INFINITY, bvmax = -INFINITY;
+        bool ok = true;
+        for (int b = 0; b < P.n_bodies; ++b) {
+            const double* Rt = pose + 12 * b;
+            for (int c = 0; c < 8; ++c) {
+                const double x = P.aabb[b][(c & 1) ? 3 : 0], y = P.aabb[b][(c & 2) ? 4 : 1],
+                             z = P.aabb[b][(c & 4) ? 5 : 2];
+                const double X = ((Rt[0] * x + Rt[1] * y) + Rt[2] * z) + Rt[9];
+                const double Y = ((Rt[3] * x + Rt[4] * y) + Rt[5] * z) + Rt[10];
+                const double Z = ((Rt[6] * x + Rt[7] * y) + Rt[8] * z) + Rt[11];
+                if (!(Z > 1e-6)) { ok = false; continue; }
+                const double u = P.fx * (X / Z) + P.cx, v = P.fy * (Y / Z) + P.cy;
+                bumin = fmin(bumin, u); bumax = fmax(bumax, u);
+                bvmin = fmin(bvmin, v); bvmax = fmax(bvmax, v);
+            }
+        }
+        if (ok) {
+            umin = fmax(umin, bumin); umax = fmin(umax, bumax);
+            vmin = fmax(vmin, bvmin); vmax = fmin(vmax, bvmax);
+        }
+    }
     Rect r;
     if (full) {
         r.x0 = 0; r.y0 = 0; r.x1 = P.cols; r.y1 = P.rows;
@@ -132,8 +160,8 @@ __device__ inline Rect particle_rect(const DevParams& P, const double* __restric
         r.y0 = (int)fmin(fmax(floor(vmin) - 1.0, 0.0), H);
         r.y1 = (int)fmin(fmax(ceil(vmax) + 2.0, 0.0), H);
     }
-    r.x0 &= ~31;
-    r.x1 = min(P.cols, (r.x1 + 31) & ~31);
+    r.x0 &= ~(kRectAlign - 1);
+    r.x1 = min(P.cols, (r.x1 + kRectAlign - 1) & ~(kRectAlign - 1));
     if (r.x1 <= r.x0 || r.y1 <= r.y0) { r.x0 = r.x1 = r.y0 = r.y1 = 0; }
     return r;
 }
