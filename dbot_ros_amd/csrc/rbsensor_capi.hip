@@ -68,6 +68,7 @@ struct rbs_handle {
     hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {}, ev_copy_start[kRing] = {}, ev_join[kRing] = {};
     bool ring_update[kRing] = {};
     long calls = 0;
+    int join_pending = -1;      // ring slot whose copy kernel later work on the planes must wait for
     std::string err;
 };
 
@@ -168,17 +169,26 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     RBS_HIP(h, hipEventRecord(h->ev_start[slot], s));
     const dim3 block(rbs::kBlock);
     const dim3 pgrid((unsigned)((n + 255) / 256));
+    // prep + scan read only the poses: they run ahead of the previous call's copy kernel
     hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(256), 0, s, P, h->d_rects, h->d_tiles);
     RBS_HIP(h, hipGetLastError());
+    if (update) {
+        // fork: the copy kernel runs on the handle's second stream, concurrently with the
+        // persistent raster kernel; it needs this call's rectangles only
+        RBS_HIP(h, hipEventRecord(h->ev_fork, s));
+        RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
+    }
     hipLaunchKernelGGL(rbs::rbs_scan_kernel, dim3(1), dim3(1024), 0, s, h->d_tiles, h->d_item_offset, n,
                        h->d_work_counter);
     RBS_HIP(h, hipGetLastError());
+    // deferred join: the raster kernel reads planes the previous updating call's copy kernel
+    // may still be writing; everything before this point overlapped with that copy's tail
+    if (h->join_pending >= 0) {
+        RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+        h->join_pending = -1;
+    }
     const dim3 rgrid((unsigned)h->raster_blocks);
     if (update) {
-        // fork: the copy kernel runs on the handle's second stream, concurrently with the
-        // persistent raster kernel; join before anything later on `s`
-        RBS_HIP(h, hipEventRecord(h->ev_fork, s));
-        RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
         hipLaunchKernelGGL((rbs::rbs_raster_kernel<true>), rgrid, block, rbs::kSmemBytes, s, P);
         RBS_HIP(h, hipGetLastError());
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
@@ -207,12 +217,27 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     }
     hipLaunchKernelGGL(rbs::rbs_reduce_kernel, pgrid, dim3(256), 0, s, P);
     RBS_HIP(h, hipGetLastError());
-    if (update) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[slot], 0));
     RBS_HIP(h, hipEventRecord(h->ev_stop[slot], s));
+    if (update) h->join_pending = slot;   // joined lazily: by the next call, or by drain()
     h->calls += 1;
     if (update) {
         h->cur = 1 - h->cur;
         h->pending_frames = 0;
+    }
+    return RBS_OK;
+}
+
+// Make stream `s` (and the host, if sync) see the planes of the last updating call complete.
+int32_t drain(rbs_handle* h, bool host_sync)
+{
+    if (h->join_pending >= 0) {
+        RBS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[h->join_pending], 0));
+        if (host_sync) RBS_HIP(h, hipEventSynchronize(h->ev_join[h->join_pending]));
+        h->join_pending = -1;
+    }
+    if (host_sync) {
+        RBS_HIP(h, hipStreamSynchronize(h->stream));
+        RBS_HIP(h, hipStreamSynchronize(h->copy_stream));
     }
     return RBS_OK;
 }
@@ -222,6 +247,7 @@ void release(rbs_handle* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     (void)hipFree(h->d_soup);
     (void)hipFree(h->d_frame);
     (void)hipFree(h->d_aux);
@@ -523,13 +549,14 @@ int32_t rbs_reset(rbs_handle* h)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
     RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = drain(h, true)) return rc;   // no copy kernel may still be writing planes
     h->cur = 0;
     h->pending_frames = 0;
     const size_t n = (size_t)h->npx * h->max_particles;
     hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(2048), dim3(256), 0, h->stream, h->d_occ[0], n,
                        (float)h->init_occ);
     RBS_HIP(h, hipGetLastError());
-    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    if (int32_t rc = drain(h, true)) return rc;
     return RBS_OK;
 }
 
@@ -627,7 +654,7 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
     if (rc != RBS_OK) return rc;
     RBS_HIP(h, hipMemcpyAsync(out_loglik, h->d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
                               h->stream));
-    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    if (int32_t rc = drain(h, true)) return rc;
     if (update)
         for (int32_t i = 0; i < n; ++i) indices[i] = i;
     return RBS_OK;
@@ -652,7 +679,7 @@ int32_t rbs_synchronize(rbs_handle* h)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
     RBS_HIP(h, hipSetDevice(h->device));
-    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    if (int32_t rc = drain(h, true)) return rc;
     return RBS_OK;
 }
 
@@ -662,7 +689,7 @@ int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out)
     if (slot < 0 || slot >= h->max_particles || !out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("get_occlusion: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
-    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    if (int32_t rc = drain(h, true)) return rc;
     RBS_HIP(h, hipMemcpy(out, h->d_occ[h->cur] + (size_t)slot * h->npx, sizeof(float) * h->npx,
                          hipMemcpyDeviceToHost));
     return RBS_OK;
@@ -674,7 +701,7 @@ int32_t rbs_set_occlusion(rbs_handle* h, int32_t slot, const float* plane)
     if (slot < 0 || slot >= h->max_particles || !plane)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("set_occlusion: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
-    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    if (int32_t rc = drain(h, true)) return rc;
     RBS_HIP(h, hipMemcpy(h->d_occ[h->cur] + (size_t)slot * h->npx, plane, sizeof(float) * h->npx,
                          hipMemcpyHostToDevice));
     return RBS_OK;
@@ -685,6 +712,8 @@ int32_t rbs_occlusion_device_ptr(rbs_handle* h, int32_t slot, void** out)
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
     if (slot < 0 || slot >= h->max_particles || !out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("occlusion_device_ptr: bad slot %d", slot));
+    RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = drain(h, true)) return rc;   // planes complete before the caller touches them
     *out = h->d_occ[h->cur] + (size_t)slot * h->npx;
     return RBS_OK;
 }
@@ -694,6 +723,8 @@ int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out)
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
     if (slot < 0 || slot >= h->max_particles || !out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("occlusion_next_device_ptr: bad slot %d", slot));
+    RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = drain(h, true)) return rc;   // planes complete before the caller touches them
     *out = h->d_occ[1 - h->cur] + (size_t)slot * h->npx;
     return RBS_OK;
 }
@@ -757,6 +788,7 @@ int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float*
         RBS_HIP(h, hipEventElapsedTime(&ms, h->ev_start[slot], h->ev_stop[slot]));
         tot += ms;
         if (h->ring_update[slot]) {
+            RBS_HIP(h, hipEventSynchronize(h->ev_join[slot]));
             RBS_HIP(h, hipEventElapsedTime(&ms, h->ev_copy_start[slot], h->ev_join[slot]));
             cpy += ms;
             ++n_copy;

@@ -641,6 +641,9 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Smem m = carve(smem);
     const int total = P.item_offset[P.n];
+#ifdef RBS_PHASE_TIMING
+    const unsigned long long c0_ = clock64(), w0_ = wall_clock64();
+#endif
     for (;;) {
         if (threadIdx.x == 0) *m.item = atomicAdd(P.work_counter, 1);
         __syncthreads();
@@ -667,6 +670,12 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
         if (threadIdx.x == 0) P.partial[item] = part;
         __syncthreads();
     }
+#ifdef RBS_PHASE_TIMING
+    if (threadIdx.x == 0) {   // block lifetime in shader cycles (clock64) and in 100 MHz wall ticks
+        atomicAdd(&P.phase[5], clock64() - c0_);
+        atomicAdd(&P.phase[6], wall_clock64() - w0_);
+    }
+#endif
 }
 
 // One thread per particle: ordered (deterministic) sum of its work items' partial sums.

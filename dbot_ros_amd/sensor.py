@@ -171,9 +171,21 @@ class RbSensor:
 
     # -- life cycle -----------------------------------------------------------------
     def close(self):
+        # device trackers borrow this handle: they must go first
+        for ref in getattr(self, "_dependents", []):
+            dep = ref()
+            if dep is not None:
+                dep.close()
+        self._dependents = []
         if getattr(self, "_h", None) and self._h.value:
             self._lib.rbs_destroy(self._h)
             self._h = C.c_void_p()
+
+    def _register_dependent(self, obj):
+        import weakref
+        if not hasattr(self, "_dependents"):
+            self._dependents = []
+        self._dependents.append(weakref.ref(obj))
 
     def __del__(self):
         try:

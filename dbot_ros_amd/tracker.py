@@ -233,6 +233,7 @@ class DeviceParticleTracker(ParticleTracker):
         rc = self._lib.rbs_tracker_create(sensor._h, C.byref(tp), C.byref(self._t))
         if rc != 0:
             sensor._check(rc)
+        sensor._register_dependent(self)   # the C tracker borrows the sensor handle
 
     def close(self):
         if getattr(self, "_t", None) is not None and self._t.value:

@@ -112,7 +112,10 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
 /* Device-pointer variant: poses/indices/out_loglik are device memory on the handle's device,
  * work is enqueued on `stream` (a hipStream_t, NULL = the handle's own stream) and the call
  * returns without synchronising.  indices is read-only; with update != 0 the caller must
- * treat the slot map as identity afterwards. */
+ * treat the slot map as identity afterwards.  d_out_loglik is complete in `stream` order.  The
+ * occlusion planes an updating call writes are finished by a second, internal stream: every
+ * later rbs_* call on the handle orders itself after them (so back-to-back calls pipeline), and
+ * rbs_synchronize / rbs_occlusion_*_device_ptr / any host-pointer entry point waits for them. */
 int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t* d_indices,
                             int32_t n, int32_t update, double* d_out_loglik, void* stream);
 
@@ -134,9 +137,9 @@ int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out);
  * launch stream around its kernels); blocks until it finished. */
 int32_t rbs_last_kernel_ms(rbs_handle* h, float* ms);
 /* Averages over the last min(last_n, 64) rbs_loglikes* calls, from HIP events the library
- * records on the streams the kernels run on: call_ms = whole call on the launch stream
- * (rect + raster kernels and the join with the copy stream); copy_kernel_ms = the copy kernel
- * alone on its own stream (updating calls only, 0 if none).  Blocks until those calls finished. */
+ * records on the streams the kernels run on: call_ms = the launch-stream part of a call
+ * (prep, scan, raster, reduce kernels); copy_kernel_ms = the copy kernel alone on its own
+ * stream (updating calls only, 0 if none).  Blocks until those calls finished. */
 int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float* copy_kernel_ms,
                            int32_t* n_used);
 
