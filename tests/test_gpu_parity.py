@@ -386,3 +386,57 @@ def test_native_frame_ingest_subsampling(gpu_lib, factor, width, height):
         g.set_observation(ref.astype(np.float64).ravel())
         b = g.loglikes_poses(poses, i2, update=False)
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomized_scenes_match_oracle(gpu_lib, seed):
+    """Random triangle soups (incl. slivers, huge and degenerate triangles, triangles crossing
+    the camera plane), random intrinsics and odd resolutions, 1-3 bodies, NaN/inf pixels, random
+    parent slots: depth bit-exact, log-likelihoods and planes as the oracle (device rule)."""
+    from dbot_ros_amd import CameraData, ObjectModel, RbSensorBuilder
+    rng = np.random.default_rng(1000 + seed)
+    cols = int(rng.choice([5, 33, 64, 80, 97, 160, 322]))
+    rows = int(rng.choice([7, 24, 60, 61, 120]))
+    nb = int(rng.integers(1, 4))
+    vs, ts = [], []
+    for b in range(nb):
+        nv = int(rng.integers(4, 60))
+        v = rng.normal(size=(nv, 3)) * rng.choice([0.01, 0.05, 0.3])
+        nt = int(rng.integers(1, 150))
+        t = rng.integers(0, nv, size=(nt, 3)).astype(np.int32)   # duplicates -> degenerate triangles too
+        vs.append(v)
+        ts.append(t)
+    om = ObjectModel(vs, ts, center=bool(rng.integers(0, 2)))
+    f = float(rng.uniform(0.4, 1.5)) * cols
+    K = np.array([[f, 0, rng.uniform(0.3, 0.7) * cols], [0, f * rng.uniform(0.8, 1.2), rng.uniform(0.3, 0.7) * rows],
+                  [0, 0, 1.0]])
+    cam = CameraData(K, rows, cols)
+    n = int(rng.integers(1, 9))
+    P = RbSensorBuilder.Parameters(sample_count=n)
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        for s in (g, eager):
+            s.reset()
+        idx_g, idx_o = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for k in range(3):
+            from dbot_ros_amd.pose import pack_Rt, rotvec_to_matrix
+            R = rotvec_to_matrix(rng.normal(size=(n, nb, 3)))
+            t = np.stack([rng.normal(0, 0.1, (n, nb)), rng.normal(0, 0.1, (n, nb)),
+                          rng.uniform(-0.1, 1.2, (n, nb))], -1)      # some bodies behind / across the camera plane
+            poses = pack_Rt(R, t)
+            frame = rng.uniform(0.2, 2.0, rows * cols)
+            frame[rng.random(frame.size) < 0.1] = np.nan
+            frame[rng.random(frame.size) < 0.02] = np.inf
+            for i in range(min(n, 2)):
+                dg, do = g.render_depth(poses[i]), eager.render_depth(poses[i])
+                assert np.array_equal(dg.view(np.uint32), do.view(np.uint32))
+            for s in (g, eager):
+                s.set_observation(frame)
+            upd = bool(rng.integers(0, 2)) or k == 2
+            lg = g.loglikes_poses(poses, idx_g, update=upd)
+            lo = eager.loglikes_poses(poses, idx_o, update=upd)
+            assert np.isfinite(lo).all() and rel_err(lg, lo).max() <= TOL_EAGER, (k, lg, lo)
+            idx_g = rng.integers(0, n, n).astype(np.int32)
+            idx_o = idx_g.copy()
+        for slot in range(n):
+            assert_planes_match(g.get_occlusion(slot), eager.get_occlusion(slot))
