@@ -225,3 +225,28 @@ def test_eager_and_lazy_occlusion_stay_close_over_a_long_sequence():
     assert worst < 1e-5, worst
     for slot in range(n):
         assert np.abs(lazy.get_occlusion(slot, now=True) - eager.get_occlusion(slot)).max() < 5e-6
+
+
+def test_occluded_density_is_the_truncated_exponential_convolved_with_the_sensor_noise(small):
+    """Independent derivation of SURVEY A.3's p_occ: the occluder depth z is a truncated
+    exponential on [0, r] (rate ln2 / half_life), observed through the same Gaussian noise as a
+    visible surface, p_occ(o|r) = int_0^r lam e^{-lam z}/(1 - e^{-lam r}) N(o; z, sigma(o)) dz.
+    The closed form the oracle implements must equal the quadrature (it does to ~1e-15 where the
+    dropped lower-tail term is negligible), and p_bg must be its r -> infinity limit."""
+    import math
+    *_, P, o_ = small
+    tw, ms, sf = P.kinect.tail_weight, P.kinect.model_sigma, P.kinect.sigma_factor
+    lam = math.log(2.0)
+    for r in (0.5, 0.7, 1.5):
+        for o in (0.2, 0.45, 0.69, 0.7, 0.705, 1.0):
+            sigma = ms + sf * o * o
+            f = lambda z: (lam * math.exp(-lam * z) / (1.0 - math.exp(-lam * r))
+                           * math.exp(-(o - z) ** 2 / (2 * sigma ** 2)) / (math.sqrt(2 * math.pi) * sigma))
+            num, _ = integrate.quad(f, 0.0, r, points=[min(max(o, 0.0), r)], limit=400, epsabs=1e-13, epsrel=1e-11)
+            closed = (o_.prob_occluded(o, r) - tw / 6.0) / (1.0 - tw)
+            assert closed == pytest.approx(num, rel=1e-8, abs=1e-12)
+    for o in (0.3, 0.7, 2.0):
+        assert o_.prob_occluded(o, 1e3) == pytest.approx(o_.prob_occluded(o, np.inf), rel=1e-12)
+    # visible branch: a Gaussian around the rendered depth
+    assert (o_.prob_visible(0.7, 0.7) - tw / 6.0) / (1 - tw) == pytest.approx(
+        1.0 / (math.sqrt(2 * math.pi) * (ms + sf * 0.49)), rel=1e-14)
