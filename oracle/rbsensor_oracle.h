@@ -97,6 +97,17 @@ double orc_prob_occluded(const orc_sensor* s, double obs, double rendered); /* r
 double orc_propagate(const orc_sensor* s, double occ, double dt);
 void orc_eager_coeffs(const orc_sensor* s, int32_t n_frames, float* alpha, float* beta);
 
+/* ---- tracker_oracle.c: transition + RBC filter step + tracker mean ---- */
+typedef struct orc_tracker orc_tracker;
+orc_tracker* orc_tracker_create(orc_sensor* s, int32_t parts, int32_t n, const double* sigma6,
+                                double velocity_factor, double max_kl_divergence);
+void orc_tracker_destroy(orc_tracker* t);
+void orc_tracker_initialize(orc_tracker* t, const double* default_state);
+/* frame: double[rows*cols]; normals [parts][n][6]; uniforms [parts][n]; out_state [parts*12] */
+void orc_tracker_track(orc_tracker* t, const double* frame, const double* normals, const double* uniforms,
+                       double* out_state, int32_t* out_resamplings);
+void orc_tracker_get(const orc_tracker* t, double* particles, double* log_weights, int32_t* indices);
+
 #ifdef __cplusplus
 }
 #endif

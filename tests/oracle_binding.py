@@ -33,7 +33,7 @@ _lib = None
 
 
 def build():
-    src = [os.path.join(ORACLE_DIR, f) for f in ("rbsensor_oracle.c", "rbsensor_oracle.h", "Makefile")]
+    src = [os.path.join(ORACLE_DIR, f) for f in ("rbsensor_oracle.c", "tracker_oracle.c", "rbsensor_oracle.h", "Makefile")]
     if (not os.path.exists(ORACLE_LIB)
             or os.path.getmtime(ORACLE_LIB) < max(os.path.getmtime(s) for s in src)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
@@ -61,6 +61,12 @@ def load():
             f.restype = C.c_double
             f.argtypes = [H, C.c_double, C.c_double]
         lib.orc_eager_coeffs.argtypes = [H, C.c_int32, fp, fp]
+        lib.orc_tracker_create.restype = H
+        lib.orc_tracker_create.argtypes = [H, C.c_int32, C.c_int32, dp, C.c_double, C.c_double]
+        lib.orc_tracker_destroy.argtypes = [H]
+        lib.orc_tracker_initialize.argtypes = [H, dp]
+        lib.orc_tracker_track.argtypes = [H, dp, dp, dp, dp, ip]
+        lib.orc_tracker_get.argtypes = [H, dp, dp, ip]
         _lib = lib
     return _lib
 
@@ -150,3 +156,45 @@ class Oracle:
         a, b = C.c_float(), C.c_float()
         self._lib.orc_eager_coeffs(self._h, int(n_frames), C.byref(a), C.byref(b))
         return a.value, b.value
+
+
+class OracleTracker:
+    """CPU restatement of the tracker loop (oracle/tracker_oracle.c) over an Oracle sensor;
+    model-coordinate states, host-supplied randomness -- the checker for rbs_tracker_*."""
+
+    def __init__(self, oracle, n, sigma6, velocity_factor=0.8, max_kl=2.0):
+        self._lib, self.oracle, self.n, self.parts = load(), oracle, n, oracle.n_bodies
+        sg = np.ascontiguousarray(sigma6, dtype=np.float64)
+        self._t = C.c_void_p(self._lib.orc_tracker_create(oracle._h, self.parts, n, sg.ctypes.data_as(C.POINTER(C.c_double)),
+                                                          float(velocity_factor), float(max_kl)))
+
+    def close(self):
+        if getattr(self, "_t", None) is not None and self._t.value:
+            self._lib.orc_tracker_destroy(self._t)
+            self._t = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+    def initialize(self, default_state):
+        d = np.ascontiguousarray(default_state, dtype=np.float64)
+        self._lib.orc_tracker_initialize(self._t, d.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def track(self, frame, normals, uniforms):
+        dp = C.POINTER(C.c_double)
+        f = np.ascontiguousarray(frame, dtype=np.float64).ravel()
+        nz = np.ascontiguousarray(normals, dtype=np.float64)
+        u = np.ascontiguousarray(uniforms, dtype=np.float64)
+        out = np.empty(self.parts * 12)
+        nres = C.c_int32()
+        self._lib.orc_tracker_track(self._t, f.ctypes.data_as(dp), nz.ctypes.data_as(dp), u.ctypes.data_as(dp),
+                                    out.ctypes.data_as(dp), C.byref(nres))
+        return out, int(nres.value)
+
+    def get_state(self):
+        p = np.empty((self.n, self.parts * 12))
+        w = np.empty(self.n)
+        i = np.empty(self.n, dtype=np.int32)
+        self._lib.orc_tracker_get(self._t, p.ctypes.data_as(C.POINTER(C.c_double)), w.ctypes.data_as(C.POINTER(C.c_double)),
+                                  i.ctypes.data_as(C.POINTER(C.c_int32)))
+        return p, w, i

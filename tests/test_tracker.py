@@ -132,3 +132,73 @@ def test_device_tracker_with_device_rng_tracks(gpu_lib):
         assert max(errs[-5:]) < 0.004, errs
         assert tr.n_resamplings >= 1
         tr.close()
+
+
+def _model_init(om, nb):
+    init = np.zeros(12 * nb)
+    for b in range(nb):
+        Rt = synth.truth_pose(nb, frame=0)[b]
+        init[12 * b + 3:12 * b + 6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+        init[12 * b:12 * b + 3] = Rt[9:]            # model coordinates: pose of the centred mesh
+    return init
+
+
+@pytest.mark.parametrize("meshes,n", [(("m1_l2",), 48), (("m1_l2", "box12"), 64)])
+def test_host_tracker_mirror_matches_the_c_oracle_tracker(meshes, n):
+    """The Python host mirror (dbot_ros_amd.tracker) against the C restatement of the same loop
+    (oracle/tracker_oracle.c), both driving oracle sensors, same normals/uniforms."""
+    nb = len(meshes)
+    om, cam, P = sc.make_scene(meshes, 80, 60, max_particles=n)
+    tp = ParticleTrackerBuilder.Parameters(evaluation_count=n, center_object_frame=False)
+    per = n // nb
+    o1 = ob.Oracle(om, cam, P, max_particles=per, mode=ob.EAGER)
+    o2 = ob.Oracle(om, cam, P, max_particles=per, mode=ob.EAGER)
+    trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=nb)).build()
+    host = ParticleTracker(trans, o1, om, tp, np.random.default_rng(1))
+    ref = ob.OracleTracker(o2, per, trans.sigma, trans.vf, tp.max_kl_divergence)
+    init = _model_init(om, nb)
+    host.initialize([init])
+    ref.initialize(init)
+    rng = np.random.default_rng(9)
+    for k in range(1, 5):
+        frame = synth.make_frame(o1.render_depth(synth.truth_pose(nb, frame=k)), 60, 80, rng, occluder=False)
+        normals, uniforms = host.draw_randomness()
+        eh = host.track(frame, normals, uniforms)
+        er, nres = ref.track(frame, normals, uniforms)
+        assert np.abs(eh - er).max() <= 1e-12
+        p, w, idx = ref.get_state()
+        assert np.abs(p - host.particles).max() <= 1e-12 and np.array_equal(idx, host.indices)
+        assert np.abs(w - host.log_weights).max() <= 1e-9 and nres == host.n_resamplings
+    assert host.n_resamplings >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("meshes,n,cols,rows", [(("m1_l2",), 64, 160, 120), (("m1_l2", "box12"), 96, 160, 120)])
+def test_device_tracker_matches_the_c_oracle_tracker(gpu_lib, meshes, n, cols, rows):
+    """rbs_tracker_* on the GPU against oracle/tracker_oracle.c over the oracle sensor (device
+    rule), same host-supplied randomness: the checker is entirely under oracle/."""
+    from dbot_ros_amd.tracker import DeviceParticleTracker
+    nb = len(meshes)
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    tp = ParticleTrackerBuilder.Parameters(evaluation_count=n, center_object_frame=False)
+    per = n // nb
+    orc = ob.Oracle(om, cam, P, max_particles=per, mode=ob.EAGER)
+    trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=nb)).build()
+    ref = ob.OracleTracker(orc, per, trans.sigma, trans.vf, tp.max_kl_divergence)
+    with RbSensor(om, cam, P, max_particles=per) as s:
+        dev = DeviceParticleTracker(trans, s, om, tp, np.random.default_rng(2))
+        init = _model_init(om, nb)
+        dev.initialize([init])
+        ref.initialize(init)
+        rng = np.random.default_rng(10)
+        for k in range(1, 6):
+            frame = synth.make_frame(orc.render_depth(synth.truth_pose(nb, frame=k)), rows, cols, rng, occluder=False)
+            normals, uniforms = dev.draw_randomness()
+            ed = dev.track(frame, normals, uniforms)
+            er, nres = ref.track(frame, normals, uniforms)
+            assert np.abs(ed - er).max() <= 1e-9, (k, np.abs(ed - er).max())
+            pd, wd, idd = dev.get_state()
+            pr, wr, idr = ref.get_state()
+            assert np.abs(pd - pr).max() <= 1e-9 and np.array_equal(idd, idr) and dev.n_resamplings == nres
+        assert nres >= 1
+        dev.close()
