@@ -61,6 +61,7 @@ struct rbs_handle {
     int copy_blocks = 1 << 30;  // cap on the copy grid (one block per (particle, band) below it)
     int raster_blocks = 512;    // persistent raster grid: 2 per CU
     int copy_rows = 2;          // rows per block of rbs_copy_rows_kernel (0: banded kernel)
+    int copy_tpb = 64;          // threads per copy block: one wave = 1 KB of a row (0: a block spans a row)
     const char* tile_override = nullptr;  // RBS_TILE env (tuning)
     // timing ring: HIP events around the whole call (on the launch stream) and around the copy
     // kernel (on the copy stream) for the last kRing loglikes calls
@@ -195,15 +196,17 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipEventRecord(h->ev_copy_start[slot], h->copy_stream));
         if ((P.cols & 3) == 0 && h->copy_rows > 0) {
             const int W4 = P.cols >> 2;
-            const dim3 rblock((unsigned)std::min(1024, (W4 + 63) / 64 * 64));
+            const int tpb = h->copy_tpb > 0 ? h->copy_tpb : std::min(1024, (W4 + 63) / 64 * 64);
+            const int nseg = (W4 + tpb - 1) / tpb;
+            const dim3 rblock((unsigned)tpb);
             const int ny = std::min(n, 32768);
-            const dim3 rg((unsigned)((P.rows + h->copy_rows - 1) / h->copy_rows), (unsigned)ny,
+            const dim3 rg((unsigned)(((P.rows + h->copy_rows - 1) / h->copy_rows) * nseg), (unsigned)ny,
                           (unsigned)((n + ny - 1) / ny));
             switch (h->copy_rows) {
-                case 1: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<1>), rg, rblock, 0, h->copy_stream, P); break;
-                case 2: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<2>), rg, rblock, 0, h->copy_stream, P); break;
-                case 4: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<4>), rg, rblock, 0, h->copy_stream, P); break;
-                default: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<8>), rg, rblock, 0, h->copy_stream, P); break;
+                case 1: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<1>), rg, rblock, 0, h->copy_stream, P, nseg); break;
+                case 2: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<2>), rg, rblock, 0, h->copy_stream, P, nseg); break;
+                case 4: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<4>), rg, rblock, 0, h->copy_stream, P, nseg); break;
+                default: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<8>), rg, rblock, 0, h->copy_stream, P, nseg); break;
             }
         } else if ((P.cols & 3) == 0)
             hipLaunchKernelGGL((rbs::rbs_copy_kernel<4>), cgrid, block, 0, h->copy_stream, P);
@@ -465,6 +468,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         if (const char* m = std::getenv("RBS_RASTER_BLOCKS")) h->raster_blocks = std::max(1, std::atoi(m));
         h->tile_override = std::getenv("RBS_TILE");
         if (const char* m = std::getenv("RBS_COPY_ROWS")) h->copy_rows = std::atoi(m);
+        if (const char* m = std::getenv("RBS_COPY_TPB")) h->copy_tpb = std::max(64, std::atoi(m) / 64 * 64);
     }
     RBS_HIP(h, hipMalloc(&h->d_soup, soup.size() * sizeof(double)));
     RBS_HIP(h, hipMemcpy(h->d_soup, soup.data(), soup.size() * sizeof(double), hipMemcpyHostToDevice));

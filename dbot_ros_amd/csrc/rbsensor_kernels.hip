@@ -701,44 +701,48 @@ __global__ __launch_bounds__(kBlock) void rbs_copy_kernel(const DevParams P)
     }
 }
 
-// Lean row-structured stream (cols % 4 == 0): one block = ROWS image rows of one particle, one
-// float4 column per lane, so there is no index arithmetic beyond the rectangle test.  Blocks
-// are tiny (<= a few KB) and dispatched in address order (x = row group fastest), which keeps
+// Lean row-structured stream (cols % 4 == 0): one block = one column segment (one wave = 64
+// float4 by default) of ROWS image rows of one particle, one float4 column per lane, so there is
+// no index arithmetic beyond the rectangle test.  Blocks are tiny (1-2 KB) and dispatched in
+// address order (x = segment, then row group fastest), which keeps
 // the chip-wide HBM access stream nearly sequential -- measured 6.2-6.6 TB/s for a plain copy
 // of this shape vs 5.3-5.8 TB/s for 32-64 KB per block (tools/copybench2.hip).
 template <int ROWS>
-__global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P)
+__global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, int nseg)
 {
     const int particle = (int)blockIdx.y + (int)blockIdx.z * (int)gridDim.y;
     if (particle >= P.n) return;
     const int W4 = P.cols >> 2;
     const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
     const int parent = P.indices[particle];
-    const int r0 = (int)blockIdx.x * ROWS;
+    // blockIdx.x = row group * nseg + column segment (segment fastest: address order)
+    const int rg = (int)blockIdx.x / nseg;
+    const int seg = (int)blockIdx.x - rg * nseg;
+    const int r0 = rg * ROWS;
+    const int c4 = seg * (int)blockDim.x + (int)threadIdx.x;
+    if (c4 >= W4) return;
     const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(P.occ_src + (size_t)parent * P.npx);
     floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(P.occ_dst + (size_t)particle * P.npx);
     const float alpha = P.alpha, beta = P.beta;
-    for (int c4 = threadIdx.x; c4 < W4; c4 += blockDim.x) {
-        const int col = c4 << 2;
-        const bool in_cols = col >= q.x && col < q.z;
-        floatx4 v[ROWS];
-        bool ok[ROWS];
+    const int col = c4 << 2;
+    const bool in_cols = col >= q.x && col < q.z;
+    floatx4 v[ROWS];
+    bool ok[ROWS];
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            const int row = r0 + k;
-            ok[k] = row < P.rows && !(in_cols && row >= q.y && row < q.w);
-            if (ok[k]) v[k] = __builtin_nontemporal_load(&s4[(size_t)row * W4 + c4]);
-        }
+    for (int k = 0; k < ROWS; ++k) {
+        const int row = r0 + k;
+        ok[k] = row < P.rows && !(in_cols && row >= q.y && row < q.w);
+        if (ok[k]) v[k] = __builtin_nontemporal_load(&s4[(size_t)row * W4 + c4]);
+    }
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            if (!ok[k]) continue;
-            floatx4 w;
-            w.x = fmaf(alpha, v[k].x, beta);
-            w.y = fmaf(alpha, v[k].y, beta);
-            w.z = fmaf(alpha, v[k].z, beta);
-            w.w = fmaf(alpha, v[k].w, beta);
-            __builtin_nontemporal_store(w, &d4[(size_t)(r0 + k) * W4 + c4]);
-        }
+    for (int k = 0; k < ROWS; ++k) {
+        if (!ok[k]) continue;
+        floatx4 w;
+        w.x = fmaf(alpha, v[k].x, beta);
+        w.y = fmaf(alpha, v[k].y, beta);
+        w.z = fmaf(alpha, v[k].z, beta);
+        w.w = fmaf(alpha, v[k].w, beta);
+        __builtin_nontemporal_store(w, &d4[(size_t)(r0 + k) * W4 + c4]);
     }
 }
 
