@@ -440,3 +440,57 @@ def test_randomized_scenes_match_oracle(gpu_lib, seed):
             idx_o = idx_g.copy()
         for slot in range(n):
             assert_planes_match(g.get_occlusion(slot), eager.get_occlusion(slot))
+
+
+def test_long_sequence_against_reference_semantics(gpu_lib):
+    """120 frames at the reference's 80x60 operating point, resampling every frame: the device
+    (eager float occlusion state) stays within north_star's 1e-5 (relative) of the oracle in
+    reference (lazy, per-pixel time stamp) mode -- the rounding of the eager state is bounded,
+    it does not accumulate with sequence length."""
+    n = 24
+    om, cam, P = sc.make_scene(("m1_l2",), 80, 60, max_particles=n)
+    lazy = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    rng = np.random.default_rng(21)
+    worst_lazy = worst_eager = 0.0
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        sensors = (g, lazy, eager)
+        for s in sensors:
+            s.reset()
+        idx = [np.zeros(n, np.int32) for _ in sensors]
+        for k in range(120):
+            truth = synth.truth_pose(1, frame=k % 40)
+            frame = synth.make_frame(lazy.render_depth(truth), 60, 80, rng)
+            poses = synth.particle_poses(truth, n, rng, scale=1.0 + (k % 7))
+            lls = []
+            for s, ix in zip(sensors, idx):
+                s.set_observation(frame)
+                lls.append(s.loglikes_poses(poses, ix, update=True))
+            worst_lazy = max(worst_lazy, float(rel_err(lls[0], lls[1]).max()))
+            worst_eager = max(worst_eager, float(rel_err(lls[0], lls[2]).max()))
+            w = np.exp(lls[1] - lls[1].max())
+            parents = np.sort(rng.choice(n, size=n, p=w / w.sum())).astype(np.int32)
+            idx = [parents.copy() for _ in sensors]
+    assert worst_eager <= TOL_EAGER, worst_eager
+    assert worst_lazy <= TOL_LAZY, worst_lazy
+
+
+def test_create_destroy_does_not_leak_device_memory(gpu_lib):
+    import torch
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=64)
+    poses = synth.particle_poses(synth.truth_pose(1), 64, np.random.default_rng(0))
+
+    def cycle():
+        with RbSensor(om, cam, P, max_particles=64) as g:
+            g.set_observation(np.full(160 * 120, 0.8))
+            g.loglikes_poses(poses, np.zeros(64, np.int32), update=True)
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, f"leaked {(free0 - free1) / 2**20:.1f} MiB over 40 create/destroy cycles"
