@@ -21,26 +21,31 @@ from dbot_ros_amd.tracker import (DeviceParticleTracker, ObjectTransitionBuilder
 
 def main():
     counts = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [200, 2000, 20000]
+    names = sys.argv[2].split(",") if len(sys.argv) > 2 else ["m1"]     # e.g. m1,m2,m3 = BASELINE config C2
     cols, rows, n_frames = 640, 480, 30
-    v, f = synth.mesh_m1()
-    om = ObjectModel([v], [f], center=True)
+    fns = {"m1": synth.mesh_m1, "m2": synth.mesh_m2, "m3": synth.mesh_m3, "m4": synth.mesh_m4}
+    meshes = [fns[k]() for k in names]
+    nb = len(meshes)
+    f = np.concatenate([t for _, t in meshes])
+    om = ObjectModel([v for v, _ in meshes], [t for _, t in meshes], center=True)
     cam = CameraData(synth.camera_matrix(cols, rows), rows, cols)
     for n, mode in [(n, m) for n in counts for m in ("device", "host")]:
         P = RbSensorBuilder.Parameters(sample_count=n)
-        with RbSensor(om, cam, P, max_particles=n) as s:
+        with RbSensor(om, cam, P, max_particles=max(1, n // nb)) as s:
             rng = np.random.default_rng(0)
-            frames = [synth.make_frame(s.render_depth(synth.truth_pose(1, frame=k)), rows, cols, rng,
+            frames = [synth.make_frame(s.render_depth(synth.truth_pose(nb, frame=k)), rows, cols, rng,
                                        occluder=False) for k in range(n_frames + 1)]
-            trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters()).build()
+            trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=nb)).build()
             tp = ParticleTrackerBuilder.Parameters(evaluation_count=n)
             if mode == "device":   # transition + filter step + mean on the GPU, device RNG
                 tr = DeviceParticleTracker(trans, s, om, tp, device_rng=True, seed=1)
             else:                  # host mirror (numpy)
                 tr = ParticleTracker(trans, s, om, tp, np.random.default_rng(1))
-            Rt = synth.truth_pose(1, frame=0)[0]
-            init = np.zeros(12)
-            init[3:6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
-            init[0:3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0]
+            init = np.zeros(12 * nb)
+            for b in range(nb):
+                Rt = synth.truth_pose(nb, frame=0)[b]
+                init[12 * b + 3:12 * b + 6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+                init[12 * b:12 * b + 3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[b]
             tr.initialize([init])
             tr.track(frames[0])  # warm-up
             t0 = time.perf_counter()
@@ -49,9 +54,9 @@ def main():
                 est = tr.track(frames[k])
                 sensor_ms += s.last_kernel_ms()
             dt = time.perf_counter() - t0
-            Rt = synth.truth_pose(1, frame=n_frames)[0]
+            Rt = synth.truth_pose(nb, frame=n_frames)[0]
             err = np.linalg.norm(est[0:3] - (Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0]))
-            print(json.dumps({"metric": "tracker FPS", "filter": mode, "particles": n, "value": n_frames / dt, "unit": "frames/s",
+            print(json.dumps({"metric": "tracker FPS", "filter": mode, "evaluation_count": n, "objects": nb, "particles": max(1, n // nb), "value": n_frames / dt, "unit": "frames/s",
                               "ms_per_frame": dt / n_frames * 1e3, "sensor_device_ms_per_frame": sensor_ms / n_frames,
                               "resamplings": tr.n_resamplings, "final_position_error_m": float(err),
                               "resolution": [cols, rows], "triangles": int(len(f)), "n_gpus": 1}), flush=True)
