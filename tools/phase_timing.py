@@ -6,14 +6,16 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dbot_ros_amd import CameraData, ObjectModel, RbSensor, RbSensorBuilder, synth, _capi
 upd = int(sys.argv[sys.argv.index("--update") + 1]) if "--update" in sys.argv else 0
-n = 2000
-v, f = synth.mesh_m1()
-om = ObjectModel([v], [f]); cam = CameraData(synth.camera_matrix(), 480, 640)
+names = sys.argv[sys.argv.index("--mesh") + 1].split(",") if "--mesh" in sys.argv else ["m1"]
+n = int(sys.argv[sys.argv.index("--particles") + 1]) if "--particles" in sys.argv else 2000
+fns = {"m1": synth.mesh_m1, "m2": synth.mesh_m2, "m3": synth.mesh_m3, "m4": synth.mesh_m4}
+ms_ = [fns[k]() for k in names]
+om = ObjectModel([v for v, _ in ms_], [t for _, t in ms_]); cam = CameraData(synth.camera_matrix(), 480, 640)
 P = RbSensorBuilder.Parameters(sample_count=n)
 with RbSensor(om, cam, P, max_particles=n) as s:
     lib = _capi.load()
     rng = np.random.default_rng(0)
-    truth = synth.truth_pose(1)
+    truth = synth.truth_pose(len(names))
     s.set_observation(synth.make_frame(s.render_depth(truth), 480, 640, rng))
     poses = synth.particle_poses(truth, n, rng)
     idx = rng.permutation(n).astype(np.int32)
