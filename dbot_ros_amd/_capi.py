@@ -25,7 +25,8 @@ EXPORTS = (
     "rbs_reset", "rbs_set_observation", "rbs_set_observation_f32",
     "rbs_set_observation_native_f32", "rbs_get_observation", "rbs_loglikes",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
-    "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_render_depth",
+    "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_export_plane", "rbs_import_plane",
+    "rbs_render_depth",
     "rbs_last_kernel_ms", "rbs_timing_summary",
     "rbs_tracker_create", "rbs_tracker_destroy", "rbs_tracker_initialize", "rbs_tracker_track",
     "rbs_tracker_get",
@@ -122,6 +123,10 @@ def load():
     lib.rbs_occlusion_device_ptr.argtypes = [H, C.c_int32, C.POINTER(C.c_void_p)]
     lib.rbs_occlusion_next_device_ptr.restype = C.c_int32
     lib.rbs_occlusion_next_device_ptr.argtypes = [H, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.rbs_export_plane.restype = C.c_int32
+    lib.rbs_export_plane.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rbs_import_plane.restype = C.c_int32
+    lib.rbs_import_plane.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rbs_render_depth.restype = C.c_int32
     lib.rbs_render_depth.argtypes = [H, dp, fp]
     lib.rbs_last_kernel_ms.restype = C.c_int32

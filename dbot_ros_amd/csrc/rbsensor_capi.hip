@@ -733,6 +733,32 @@ int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out)
     return RBS_OK;
 }
 
+int32_t rbs_export_plane(rbs_handle* h, int32_t slot, void* d_dst, void* stream)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (slot < 0 || slot >= h->max_particles || !d_dst)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("export_plane: bad slot %d", slot));
+    RBS_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    RBS_HIP(h, hipMemcpyAsync(d_dst, h->d_occ[h->cur] + (size_t)slot * h->npx, sizeof(float) * h->npx,
+                              hipMemcpyDeviceToDevice, s));
+    return RBS_OK;
+}
+
+int32_t rbs_import_plane(rbs_handle* h, int32_t slot, const void* d_src, void* stream)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (slot < 0 || slot >= h->max_particles || !d_src)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("import_plane: bad slot %d", slot));
+    RBS_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    RBS_HIP(h, hipMemcpyAsync(h->d_occ[h->cur] + (size_t)slot * h->npx, d_src, sizeof(float) * h->npx,
+                              hipMemcpyDeviceToDevice, s));
+    return RBS_OK;
+}
+
 int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;

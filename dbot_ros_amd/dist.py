@@ -126,21 +126,31 @@ class ShardedSensor:
                         for j in range(len(parents)) if owner[j] != child_rank[j]})
         staging, ops, keep = {}, [], []
         npx = self.sensor.rows * self.sensor.cols
+        on_device = self.device is not None and hasattr(self.sensor, "export_plane")
+        stream = torch.cuda.current_stream().cuda_stream if on_device else None
         for src, dst, g in moves:
             if src == self.rank:
-                t = torch.from_numpy(np.ascontiguousarray(self.sensor.get_occlusion(g - self.lo)))
-                t = t.to(self.device) if self.device is not None else t
+                if on_device:   # device-to-device out of the sensor, then RCCL straight from HBM
+                    t = torch.empty(npx, dtype=torch.float32, device=self.device)
+                    self.sensor.export_plane(g - self.lo, t.data_ptr(), stream)
+                else:
+                    t = torch.from_numpy(np.ascontiguousarray(self.sensor.get_occlusion(g - self.lo)))
                 ops.append(dist.P2POp(dist.isend, t, dst, group=self.group))
                 keep.append(t)
             elif dst == self.rank:
-                t = torch.empty(npx, dtype=torch.float32, device=self.device)
+                t = torch.empty(npx, dtype=torch.float32, device=self.device if on_device else None)
                 ops.append(dist.P2POp(dist.irecv, t, src, group=self.group))
                 staging[g] = (self.stage0 + len(staging), t)
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         for g, (slot, t) in staging.items():
-            self.sensor.set_occlusion(slot, t.cpu().numpy())
+            if on_device:
+                self.sensor.import_plane(slot, t.data_ptr(), stream)
+            else:
+                self.sensor.set_occlusion(slot, t.cpu().numpy())
+        if on_device and staging:
+            torch.cuda.current_stream().synchronize()   # staging tensors die with this scope
         new_layout = np.empty(self.n_total, dtype=np.int64)
         new_layout[self.bounds[child_rank] + child_slot] = np.arange(self.n_total)
         self.layout = new_layout

@@ -278,6 +278,13 @@ class RbSensor:
         self._check(self._lib.rbs_set_occlusion(self._h, int(slot),
                                                 a.ctypes.data_as(C.POINTER(C.c_float))))
 
+    def export_plane(self, slot, d_dst_ptr, stream=None):
+        """Device-to-device copy of a slot's plane into caller-owned device memory (raw address)."""
+        self._check(self._lib.rbs_export_plane(self._h, int(slot), d_dst_ptr, stream))
+
+    def import_plane(self, slot, d_src_ptr, stream=None):
+        self._check(self._lib.rbs_import_plane(self._h, int(slot), d_src_ptr, stream))
+
     def occlusion_device_ptr(self, slot, next_buffer=False):
         p = C.c_void_p()
         fn = self._lib.rbs_occlusion_next_device_ptr if next_buffer else self._lib.rbs_occlusion_device_ptr

@@ -131,6 +131,12 @@ int32_t rbs_set_occlusion(rbs_handle* h, int32_t slot, const float* plane);
 int32_t rbs_occlusion_device_ptr(rbs_handle* h, int32_t slot, void** out);
 /* Device address of slot's plane in the buffer the NEXT updating call will write. */
 int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out);
+/* Device-to-device copy of a slot's plane to / from caller-owned device memory (float[rows*cols]
+ * on the handle's device), enqueued on `stream` (NULL = the handle's stream) after the planes of
+ * the last updating call are complete: the migration path between GPUs (a torch.distributed /
+ * RCCL send or recv of the caller's buffer), without staging through the host. */
+int32_t rbs_export_plane(rbs_handle* h, int32_t slot, void* d_dst, void* stream);
+int32_t rbs_import_plane(rbs_handle* h, int32_t slot, const void* d_src, void* stream);
 /* Rasterize one pose [n_objects][12] -> host float[rows*cols], +inf where uncovered. */
 int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out);
 /* Device time in milliseconds of the most recent rbs_loglikes* call (HIP events recorded on the

@@ -494,3 +494,25 @@ def test_create_destroy_does_not_leak_device_memory(gpu_lib):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, f"leaked {(free0 - free1) / 2**20:.1f} MiB over 40 create/destroy cycles"
+
+
+def test_device_plane_export_import(gpu_lib):
+    """rbs_export_plane / rbs_import_plane: the device-to-device leg of cross-GPU plane migration."""
+    import torch
+    n = 6
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    frames = sc.make_frames(eager, 1, 2, seed=2)
+    with RbSensor(om, cam, P, max_particles=n) as a, RbSensor(om, cam, P, max_particles=n) as b:
+        sc.run_sequence(a, frames, n)
+        buf = torch.empty(160 * 120, dtype=torch.float32, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        for slot in range(n):
+            a.export_plane(slot, buf.data_ptr(), st)          # right after an updating call: must see the finished plane
+            b.import_plane(n - 1 - slot, buf.data_ptr(), st)
+            torch.cuda.current_stream().synchronize()
+            assert np.array_equal(buf.cpu().numpy(), a.get_occlusion(slot))
+        for slot in range(n):
+            assert np.array_equal(b.get_occlusion(n - 1 - slot), a.get_occlusion(slot))
+        with pytest.raises(RbSensorError):
+            a.export_plane(n, buf.data_ptr(), st)
