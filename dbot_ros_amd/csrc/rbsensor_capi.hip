@@ -138,6 +138,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.occ_dst = h->d_occ[1 - h->cur];
     P.poses = d_poses;
     P.indices = d_indices;
+    P.slots = h->max_particles;
     P.out = d_out;
     P.n = n;
     const int slot = (int)(h->calls % rbs_handle::kRing);

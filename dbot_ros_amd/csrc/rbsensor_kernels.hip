@@ -80,6 +80,7 @@ struct DevParams {
     float* occ_dst;                // [slots][npx]
     const double* poses;           // [n][n_bodies][12]
     const int* indices;            // [n] parent slot
+    int slots;                     // occlusion slots allocated (valid parents: 0..slots-1)
     double* out;                   // [n]
     int n;
     int bands, band_rows;          // copy blocks per particle, rows per band
@@ -440,6 +441,9 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
 
     const double* pose = P.poses + (size_t)particle * 12 * P.n_bodies;
     const int parent = P.indices[particle];
+    // a parent slot outside the allocation (only possible through the unchecked device-pointer
+    // API) must not turn into a wild read: the particle's likelihood becomes NaN instead
+    if ((unsigned)parent >= (unsigned)P.slots) return NAN;
     const float* __restrict__ src = P.occ_src + (size_t)parent * P.npx;
     float* __restrict__ dst = UPDATE ? P.occ_dst + (size_t)particle * P.npx : nullptr;
 
@@ -535,6 +539,7 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
     const int row1 = min(P.rows, row0 + P.band_rows);
     if (row0 >= row1) return;
     const int parent = P.indices[particle];
+    if ((unsigned)parent >= (unsigned)P.slots) return;
     const float* __restrict__ src = P.occ_src + (size_t)parent * P.npx + (size_t)row0 * P.cols;
     float* __restrict__ dst = P.occ_dst + (size_t)particle * P.npx + (size_t)row0 * P.cols;
     const float alpha = P.alpha, beta = P.beta;
@@ -715,6 +720,7 @@ __global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, 
     const int W4 = P.cols >> 2;
     const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
     const int parent = P.indices[particle];
+    if ((unsigned)parent >= (unsigned)P.slots) return;
     // blockIdx.x = row group * nseg + column segment (segment fastest: address order)
     const int rg = (int)blockIdx.x / nseg;
     const int seg = (int)blockIdx.x - rg * nseg;

@@ -516,3 +516,30 @@ def test_device_plane_export_import(gpu_lib):
             assert np.array_equal(b.get_occlusion(n - 1 - slot), a.get_occlusion(slot))
         with pytest.raises(RbSensorError):
             a.export_plane(n, buf.data_ptr(), st)
+
+
+def test_device_api_bad_parent_slot_is_contained(gpu_lib):
+    """The device-pointer API cannot validate parent slots on the host; an out-of-range slot
+    must give NaN for that particle, not a wild read, and leave the others untouched."""
+    import torch
+    n = 8
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    frames = sc.make_frames(eager, 1, 1, seed=2)
+    poses = synth.particle_poses(frames[0][0], n, np.random.default_rng(0))
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        for s in (g, eager):
+            s.reset()
+            s.set_observation(frames[0][1])
+        ref = eager.loglikes_poses(poses, np.zeros(n, np.int32), update=True)
+        d_poses = torch.from_numpy(poses.reshape(n, -1)).cuda()
+        idx = np.zeros(n, np.int32)
+        idx[3], idx[5] = 10 ** 6, -7
+        d_idx = torch.from_numpy(idx).cuda()
+        d_out = torch.empty(n, dtype=torch.float64, device="cuda")
+        g.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, True, d_out.data_ptr(), None)
+        g.synchronize()
+        out = d_out.cpu().numpy()
+        assert np.isnan(out[3]) and np.isnan(out[5])
+        ok = np.array([i not in (3, 5) for i in range(n)])
+        assert rel_err(out[ok], ref[ok]).max() <= TOL_EAGER
