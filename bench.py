@@ -152,6 +152,8 @@ def main():
     # live on it (a NULL stream would select the handle's private stream instead)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
+    d_out.zero_()                  # first submission creates the stream's hardware queue: setup, not a step
+    torch.cuda.synchronize()
 
     def exchange():
         # the weight exchange before resampling: every rank gets all N*world log-likelihoods

@@ -501,6 +501,20 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_render_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
 
+    {   // per-item partial sums: sized for the default tiling so no call ever allocates
+        const size_t t128 = (size_t)((h->cols + 127) / 128 + 1) * ((h->rows + 127) / 128 + 1);
+        const size_t t64 = (size_t)((h->cols + 63) / 64 + 1) * ((h->rows + 63) / 64 + 1);
+        const size_t need = std::max((size_t)h->max_particles * t128,
+                                     (size_t)std::min(h->max_particles, 2 * h->raster_blocks) * t64);
+        RBS_HIP(h, hipMalloc(&h->d_partial, sizeof(double) * need));
+        h->partial_cap = need;
+    }
+    // HIP creates a stream's hardware queue at its first submission: do that now, not inside the
+    // first updating call
+    hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(1), dim3(64), 0, h->copy_stream, h->d_render, (size_t)1, 0.f);
+    RBS_HIP(h, hipGetLastError());
+    RBS_HIP(h, hipEventRecord(h->ev_fork, h->copy_stream));
+    RBS_HIP(h, hipStreamSynchronize(h->copy_stream));
     // no observation yet: every pixel "no reading"
     for (int p = 0; p < h->npx; ++p) h->h_frame[p] = NAN;
     if (int32_t rc = upload_frame(h)) return rc;
@@ -559,6 +573,9 @@ int32_t rbs_reset(rbs_handle* h)
     h->pending_frames = 0;
     const size_t n = (size_t)h->npx * h->max_particles;
     hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(2048), dim3(256), 0, h->stream, h->d_occ[0], n,
+                       (float)h->init_occ);
+    // the second buffer too: touches every page now instead of inside the first updating call
+    hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(2048), dim3(256), 0, h->stream, h->d_occ[1], n,
                        (float)h->init_occ);
     RBS_HIP(h, hipGetLastError());
     if (int32_t rc = drain(h, true)) return rc;
