@@ -56,6 +56,23 @@ def coverage():
     np.savez_compressed(os.path.join(HERE, "coverage.npz"), **out)
 
 
+def coverage_vga():
+    """640x480 coverage of the 5 120-triangle meshes, stored sparsely (covered pixel ids + depths)."""
+    out = {}
+    for mesh in ("m1", "m3", "box12"):
+        om, cam, P = sc.make_scene((mesh,), 640, 480, max_particles=1)
+        o = ob.Oracle(om, cam, P, max_particles=1)
+        rng = np.random.default_rng(23)
+        for k in range(5):
+            pose = synth.particle_poses(synth.truth_pose(1, z=0.45 + 0.12 * k, frame=4 * k), 1, rng, scale=5.0)[0]
+            d = o.render_depth(pose)
+            ids = np.nonzero(np.isfinite(d))[0].astype(np.int32)
+            out[f"{mesh}_{k}_pose"] = pose
+            out[f"{mesh}_{k}_ids"] = ids
+            out[f"{mesh}_{k}_depth"] = d[ids]
+    np.savez_compressed(os.path.join(HERE, "coverage_vga.npz"), **out)
+
+
 def sequences():
     out = {}
     for name, meshes, cols, rows, n in (("single", ("m1_l2",), 80, 60, 16), ("multi", ("m1_l2", "box12"), 160, 120, 16)):
@@ -75,6 +92,7 @@ def sequences():
 if __name__ == "__main__":
     pixel_model()
     coverage()
+    coverage_vga()
     sequences()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -543,3 +543,16 @@ def test_device_api_bad_parent_slot_is_contained(gpu_lib):
         assert np.isnan(out[3]) and np.isnan(out[5])
         ok = np.array([i not in (3, 5) for i in range(n)])
         assert rel_err(out[ok], ref[ok]).max() <= TOL_EAGER
+
+
+@pytest.mark.parametrize("mesh", ["m1", "m3", "box12"])
+def test_golden_coverage_vga(gpu_lib, mesh):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "coverage_vga.npz"))
+    om, cam, P = sc.make_scene((mesh,), 640, 480, max_particles=1)
+    with RbSensor(om, cam, P, max_particles=1) as s:
+        for k in range(5):
+            d = s.render_depth(g[f"{mesh}_{k}_pose"])
+            ids = np.nonzero(np.isfinite(d))[0]
+            assert np.array_equal(ids, g[f"{mesh}_{k}_ids"])
+            assert np.array_equal(d[ids].view(np.uint32), g[f"{mesh}_{k}_depth"].view(np.uint32))

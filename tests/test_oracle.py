@@ -250,3 +250,17 @@ def test_occluded_density_is_the_truncated_exponential_convolved_with_the_sensor
     # visible branch: a Gaussian around the rendered depth
     assert (o_.prob_visible(0.7, 0.7) - tw / 6.0) / (1 - tw) == pytest.approx(
         1.0 / (math.sqrt(2 * math.pi) * (ms + sf * 0.49)), rel=1e-14)
+
+
+@pytest.mark.parametrize("mesh", ["m1", "m3", "box12"])
+def test_vga_coverage_golden(mesh):
+    """640x480 coverage masks + depths of the full-size meshes (stored sparsely)."""
+    g = np.load(os.path.join(GOLD, "coverage_vga.npz"))
+    om, cam, P = sc.make_scene((mesh,), 640, 480, max_particles=1)
+    o = ob.Oracle(om, cam, P, max_particles=1)
+    for k in range(5):
+        d = o.render_depth(g[f"{mesh}_{k}_pose"])
+        ids = np.nonzero(np.isfinite(d))[0]
+        assert np.array_equal(ids, g[f"{mesh}_{k}_ids"])
+        assert np.array_equal(d[ids].view(np.uint32), g[f"{mesh}_{k}_depth"].view(np.uint32))
+        assert len(ids) > 1000
