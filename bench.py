@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- particle-likelihoods/s of the RbSensor hot path on MI355X.
 
-A "step" is one RbSensor::loglikes(update=true) pass over one batch of particles:
-BASELINE.json config C1 per GPU = 2 000 particles, one 5 120-triangle mesh (M1), one 640x480
-synthetic frame, every child inheriting from a distinct random parent slot (permutation: no
-occlusion plane is read twice, the worst case for HBM traffic).  Inputs (frame, poses, parent
-indices, occlusion planes) are resident in HBM before the timed region.  With --gpus N each
+A "step" is one frame of BASELINE.json config C1 on one GPU: set_observation(frame k) +
+RbSensor::loglikes(update=true) over 2 000 particles, one 5 120-triangle mesh (M1), 640x480
+synthetic frames of SURVEY 8d's sequence (the object translates 2 mm and turns 1 degree per
+frame; 30 frames played forwards and backwards), every child inheriting from a distinct random
+parent slot (permutation: no occlusion plane is read twice, the worst case for HBM traffic).
+Inputs (frames, poses, parent indices, occlusion planes) are resident in HBM before the timed
+region.  --sequence 0 replays one frame and one pose set for ever (a resting object).  With --gpus N each
 rank evaluates its own 2 000-particle shard (weak scaling) and the per-particle
 log-likelihoods are all-gathered over RCCL every step (the weight exchange before resampling).
 
@@ -40,6 +42,8 @@ def parse():
     ap.add_argument("--parents", default="permutation",
                     choices=["permutation", "identity", "resampled", "peaked", "peaked_unsorted"])
     ap.add_argument("--update", type=int, default=1, help="0: read-only evaluation (non-final blocks)")
+    ap.add_argument("--sequence", type=int, default=30, help="frames in the moving-object sequence (0: one static frame)")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the whole-plane (RBS_STATE=dense) comparison run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -123,10 +127,13 @@ def main():
 
     # synthetic frame: the product's own render hook supplies the object's depth
     rng = np.random.default_rng(0)
-    truth = synth.truth_pose(nb)
-    frame = synth.make_frame(sensor.render_depth(truth), a.rows, a.cols, rng)
     prng = np.random.default_rng(1 + rank)
-    poses = synth.particle_poses(truth, n, prng)
+    F = max(1, a.sequence)
+    truths = [synth.truth_pose(nb, frame=k) for k in range(F)]
+    frames = np.stack([synth.make_frame(sensor.render_depth(t), a.rows, a.cols, rng) for t in truths])
+    poses_seq = np.stack([synth.particle_poses(t, n, prng).reshape(n, -1) for t in truths])
+    order = list(range(F)) + list(range(F - 2, 0, -1))      # forwards, then backwards
+    truth, frame = truths[0], frames[0]
     if a.parents == "permutation":
         parents = synth.resample_like_indices(n, prng)
     elif a.parents == "identity":
@@ -141,7 +148,8 @@ def main():
         print(f"# parents={a.parents}: {len(np.unique(parents))} distinct of {n}", file=sys.stderr)
 
     dev = torch.device("cuda", local)
-    d_poses = torch.from_numpy(poses.reshape(n, -1)).to(dev)
+    d_poses = torch.from_numpy(poses_seq).to(dev)                       # [F][n][12*bodies]
+    d_frames = torch.from_numpy(frames.astype(np.float32)).to(dev)     # [F][rows*cols]
     d_idx = torch.from_numpy(parents).to(dev)
     d_out = torch.empty(n, dtype=torch.float64, device=dev)
     d_all = torch.empty(n * world, dtype=torch.float64, device=dev) if world > 1 else None
@@ -164,9 +172,20 @@ def main():
             dist.all_gather(host, d_out.cpu())
             d_all.copy_(torch.cat(host))
 
+    pose_bytes = d_poses[0].numel() * 8
+    frame_bytes = d_frames[0].numel() * 4
+    counter = [0]
+
+    def launch(sn):
+        k = order[counter[0] % len(order)]
+        counter[0] += 1
+        if a.sequence > 0:
+            sn.set_observation_device(d_frames.data_ptr() + k * frame_bytes, stream.cuda_stream)
+        sn.loglikes_device(d_poses.data_ptr() + k * pose_bytes, d_idx.data_ptr(), n, bool(a.update),
+                           d_out.data_ptr(), stream.cuda_stream)
+
     def step():
-        sensor.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, bool(a.update), d_out.data_ptr(),
-                               stream.cuda_stream)
+        launch(sensor)
         if world > 1:
             exchange()
 
@@ -181,8 +200,7 @@ def main():
     t0 = time.perf_counter()
     for s, e in k_ev:
         s.record(stream)
-        sensor.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, bool(a.update), d_out.data_ptr(),
-                               stream.cuda_stream)
+        launch(sensor)
         e.record(stream)
         if world > 1:
             exchange()
@@ -203,7 +221,11 @@ def main():
     # the dominant kernel (rbs_copy_kernel) runs on the library's second stream: its duration
     # comes from the HIP events the library records on THAT stream, averaged over the timed steps
     lib_call_ms, copy_ms, n_used = sensor.timing_summary(a.steps)
-    kernel_ms = copy_ms if a.update else lib_call_ms
+    raster_ms = sensor.raster_kernel_ms(a.steps)
+    # the dominant kernel: the raster kernel on windowed planes, the copy kernel on whole planes
+    kernel_name, kernel_ms = ("rbs_copy_kernel", copy_ms) if (a.update and copy_ms > raster_ms) else ("rbs_raster_kernel", raster_ms)
+    windows = np.array([sensor.get_window(s_) for s_ in range(0, n, max(1, n // 64))])
+    win_frac = float(np.mean(np.maximum(0, windows[:, 2] - windows[:, 0]) * np.maximum(0, windows[:, 3] - windows[:, 1]))) / (a.rows * a.cols)
     ll = d_out.cpu().numpy()
     if not np.isfinite(ll).all():
         raise SystemExit("non-finite log-likelihoods in the timed run")
@@ -211,11 +233,14 @@ def main():
     if rank == 0:
         alg_bytes = (2.0 if a.update else 1.0) * 4.0 * a.rows * a.cols * n  # per launch, SURVEY 8d
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        layout = "dense" if os.environ.get("RBS_STATE") == "dense" else "window"
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                j = json.load(open(pmc))
+                if j.get("state_layout", "dense") == layout:
+                    traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -229,16 +254,44 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C1: {n} particles/GPU x loglikes(update={'true' if a.update else 'false'}), {a.cols}x{a.rows} "
                                    f"synthetic depth frame, mesh {a.mesh} ({len(f)} triangles), "
-                                   f"parents={a.parents}",
+                                   f"parents={a.parents}, " + (f"{F}-frame moving-object sequence" if a.sequence > 0 else "one static frame"),
                        "particles_per_gpu": n, "resolution": [a.cols, a.rows], "triangles": int(len(f)),
                        "sharding": f"particles/{world}" + (" + RCCL all-gather of log-likelihoods" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rbs_copy_rows_kernel" if a.update else "rbs_raster_kernel",
+                         "kernel": kernel_name,
                          "kernel_ms": kernel_ms, "kernel_launches_averaged": n_used,
+                         "raster_kernel_ms": raster_ms, "copy_kernel_ms": copy_ms,
+                         "state_layout": layout, "stored_window_fraction_of_plane": win_frac,
                          "call_ms_launch_stream": call_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if world == 1 and a.update and layout == "window" and not a.no_dense_leg:
+            # the same steps on whole planes (every updating call copies every plane in full):
+            # what the windowed layout falls back to when windows grow to the whole frame
+            os.environ["RBS_STATE"] = "dense"
+            dense = RbSensor(om, cam, P, device_id=local, max_particles=n)
+            os.environ.pop("RBS_STATE")
+            dense.reset()
+            dense.set_observation(frame)
+            dense.synchronize()
+            counter[0] = 0
+            for _ in range(a.warmup):
+                launch(dense)
+            torch.cuda.synchronize()
+            dsteps = min(a.steps, 60)
+            td = time.perf_counter()
+            for _ in range(dsteps):
+                launch(dense)
+            torch.cuda.synchronize()
+            td = time.perf_counter() - td
+            _, dcopy_ms, _ = dense.timing_summary(dsteps)
+            out["dense_state"] = {"value": n * dsteps / td, "unit": "particle-likelihoods/s", "steps": dsteps,
+                                  "ms_per_step": td / dsteps * 1e3,
+                                  "roofline": {"bound": "hbm", "kernel": "rbs_copy_rows_kernel", "kernel_ms": dcopy_ms,
+                                               "achieved": alg_bytes / (dcopy_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                                               "unit": "GB/s", "frac": alg_bytes / (dcopy_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+            dense.close()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(om, cam, P, truth, frame, a.cpu_seconds)
         print(json.dumps(out), flush=True)

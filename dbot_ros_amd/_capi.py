@@ -23,9 +23,10 @@ RBS_ERR_UNSUPPORTED = -5
 EXPORTS = (
     "rbs_abi_version", "rbs_device_count", "rbs_create", "rbs_destroy", "rbs_last_error",
     "rbs_reset", "rbs_set_observation", "rbs_set_observation_f32",
-    "rbs_set_observation_native_f32", "rbs_get_observation", "rbs_loglikes",
+    "rbs_set_observation_native_f32", "rbs_set_observation_device", "rbs_get_observation", "rbs_loglikes",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_export_plane", "rbs_import_plane",
+    "rbs_get_window", "rbs_get_background", "rbs_raster_kernel_ms",
     "rbs_render_depth",
     "rbs_last_kernel_ms", "rbs_timing_summary",
     "rbs_tracker_create", "rbs_tracker_destroy", "rbs_tracker_initialize", "rbs_tracker_track",
@@ -123,6 +124,14 @@ def load():
     lib.rbs_occlusion_device_ptr.argtypes = [H, C.c_int32, C.POINTER(C.c_void_p)]
     lib.rbs_occlusion_next_device_ptr.restype = C.c_int32
     lib.rbs_occlusion_next_device_ptr.argtypes = [H, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.rbs_set_observation_device.restype = C.c_int32
+    lib.rbs_set_observation_device.argtypes = [H, C.c_void_p, C.c_void_p]
+    lib.rbs_get_window.restype = C.c_int32
+    lib.rbs_get_window.argtypes = [H, C.c_int32, C.POINTER(C.c_int32)]
+    lib.rbs_get_background.restype = C.c_int32
+    lib.rbs_get_background.argtypes = [H, C.POINTER(C.c_float)]
+    lib.rbs_raster_kernel_ms.restype = C.c_int32
+    lib.rbs_raster_kernel_ms.argtypes = [H, C.c_int32, C.POINTER(C.c_float)]
     lib.rbs_export_plane.restype = C.c_int32
     lib.rbs_export_plane.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rbs_import_plane.restype = C.c_int32

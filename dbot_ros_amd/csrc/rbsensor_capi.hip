@@ -42,7 +42,13 @@ struct rbs_handle {
     double* d_poses = nullptr;
     int* d_indices = nullptr;
     double* d_out = nullptr;
-    int* d_rects = nullptr;     // [max_particles][4]
+    int* d_rects[2] = {nullptr, nullptr};  // [max_particles][4], alternating per call: the previous
+                                // call's copy kernel may still be reading its rectangles
+    int4* d_win[2] = {nullptr, nullptr};   // [max_particles] window of each plane, per buffer
+    int4* d_win_used = nullptr; // [max_particles] region the copy kernel writes this call
+    bool windowed = true;       // planes valid inside their window only (RBS_STATE=dense: whole plane)
+    int win_chunks = 8;         // row chunks (blocks) per particle of the windowed copy kernel
+    float background = 0.f;     // never-covered occlusion level of the current buffer
     int* d_tiles = nullptr;     // [max_particles] tiles per particle
     int* d_item_offset = nullptr; // [max_particles+1]
     int* d_work_counter = nullptr;
@@ -67,6 +73,7 @@ struct rbs_handle {
     // kernel (on the copy stream) for the last kRing loglikes calls
     static constexpr int kRing = 64;
     hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {}, ev_copy_start[kRing] = {}, ev_join[kRing] = {};
+    hipEvent_t ev_raster_start[kRing] = {}, ev_raster_stop[kRing] = {};
     bool ring_update[kRing] = {};
     long calls = 0;
     int join_pending = -1;      // ring slot whose copy kernel later work on the planes must wait for
@@ -131,6 +138,12 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
 {
     DevParams P = h->base;
     occlusion_coeffs(h, h->pending_frames, &P.alpha, &P.beta);
+    P.bg_old = h->background;
+    P.bg_new = std::fmaf(P.alpha, h->background, P.beta);
+    P.windowed = h->windowed ? 1 : 0;
+    P.win_src = h->d_win[h->cur];
+    P.win_dst = h->d_win[1 - h->cur];
+    P.win_used = h->d_win_used;
     P.frame = h->d_frame;
     P.aux = h->d_aux;
     P.pbg = h->d_pbg;
@@ -160,7 +173,8 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipMalloc(&h->d_partial, sizeof(double) * need));
         h->partial_cap = need;
     }
-    P.rects = h->d_rects;
+    int* const d_rects = h->d_rects[h->calls & 1];
+    P.rects = d_rects;
     P.item_offset = h->d_item_offset;
     P.work_counter = h->d_work_counter;
     P.partial = h->d_partial;
@@ -171,8 +185,14 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     RBS_HIP(h, hipEventRecord(h->ev_start[slot], s));
     const dim3 block(rbs::kBlock);
     const dim3 pgrid((unsigned)((n + 255) / 256));
-    // prep + scan read only the poses: they run ahead of the previous call's copy kernel
-    hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(256), 0, s, P, h->d_rects, h->d_tiles);
+    // dense planes: prep + scan read only the poses and run ahead of the previous call's copy
+    // kernel (which reads the other rectangle buffer); windowed planes: prep reads the windows
+    // that copy kernel is still growing, so the join comes first (that copy is short)
+    if (h->windowed && h->join_pending >= 0) {
+        RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+        h->join_pending = -1;
+    }
+    hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(256), 0, s, P, d_rects, h->d_tiles, update ? 1 : 0);
     RBS_HIP(h, hipGetLastError());
     if (update) {
         // fork: the copy kernel runs on the handle's second stream, concurrently with the
@@ -190,12 +210,18 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         h->join_pending = -1;
     }
     const dim3 rgrid((unsigned)h->raster_blocks);
+    RBS_HIP(h, hipEventRecord(h->ev_raster_start[slot], s));
     if (update) {
         hipLaunchKernelGGL((rbs::rbs_raster_kernel<true>), rgrid, block, rbs::kSmemBytes, s, P);
         RBS_HIP(h, hipGetLastError());
+        RBS_HIP(h, hipEventRecord(h->ev_raster_stop[slot], s));
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
         RBS_HIP(h, hipEventRecord(h->ev_copy_start[slot], h->copy_stream));
-        if ((P.cols & 3) == 0 && h->copy_rows > 0) {
+        if (h->windowed) {
+            const int ny = std::min(n, 32768);
+            const dim3 wg((unsigned)h->win_chunks, (unsigned)ny, (unsigned)((n + ny - 1) / ny));
+            hipLaunchKernelGGL(rbs::rbs_copy_window_kernel, wg, dim3(64), 0, h->copy_stream, P);
+        } else if ((P.cols & 3) == 0 && h->copy_rows > 0) {
             const int W4 = P.cols >> 2;
             const int tpb = h->copy_tpb > 0 ? h->copy_tpb : std::min(1024, (W4 + 63) / 64 * 64);
             const int nseg = (W4 + tpb - 1) / tpb;
@@ -218,6 +244,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     } else {
         hipLaunchKernelGGL((rbs::rbs_raster_kernel<false>), rgrid, block, rbs::kSmemBytes, s, P);
         RBS_HIP(h, hipGetLastError());
+        RBS_HIP(h, hipEventRecord(h->ev_raster_stop[slot], s));
     }
     hipLaunchKernelGGL(rbs::rbs_reduce_kernel, pgrid, dim3(256), 0, s, P);
     RBS_HIP(h, hipGetLastError());
@@ -227,7 +254,23 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     if (update) {
         h->cur = 1 - h->cur;
         h->pending_frames = 0;
+        h->background = P.bg_new;
     }
+    return RBS_OK;
+}
+
+// Windowed planes: make slot's current plane dense in place (background outside its window) and
+// mark its window full, on stream s.  Dense planes: nothing to do.
+int32_t materialize(rbs_handle* h, int slot, hipStream_t s)
+{
+    if (!h->windowed) return RBS_OK;
+    hipLaunchKernelGGL(rbs::rbs_materialize_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s,
+                       h->d_occ[h->cur] + (size_t)slot * h->npx, h->d_win[h->cur] + slot, h->rows, h->cols,
+                       h->background);
+    RBS_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_win[h->cur] + slot, 1,
+                       make_int4(0, 0, h->cols, h->rows));
+    RBS_HIP(h, hipGetLastError());
     return RBS_OK;
 }
 
@@ -261,7 +304,11 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_poses);
     (void)hipFree(h->d_indices);
     (void)hipFree(h->d_out);
-    (void)hipFree(h->d_rects);
+    (void)hipFree(h->d_rects[0]);
+    (void)hipFree(h->d_rects[1]);
+    (void)hipFree(h->d_win[0]);
+    (void)hipFree(h->d_win[1]);
+    (void)hipFree(h->d_win_used);
     (void)hipFree(h->d_tiles);
     (void)hipFree(h->d_item_offset);
     (void)hipFree(h->d_work_counter);
@@ -277,6 +324,8 @@ void release(rbs_handle* h)
         if (h->ev_stop[i]) (void)hipEventDestroy(h->ev_stop[i]);
         if (h->ev_copy_start[i]) (void)hipEventDestroy(h->ev_copy_start[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+        if (h->ev_raster_start[i]) (void)hipEventDestroy(h->ev_raster_start[i]);
+        if (h->ev_raster_stop[i]) (void)hipEventDestroy(h->ev_raster_stop[i]);
     }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -460,6 +509,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         RBS_HIP(h, hipEventCreate(&h->ev_stop[i]));
         RBS_HIP(h, hipEventCreate(&h->ev_copy_start[i]));
         RBS_HIP(h, hipEventCreate(&h->ev_join[i]));
+        RBS_HIP(h, hipEventCreate(&h->ev_raster_start[i]));
+        RBS_HIP(h, hipEventCreate(&h->ev_raster_stop[i]));
     }
     {
         hipDeviceProp_t prop;
@@ -470,6 +521,9 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         h->tile_override = std::getenv("RBS_TILE");
         if (const char* m = std::getenv("RBS_COPY_ROWS")) h->copy_rows = std::atoi(m);
         if (const char* m = std::getenv("RBS_COPY_TPB")) h->copy_tpb = std::max(64, std::atoi(m) / 64 * 64);
+        if (const char* m = std::getenv("RBS_STATE")) h->windowed = std::strcmp(m, "dense") != 0;
+        if (const char* m = std::getenv("RBS_WIN_CHUNKS")) h->win_chunks = std::min(1024, std::max(1, std::atoi(m)));
+        if (h->cols & 3) h->windowed = false;   // windows move whole float4s
     }
     RBS_HIP(h, hipMalloc(&h->d_soup, soup.size() * sizeof(double)));
     RBS_HIP(h, hipMemcpy(h->d_soup, soup.data(), soup.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -483,7 +537,11 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMalloc(&h->d_poses, sizeof(double) * 12 * h->n_bodies * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_indices, sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_out, sizeof(double) * (size_t)h->max_particles));
-    RBS_HIP(h, hipMalloc(&h->d_rects, sizeof(int) * 4 * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_rects[0], sizeof(int) * 4 * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_rects[1], sizeof(int) * 4 * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_win[0], sizeof(int4) * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_win[1], sizeof(int4) * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_win_used, sizeof(int4) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_tiles, sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_item_offset, sizeof(int) * ((size_t)h->max_particles + 1)));
     RBS_HIP(h, hipMalloc(&h->d_work_counter, sizeof(int)));
@@ -571,6 +629,14 @@ int32_t rbs_reset(rbs_handle* h)
     if (int32_t rc = drain(h, true)) return rc;   // no copy kernel may still be writing planes
     h->cur = 0;
     h->pending_frames = 0;
+    h->background = (float)h->init_occ;
+    {   // windowed: every plane is all background (empty window); dense: full windows for ever
+        const int4 w0 = h->windowed ? make_int4(h->cols, h->rows, 0, 0) : make_int4(0, 0, h->cols, h->rows);
+        const unsigned g = (unsigned)((h->max_particles + 255) / 256);
+        for (int b = 0; b < 2; ++b)
+            hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(g), dim3(256), 0, h->stream, h->d_win[b],
+                               h->max_particles, w0);
+    }
     const size_t n = (size_t)h->npx * h->max_particles;
     hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(2048), dim3(256), 0, h->stream, h->d_occ[0], n,
                        (float)h->init_occ);
@@ -637,6 +703,22 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
     hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0,
                        h->stream, h->d_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms,
                        h->base.sf, h->base.lambda);
+    RBS_HIP(h, hipGetLastError());
+    h->pending_frames += 1;
+    return RBS_OK;
+}
+
+int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* stream)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!d_depth) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_observation_device: null pointer");
+    RBS_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    const size_t n = (size_t)h->npx;
+    RBS_HIP(h, hipMemcpyAsync(h->d_frame, d_depth, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       h->d_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms, h->base.sf,
+                       h->base.lambda);
     RBS_HIP(h, hipGetLastError());
     h->pending_frames += 1;
     return RBS_OK;
@@ -712,6 +794,8 @@ int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("get_occlusion: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;
+    if (int32_t rc = materialize(h, slot, h->stream)) return rc;
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
     RBS_HIP(h, hipMemcpy(out, h->d_occ[h->cur] + (size_t)slot * h->npx, sizeof(float) * h->npx,
                          hipMemcpyDeviceToHost));
     return RBS_OK;
@@ -726,6 +810,12 @@ int32_t rbs_set_occlusion(rbs_handle* h, int32_t slot, const float* plane)
     if (int32_t rc = drain(h, true)) return rc;
     RBS_HIP(h, hipMemcpy(h->d_occ[h->cur] + (size_t)slot * h->npx, plane, sizeof(float) * h->npx,
                          hipMemcpyHostToDevice));
+    if (h->windowed) {   // the whole plane is explicit now; the next updating call tightens it again
+        hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, h->stream, h->d_win[h->cur] + slot,
+                           1, make_int4(0, 0, h->cols, h->rows));
+        RBS_HIP(h, hipGetLastError());
+        RBS_HIP(h, hipStreamSynchronize(h->stream));
+    }
     return RBS_OK;
 }
 
@@ -736,6 +826,8 @@ int32_t rbs_occlusion_device_ptr(rbs_handle* h, int32_t slot, void** out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("occlusion_device_ptr: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;   // planes complete before the caller touches them
+    if (int32_t rc = materialize(h, slot, h->stream)) return rc;   // and dense, whatever the caller does next
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
     *out = h->d_occ[h->cur] + (size_t)slot * h->npx;
     return RBS_OK;
 }
@@ -759,6 +851,7 @@ int32_t rbs_export_plane(rbs_handle* h, int32_t slot, void* d_dst, void* stream)
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    if (int32_t rc = materialize(h, slot, s)) return rc;
     RBS_HIP(h, hipMemcpyAsync(d_dst, h->d_occ[h->cur] + (size_t)slot * h->npx, sizeof(float) * h->npx,
                               hipMemcpyDeviceToDevice, s));
     return RBS_OK;
@@ -774,6 +867,11 @@ int32_t rbs_import_plane(rbs_handle* h, int32_t slot, const void* d_src, void* s
     if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
     RBS_HIP(h, hipMemcpyAsync(h->d_occ[h->cur] + (size_t)slot * h->npx, d_src, sizeof(float) * h->npx,
                               hipMemcpyDeviceToDevice, s));
+    if (h->windowed) {
+        hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_win[h->cur] + slot, 1,
+                           make_int4(0, 0, h->cols, h->rows));
+        RBS_HIP(h, hipGetLastError());
+    }
     return RBS_OK;
 }
 
@@ -845,6 +943,44 @@ int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float*
     *call_ms = (float)(tot / (double)n);
     *copy_kernel_ms = n_copy ? (float)(cpy / n_copy) : 0.f;
     *n_used = (int32_t)n;
+    return RBS_OK;
+}
+
+int32_t rbs_raster_kernel_ms(rbs_handle* h, int32_t last_n, float* raster_kernel_ms)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!raster_kernel_ms || last_n <= 0) return fail(h, RBS_ERR_INVALID_ARGUMENT, "raster_kernel_ms: bad argument");
+    if (h->calls == 0) return fail(h, RBS_ERR_INVALID_ARGUMENT, "raster_kernel_ms: no loglikes launched yet");
+    RBS_HIP(h, hipSetDevice(h->device));
+    const long n = std::min<long>({(long)last_n, h->calls, (long)rbs_handle::kRing});
+    double tot = 0.0;
+    for (long k = 0; k < n; ++k) {
+        const int slot = (int)((h->calls - 1 - k) % rbs_handle::kRing);
+        float ms = 0.f;
+        RBS_HIP(h, hipEventSynchronize(h->ev_raster_stop[slot]));
+        RBS_HIP(h, hipEventElapsedTime(&ms, h->ev_raster_start[slot], h->ev_raster_stop[slot]));
+        tot += ms;
+    }
+    *raster_kernel_ms = (float)(tot / (double)n);
+    return RBS_OK;
+}
+
+int32_t rbs_get_window(rbs_handle* h, int32_t slot, int32_t out[4])
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (slot < 0 || slot >= h->max_particles || !out)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("get_window: bad slot %d", slot));
+    RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = drain(h, true)) return rc;
+    RBS_HIP(h, hipMemcpy(out, h->d_win[h->cur] + slot, sizeof(int32_t) * 4, hipMemcpyDeviceToHost));
+    return RBS_OK;
+}
+
+int32_t rbs_get_background(rbs_handle* h, float* out)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!out) return fail(h, RBS_ERR_INVALID_ARGUMENT, "get_background: null pointer");
+    *out = h->background;
     return RBS_OK;
 }
 

@@ -53,6 +53,7 @@ constexpr int kBigThresh = RBS_BIG_THRESH; // bbox pixels above which a triangle
 constexpr int kCopyUnroll = RBS_COPY_UNROLL; // float4 loads in flight per lane in copy blocks
 constexpr int kEvalQueue = 128;             // per-wave queue of covered pixels awaiting evaluation
 constexpr int kRectAlign = 16;              // rectangle x-alignment in pixels (64 B)
+constexpr float kSnapTau = 0x1p-18f;         // background snap of the occlusion process (oracle ORC_SNAP_TAU)
 constexpr unsigned kInfBits = 0x7f800000u;
 constexpr int kMaxBodies = 16;
 constexpr double kMaxDepth = 6.0;    // KinectPixelModel max_depth
@@ -76,6 +77,11 @@ struct DevParams {
     const float* pbg;              // per-frame-pixel background density, rounded to float
     double tw, ms, sf, lambda;     // tail_weight, model_sigma, sigma_factor, ln2/half_life
     float alpha, beta;             // occlusion process over the elapsed frames
+    float bg_old, bg_new;          // never-covered level before / after this call's step
+    int windowed;                  // planes are valid inside their window only (else implicit bg)
+    const int4* win_src;           // [slots] window of each parent plane (x0,y0,x1,y1)
+    int4* win_dst;                 // [slots] window of each child plane: tight bbox, grown atomically
+    int4* win_used;                // [n] region the copy kernel writes: bbox(parent window, rect)
     const float* occ_src;          // [slots][npx]
     float* occ_dst;                // [slots][npx]
     const double* poses;           // [n][n_bodies][12]
@@ -101,6 +107,14 @@ struct DevParams {
 #endif
 
 struct Rect { int x0, y0, x1, y1; };
+
+// The occlusion process on one stored value: affine step, then the background snap (same rule
+// and constant as oracle orc_eager_prior).
+__device__ inline float occ_step(float alpha, float beta, float v, float bg_new)
+{
+    const float x = fmaf(alpha, v, beta);
+    return fabsf(x - bg_new) <= kSnapTau ? bg_new : x;
+}
 
 // ------------------------------------------------------------------ screen rectangle
 // Conservative pixel rectangle containing every pixel the particle's bodies can cover, from
@@ -446,6 +460,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     if ((unsigned)parent >= (unsigned)P.slots) return NAN;
     const float* __restrict__ src = P.occ_src + (size_t)parent * P.npx;
     float* __restrict__ dst = UPDATE ? P.occ_dst + (size_t)particle * P.npx : nullptr;
+    const int4 pw = P.win_src[parent];   // outside it the parent's plane is implicitly bg_old
 
     RBS_TICK_DECL;
     for (int p = threadIdx.x; p < npx; p += kBlock) m.tile[p] = kInfBits;
@@ -475,22 +490,25 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
             valid[u] = p < npx;
             gi[u] = 0;
             dbits[u] = kInfBits;
-            sv[u] = 0.f;
+            sv[u] = P.bg_old;
             ov[u] = 0.f;
+            bool stored = false;
             if (valid[u]) {
                 const int lr = p / tw;
-                gi[u] = (wy0 + lr) * P.cols + wx0 + (p - lr * tw);
+                const int gy = wy0 + lr, gx = wx0 + (p - lr * tw);
+                gi[u] = gy * P.cols + gx;
                 dbits[u] = m.tile[p];
+                stored = gx >= pw.x && gx < pw.z && gy >= pw.y && gy < pw.w;
             }
             const bool covered = dbits[u] != kInfBits;
-            if (valid[u] && (UPDATE || covered)) sv[u] = src[gi[u]];
+            if (stored && (UPDATE || covered)) sv[u] = src[gi[u]];
             if (covered) ov[u] = P.frame[gi[u]];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < kScanUnroll; ++u) {
             if (p0 + u * kBlock >= npx) break;   // wave-uniform
-            const float prior = fmaf(P.alpha, sv[u], P.beta);
+            const float prior = occ_step(P.alpha, P.beta, sv[u], P.bg_new);
             const bool active = dbits[u] != kInfBits && isfinite(ov[u]);
             if (UPDATE && valid[u] && !active) dst[gi[u]] = prior;
             const unsigned long long mask = __ballot(active);
@@ -542,7 +560,7 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
     if ((unsigned)parent >= (unsigned)P.slots) return;
     const float* __restrict__ src = P.occ_src + (size_t)parent * P.npx + (size_t)row0 * P.cols;
     float* __restrict__ dst = P.occ_dst + (size_t)particle * P.npx + (size_t)row0 * P.cols;
-    const float alpha = P.alpha, beta = P.beta;
+    const float alpha = P.alpha, beta = P.beta, bg_new = P.bg_new;
 
     if (VEC == 4) {
         const int W4 = P.cols >> 2;
@@ -572,10 +590,10 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
             for (int k = 0; k < kCopyUnroll; ++k) {
                 if (!ok[k]) continue;
                 floatx4 w;
-                w.x = fmaf(alpha, v[k].x, beta);
-                w.y = fmaf(alpha, v[k].y, beta);
-                w.z = fmaf(alpha, v[k].z, beta);
-                w.w = fmaf(alpha, v[k].w, beta);
+                w.x = occ_step(alpha, beta, v[k].x, bg_new);
+                w.y = occ_step(alpha, beta, v[k].y, bg_new);
+                w.z = occ_step(alpha, beta, v[k].z, bg_new);
+                w.w = occ_step(alpha, beta, v[k].w, bg_new);
 #if RBS_NT
                 __builtin_nontemporal_store(w, &d4[base + k * kBlock]);
 #else
@@ -590,7 +608,7 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
             const int lr = idx / W;
             const int row = row0 + lr, col = idx - lr * W;
             if (row >= r.y0 && row < r.y1 && col >= r.x0 && col < r.x1) continue;
-            dst[idx] = fmaf(alpha, src[idx], beta);
+            dst[idx] = occ_step(alpha, beta, src[idx], bg_new);
         }
     }
 }
@@ -598,7 +616,12 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
 // ------------------------------------------------------------------ kernels
 // One thread per particle: the screen rectangle both the raster and the copy kernel use, and
 // the number of tiles it splits into.
-__global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int* __restrict__ tiles)
+// An updating call on windowed planes also fixes the region the copy kernel writes -- the
+// bounding box of the parent's window and the rectangle -- and seeds the child's window with the
+// rectangle (the copy kernel grows it over every value it writes that differs from the
+// background).  An empty window is (cols, rows, 0, 0), so unions are plain min/max.
+__global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int* __restrict__ tiles,
+                                int update)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
@@ -606,6 +629,14 @@ __global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int*
     reinterpret_cast<int4*>(rects)[i] = make_int4(r.x0, r.y0, r.x1, r.y1);
     const int tx = (r.x1 - r.x0 + P.tile_w - 1) / P.tile_w, ty = (r.y1 - r.y0 + P.tile_h - 1) / P.tile_h;
     tiles[i] = max(1, tx * ty);   // an empty rectangle still owns one (empty) item
+    if (update && P.windowed) {
+        const int4 rw = r.x1 > r.x0 ? make_int4(r.x0, r.y0, r.x1, r.y1) : make_int4(P.cols, P.rows, 0, 0);
+        const int parent = P.indices[i];
+        int4 pw = make_int4(P.cols, P.rows, 0, 0);
+        if ((unsigned)parent < (unsigned)P.slots) pw = P.win_src[parent];
+        P.win_used[i] = make_int4(min(pw.x, rw.x), min(pw.y, rw.y), max(pw.z, rw.z), max(pw.w, rw.w));
+        P.win_dst[i] = rw;
+    }
 }
 
 // Single block: exclusive scan tiles[0..n) -> offset[0..n]; resets the work queue.
@@ -729,7 +760,7 @@ __global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, 
     if (c4 >= W4) return;
     const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(P.occ_src + (size_t)parent * P.npx);
     floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(P.occ_dst + (size_t)particle * P.npx);
-    const float alpha = P.alpha, beta = P.beta;
+    const float alpha = P.alpha, beta = P.beta, bg_new = P.bg_new;
     const int col = c4 << 2;
     const bool in_cols = col >= q.x && col < q.z;
     floatx4 v[ROWS];
@@ -744,12 +775,110 @@ __global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, 
     for (int k = 0; k < ROWS; ++k) {
         if (!ok[k]) continue;
         floatx4 w;
-        w.x = fmaf(alpha, v[k].x, beta);
-        w.y = fmaf(alpha, v[k].y, beta);
-        w.z = fmaf(alpha, v[k].z, beta);
-        w.w = fmaf(alpha, v[k].w, beta);
+        w.x = occ_step(alpha, beta, v[k].x, bg_new);
+        w.y = occ_step(alpha, beta, v[k].y, bg_new);
+        w.z = occ_step(alpha, beta, v[k].z, bg_new);
+        w.w = occ_step(alpha, beta, v[k].w, bg_new);
         __builtin_nontemporal_store(w, &d4[(size_t)(r0 + k) * W4 + c4]);
     }
+}
+
+// Windowed planes: the child's plane is written over win_used = bbox(parent window, rectangle)
+// minus the rectangle (the raster kernel's share).  A float4 inside the parent's window is read
+// and stepped; one outside it is the background.  blockIdx.x splits the region's rows into
+// gridDim.x chunks; one wave per block, lanes run over the chunk's float4s row-major.  Every
+// written float4 that differs from the background grows the child's window (atomic min/max once
+// per wave), so a window shrinks again as soon as the values it held have decayed into the
+// background snap.
+constexpr int kWinUnroll = 4;
+__global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
+{
+    const int particle = (int)blockIdx.y + (int)blockIdx.z * (int)gridDim.y;
+    if (particle >= P.n) return;
+    const int parent = P.indices[particle];
+    if ((unsigned)parent >= (unsigned)P.slots) return;
+    const int4 u = P.win_used[particle];
+    if (u.z <= u.x || u.w <= u.y) return;
+    const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
+    if (q.z > q.x && q.x == u.x && q.y == u.y && q.z == u.z && q.w == u.w) return;   // all raster's
+    const int4 pw = P.win_src[parent];
+    const int w4 = (u.z - u.x) >> 2, ux4 = u.x >> 2, W4 = P.cols >> 2;
+    const int rpc = (u.w - u.y + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int ry0 = u.y + (int)blockIdx.x * rpc, ry1 = min(u.w, ry0 + rpc);
+    if (ry0 >= ry1) return;
+    const int n4 = (ry1 - ry0) * w4;
+    const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(P.occ_src + (size_t)parent * P.npx);
+    floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(P.occ_dst + (size_t)particle * P.npx);
+    const float alpha = P.alpha, beta = P.beta, bg_new = P.bg_new;
+    const int lane = (int)threadIdx.x;
+    const int qstep = 64 / w4, rstep = 64 - qstep * w4;
+    int row = ry0 + lane / w4;
+    int c4 = lane - (lane / w4) * w4;
+    int bx0 = P.cols, by0 = P.rows, bx1 = 0, by1 = 0;
+    for (int base = 0; base < n4; base += 64 * kWinUnroll) {
+        floatx4 v[kWinUnroll];
+        int st[kWinUnroll], at[kWinUnroll], rr[kWinUnroll];
+#pragma unroll
+        for (int k = 0; k < kWinUnroll; ++k) {
+            const int idx = base + k * 64 + lane;
+            const int col = (ux4 + c4) << 2;
+            const bool live = idx < n4 && !(row >= q.y && row < q.w && col >= q.x && col < q.z);
+            const bool stored = live && col >= pw.x && col < pw.z && row >= pw.y && row < pw.w;
+            st[k] = live ? (stored ? 2 : 1) : 0;
+            at[k] = row * W4 + ux4 + c4;
+            rr[k] = row;
+            if (stored) v[k] = __builtin_nontemporal_load(&s4[at[k]]);
+            c4 += rstep; row += qstep;
+            if (c4 >= w4) { c4 -= w4; ++row; }
+        }
+#pragma unroll
+        for (int k = 0; k < kWinUnroll; ++k) {
+            if (!st[k]) continue;
+            floatx4 w;
+            if (st[k] == 2) {
+                w.x = occ_step(alpha, beta, v[k].x, bg_new);
+                w.y = occ_step(alpha, beta, v[k].y, bg_new);
+                w.z = occ_step(alpha, beta, v[k].z, bg_new);
+                w.w = occ_step(alpha, beta, v[k].w, bg_new);
+            } else {
+                w.x = w.y = w.z = w.w = bg_new;
+            }
+            __builtin_nontemporal_store(w, &d4[at[k]]);
+            if (w.x != bg_new || w.y != bg_new || w.z != bg_new || w.w != bg_new) {
+                const int col = (at[k] - rr[k] * W4) << 2;
+                bx0 = min(bx0, col); bx1 = max(bx1, col + 4);
+                by0 = min(by0, rr[k]); by1 = max(by1, rr[k] + 1);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, off)); by0 = min(by0, __shfl_xor(by0, off));
+        bx1 = max(bx1, __shfl_xor(bx1, off)); by1 = max(by1, __shfl_xor(by1, off));
+    }
+    if (lane == 0 && bx1 > bx0) {
+        int* w = reinterpret_cast<int*>(&P.win_dst[particle]);
+        atomicMin(w + 0, bx0); atomicMin(w + 1, by0);
+        atomicMax(w + 2, bx1); atomicMax(w + 3, by1);
+    }
+}
+
+// Make one windowed plane dense in place: pixels outside its window become the background.
+// (The caller then marks the window full with rbs_set_window_kernel.)
+__global__ void rbs_materialize_kernel(float* __restrict__ plane, const int4* __restrict__ win,
+                                       int rows, int cols, float bg)
+{
+    const int4 w = *win;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int y = i / cols, x = i - y * cols;
+    if (!(x >= w.x && x < w.z && y >= w.y && y < w.w)) plane[i] = bg;
+}
+
+__global__ void rbs_set_window_kernel(int4* __restrict__ win, int n, int4 value)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) win[i] = value;
 }
 
 // Inspection hook: depth image of one pose through the same raster_window path.

@@ -256,6 +256,10 @@ class RbSensor:
             out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def set_observation_device(self, d_depth_ptr, stream=None):
+        """Frame already on the device (float32 [rows*cols], raw address); asynchronous."""
+        self._check(self._lib.rbs_set_observation_device(self._h, d_depth_ptr, stream))
+
     def loglikes_device(self, d_poses_ptr, d_indices_ptr, n, update, d_out_ptr, stream=None):
         """Asynchronous device-pointer variant (raw addresses, e.g. torch.Tensor.data_ptr())."""
         self._check(self._lib.rbs_loglikes_device(self._h, d_poses_ptr, d_indices_ptr, int(n),
@@ -277,6 +281,22 @@ class RbSensor:
             raise RbSensorError(_capi.RBS_ERR_INVALID_ARGUMENT, "plane has the wrong size")
         self._check(self._lib.rbs_set_occlusion(self._h, int(slot),
                                                 a.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def get_window(self, slot):
+        """(x0, y0, x1, y1) of the slot's stored window; outside it the plane is the background."""
+        w = (C.c_int32 * 4)()
+        self._check(self._lib.rbs_get_window(self._h, int(slot), w))
+        return tuple(int(x) for x in w)
+
+    def get_background(self):
+        v = C.c_float()
+        self._check(self._lib.rbs_get_background(self._h, C.byref(v)))
+        return float(np.float32(v.value))
+
+    def raster_kernel_ms(self, last_n=64):
+        v = C.c_float()
+        self._check(self._lib.rbs_raster_kernel_ms(self._h, int(last_n), C.byref(v)))
+        return float(v.value)
 
     def export_plane(self, slot, d_dst_ptr, stream=None):
         """Device-to-device copy of a slot's plane into caller-owned device memory (raw address)."""

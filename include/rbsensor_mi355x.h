@@ -98,6 +98,11 @@ int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n);
  * (R:source/dbot_ros/object_tracker_ros.hpp:82,119, ros_interface.h:156-165). */
 int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32_t width,
                                        int32_t height, int32_t downsampling_factor);
+/* The same from DEVICE memory on the handle's device (float[rows*cols], evaluated resolution):
+ * for frames that are already on the GPU (a driver / preprocessing stage there, or a caller
+ * replaying a resident sequence).  Enqueued on `stream` (NULL = the handle's own stream), no
+ * host synchronisation; the caller keeps `d_depth` alive until that work has run. */
+int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* stream);
 /* Current evaluated observation -> host float[rows*cols] (inspection). */
 int32_t rbs_get_observation(rbs_handle* h, float* out);
 
@@ -122,12 +127,28 @@ int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t*
 /* Block until everything enqueued on the handle's own stream has finished. */
 int32_t rbs_synchronize(rbs_handle* h);
 
+/* --- occlusion state layout -------------------------------------------------------------
+ * A slot's plane is stored as a WINDOW (a pixel rectangle) plus the handle-wide background
+ * level: outside its window a plane equals the value a never-covered pixel has reached
+ * (initial_occlusion_prob stepped by the occlusion process at every updating call).  An
+ * updating call writes only bbox(parent's window, the particle's screen rectangle) and
+ * re-tightens the child's window to the values that still differ from the background; the
+ * process snaps a value within 2^-18 of the background onto it, so a window follows the object
+ * instead of growing for ever.  The numbers are those of whole planes (oracle mode EAGER);
+ * only the bytes moved change.  RBS_STATE=dense in the environment at rbs_create keeps whole
+ * planes (every updating call then copies every plane in full).  Every entry point below
+ * hands out / accepts whole planes in either layout. */
 /* --- inspection hooks (tests, state migration between devices) --- */
+/* Window (x0, y0, x1, y1) of a slot's current plane; (cols, rows, 0, 0) = empty (all
+ * background); (0, 0, cols, rows) always with RBS_STATE=dense. */
+int32_t rbs_get_window(rbs_handle* h, int32_t slot, int32_t out[4]);
+/* Never-covered occlusion level of the current planes. */
+int32_t rbs_get_background(rbs_handle* h, float* out);
 /* Stored occlusion plane of a slot -> host float[rows*cols]. */
 int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out);
 /* Overwrite a slot's plane from host float[rows*cols]. */
 int32_t rbs_set_occlusion(rbs_handle* h, int32_t slot, const float* plane);
-/* Device address of a slot's current plane (valid until the next updating call). */
+/* Device address of a slot's current plane, made whole first (valid until the next updating call). */
 int32_t rbs_occlusion_device_ptr(rbs_handle* h, int32_t slot, void** out);
 /* Device address of slot's plane in the buffer the NEXT updating call will write. */
 int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out);
@@ -148,6 +169,8 @@ int32_t rbs_last_kernel_ms(rbs_handle* h, float* ms);
  * stream (updating calls only, 0 if none).  Blocks until those calls finished. */
 int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float* copy_kernel_ms,
                            int32_t* n_used);
+/* Same window of calls: the raster kernel alone (HIP events around it on the launch stream). */
+int32_t rbs_raster_kernel_ms(rbs_handle* h, int32_t last_n, float* raster_kernel_ms);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side tracker (the callers either side of the hot path): the object

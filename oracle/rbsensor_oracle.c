@@ -30,6 +30,7 @@ struct orc_sensor {
     int cur;
     int32_t clock;       /* frame counter: t_now = clock * delta_time       */
     int32_t last_update_clock; /* EAGER: clock at the last updating call    */
+    float background;    /* EAGER: value of a never-covered pixel at the last updating call */
     /* scratch */
     float* depth;        /* [npx] */
     int32_t* covered;    /* [npx] list of covered pixel ids */
@@ -89,6 +90,17 @@ void orc_eager_coeffs(const orc_sensor* s, int32_t n_frames, float* alpha, float
     const double g = (1.0 - p_oo) * (a - 1.0) / (c - 1.0);
     *alpha = (float)a;
     *beta = (float)((1.0 - a) - g);
+}
+
+/* EAGER prior of one pixel: the affine step, then the background snap -- a value within
+ * ORC_SNAP_TAU of the never-covered level `bg_now` (the same step applied to the background
+ * scalar) IS the background.  The snap makes "differs from the background" a finite-time
+ * property (a float contraction otherwise stalls up to 0.5 ulp / (1 - alpha) away from its
+ * limit for ever), which is what lets an implementation keep only a window of each plane. */
+float orc_eager_prior(float alpha, float beta, float occ, float bg_now)
+{
+    const float x = fmaf(alpha, occ, beta);
+    return fabsf(x - bg_now) <= ORC_SNAP_TAU ? bg_now : x;
 }
 
 /* ---------------------------------------------------------------- renderer */
@@ -255,6 +267,7 @@ void orc_reset(orc_sensor* s)
     s->cur = 0;
     s->clock = 0;
     s->last_update_clock = 0;
+    s->background = init;
     for (size_t p = 0; p < plane; ++p) s->occ[0][p] = init;
     if (s->stamp[0]) memset(s->stamp[0], 0, sizeof(int32_t) * plane);
 }
@@ -272,7 +285,8 @@ void orc_set_observation(orc_sensor* s, const double* depth)
 /* One particle of orc_loglikes; depth/covered are per-thread scratch (depth all +inf on entry
  * and on exit). */
 static double loglik_one(orc_sensor* s, const double* pose, int32_t parent, int32_t child,
-                         int32_t update, float alpha, float beta, float* depth, int32_t* covered)
+                         int32_t update, float alpha, float beta, float bg_now, float* depth,
+                         int32_t* covered)
 {
     const int lazy = s->cfg.occlusion_mode == ORC_OCC_LAZY;
     const int src = s->cur, dst = 1 - s->cur;
@@ -288,7 +302,7 @@ static double loglik_one(orc_sensor* s, const double* pose, int32_t parent, int3
             memcpy(cocc, pocc, sizeof(float) * s->npx);
             memcpy(cstamp, pstamp, sizeof(int32_t) * s->npx);
         } else {
-            for (size_t p = 0; p < s->npx; ++p) cocc[p] = fmaf(alpha, pocc[p], beta);
+            for (size_t p = 0; p < s->npx; ++p) cocc[p] = orc_eager_prior(alpha, beta, pocc[p], bg_now);
         }
     }
 
@@ -306,7 +320,7 @@ static double loglik_one(orc_sensor* s, const double* pose, int32_t parent, int3
             const double dt = (double)(s->clock - pstamp[p]) * s->cfg.delta_time;
             occ = (float)orc_propagate(s, (double)pocc[p], dt);
         } else {
-            occ = fmaf(alpha, pocc[p], beta);
+            occ = orc_eager_prior(alpha, beta, pocc[p], bg_now);
         }
         const float a = (float)(orc_prob_visible(s, (double)o, (double)r) * (1.0 - (double)occ));
         const float b = (float)(orc_prob_occluded(s, (double)o, (double)r) * (double)occ);
@@ -336,11 +350,12 @@ void orc_loglikes_mt(orc_sensor* s, const double* poses, int32_t* indices, int32
     float alpha = 1.0f, beta = 0.0f;
     if (s->cfg.occlusion_mode != ORC_OCC_LAZY)
         orc_eager_coeffs(s, s->clock - s->last_update_clock, &alpha, &beta);
+    const float bg_now = fmaf(alpha, s->background, beta);
     const size_t pstride = (size_t)12 * s->cfg.n_objects;
     if (n_threads <= 1) {
         for (int32_t i = 0; i < n; ++i)
             out_loglik[i] = loglik_one(s, poses + (size_t)i * pstride, indices[i], i, update, alpha, beta,
-                                       s->depth, s->covered);
+                                       bg_now, s->depth, s->covered);
     } else {
 #ifdef _OPENMP
 #pragma omp parallel num_threads(n_threads)
@@ -351,19 +366,20 @@ void orc_loglikes_mt(orc_sensor* s, const double* poses, int32_t* indices, int32
 #pragma omp for schedule(dynamic, 1)
             for (int32_t i = 0; i < n; ++i)
                 out_loglik[i] = loglik_one(s, poses + (size_t)i * pstride, indices[i], i, update, alpha,
-                                           beta, depth, covered);
+                                           beta, bg_now, depth, covered);
             free(depth);
             free(covered);
         }
 #else
         for (int32_t i = 0; i < n; ++i)
             out_loglik[i] = loglik_one(s, poses + (size_t)i * pstride, indices[i], i, update, alpha, beta,
-                                       s->depth, s->covered);
+                                       bg_now, s->depth, s->covered);
 #endif
     }
     if (update) {
         s->cur = 1 - s->cur;
         s->last_update_clock = s->clock;
+        if (s->cfg.occlusion_mode != ORC_OCC_LAZY) s->background = bg_now;
         for (int32_t i = 0; i < n; ++i) indices[i] = i;
     }
 }
@@ -399,6 +415,9 @@ void orc_get_occlusion_now(const orc_sensor* s, int32_t slot, float* out)
     } else {
         float alpha, beta;
         orc_eager_coeffs(s, s->clock - s->last_update_clock, &alpha, &beta);
-        for (size_t p = 0; p < s->npx; ++p) out[p] = fmaf(alpha, occ[p], beta);
+        const float bg_now = fmaf(alpha, s->background, beta);
+        for (size_t p = 0; p < s->npx; ++p) out[p] = orc_eager_prior(alpha, beta, occ[p], bg_now);
     }
 }
+
+float orc_background(const orc_sensor* s) { return s->background; }

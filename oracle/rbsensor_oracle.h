@@ -36,8 +36,12 @@ enum {
     ORC_OCC_LAZY = 0,  /* reference CPU semantics: per-pixel last-update stamp, propagate by
                           the pixel's own elapsed time in double            */
     ORC_OCC_EAGER = 1  /* the device rule: every pixel advanced on every updating call with
-                          occ' = fmaf(alpha_f, occ, beta_f) (float), no stamps                */
+                          occ' = snap(fmaf(alpha_f, occ, beta_f)) (float), no stamps; snap(x)
+                          = bg' if |x - bg'| <= ORC_SNAP_TAU, where bg' is the same step
+                          applied to the never-covered level bg (initial_occlusion_prob at
+                          reset)                                                              */
 };
+#define ORC_SNAP_TAU 0x1p-18f
 
 typedef struct orc_config {
     int32_t rows, cols;
@@ -96,6 +100,8 @@ double orc_prob_visible(const orc_sensor* s, double obs, double rendered);  /* r
 double orc_prob_occluded(const orc_sensor* s, double obs, double rendered); /* rendered may be +inf */
 double orc_propagate(const orc_sensor* s, double occ, double dt);
 void orc_eager_coeffs(const orc_sensor* s, int32_t n_frames, float* alpha, float* beta);
+float orc_eager_prior(float alpha, float beta, float occ, float bg_now);
+float orc_background(const orc_sensor* s);  /* EAGER: never-covered level at the last updating call */
 
 /* ---- tracker_oracle.c: transition + RBC filter step + tracker mean ---- */
 typedef struct orc_tracker orc_tracker;

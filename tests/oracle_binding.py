@@ -61,6 +61,10 @@ def load():
             f.restype = C.c_double
             f.argtypes = [H, C.c_double, C.c_double]
         lib.orc_eager_coeffs.argtypes = [H, C.c_int32, fp, fp]
+        lib.orc_background.restype = C.c_float
+        lib.orc_background.argtypes = [H]
+        lib.orc_eager_prior.restype = C.c_float
+        lib.orc_eager_prior.argtypes = [C.c_float] * 4
         lib.orc_tracker_create.restype = H
         lib.orc_tracker_create.argtypes = [H, C.c_int32, C.c_int32, dp, C.c_double, C.c_double]
         lib.orc_tracker_destroy.argtypes = [H]
@@ -151,6 +155,13 @@ class Oracle:
 
     def propagate(self, occ, dt):
         return self._lib.orc_propagate(self._h, float(occ), float(dt))
+
+    def background(self):
+        """EAGER: the never-covered occlusion level at the last updating call."""
+        return float(np.float32(self._lib.orc_background(self._h)))
+
+    def eager_prior(self, alpha, beta, occ, bg_now):
+        return float(np.float32(self._lib.orc_eager_prior(alpha, beta, occ, bg_now)))
 
     def eager_coeffs(self, n_frames):
         a, b = C.c_float(), C.c_float()

@@ -21,6 +21,14 @@ TOL_EAGER = 1e-9
 TOL_LAZY = 1e-5
 
 
+@pytest.fixture(autouse=True, params=["window", "dense"])
+def state_layout(request, monkeypatch):
+    """Every parity test runs on both layouts of the occlusion state: windowed planes (default)
+    and whole planes (RBS_STATE=dense).  The numbers must not depend on the layout."""
+    monkeypatch.setenv("RBS_STATE", request.param)
+    return request.param
+
+
 def rel_err(a, b):
     return np.abs(a - b) / np.maximum(1.0, np.abs(b))
 
@@ -556,3 +564,45 @@ def test_golden_coverage_vga(gpu_lib, mesh):
             ids = np.nonzero(np.isfinite(d))[0]
             assert np.array_equal(ids, g[f"{mesh}_{k}_ids"])
             assert np.array_equal(d[ids].view(np.uint32), g[f"{mesh}_{k}_depth"].view(np.uint32))
+
+
+def test_windows_follow_the_object(gpu_lib, state_layout):
+    """An object sweeps across the image and then rests.  Planes stay those of the whole-plane
+    oracle throughout; the stored windows (windowed layout) cover the swept region while its
+    values still differ from the background and shrink back around the object afterwards."""
+    n, cols, rows = 12, 160, 120
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    P.delta_time = 0.5          # fast occlusion dynamics: the sweep decays within this test
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    rng = np.random.default_rng(5)
+    areas = []
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        assert g.get_window(0) == ((cols, rows, 0, 0) if state_layout == "window" else (0, 0, cols, rows))
+        idx_g = np.zeros(n, np.int32)
+        idx_o = np.zeros(n, np.int32)
+        for k in range(90):
+            truth = synth.truth_pose(1, z=0.7).copy()
+            truth[0, 9] = -0.12 + 0.008 * min(k, 30)      # 30 frames of motion, then rest
+            frame = synth.make_frame(eager.render_depth(truth), rows, cols, rng)
+            poses = synth.particle_poses(truth, n, rng, scale=2.0)
+            g.set_observation(frame)
+            eager.set_observation(frame)
+            ll_g = g.loglikes_poses(poses, idx_g, update=True)
+            ll_o = eager.loglikes_poses(poses, idx_o, update=True)
+            assert rel_err(ll_g, ll_o).max() <= TOL_EAGER
+            assert g.get_background() == eager.background()
+            if k % 10 == 9 or k == 31:
+                ws = [g.get_window(s) for s in range(n)]   # before get_occlusion makes them whole
+                areas.append((k, max((w[2] - w[0]) * (w[3] - w[1]) for w in ws)))
+                for slot in range(n):
+                    assert_planes_match(g.get_occlusion(slot), eager.get_occlusion(slot))
+            w = np.exp(ll_o - ll_o.max())
+            parents = np.sort(rng.choice(n, size=n, p=w / w.sum())).astype(np.int32)
+            idx_g, idx_o = parents.copy(), parents.copy()
+    a = dict(areas)
+    if state_layout == "dense":
+        assert all(v == cols * rows for v in a.values())
+    else:
+        assert a[31] >= 1.5 * a[89], areas         # swept region held at the end of the motion ...
+        assert a[89] <= 64 * 64, areas             # ... and released once it has decayed
+        assert a[31] < cols * rows

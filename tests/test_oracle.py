@@ -264,3 +264,30 @@ def test_vga_coverage_golden(mesh):
         assert np.array_equal(ids, g[f"{mesh}_{k}_ids"])
         assert np.array_equal(d[ids].view(np.uint32), g[f"{mesh}_{k}_depth"].view(np.uint32))
         assert len(ids) > 1000
+
+
+def test_eager_background_snap():
+    """EAGER rule: a pixel that was fully occluded (or fully visible) rejoins the never-covered
+    level exactly, in finite time, by the 2^-18 snap; the bare float contraction never does (it
+    stalls some ulps away), which is why the snap is part of the rule."""
+    om, cam, P = sc.make_scene(("box12",), 80, 60, max_particles=1)
+    o = ob.Oracle(om, cam, P, max_particles=1, mode=ob.EAGER)
+    a, b = o.eager_coeffs(1)
+    inf = float("inf")
+    for start in (1.0, 0.0):
+        bg, v, raw = 0.1, start, start
+        joined = None
+        for k in range(3000):
+            bg = o.eager_prior(a, b, bg, inf)          # bare step of the background scalar
+            raw = o.eager_prior(a, b, raw, inf)        # bare step of the pixel
+            nv = o.eager_prior(a, b, v, bg)            # the rule
+            if joined is None and nv == bg:
+                assert abs(o.eager_prior(a, b, v, inf) - bg) <= 2.0 ** -18
+                joined = k
+            v = nv
+            if joined is not None:
+                assert v == bg
+        assert joined is not None and joined < 1000, joined   # < 34 s at 30 Hz
+        if start > 0.25:
+            assert raw != bg                                    # from above the bare contraction stalls
+        assert abs(raw - bg) < 2.0 ** -19                       # ... well inside the snap radius
