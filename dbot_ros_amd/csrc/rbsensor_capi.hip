@@ -133,6 +133,17 @@ int copy_bands_for(int rows, int cols)
     return (int)b;
 }
 
+// Most work items any rectangle inside the frame can split into (sizes the partial-sum buffer).
+size_t tiles_upper_bound(int cols, int rows, int max_w, int cap_px)
+{
+    size_t worst = 1;
+    for (int rw = 16; rw <= ((cols + 15) & ~15); rw += 16) {
+        const rbs::TileGrid g = rbs::tile_grid(rw, rows, max_w, cap_px);
+        worst = std::max(worst, (size_t)g.nx * g.ny);
+    }
+    return worst;
+}
+
 int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indices, int n,
                          bool update, double* d_out, hipStream_t s)
 {
@@ -156,13 +167,13 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.n = n;
     const int slot = (int)(h->calls % rbs_handle::kRing);
     h->ring_update[slot] = update;
-    // tile size: full 128x128 tiles when there are enough particles to fill the persistent
-    // grid, smaller tiles (more work items per particle) when there are few
-    const int tile = n >= 2 * h->raster_blocks ? 128 : 64;
-    P.tile_w = tile < 32 ? 32 : tile;
-    P.tile_h = tile;
-    if (const char* m = h->tile_override) { P.tile_w = std::max(32, std::atoi(m) / 32 * 32); P.tile_h = std::max(1, std::atoi(m)); }
-    const size_t tiles_max = (size_t)((h->cols + P.tile_w - 1) / P.tile_w + 1) * ((h->rows + P.tile_h - 1) / P.tile_h + 1);
+    // tile limits: as large as the LDS tile allows when there are enough particles to fill the
+    // persistent grid (a particle's rectangle is then usually ONE item, whatever its aspect),
+    // 64x64 (more work items per particle) when there are few
+    if (n >= 2 * h->raster_blocks) { P.tile_w = 256; P.tile_h = rbs::kTilePx / 256; }
+    else { P.tile_w = 64; P.tile_h = 64; }
+    if (const char* m = h->tile_override) { P.tile_w = std::max(16, std::atoi(m) / 16 * 16); P.tile_h = std::max(1, std::atoi(m)); }
+    const size_t tiles_max = tiles_upper_bound(h->cols, h->rows, P.tile_w, std::min(P.tile_w * P.tile_h, rbs::kTilePx));
     const size_t need = (size_t)n * tiles_max;
     if (need > h->partial_cap) {
         RBS_HIP(h, hipStreamSynchronize(s));
@@ -560,8 +571,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
 
     {   // per-item partial sums: sized for the default tiling so no call ever allocates
-        const size_t t128 = (size_t)((h->cols + 127) / 128 + 1) * ((h->rows + 127) / 128 + 1);
-        const size_t t64 = (size_t)((h->cols + 63) / 64 + 1) * ((h->rows + 63) / 64 + 1);
+        const size_t t128 = tiles_upper_bound(h->cols, h->rows, 256, rbs::kTilePx);
+        const size_t t64 = tiles_upper_bound(h->cols, h->rows, 64, 4096);
         const size_t need = std::max((size_t)h->max_particles * t128,
                                      (size_t)std::min(h->max_particles, 2 * h->raster_blocks) * t64);
         RBS_HIP(h, hipMalloc(&h->d_partial, sizeof(double) * need));
@@ -887,8 +898,8 @@ int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out)
     DevParams P = h->base;
     P.poses = h->d_poses;
     P.n = 1;
-    P.tile_w = 128;
-    P.tile_h = 128;
+    P.tile_w = 256;
+    P.tile_h = rbs::kTilePx / 256;
     hipLaunchKernelGGL(rbs::rbs_render_kernel, dim3(1), dim3(rbs::kBlock), rbs::kSmemBytes,
                        h->stream, P, h->d_render);
     RBS_HIP(h, hipGetLastError());

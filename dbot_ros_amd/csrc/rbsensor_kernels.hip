@@ -46,7 +46,10 @@ namespace rbs {
 #define RBS_BIG_THRESH 96
 #endif
 
-constexpr int kBlock = 256;                // 4 waves
+#ifndef RBS_BLOCK
+#define RBS_BLOCK 256
+#endif
+constexpr int kBlock = RBS_BLOCK;          // threads per raster block (a multiple of 64)
 constexpr int kTilePx = RBS_TILE_PX;       // LDS depth tile (u32 per pixel)
 constexpr int kBigCap = 1024;              // triangles deferred to the cooperative path per chunk
 constexpr int kBigThresh = RBS_BIG_THRESH; // bbox pixels above which a triangle is "big"
@@ -67,7 +70,7 @@ struct DevParams {
     int n_tri;                     // soup length: every body padded to a multiple of 64
     int tri_begin[kMaxBodies + 1]; // triangle range per body (multiples of 64)
     const float* cluster_sphere;   // [n_tri/64][4] model-space bounding sphere of each cluster
-    int tile_w, tile_h;            // work-item tile: tile_w % 32 == 0, tile_w*tile_h <= kTilePx
+    int tile_w, tile_h;            // work-item tile limits: width <= tile_w, pixels <= min(tile_w*tile_h, kTilePx)
     double fx, fy, cx, cy;
     double sphere[kMaxBodies][4];  // model-space bounding sphere: centre xyz, radius
     double aabb[kMaxBodies][6];    // model-space bounding box: lo xyz, hi xyz
@@ -107,6 +110,26 @@ struct DevParams {
 #endif
 
 struct Rect { int x0, y0, x1, y1; };
+
+// How a rectangle of rw x rh pixels splits into work-item tiles: nx columns of equal 16-aligned
+// width <= max_w, then as few equal rows as keep a tile within cap_px pixels.  A rectangle that
+// fits one tile -- the usual case -- is one item whatever its aspect.
+struct TileGrid { int tw, th, nx, ny; };
+__host__ __device__ inline TileGrid tile_grid(int rw, int rh, int max_w, int cap_px)
+{
+    TileGrid g;
+    g.nx = (rw + max_w - 1) / max_w;
+    if (g.nx < 1) g.nx = 1;
+    g.tw = ((rw + g.nx - 1) / g.nx + 15) & ~15;
+    if (g.tw < 16) g.tw = 16;
+    int hmax = cap_px / g.tw;
+    if (hmax < 1) hmax = 1;
+    g.ny = (rh + hmax - 1) / hmax;
+    if (g.ny < 1) g.ny = 1;
+    g.th = (rh + g.ny - 1) / g.ny;
+    if (g.th < 1) g.th = 1;
+    return g;
+}
 
 // The occlusion process on one stored value: affine step, then the background snap (same rule
 // and constant as oracle orc_eager_prior).
@@ -310,7 +333,9 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x == 0) *nbig = 0;
     __syncthreads();
-    int taken = 0;  // surviving clusters so far: dealt round-robin to the block's waves
+    // surviving clusters so far: dealt round-robin to the block's waves (an LDS ticket per
+    // cluster instead measured no better: the waves of a block finish within a few percent)
+    int taken = 0;
     for (int b = 0; b < P.n_bodies; ++b) {
         const double* Rt = pose + 12 * b;
         const int c0 = P.tri_begin[b] >> 6, c1 = P.tri_begin[b + 1] >> 6;
@@ -323,7 +348,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
             while (mask) {
                 const int bit = __builtin_ctzll(mask);
                 mask &= mask - 1;
-                if (((taken++) & (kBlock / 64 - 1)) != wave) continue;
+                if ((taken++) % (kBlock / 64) != wave) continue;
                 const int t = ((base + bit) << 6) + lane;
                 Tri T;
                 if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, T)) continue;
@@ -446,10 +471,10 @@ template <bool UPDATE>
 __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect r, int tile_id,
                                           const Smem& m)
 {
-    const int tiles_x = (r.x1 - r.x0 + P.tile_w - 1) / P.tile_w;
-    const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
-    const int wx0 = r.x0 + tx * P.tile_w, wy0 = r.y0 + ty * P.tile_h;
-    const int wx1 = min(r.x1, wx0 + P.tile_w), wy1 = min(r.y1, wy0 + P.tile_h);
+    const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, kTilePx));
+    const int ty = tile_id / tg.nx, tx = tile_id - ty * tg.nx;
+    const int wx0 = r.x0 + tx * tg.tw, wy0 = r.y0 + ty * tg.th;
+    const int wx1 = min(r.x1, wx0 + tg.tw), wy1 = min(r.y1, wy0 + tg.th);
     const int tw = wx1 - wx0, npx = tw * (wy1 - wy0);
     const bool whole = (wx0 == r.x0 && wy0 == r.y0 && wx1 == r.x1 && wy1 == r.y1);
 
@@ -627,8 +652,8 @@ __global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int*
     if (i >= P.n) return;
     const Rect r = particle_rect(P, P.poses + (size_t)i * 12 * P.n_bodies);
     reinterpret_cast<int4*>(rects)[i] = make_int4(r.x0, r.y0, r.x1, r.y1);
-    const int tx = (r.x1 - r.x0 + P.tile_w - 1) / P.tile_w, ty = (r.y1 - r.y0 + P.tile_h - 1) / P.tile_h;
-    tiles[i] = max(1, tx * ty);   // an empty rectangle still owns one (empty) item
+    const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, kTilePx));
+    tiles[i] = r.x1 > r.x0 ? tg.nx * tg.ny : 1;   // an empty rectangle still owns one (empty) item
     if (update && P.windowed) {
         const int4 rw = r.x1 > r.x0 ? make_int4(r.x0, r.y0, r.x1, r.y1) : make_int4(P.cols, P.rows, 0, 0);
         const int parent = P.indices[i];
@@ -888,9 +913,10 @@ __global__ __launch_bounds__(kBlock) void rbs_render_kernel(const DevParams P, f
     const Smem m = carve(smem);
     const Rect r = particle_rect(P, P.poses);
     if (r.x1 <= r.x0) return;
-    for (int wy0 = r.y0; wy0 < r.y1; wy0 += P.tile_h)
-        for (int wx0 = r.x0; wx0 < r.x1; wx0 += P.tile_w) {
-            const int wx1 = min(r.x1, wx0 + P.tile_w), wy1 = min(r.y1, wy0 + P.tile_h);
+    const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, kTilePx));
+    for (int wy0 = r.y0; wy0 < r.y1; wy0 += tg.th)
+        for (int wx0 = r.x0; wx0 < r.x1; wx0 += tg.tw) {
+            const int wx1 = min(r.x1, wx0 + tg.tw), wy1 = min(r.y1, wy0 + tg.th);
             const int tw = wx1 - wx0, npx = tw * (wy1 - wy0);
             for (int p = threadIdx.x; p < npx; p += kBlock) m.tile[p] = kInfBits;
             __syncthreads();

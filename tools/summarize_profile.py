@@ -20,6 +20,7 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+layout = "dense" if tag.endswith("_dense") else "window"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -59,7 +60,8 @@ if os.path.exists(cal_f):
                               "fetch_correction": fetch_scale, "write_correction": write_scale}
 total = 0.0
 for (k, c), v in sorted(fetch.items()):
-    if any(t in k for t in ("rbs_copy_kernel", "rbs_copy_rows_kernel", "rbs_raster_kernel", "rbs_prep_kernel", "rbs_scan_kernel", "rbs_reduce_kernel")):
+    if any(t in k for t in ("rbs_copy_kernel", "rbs_copy_rows_kernel", "rbs_copy_window_kernel", "rbs_raster_kernel", "rbs_prep_kernel",
+                                "rbs_scan_kernel", "rbs_reduce_kernel", "frame_aux_kernel")):
         wv = write.get((k, "WRITE_SIZE"), 0.0)
         # the x2 fetch correction is calibrated for 16 B/lane streams (the copy kernel); the raster
         # kernel's narrow reads are uncalibrated and reported with the same factor as an upper bound
@@ -72,10 +74,17 @@ for (k, c), v in sorted(fetch.items()):
 out["hbm_bytes_per_loglikes_call"] = total
 out["algorithmic_bytes_per_loglikes_call"] = 2.0 * KNOWN
 out["traffic_over_algorithmic"] = total / (2.0 * KNOWN)
+out["state_layout"] = layout
+# roofline.traffic in bench.py is per launch of the dominant kernel: the raster kernel on windowed
+# planes, the copy kernel on whole planes
+dom = "rbs_raster_kernel" if layout == "window" else "rbs_copy_rows_kernel"
+dom_bytes = sum(v["hbm_bytes_per_dispatch_corrected"] for k, v in out["kernels"].items() if dom in k)
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
-json.dump({"hbm_bytes_per_launch": total, "source": f"profiles/{tag}_pmc_hbm.json",
-           "workload": "bench.py default (C1: 2000 particles, 640x480, update=true)"},
-          open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+if layout == "window":
+    json.dump({"state_layout": layout, "kernel": dom, "hbm_bytes_per_launch": dom_bytes,
+               "hbm_bytes_per_loglikes_call_all_kernels": total, "source": f"profiles/{tag}_pmc_hbm.json",
+               "workload": "bench.py default (C1: 2000 particles, 640x480, update=true, 30-frame sequence)"},
+              open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 sq_path = os.path.join(src, "sq", "sq_counter_collection.csv")
 if os.path.exists(sq_path):
     sq, nd = per_dispatch(sq_path)
@@ -84,7 +93,7 @@ if os.path.exists(sq_path):
         k = k[0]
         g = lambda c: sq.get((k, c), 0.0)
         # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves
-        summary = {"kernel": k, "workload": "bench.py --update 0 (raster kernel alone, 2000 particles)",
+        summary = {"kernel": k, "workload": "bench.py default step (raster kernel of loglikes(update=true), 2000 particles)",
                    "per_dispatch": {c: g(c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
                                                       "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
                                                       "SQ_BUSY_CYCLES")},
