@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <array>
+#include <map>
 #include <new>
 #include <string>
 #include <utility>
@@ -56,6 +58,7 @@ struct rbs_handle {
     unsigned long long* d_phase = nullptr;  // RBS_PHASE_TIMING builds
     size_t partial_cap = 0;
     float* d_cluster_sphere = nullptr;
+    float* d_cluster_cone = nullptr;
     float* d_render = nullptr;
     float* h_frame = nullptr;   // pinned staging
     float* h_native = nullptr;  // pinned staging for full-resolution frames
@@ -325,6 +328,7 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_work_counter);
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_cluster_sphere);
+    (void)hipFree(h->d_cluster_cone);
     (void)hipFree(h->d_render);
     if (h->h_frame) (void)hipHostFree(h->h_frame);
     if (h->h_native) (void)hipHostFree(h->h_native);
@@ -426,6 +430,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     const size_t n_alloc = (size_t)(n_tri > 0 ? n_tri : 64);
     std::vector<double> soup((size_t)9 * n_alloc, std::nan(""));
     std::vector<float> cluster_sphere(4 * (n_alloc / 64), 0.f);
+    std::vector<float> cluster_cone(4 * (n_alloc / 64), -2.f);   // min cos -2: never culled
+    const bool allow_cull = !(std::getenv("RBS_NO_CULL") && std::atoi(std::getenv("RBS_NO_CULL")));
     size_t voff = 0, toff = 0;
     for (int b = 0; b < h->n_bodies; ++b) {
         const int nv = cfg->vertex_counts[b], nt = cfg->triangle_counts[b];
@@ -458,6 +464,38 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
                 if (T[3 * t + k] < 0 || T[3 * t + k] >= nv)
                     return fail(h, RBS_ERR_INVALID_ARGUMENT,
                                 fmt("object %d triangle %d: vertex index %d out of range", b, t, T[3 * t + k]));
+        // Back-face culling is exact only for a closed, consistently oriented surface: after
+        // welding vertices by position and dropping degenerate triangles every directed edge
+        // must occur exactly once, and its reverse exactly once.  The sign of the signed volume
+        // tells which winding is outward.
+        B.body_cull[b] = 0;
+        if (allow_cull && nt >= 4) {
+            std::map<std::array<double, 3>, int> weld;
+            std::vector<int> wid(nv);
+            for (int i = 0; i < nv; ++i) {
+                const std::array<double, 3> key = {V[3 * i] + 0.0, V[3 * i + 1] + 0.0, V[3 * i + 2] + 0.0};  // -0 -> +0
+                wid[i] = weld.emplace(key, (int)weld.size()).first->second;
+            }
+            std::map<std::pair<int, int>, int> edges;
+            double vol6 = 0.0, avol6 = 0.0;
+            bool ok = true;
+            for (int t = 0; t < nt && ok; ++t) {
+                const int a = wid[T[3 * t]], bb = wid[T[3 * t + 1]], c3 = wid[T[3 * t + 2]];
+                if (a == bb || bb == c3 || a == c3) continue;
+                for (const auto& e : {std::make_pair(a, bb), std::make_pair(bb, c3), std::make_pair(c3, a)})
+                    if (++edges[e] > 1) ok = false;
+                const double* p0 = V + 3 * T[3 * t]; const double* p1 = V + 3 * T[3 * t + 1]; const double* p2 = V + 3 * T[3 * t + 2];
+                const double d = (p0[0] - ctr[0]) * ((p1[1] - ctr[1]) * (p2[2] - ctr[2]) - (p1[2] - ctr[2]) * (p2[1] - ctr[1])) -
+                                 (p0[1] - ctr[1]) * ((p1[0] - ctr[0]) * (p2[2] - ctr[2]) - (p1[2] - ctr[2]) * (p2[0] - ctr[0])) +
+                                 (p0[2] - ctr[2]) * ((p1[0] - ctr[0]) * (p2[1] - ctr[1]) - (p1[1] - ctr[1]) * (p2[0] - ctr[0]));
+                vol6 += d;
+                avol6 += std::fabs(d);
+            }
+            if (ok)
+                for (const auto& e : edges)
+                    if (edges.find({e.first.second, e.first.first}) == edges.end()) { ok = false; break; }
+            if (ok && !edges.empty() && std::fabs(vol6) > 1e-6 * avol6) B.body_cull[b] = vol6 > 0.0 ? 1 : -1;
+        }
         // Morton order of the triangle centroids (10 bits per axis over the body's bbox)
         std::vector<std::pair<uint32_t, int>> order(nt);
         const double ext[3] = {std::fmax(hi[0] - lo[0], 1e-300), std::fmax(hi[1] - lo[1], 1e-300),
@@ -505,6 +543,29 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
                 }
             for (int c3 = 0; c3 < 3; ++c3) cluster_sphere[4 * c + c3] = (float)cc[c3];
             cluster_sphere[4 * c + 3] = (float)(std::sqrt(cr2) * 1.0001 + 1e-6);
+            if (B.body_cull[b] != 0) {   // cone of the cluster's outward unit normals
+                std::vector<std::array<double, 3>> nrm;
+                double ax[3] = {0, 0, 0};
+                for (size_t j = j0; j < j1; ++j) {
+                    double p[3][3];
+                    for (int k = 0; k < 3; ++k)
+                        for (int c3 = 0; c3 < 3; ++c3) p[k][c3] = soup[(size_t)(3 * k + c3) * n_alloc + base + j];
+                    const double e1[3] = {p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]};
+                    const double e2[3] = {p[2][0] - p[0][0], p[2][1] - p[0][1], p[2][2] - p[0][2]};
+                    double n3[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                    const double len = std::sqrt(n3[0] * n3[0] + n3[1] * n3[1] + n3[2] * n3[2]);
+                    if (!(len > 0.0)) continue;   // zero area: never rendered
+                    for (int c3 = 0; c3 < 3; ++c3) { n3[c3] *= (double)B.body_cull[b] / len; ax[c3] += n3[c3]; }
+                    nrm.push_back({n3[0], n3[1], n3[2]});
+                }
+                const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+                if (al > 1e-9 && !nrm.empty()) {
+                    double mindp = 1.0;
+                    for (const auto& n3 : nrm) mindp = std::fmin(mindp, (n3[0] * ax[0] + n3[1] * ax[1] + n3[2] * ax[2]) / al);
+                    for (int c3 = 0; c3 < 3; ++c3) cluster_cone[4 * c + c3] = (float)(ax[c3] / al);
+                    cluster_cone[4 * c + 3] = (float)(mindp - 1e-4);   // <= 0: the cone is too wide to cull by
+                }
+            }
         }
         voff += nv;
         toff += nt;
@@ -560,6 +621,10 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMemcpy(h->d_cluster_sphere, cluster_sphere.data(), sizeof(float) * cluster_sphere.size(),
                          hipMemcpyHostToDevice));
     B.cluster_sphere = h->d_cluster_sphere;
+    RBS_HIP(h, hipMalloc(&h->d_cluster_cone, sizeof(float) * cluster_cone.size()));
+    RBS_HIP(h, hipMemcpy(h->d_cluster_cone, cluster_cone.data(), sizeof(float) * cluster_cone.size(),
+                         hipMemcpyHostToDevice));
+    B.cluster_cone = h->d_cluster_cone;
     RBS_HIP(h, hipHostMalloc(&h->h_frame, plane, hipHostMallocDefault));
 
     // the raster / render kernels carve the LDS depth tile from dynamic shared memory

@@ -70,6 +70,10 @@ struct DevParams {
     int n_tri;                     // soup length: every body padded to a multiple of 64
     int tri_begin[kMaxBodies + 1]; // triangle range per body (multiples of 64)
     const float* cluster_sphere;   // [n_tri/64][4] model-space bounding sphere of each cluster
+    const float* cluster_cone;     // [n_tri/64][4] outward-normal cone of each cluster: unit axis, min cos
+                                   //   (min cos <= -1: never cull this cluster)
+    int body_cull[kMaxBodies];     // 0: keep every triangle; +1/-1: the body is a closed, consistently
+                                   //   oriented surface (sign of its signed volume): back faces may go
     int tile_w, tile_h;            // work-item tile limits: width <= tile_w, pixels <= min(tile_w*tile_h, kTilePx)
     double fx, fy, cx, cy;
     double sphere[kMaxBodies][4];  // model-space bounding sphere: centre xyz, radius
@@ -215,8 +219,12 @@ struct Tri {
 // Same operations, same order as oracle/rbsensor_oracle.c raster_triangle().  The clip window
 // [wx0,wx1) x [wy0,wy1) is a sub-rectangle of the image, so clipping to it instead of to the
 // image changes nothing inside the window.
+// cullsign != 0: the body is a closed surface wholly in front of the camera and cullsign is its
+// orientation; a triangle whose projected area has that sign faces away from the camera and is
+// dropped -- every sample it covers is covered, no farther away, by a front face (see
+// raster_window).
 __device__ inline bool tri_setup(const DevParams& P, int t, const double* __restrict__ Rt,
-                                 int wx0, int wy0, int wx1, int wy1, Tri& T)
+                                 int wx0, int wy0, int wx1, int wy1, int cullsign, Tri& T)
 {
     const double* __restrict__ s = P.soup;
     const size_t n = (size_t)P.n_tri;
@@ -255,6 +263,7 @@ __device__ inline bool tri_setup(const DevParams& P, int t, const double* __rest
     T.e20u = u[0] - u[2]; T.e20v = v[0] - v[2];
     const double area2 = T.e01u * (v[2] - v[0]) - T.e01v * (u[2] - u[0]);
     if (!(area2 != 0.0) || !(fabs(area2) < INFINITY)) return false;
+    if (cullsign != 0 && (cullsign > 0 ? area2 > 0.0 : area2 < 0.0)) return false;
 
     const double ax = X[1] - X[0], ay = Y[1] - Y[0], az = Z[1] - Z[0];
     const double bx = X[2] - X[0], by = Y[2] - Y[0], bz = Z[2] - Z[0];
@@ -318,6 +327,50 @@ __device__ inline bool cluster_may_touch(const DevParams& P, const double* __res
     return true;
 }
 
+// Conservative float32 test: does every triangle of the cluster face away from the camera?
+// The cluster's outward normals lie within angle phi (cos phi = cone[3]) of the axis, its points
+// within rho of the centre c; for a point p of a triangle with outward normal n,
+//   n.(p - eye) >= n.(c - eye) - rho >= |c| cos(psi + phi) - rho,   psi = angle(axis, c - eye),
+// so the cluster is back-facing when |c| (cos psi cos phi - sin psi sin phi) - rho > 0; a
+// margin of 1e-3 (|c| + rho) + 1e-4 absorbs the float rounding.  One cluster per lane.
+__device__ inline bool cluster_faces_away(const double* __restrict__ Rt, const float* __restrict__ sph,
+                                          const float* __restrict__ cone)
+{
+    const float m = cone[3];
+    if (!(m > 0.0f)) return false;
+    const float r0 = (float)Rt[0], r1 = (float)Rt[1], r2 = (float)Rt[2], r3 = (float)Rt[3], r4 = (float)Rt[4],
+                r5 = (float)Rt[5], r6 = (float)Rt[6], r7 = (float)Rt[7], r8 = (float)Rt[8];
+    const float X = r0 * sph[0] + r1 * sph[1] + r2 * sph[2] + (float)Rt[9];
+    const float Y = r3 * sph[0] + r4 * sph[1] + r5 * sph[2] + (float)Rt[10];
+    const float Z = r6 * sph[0] + r7 * sph[1] + r8 * sph[2] + (float)Rt[11];
+    const float ax = r0 * cone[0] + r1 * cone[1] + r2 * cone[2];
+    const float ay = r3 * cone[0] + r4 * cone[1] + r5 * cone[2];
+    const float az = r6 * cone[0] + r7 * cone[1] + r8 * cone[2];
+    const float rho = sph[3] * 1.001f + 1e-3f;
+    const float D = sqrtf(X * X + Y * Y + Z * Z);
+    const float ad = ax * X + ay * Y + az * Z;           // |c| cos psi
+    const float sp = sqrtf(fmaxf(D * D - ad * ad, 0.0f)); // |c| sin psi
+    const float lhs = ad * m - sp * sqrtf(fmaxf(1.0f - m * m, 0.0f)) - rho;
+    return lhs > 1e-3f * (D + rho) + 1e-4f;
+}
+
+// Back-face culling.  A body whose mesh is a closed, consistently oriented surface (checked at
+// create time) and whose bounding sphere lies wholly in front of the camera plane (so no
+// triangle is dropped by the Z <= 0 rule and the camera is outside it) cannot show a back face:
+// the ray through a sample enters the solid through a front face no farther than any back face
+// it meets, so the z-min -- the only thing the tile keeps -- is decided by front faces alone.
+// Dropping back faces (whole clusters by their normal cone, single triangles by the sign of
+// their projected area) therefore leaves every depth unchanged; in binary64 the two can differ
+// only for a sample within rounding distance of a silhouette EDGE itself.  Bodies that fail the
+// create-time check keep every triangle.
+__device__ inline int body_cullsign(const DevParams& P, const double* __restrict__ Rt, int b)
+{
+    if (P.body_cull[b] == 0) return 0;
+    const double sx = P.sphere[b][0], sy = P.sphere[b][1], sz = P.sphere[b][2];
+    const double Z = ((Rt[6] * sx + Rt[7] * sy) + Rt[8] * sz) + Rt[11];
+    return (Z - P.sphere[b][3] > 1e-6) ? P.body_cull[b] : 0;
+}
+
 // Rasterize every body of one particle into the LDS tile covering window
 // [wx0,wx1) x [wy0,wy1).  One wave takes one 64-triangle cluster at a time (triangles were
 // ordered along a space-filling curve at create time, so a cluster is a compact surface
@@ -339,11 +392,14 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
     for (int b = 0; b < P.n_bodies; ++b) {
         const double* Rt = pose + 12 * b;
         const int c0 = P.tri_begin[b] >> 6, c1 = P.tri_begin[b + 1] >> 6;
+        const int cullsign = body_cullsign(P, Rt, b);
         for (int base = c0; base < c1; base += 64) {
             // 64 clusters culled at once, one per lane (every wave computes the same mask)
             const int ci = base + lane;
             const bool hit = ci < c1 && (!cull || cluster_may_touch(P, Rt, P.cluster_sphere + 4 * ci,
-                                                                    wx0, wy0, wx1, wy1));
+                                                                    wx0, wy0, wx1, wy1)) &&
+                             !(cullsign != 0 && cluster_faces_away(Rt, P.cluster_sphere + 4 * ci,
+                                                                   P.cluster_cone + 4 * ci));
             unsigned long long mask = __ballot(hit);
             while (mask) {
                 const int bit = __builtin_ctzll(mask);
@@ -351,7 +407,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
                 if ((taken++) % (kBlock / 64) != wave) continue;
                 const int t = ((base + bit) << 6) + lane;
                 Tri T;
-                if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, T)) continue;
+                if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, cullsign, T)) continue;
                 const int bw = T.xhi - T.xlo + 1, bh = T.yhi - T.ylo + 1;
                 if (bw * bh > kBigThresh) {
                     const int slot = atomicAdd(nbig, 1);
@@ -369,7 +425,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
         const int t = big[e];
         const double* Rt = pose + 12 * body_of(P, t);
         Tri T;
-        if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, T)) continue;  // uniform across the block
+        if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, 0, T)) continue;  // uniform across the block; culled before queueing
         const int bw = T.xhi - T.xlo + 1, bh = T.yhi - T.ylo + 1;
         for (int k = threadIdx.x; k < bw * bh; k += kBlock) {
             const int r = k / bw;

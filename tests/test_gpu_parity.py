@@ -606,3 +606,46 @@ def test_windows_follow_the_object(gpu_lib, state_layout):
         assert a[31] >= 1.5 * a[89], areas         # swept region held at the end of the motion ...
         assert a[89] <= 64 * 64, areas             # ... and released once it has decayed
         assert a[31] < cols * rows
+
+
+def _mesh_variants():
+    v, t = synth.mesh_m1(level=2)
+    v = np.asarray(v, np.float64)
+    t = np.asarray(t, np.int32)
+    rng = np.random.default_rng(3)
+    flipped = t[:, ::-1].copy()
+    holes = np.delete(t, rng.choice(len(t), 40, replace=False), axis=0)
+    mixed = t.copy()
+    sel = rng.choice(len(t), len(t) // 2, replace=False)
+    mixed[sel] = mixed[sel][:, ::-1]
+    shells_v = np.concatenate([v, v * 0.5 + np.array([0.0, 0.0, 0.09])])
+    shells_t = np.concatenate([t, t + len(v)])
+    soup_v = v[t].reshape(-1, 3)                      # every triangle owns its three vertices
+    soup_t = np.arange(len(soup_v), dtype=np.int32).reshape(-1, 3)
+    return {"closed": (v, t), "closed_inward": (v, flipped), "with_holes": (v, holes),
+            "mixed_winding": (v, mixed), "two_shells": (shells_v, shells_t), "unwelded": (soup_v, soup_t)}
+
+
+@pytest.mark.parametrize("variant", ["closed", "closed_inward", "with_holes", "mixed_winding", "two_shells",
+                                     "unwelded"])
+def test_backface_culling_never_changes_a_depth(gpu_lib, variant):
+    """Back faces are dropped only where that is exact: closed, consistently oriented bodies
+    wholly in front of the camera.  Whatever the mesh -- inward winding, holes that show the
+    inside, inconsistent winding, several shells, unwelded vertices -- and wherever it is (also
+    around and across the camera plane), the rendered depth is the oracle's, bit for bit."""
+    from dbot_ros_amd import CameraData, ObjectModel, RbSensorBuilder
+    v, t = _mesh_variants()[variant]
+    cols, rows = 320, 240
+    om = ObjectModel([v], [t], center=True)
+    cam = CameraData(synth.camera_matrix(cols, rows), rows, cols)
+    P = RbSensorBuilder.Parameters(sample_count=2)
+    o = ob.Oracle(om, cam, P, max_particles=2)
+    rng = np.random.default_rng(11)
+    with RbSensor(om, cam, P, max_particles=2) as g:
+        for k in range(14):
+            z = [0.7, 0.4, 0.25, 0.12, 0.06, 0.03, 0.0][k % 7]      # far ... camera inside the body
+            pose = synth.particle_poses(synth.truth_pose(1, z=z, frame=5 * k), 1, rng, scale=20.0)[0]
+            pose[0, 9:11] *= 0.3 if z < 0.2 else 1.0
+            dg, do = g.render_depth(pose), o.render_depth(pose)
+            assert np.array_equal(dg.view(np.uint32), do.view(np.uint32)), \
+                f"{variant} pose {k}: {(dg.view(np.uint32) != do.view(np.uint32)).sum()} depth pixels differ"
