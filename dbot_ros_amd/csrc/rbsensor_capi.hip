@@ -414,7 +414,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     B.band_rows = (h->rows + B.bands - 1) / B.bands;
 
     // triangle soup (SoA) + bounding spheres.  Per body the triangles are ordered along a
-    // Morton curve of their centroids and padded to a multiple of 64 with NaN triangles, so
+    // bisection of positions and normals (below) and padded to a multiple of 64 with NaN triangles, so
     // that every aligned run of 64 is a compact surface patch ("cluster") one wave rasterizes.
     long n_tri = 0;
     B.tri_begin[0] = 0;
@@ -496,24 +496,50 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
                     if (edges.find({e.first.second, e.first.first}) == edges.end()) { ok = false; break; }
             if (ok && !edges.empty() && std::fabs(vol6) > 1e-6 * avol6) B.body_cull[b] = vol6 > 0.0 ? 1 : -1;
         }
-        // Morton order of the triangle centroids (10 bits per axis over the body's bbox)
+        // Cluster order: recursive median bisection of the triangles in (centroid / extent,
+        // 0.5 * unit normal) space, always along the widest of the six axes, left halves a whole
+        // number of 64-triangle clusters.  Every aligned run of 64 is then a compact surface
+        // patch with a narrow normal cone (a plain Morton order of the centroids mixes the two
+        // sides of thin parts and gives cones too wide to cull by).
         std::vector<std::pair<uint32_t, int>> order(nt);
-        const double ext[3] = {std::fmax(hi[0] - lo[0], 1e-300), std::fmax(hi[1] - lo[1], 1e-300),
-                               std::fmax(hi[2] - lo[2], 1e-300)};
-        auto spread = [](uint32_t v) {
-            v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu;
-            v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u; return v;
-        };
-        for (int t = 0; t < nt; ++t) {
-            uint32_t code = 0;
-            for (int c3 = 0; c3 < 3; ++c3) {
-                const double m = (V[3 * T[3 * t] + c3] + V[3 * T[3 * t + 1] + c3] + V[3 * T[3 * t + 2] + c3]) / 3.0;
-                const uint32_t q = (uint32_t)std::fmin(1023.0, std::fmax(0.0, (m - lo[c3]) / ext[c3] * 1023.0));
-                code |= spread(q) << c3;
+        {
+            const double ext = std::fmax(std::fmax(hi[0] - lo[0], hi[1] - lo[1]), std::fmax(hi[2] - lo[2], 1e-300));
+            std::vector<std::array<double, 6>> feat(nt);
+            for (int t = 0; t < nt; ++t) {
+                const double* p0 = V + 3 * T[3 * t]; const double* p1 = V + 3 * T[3 * t + 1]; const double* p2 = V + 3 * T[3 * t + 2];
+                const double e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+                const double e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+                const double n3[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                const double len = std::sqrt(n3[0] * n3[0] + n3[1] * n3[1] + n3[2] * n3[2]);
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    feat[t][c3] = (p0[c3] + p1[c3] + p2[c3]) / (3.0 * ext);
+                    feat[t][3 + c3] = len > 0.0 ? 0.5 * n3[c3] / len : 0.0;
+                }
             }
-            order[t] = {code, t};
+            std::vector<int> idx(nt);
+            for (int t = 0; t < nt; ++t) idx[t] = t;
+            std::vector<std::pair<int, int>> stack;   // [begin, end) ranges still to split
+            stack.push_back({0, nt});
+            while (!stack.empty()) {
+                const auto rg = stack.back();
+                stack.pop_back();
+                const int cnt = rg.second - rg.first;
+                if (cnt <= 64) continue;
+                int dim = 0;
+                double best = -1.0;
+                for (int d = 0; d < 6; ++d) {
+                    double mn = 1e300, mx = -1e300;
+                    for (int i = rg.first; i < rg.second; ++i) { mn = std::fmin(mn, feat[idx[i]][d]); mx = std::fmax(mx, feat[idx[i]][d]); }
+                    if (mx - mn > best) { best = mx - mn; dim = d; }
+                }
+                std::stable_sort(idx.begin() + rg.first, idx.begin() + rg.second,
+                                 [&](int x, int y) { return feat[x][dim] < feat[y][dim]; });
+                const int left = ((cnt + 63) / 64 / 2) * 64;
+                stack.push_back({rg.first, rg.first + left});
+                stack.push_back({rg.first + left, rg.second});
+            }
+            for (int j = 0; j < nt; ++j) order[j] = {0u, idx[j]};
         }
-        std::stable_sort(order.begin(), order.end());
         const size_t base = (size_t)B.tri_begin[b];
         for (int j = 0; j < nt; ++j) {
             const int t = order[j].second;

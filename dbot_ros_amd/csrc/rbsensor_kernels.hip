@@ -408,6 +408,9 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
                 const int t = ((base + bit) << 6) + lane;
                 Tri T;
                 if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, cullsign, T)) continue;
+#ifdef RBS_EXP_SKIP_PIXELS   // profiling builds (tools/phase_timing.py): triangle setup only
+                if (T.nv0 != 12345.678) continue;
+#endif
                 const int bw = T.xhi - T.xlo + 1, bh = T.yhi - T.ylo + 1;
                 if (bw * bh > kBigThresh) {
                     const int slot = atomicAdd(nbig, 1);
@@ -480,6 +483,10 @@ __device__ inline double pixel_loglik(const DevParams& P, int gi, float o, float
     const double eo = P.aux[(size_t)AUX_EO * n + gi];
     const float pbg = P.pbg[gi];
     __builtin_amdgcn_sched_barrier(0);
+#ifdef RBS_EXP_SKIP_EVAL     // profiling builds: the loads, none of the transcendental work
+    posterior = prior;
+    return inv_s2s + kk + cv + eo + (double)pbg + (double)r + (double)o;
+#endif
     const double w = ((double)r - (double)o) * inv_s2s;
     const double twD = P.tw / kMaxDepth;
     const double pv = twD + cv * exp(-(w * w));
