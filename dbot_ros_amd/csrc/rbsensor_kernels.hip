@@ -566,61 +566,99 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int4* q = m.evalq + wave * kEvalQueue;
     int qn = 0;
-    constexpr int kScanUnroll = 4;   // chunks whose loads are in flight together (latency, not VALU, bounds the scan)
-    for (int p0 = wave * 64; p0 < npx; p0 += kBlock * kScanUnroll) {
-        int gi[kScanUnroll];
-        unsigned dbits[kScanUnroll];
-        float sv[kScanUnroll], ov[kScanUnroll];
-        bool valid[kScanUnroll];
-#pragma unroll
-        for (int u = 0; u < kScanUnroll; ++u) {
-            const int p = p0 + u * kBlock + lane;
-            valid[u] = p < npx;
-            gi[u] = 0;
-            dbits[u] = kInfBits;
-            sv[u] = P.bg_old;
-            ov[u] = 0.f;
-            bool stored = false;
-            if (valid[u]) {
+    // push this lane's pixel if `active`; evaluate 64 queued pixels as soon as there are 64
+#define RBS_PUSH_EVAL(active, gidx, depthbits, prior, obs)                                              \
+    do {                                                                                                \
+        const unsigned long long mask_ = __ballot(active);                                              \
+        if (mask_) {                                                                                    \
+            if (active) {                                                                               \
+                const int pos_ = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask_ >> 32),                \
+                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask_, 0));               \
+                q[pos_] = make_int4((gidx), (int)(depthbits), __float_as_int(prior), __float_as_int(obs)); \
+            }                                                                                           \
+            qn += __popcll(mask_);                                                                      \
+            if (qn >= 64) {                                                                             \
+                __builtin_amdgcn_wave_barrier();                                                        \
+                const int4 e_ = q[lane];                                                                \
+                float post_;                                                                            \
+                ll += pixel_loglik(P, e_.x, __int_as_float(e_.w), __uint_as_float((unsigned)e_.y),      \
+                                   __int_as_float(e_.z), post_);                                        \
+                if (UPDATE) dst[e_.x] = post_;                                                          \
+                qn -= 64;                                                                               \
+                int4 carry_ = make_int4(0, 0, 0, 0);                                                    \
+                if (lane < qn) carry_ = q[64 + lane];                                                   \
+                __builtin_amdgcn_wave_barrier();                                                        \
+                if (lane < qn) q[lane] = carry_;                                                        \
+            }                                                                                           \
+        }                                                                                               \
+    } while (0)
+
+    if ((P.cols & 3) == 0) {
+        // Four pixels per lane: rows of the tile, of both planes and of the frame are 16-byte
+        // aligned (rectangles and windows move in float4 columns), so one ds_read_b128 + two
+        // dwordx4 loads + one dwordx4 store serve four pixels, and the row/column walk is
+        // incremental.  An active pixel's prior is stored with its quad and overwritten by its
+        // posterior when the same wave evaluates it later (same wave, same address: in order).
+        const int tq = tw >> 2, nq = npx >> 2;
+        const int qstep = kBlock / tq, rstep = kBlock - qstep * tq;
+        int lr = (int)threadIdx.x / tq;
+        int qc = (int)threadIdx.x - lr * tq;
+        const uint4* __restrict__ tile4 = reinterpret_cast<const uint4*>(m.tile);
+        for (int q0 = wave * 64; q0 < nq; q0 += kBlock) {
+            const int qd = q0 + lane;
+            const bool valid = qd < nq;
+            uint4 d4 = make_uint4(kInfBits, kInfBits, kInfBits, kInfBits);
+            floatx4 s4 = {P.bg_old, P.bg_old, P.bg_old, P.bg_old};
+            floatx4 o4 = {0.f, 0.f, 0.f, 0.f};
+            int gbase = 0;
+            bool anyc = false;
+            if (valid) {
+                const int gy = wy0 + lr, gx = wx0 + (qc << 2);
+                gbase = gy * P.cols + gx;
+                d4 = tile4[qd];
+                anyc = (d4.x & d4.y & d4.z & d4.w) != kInfBits;   // a finite depth lacks an exponent bit
+                const bool stored = gx >= pw.x && gx < pw.z && gy >= pw.y && gy < pw.w;
+                if (stored && (UPDATE || anyc)) s4 = *reinterpret_cast<const floatx4*>(src + gbase);
+                if (anyc) o4 = *reinterpret_cast<const floatx4*>(P.frame + gbase);
+            }
+            qc += rstep; lr += qstep;
+            if (qc >= tq) { qc -= tq; ++lr; }
+            floatx4 pr;
+            pr.x = occ_step(P.alpha, P.beta, s4.x, P.bg_new);
+            pr.y = occ_step(P.alpha, P.beta, s4.y, P.bg_new);
+            pr.z = occ_step(P.alpha, P.beta, s4.z, P.bg_new);
+            pr.w = occ_step(P.alpha, P.beta, s4.w, P.bg_new);
+            if (UPDATE && valid) *reinterpret_cast<floatx4*>(dst + gbase) = pr;
+            if (__ballot(anyc) == 0) continue;   // wave-uniform: nothing of the object in these 256 pixels
+            RBS_PUSH_EVAL(d4.x != kInfBits && isfinite(o4.x), gbase + 0, d4.x, pr.x, o4.x);
+            RBS_PUSH_EVAL(d4.y != kInfBits && isfinite(o4.y), gbase + 1, d4.y, pr.y, o4.y);
+            RBS_PUSH_EVAL(d4.z != kInfBits && isfinite(o4.z), gbase + 2, d4.z, pr.z, o4.z);
+            RBS_PUSH_EVAL(d4.w != kInfBits && isfinite(o4.w), gbase + 3, d4.w, pr.w, o4.w);
+        }
+    } else {
+        // any width: one pixel per lane
+        for (int p0 = wave * 64; p0 < npx; p0 += kBlock) {
+            const int p = p0 + lane;
+            const bool valid = p < npx;
+            int gi = 0;
+            unsigned dbits = kInfBits;
+            float sv = P.bg_old, ov = 0.f;
+            if (valid) {
                 const int lr = p / tw;
                 const int gy = wy0 + lr, gx = wx0 + (p - lr * tw);
-                gi[u] = gy * P.cols + gx;
-                dbits[u] = m.tile[p];
-                stored = gx >= pw.x && gx < pw.z && gy >= pw.y && gy < pw.w;
+                gi = gy * P.cols + gx;
+                dbits = m.tile[p];
+                const bool stored = gx >= pw.x && gx < pw.z && gy >= pw.y && gy < pw.w;
+                if (stored && (UPDATE || dbits != kInfBits)) sv = src[gi];
+                if (dbits != kInfBits) ov = P.frame[gi];
             }
-            const bool covered = dbits[u] != kInfBits;
-            if (stored && (UPDATE || covered)) sv[u] = src[gi[u]];
-            if (covered) ov[u] = P.frame[gi[u]];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < kScanUnroll; ++u) {
-            if (p0 + u * kBlock >= npx) break;   // wave-uniform
-            const float prior = occ_step(P.alpha, P.beta, sv[u], P.bg_new);
-            const bool active = dbits[u] != kInfBits && isfinite(ov[u]);
-            if (UPDATE && valid[u] && !active) dst[gi[u]] = prior;
-            const unsigned long long mask = __ballot(active);
-            if (active) {
-                const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                q[pos] = make_int4(gi[u], (int)dbits[u], __float_as_int(prior), __float_as_int(ov[u]));
-            }
-            qn += __popcll(mask);
-            if (qn >= 64) {
-                __builtin_amdgcn_wave_barrier();
-                const int4 e = q[lane];
-                float post;
-                ll += pixel_loglik(P, e.x, __int_as_float(e.w), __uint_as_float((unsigned)e.y),
-                                   __int_as_float(e.z), post);
-                if (UPDATE) dst[e.x] = post;
-                qn -= 64;
-                int4 carry = make_int4(0, 0, 0, 0);
-                if (lane < qn) carry = q[64 + lane];
-                __builtin_amdgcn_wave_barrier();
-                if (lane < qn) q[lane] = carry;
-            }
+            const float prior = occ_step(P.alpha, P.beta, sv, P.bg_new);
+            const bool active = dbits != kInfBits && isfinite(ov);
+            if (UPDATE && valid && !active) dst[gi] = prior;
+            RBS_PUSH_EVAL(active, gi, dbits, prior, ov);
         }
     }
+#undef RBS_PUSH_EVAL
     __builtin_amdgcn_wave_barrier();
     if (lane < qn) {
         const int4 e = q[lane];
