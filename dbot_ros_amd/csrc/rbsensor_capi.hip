@@ -49,11 +49,13 @@ struct rbs_handle {
     int4* d_win[2] = {nullptr, nullptr};   // [max_particles] window of each plane, per buffer
     int4* d_win_used = nullptr; // [max_particles] region the copy kernel writes this call
     bool windowed = true;       // planes valid inside their window only (RBS_STATE=dense: whole plane)
+    int prep_fuse_max = 512;    // up to this many particles: rectangles + scan in one single-block launch
     int win_chunks = 8;         // row chunks (blocks) per particle of the windowed copy kernel
     float background = 0.f;     // never-covered occlusion level of the current buffer
     int* d_tiles = nullptr;     // [max_particles] tiles per particle
     int* d_item_offset = nullptr; // [max_particles+1]
     int* d_work_counter = nullptr;
+    int* d_done = nullptr;      // [max_particles] finished work items per particle
     double* d_partial = nullptr; // [partial_cap] per-item partial sums
     unsigned long long* d_phase = nullptr;  // RBS_PHASE_TIMING builds
     size_t partial_cap = 0;
@@ -170,11 +172,11 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.n = n;
     const int slot = (int)(h->calls % rbs_handle::kRing);
     h->ring_update[slot] = update;
-    // tile limits: as large as the LDS tile allows when there are enough particles to fill the
-    // persistent grid (a particle's rectangle is then usually ONE item, whatever its aspect),
-    // 64x64 (more work items per particle) when there are few
-    if (n >= 2 * h->raster_blocks) { P.tile_w = 256; P.tile_h = rbs::kTilePx / 256; }
-    else { P.tile_w = 64; P.tile_h = 64; }
+    // tile limits: as large as the LDS tile allows (a particle's rectangle is then usually ONE
+    // work item, whatever its aspect); with fewer particles than persistent blocks the pixel
+    // budget is divided so that a rectangle splits into about blocks/n row bands
+    P.tile_w = 256;
+    P.tile_h = std::max(4, rbs::kTilePx / 256 / std::max(1, h->raster_blocks / std::max(1, n)));
     if (const char* m = h->tile_override) { P.tile_w = std::max(16, std::atoi(m) / 16 * 16); P.tile_h = std::max(1, std::atoi(m)); }
     const size_t tiles_max = tiles_upper_bound(h->cols, h->rows, P.tile_w, std::min(P.tile_w * P.tile_h, rbs::kTilePx));
     const size_t need = (size_t)n * tiles_max;
@@ -191,6 +193,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.rects = d_rects;
     P.item_offset = h->d_item_offset;
     P.work_counter = h->d_work_counter;
+    P.done = h->d_done;
     P.partial = h->d_partial;
 #ifdef RBS_PHASE_TIMING
     if (!h->d_phase) { RBS_HIP(h, hipMalloc(&h->d_phase, 64)); RBS_HIP(h, hipMemset(h->d_phase, 0, 64)); }
@@ -206,7 +209,12 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
         h->join_pending = -1;
     }
-    hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(256), 0, s, P, d_rects, h->d_tiles, update ? 1 : 0);
+    const bool fused_prep = n <= std::min(h->prep_fuse_max, rbs::kPrepScanMax);
+    if (fused_prep)
+        hipLaunchKernelGGL(rbs::rbs_prep_scan_kernel, dim3(1), dim3(1024), 0, s, P, d_rects, h->d_item_offset,
+                           h->d_work_counter, update ? 1 : 0);
+    else
+        hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(256), 0, s, P, d_rects, h->d_tiles, update ? 1 : 0);
     RBS_HIP(h, hipGetLastError());
     if (update) {
         // fork: the copy kernel runs on the handle's second stream, concurrently with the
@@ -214,9 +222,11 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipEventRecord(h->ev_fork, s));
         RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
     }
-    hipLaunchKernelGGL(rbs::rbs_scan_kernel, dim3(1), dim3(1024), 0, s, h->d_tiles, h->d_item_offset, n,
-                       h->d_work_counter);
-    RBS_HIP(h, hipGetLastError());
+    if (!fused_prep) {
+        hipLaunchKernelGGL(rbs::rbs_scan_kernel, dim3(1), dim3(1024), 0, s, h->d_tiles, h->d_item_offset, n,
+                           h->d_work_counter);
+        RBS_HIP(h, hipGetLastError());
+    }
     // deferred join: the raster kernel reads planes the previous updating call's copy kernel
     // may still be writing; everything before this point overlapped with that copy's tail
     if (h->join_pending >= 0) {
@@ -260,8 +270,6 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipGetLastError());
         RBS_HIP(h, hipEventRecord(h->ev_raster_stop[slot], s));
     }
-    hipLaunchKernelGGL(rbs::rbs_reduce_kernel, pgrid, dim3(256), 0, s, P);
-    RBS_HIP(h, hipGetLastError());
     RBS_HIP(h, hipEventRecord(h->ev_stop[slot], s));
     if (update) h->join_pending = slot;   // joined lazily: by the next call, or by drain()
     h->calls += 1;
@@ -326,6 +334,7 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_tiles);
     (void)hipFree(h->d_item_offset);
     (void)hipFree(h->d_work_counter);
+    (void)hipFree(h->d_done);
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_cluster_sphere);
     (void)hipFree(h->d_cluster_cone);
@@ -355,7 +364,7 @@ int32_t upload_frame(rbs_handle* h)
                               h->stream));
     hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        h->stream, h->d_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms,
-                       h->base.sf, h->base.lambda);
+                       h->base.sf, h->base.lambda, (float*)nullptr);
     RBS_HIP(h, hipGetLastError());
     return RBS_OK;
 }
@@ -620,6 +629,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         if (const char* m = std::getenv("RBS_COPY_ROWS")) h->copy_rows = std::atoi(m);
         if (const char* m = std::getenv("RBS_COPY_TPB")) h->copy_tpb = std::max(64, std::atoi(m) / 64 * 64);
         if (const char* m = std::getenv("RBS_STATE")) h->windowed = std::strcmp(m, "dense") != 0;
+        if (const char* m = std::getenv("RBS_PREP_FUSE_MAX")) h->prep_fuse_max = std::atoi(m);
         if (const char* m = std::getenv("RBS_WIN_CHUNKS")) h->win_chunks = std::min(1024, std::max(1, std::atoi(m)));
         if (h->cols & 3) h->windowed = false;   // windows move whole float4s
     }
@@ -643,6 +653,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMalloc(&h->d_tiles, sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_item_offset, sizeof(int) * ((size_t)h->max_particles + 1)));
     RBS_HIP(h, hipMalloc(&h->d_work_counter, sizeof(int)));
+    RBS_HIP(h, hipMalloc(&h->d_done, sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_cluster_sphere, sizeof(float) * cluster_sphere.size()));
     RBS_HIP(h, hipMemcpy(h->d_cluster_sphere, cluster_sphere.data(), sizeof(float) * cluster_sphere.size(),
                          hipMemcpyHostToDevice));
@@ -662,10 +673,11 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
 
     {   // per-item partial sums: sized for the default tiling so no call ever allocates
-        const size_t t128 = tiles_upper_bound(h->cols, h->rows, 256, rbs::kTilePx);
-        const size_t t64 = tiles_upper_bound(h->cols, h->rows, 64, 4096);
-        const size_t need = std::max((size_t)h->max_particles * t128,
-                                     (size_t)std::min(h->max_particles, 2 * h->raster_blocks) * t64);
+        size_t need = (size_t)h->max_particles * tiles_upper_bound(h->cols, h->rows, 256, rbs::kTilePx);
+        for (int nn = 1; nn < std::min(h->max_particles, h->raster_blocks); nn *= 2) {
+            const int th = std::max(4, rbs::kTilePx / 256 / std::max(1, h->raster_blocks / nn));
+            need = std::max(need, (size_t)std::min(2 * nn, h->max_particles) * tiles_upper_bound(h->cols, h->rows, 256, 256 * th));
+        }
         RBS_HIP(h, hipMalloc(&h->d_partial, sizeof(double) * need));
         h->partial_cap = need;
     }
@@ -804,7 +816,7 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
     RBS_HIP(h, hipGetLastError());
     hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0,
                        h->stream, h->d_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms,
-                       h->base.sf, h->base.lambda);
+                       h->base.sf, h->base.lambda, (float*)nullptr);
     RBS_HIP(h, hipGetLastError());
     h->pending_frames += 1;
     return RBS_OK;
@@ -817,10 +829,10 @@ int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* st
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     const size_t n = (size_t)h->npx;
-    RBS_HIP(h, hipMemcpyAsync(h->d_frame, d_depth, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // one kernel: copy the frame into the handle's buffer and derive the per-pixel model terms
     hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                       h->d_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms, h->base.sf,
-                       h->base.lambda);
+                       d_depth, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms, h->base.sf,
+                       h->base.lambda, h->d_frame);
     RBS_HIP(h, hipGetLastError());
     h->pending_frames += 1;
     return RBS_OK;

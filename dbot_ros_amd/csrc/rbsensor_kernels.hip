@@ -101,6 +101,7 @@ struct DevParams {
     const int* item_offset;        // [n+1] exclusive scan of tiles per particle
     int* work_counter;             // atomic queue head over the (particle, tile) items
     double* partial;               // [items] partial log-likelihood per work item
+    int* done;                     // [n] finished work items per particle (the last one sums them)
 #ifdef RBS_PHASE_TIMING
     unsigned long long* phase;     // [8] accumulated wave-0 cycles per phase (profiling builds only)
 #endif
@@ -453,13 +454,16 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
 // oracle's expression order by a few ulp, far below the float rounding of a, b that follows.
 enum { AUX_INV_S2S = 0, AUX_K = 1, AUX_CV = 2, AUX_EO = 3, AUX_PLANES = 4 };
 
+// keep != nullptr: `frame` is the caller's buffer and is also copied into the handle's own.
 __global__ void frame_aux_kernel(const float* __restrict__ frame, double* __restrict__ aux,
                                  float* __restrict__ pbg, int npx, double tw, double ms, double sf,
-                                 double lam)
+                                 double lam, float* __restrict__ keep)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npx) return;
-    const double o = (double)frame[i];
+    const float of = frame[i];
+    if (keep) keep[i] = of;
+    const double o = (double)of;
     const double sigma = ms + sf * o * o;
     const double eo = exp(0.5 * lam * (-2.0 * o + lam * sigma * sigma));
     aux[(size_t)AUX_INV_S2S * npx + i] = 1.0 / (sqrt(2.0) * sigma);
@@ -746,15 +750,12 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
 // bounding box of the parent's window and the rectangle -- and seeds the child's window with the
 // rectangle (the copy kernel grows it over every value it writes that differs from the
 // background).  An empty window is (cols, rows, 0, 0), so unions are plain min/max.
-__global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int* __restrict__ tiles,
-                                int update)
+__device__ inline int prep_particle(const DevParams& P, int i, int* __restrict__ rects, int update)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
     const Rect r = particle_rect(P, P.poses + (size_t)i * 12 * P.n_bodies);
     reinterpret_cast<int4*>(rects)[i] = make_int4(r.x0, r.y0, r.x1, r.y1);
     const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, kTilePx));
-    tiles[i] = r.x1 > r.x0 ? tg.nx * tg.ny : 1;   // an empty rectangle still owns one (empty) item
+    P.done[i] = 0;
     if (update && P.windowed) {
         const int4 rw = r.x1 > r.x0 ? make_int4(r.x0, r.y0, r.x1, r.y1) : make_int4(P.cols, P.rows, 0, 0);
         const int parent = P.indices[i];
@@ -763,6 +764,49 @@ __global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int*
         P.win_used[i] = make_int4(min(pw.x, rw.x), min(pw.y, rw.y), max(pw.z, rw.z), max(pw.w, rw.w));
         P.win_dst[i] = rw;
     }
+    return r.x1 > r.x0 ? tg.nx * tg.ny : 1;   // an empty rectangle still owns one (empty) item
+}
+
+__global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int* __restrict__ tiles,
+                                int update)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    tiles[i] = prep_particle(P, i, rects, update);
+}
+
+// Up to 4096 particles: rectangles AND the scan in one single-block launch (each thread owns up
+// to four consecutive particles) -- one kernel and one launch gap less on the per-frame chain.
+constexpr int kPrepScanMax = 4096;
+__global__ __launch_bounds__(1024) void rbs_prep_scan_kernel(const DevParams P, int* __restrict__ rects,
+                                                              int* __restrict__ offset,
+                                                              int* __restrict__ work_counter, int update)
+{
+    __shared__ int part[1024];
+    const int n = P.n;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    int cnt[kPrepScanMax / 1024];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPrepScanMax / 1024; ++k) {
+        cnt[k] = 0;
+        if (lo + k < hi) { cnt[k] = prep_particle(P, lo + k, rects, update); sum += cnt[k]; }
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+        const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+#pragma unroll
+    for (int k = 0; k < kPrepScanMax / 1024; ++k)
+        if (lo + k < hi) { offset[lo + k] = run; run += cnt[k]; }
+    if (threadIdx.x == 1023) offset[n] = part[1023];
+    if (threadIdx.x == 0) *work_counter = 0;
 }
 
 // Single block: exclusive scan tiles[0..n) -> offset[0..n]; resets the work queue.
@@ -827,9 +871,26 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
         const int particle = __builtin_amdgcn_readfirstlane(lo);
         const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
         const Rect r = {q.x, q.y, q.z, q.w};
+        const int first = P.item_offset[particle];
         double part = 0.0;
-        if (r.x1 > r.x0) part = raster_eval_tile<UPDATE>(P, particle, r, item - P.item_offset[particle], m);
-        if (threadIdx.x == 0) P.partial[item] = part;
+        if (r.x1 > r.x0) part = raster_eval_tile<UPDATE>(P, particle, r, item - first, m);
+        if (threadIdx.x == 0) {
+            // the particle's log-likelihood: its only item's sum, or -- by whichever block
+            // finishes the particle's last item -- the items' sums added in item order
+            const int cnt = P.item_offset[particle + 1] - first;
+            if (cnt == 1) {
+                P.out[particle] = part;
+            } else {
+                P.partial[item] = part;
+                __threadfence();
+                if (atomicAdd(&P.done[particle], 1) == cnt - 1) {
+                    __threadfence();
+                    double sum = 0.0;
+                    for (int k = 0; k < cnt; ++k) sum += __builtin_nontemporal_load(&P.partial[first + k]);
+                    P.out[particle] = sum;
+                }
+            }
+        }
         __syncthreads();
     }
 #ifdef RBS_PHASE_TIMING
@@ -838,16 +899,6 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
         atomicAdd(&P.phase[6], wall_clock64() - w0_);
     }
 #endif
-}
-
-// One thread per particle: ordered (deterministic) sum of its work items' partial sums.
-__global__ void rbs_reduce_kernel(const DevParams P)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
-    double s = 0.0;
-    for (int k = P.item_offset[i]; k < P.item_offset[i + 1]; ++k) s += P.partial[k];
-    P.out[i] = s;
 }
 
 template <int VEC>

@@ -649,3 +649,34 @@ def test_backface_culling_never_changes_a_depth(gpu_lib, variant):
             dg, do = g.render_depth(pose), o.render_depth(pose)
             assert np.array_equal(dg.view(np.uint32), do.view(np.uint32)), \
                 f"{variant} pose {k}: {(dg.view(np.uint32) != do.view(np.uint32)).sum()} depth pixels differ"
+
+
+def test_many_particles_and_many_tiles(gpu_lib):
+    """More than 4 096 particles (separate rectangle and scan kernels) and rectangles that split
+    into several work items (several blocks add up one particle's log-likelihood): the first 48
+    particles against the oracle over two frames, the rest through determinism."""
+    n = 5000
+    om, cam, P = sc.make_scene(("m1_l2",), 320, 240, max_particles=n)
+    eager = ob.Oracle(om, cam, P, max_particles=48, mode=ob.EAGER)
+    rng = np.random.default_rng(17)
+    truth = synth.truth_pose(1, z=0.16)            # close: the rectangle is most of the image
+    poses = synth.particle_poses(truth, n, rng, scale=2.0)
+    runs = []
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        for rep in range(2):
+            g.reset()
+            eager.reset()
+            idx, io = np.zeros(n, np.int32), np.zeros(48, np.int32)
+            lls = []
+            frng = np.random.default_rng(3)
+            for k in range(2):
+                frame = synth.make_frame(eager.render_depth(truth), 240, 320, frng)
+                g.set_observation(frame)
+                eager.set_observation(frame)
+                ll = g.loglikes_poses(poses, idx, update=True)
+                lo = eager.loglikes_poses(poses[:48], io, update=True)
+                assert rel_err(ll[:48], lo).max() <= TOL_EAGER
+                lls.append(ll)
+            assert_planes_match(g.get_occlusion(47), eager.get_occlusion(47))
+            runs.append(np.concatenate(lls))
+    assert np.array_equal(runs[0], runs[1])
