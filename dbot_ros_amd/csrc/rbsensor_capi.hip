@@ -49,6 +49,8 @@ struct rbs_handle {
     int4* d_win[2] = {nullptr, nullptr};   // [max_particles] window of each plane, per buffer
     int4* d_win_used = nullptr; // [max_particles] region the copy kernel writes this call
     bool windowed = true;       // planes valid inside their window only (RBS_STATE=dense: whole plane)
+    int smalln_target = 768;    // few particles: aim at about this many work items per call
+    int rect_align = 4;         // windowed planes: rectangles move in float4 columns
     int prep_fuse_max = 512;    // up to this many particles: rectangles + scan in one single-block launch
     int win_chunks = 8;         // row chunks (blocks) per particle of the windowed copy kernel
     float background = 0.f;     // never-covered occlusion level of the current buffer
@@ -70,7 +72,7 @@ struct rbs_handle {
     hipStream_t copy_stream = nullptr;   // the copy kernel runs here, beside the raster kernel
     hipEvent_t ev_fork = nullptr;
     int copy_blocks = 1 << 30;  // cap on the copy grid (one block per (particle, band) below it)
-    int raster_blocks = 512;    // persistent raster grid: 2 per CU
+    int raster_blocks = 768;    // persistent raster grid: 3 per CU
     int copy_rows = 2;          // rows per block of rbs_copy_rows_kernel (0: banded kernel)
     int copy_tpb = 64;          // threads per copy block: one wave = 1 KB of a row (0: a block spans a row)
     const char* tile_override = nullptr;  // RBS_TILE env (tuning)
@@ -78,8 +80,13 @@ struct rbs_handle {
     // kernel (on the copy stream) for the last kRing loglikes calls
     static constexpr int kRing = 64;
     hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {}, ev_copy_start[kRing] = {}, ev_join[kRing] = {};
-    hipEvent_t ev_raster_start[kRing] = {}, ev_raster_stop[kRing] = {};
+    hipEvent_t ev_raster_start[kRing] = {}, ev_raster_stop[kRing] = {}, ev_copy_stop[kRing] = {};
     bool ring_update[kRing] = {};
+    // every event is a packet the stream must retire between two kernels: only every
+    // timing_every-th call carries the timing events (ring slots count TIMED calls); ev_join, which
+    // orders later work after the copy kernel, is recorded on every updating call
+    int timing_every = 8;
+    long timed_calls = 0;
     long calls = 0;
     int join_pending = -1;      // ring slot whose copy kernel later work on the planes must wait for
     std::string err;
@@ -157,6 +164,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.bg_old = h->background;
     P.bg_new = std::fmaf(P.alpha, h->background, P.beta);
     P.windowed = h->windowed ? 1 : 0;
+    P.rect_align = h->windowed ? h->rect_align : rbs::kRectAlign;
     P.win_src = h->d_win[h->cur];
     P.win_dst = h->d_win[1 - h->cur];
     P.win_used = h->d_win_used;
@@ -170,13 +178,15 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.slots = h->max_particles;
     P.out = d_out;
     P.n = n;
-    const int slot = (int)(h->calls % rbs_handle::kRing);
-    h->ring_update[slot] = update;
+    const int slot = (int)(h->calls % rbs_handle::kRing);          // ev_join
+    const bool timed = h->timing_every <= 1 || h->calls % h->timing_every == 0;
+    const int tslot = (int)(h->timed_calls % rbs_handle::kRing);    // timing events
+    if (timed) h->ring_update[tslot] = update;
     // tile limits: as large as the LDS tile allows (a particle's rectangle is then usually ONE
     // work item, whatever its aspect); with fewer particles than persistent blocks the pixel
     // budget is divided so that a rectangle splits into about blocks/n row bands
     P.tile_w = 256;
-    P.tile_h = std::max(4, rbs::kTilePx / 256 / std::max(1, h->raster_blocks / std::max(1, n)));
+    P.tile_h = std::max(4, rbs::kTilePx / 256 / std::max(1, h->smalln_target / std::max(1, n)));
     if (const char* m = h->tile_override) { P.tile_w = std::max(16, std::atoi(m) / 16 * 16); P.tile_h = std::max(1, std::atoi(m)); }
     const size_t tiles_max = tiles_upper_bound(h->cols, h->rows, P.tile_w, std::min(P.tile_w * P.tile_h, rbs::kTilePx));
     const size_t need = (size_t)n * tiles_max;
@@ -199,7 +209,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     if (!h->d_phase) { RBS_HIP(h, hipMalloc(&h->d_phase, 64)); RBS_HIP(h, hipMemset(h->d_phase, 0, 64)); }
     P.phase = h->d_phase;
 #endif
-    RBS_HIP(h, hipEventRecord(h->ev_start[slot], s));
+    if (timed) RBS_HIP(h, hipEventRecord(h->ev_start[tslot], s));
     const dim3 block(rbs::kBlock);
     const dim3 pgrid((unsigned)((n + 255) / 256));
     // dense planes: prep + scan read only the poses and run ahead of the previous call's copy
@@ -221,6 +231,18 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         // persistent raster kernel; it needs this call's rectangles only
         RBS_HIP(h, hipEventRecord(h->ev_fork, s));
         RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
+        if (h->windowed) {
+            // the windowed copy is small and the raster blocks leave it no registers once they
+            // are resident (3 x 168 VGPRs per SIMD): it goes first, under the scan kernel and the
+            // raster kernel's ramp-up
+            if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
+            const int ny = std::min(n, 32768);
+            const dim3 wg((unsigned)h->win_chunks, (unsigned)ny, (unsigned)((n + ny - 1) / ny));
+            hipLaunchKernelGGL(rbs::rbs_copy_window_kernel, wg, dim3(64), 0, h->copy_stream, P);
+            RBS_HIP(h, hipGetLastError());
+            if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_stop[tslot], h->copy_stream));
+            RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
+        }
     }
     if (!fused_prep) {
         hipLaunchKernelGGL(rbs::rbs_scan_kernel, dim3(1), dim3(1024), 0, s, h->d_tiles, h->d_item_offset, n,
@@ -234,17 +256,15 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         h->join_pending = -1;
     }
     const dim3 rgrid((unsigned)h->raster_blocks);
-    RBS_HIP(h, hipEventRecord(h->ev_raster_start[slot], s));
+    if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
     if (update) {
         hipLaunchKernelGGL((rbs::rbs_raster_kernel<true>), rgrid, block, rbs::kSmemBytes, s, P);
         RBS_HIP(h, hipGetLastError());
-        RBS_HIP(h, hipEventRecord(h->ev_raster_stop[slot], s));
+        if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
-        RBS_HIP(h, hipEventRecord(h->ev_copy_start[slot], h->copy_stream));
+        if (timed && !h->windowed) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
         if (h->windowed) {
-            const int ny = std::min(n, 32768);
-            const dim3 wg((unsigned)h->win_chunks, (unsigned)ny, (unsigned)((n + ny - 1) / ny));
-            hipLaunchKernelGGL(rbs::rbs_copy_window_kernel, wg, dim3(64), 0, h->copy_stream, P);
+            // launched above, ahead of the raster kernel
         } else if ((P.cols & 3) == 0 && h->copy_rows > 0) {
             const int W4 = P.cols >> 2;
             const int tpb = h->copy_tpb > 0 ? h->copy_tpb : std::min(1024, (W4 + 63) / 64 * 64);
@@ -264,13 +284,16 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         else
             hipLaunchKernelGGL((rbs::rbs_copy_kernel<1>), cgrid, block, 0, h->copy_stream, P);
         RBS_HIP(h, hipGetLastError());
-        RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
+        if (!h->windowed) {
+            if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_stop[tslot], h->copy_stream));
+            RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
+        }
     } else {
         hipLaunchKernelGGL((rbs::rbs_raster_kernel<false>), rgrid, block, rbs::kSmemBytes, s, P);
         RBS_HIP(h, hipGetLastError());
-        RBS_HIP(h, hipEventRecord(h->ev_raster_stop[slot], s));
+        if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
     }
-    RBS_HIP(h, hipEventRecord(h->ev_stop[slot], s));
+    if (timed) { RBS_HIP(h, hipEventRecord(h->ev_stop[tslot], s)); h->timed_calls += 1; }
     if (update) h->join_pending = slot;   // joined lazily: by the next call, or by drain()
     h->calls += 1;
     if (update) {
@@ -350,6 +373,7 @@ void release(rbs_handle* h)
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
         if (h->ev_raster_start[i]) (void)hipEventDestroy(h->ev_raster_start[i]);
         if (h->ev_raster_stop[i]) (void)hipEventDestroy(h->ev_raster_stop[i]);
+        if (h->ev_copy_stop[i]) (void)hipEventDestroy(h->ev_copy_stop[i]);
     }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -618,20 +642,26 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         RBS_HIP(h, hipEventCreate(&h->ev_join[i]));
         RBS_HIP(h, hipEventCreate(&h->ev_raster_start[i]));
         RBS_HIP(h, hipEventCreate(&h->ev_raster_stop[i]));
+        RBS_HIP(h, hipEventCreate(&h->ev_copy_stop[i]));
     }
     {
         hipDeviceProp_t prop;
         RBS_HIP(h, hipGetDeviceProperties(&prop, h->device));
-        h->raster_blocks = 2 * std::max(1, prop.multiProcessorCount);
+        h->raster_blocks = 3 * std::max(1, prop.multiProcessorCount);
         // tuning overrides (defaults are the measured best on MI355X)
         if (const char* m = std::getenv("RBS_RASTER_BLOCKS")) h->raster_blocks = std::max(1, std::atoi(m));
         h->tile_override = std::getenv("RBS_TILE");
         if (const char* m = std::getenv("RBS_COPY_ROWS")) h->copy_rows = std::atoi(m);
         if (const char* m = std::getenv("RBS_COPY_TPB")) h->copy_tpb = std::max(64, std::atoi(m) / 64 * 64);
         if (const char* m = std::getenv("RBS_STATE")) h->windowed = std::strcmp(m, "dense") != 0;
+        h->smalln_target = 2 * std::max(1, prop.multiProcessorCount);   // measured best at 64..500 particles
+        if (const char* m = std::getenv("RBS_SMALLN_TARGET")) h->smalln_target = std::max(1, std::atoi(m));
+        if (const char* m = std::getenv("RBS_RECT_ALIGN")) h->rect_align = std::atoi(m) >= 16 ? 16 : (std::atoi(m) >= 8 ? 8 : 4);
+        if (const char* m = std::getenv("RBS_TIMING_EVERY")) h->timing_every = std::max(1, std::atoi(m));
         if (const char* m = std::getenv("RBS_PREP_FUSE_MAX")) h->prep_fuse_max = std::atoi(m);
         if (const char* m = std::getenv("RBS_WIN_CHUNKS")) h->win_chunks = std::min(1024, std::max(1, std::atoi(m)));
         if (h->cols & 3) h->windowed = false;   // windows move whole float4s
+        h->base.rect_align = h->windowed ? h->rect_align : rbs::kRectAlign;
     }
     RBS_HIP(h, hipMalloc(&h->d_soup, soup.size() * sizeof(double)));
     RBS_HIP(h, hipMemcpy(h->d_soup, soup.data(), soup.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -675,7 +705,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     {   // per-item partial sums: sized for the default tiling so no call ever allocates
         size_t need = (size_t)h->max_particles * tiles_upper_bound(h->cols, h->rows, 256, rbs::kTilePx);
         for (int nn = 1; nn < std::min(h->max_particles, h->raster_blocks); nn *= 2) {
-            const int th = std::max(4, rbs::kTilePx / 256 / std::max(1, h->raster_blocks / nn));
+            const int th = std::max(4, rbs::kTilePx / 256 / std::max(1, std::max(h->smalln_target, h->raster_blocks) / nn));
             need = std::max(need, (size_t)std::min(2 * nn, h->max_particles) * tiles_upper_bound(h->cols, h->rows, 256, 256 * th));
         }
         RBS_HIP(h, hipMalloc(&h->d_partial, sizeof(double) * need));
@@ -1038,18 +1068,20 @@ int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float*
         return fail(h, RBS_ERR_INVALID_ARGUMENT, "timing_summary: bad argument");
     if (h->calls == 0) return fail(h, RBS_ERR_INVALID_ARGUMENT, "timing_summary: no loglikes launched yet");
     RBS_HIP(h, hipSetDevice(h->device));
-    const long n = std::min<long>({(long)last_n, h->calls, (long)rbs_handle::kRing});
+    // the timed calls among the last last_n calls (at least the most recent timed one)
+    const long n = std::max<long>(1, std::min<long>({((long)last_n + h->timing_every - 1) / h->timing_every,
+                                                      h->timed_calls, (long)rbs_handle::kRing}));
     double tot = 0.0, cpy = 0.0;
     int n_copy = 0;
     for (long k = 0; k < n; ++k) {
-        const int slot = (int)((h->calls - 1 - k) % rbs_handle::kRing);
+        const int slot = (int)((h->timed_calls - 1 - k) % rbs_handle::kRing);
         float ms = 0.f;
         RBS_HIP(h, hipEventSynchronize(h->ev_stop[slot]));
         RBS_HIP(h, hipEventElapsedTime(&ms, h->ev_start[slot], h->ev_stop[slot]));
         tot += ms;
         if (h->ring_update[slot]) {
-            RBS_HIP(h, hipEventSynchronize(h->ev_join[slot]));
-            RBS_HIP(h, hipEventElapsedTime(&ms, h->ev_copy_start[slot], h->ev_join[slot]));
+            RBS_HIP(h, hipEventSynchronize(h->ev_copy_stop[slot]));
+            RBS_HIP(h, hipEventElapsedTime(&ms, h->ev_copy_start[slot], h->ev_copy_stop[slot]));
             cpy += ms;
             ++n_copy;
         }
@@ -1066,10 +1098,11 @@ int32_t rbs_raster_kernel_ms(rbs_handle* h, int32_t last_n, float* raster_kernel
     if (!raster_kernel_ms || last_n <= 0) return fail(h, RBS_ERR_INVALID_ARGUMENT, "raster_kernel_ms: bad argument");
     if (h->calls == 0) return fail(h, RBS_ERR_INVALID_ARGUMENT, "raster_kernel_ms: no loglikes launched yet");
     RBS_HIP(h, hipSetDevice(h->device));
-    const long n = std::min<long>({(long)last_n, h->calls, (long)rbs_handle::kRing});
+    const long n = std::max<long>(1, std::min<long>({((long)last_n + h->timing_every - 1) / h->timing_every,
+                                                      h->timed_calls, (long)rbs_handle::kRing}));
     double tot = 0.0;
     for (long k = 0; k < n; ++k) {
-        const int slot = (int)((h->calls - 1 - k) % rbs_handle::kRing);
+        const int slot = (int)((h->timed_calls - 1 - k) % rbs_handle::kRing);
         float ms = 0.f;
         RBS_HIP(h, hipEventSynchronize(h->ev_raster_stop[slot]));
         RBS_HIP(h, hipEventElapsedTime(&ms, h->ev_raster_start[slot], h->ev_raster_stop[slot]));

@@ -33,8 +33,13 @@
 namespace rbs {
 
 // tuning knobs (overridable with -D for A/B experiments; defaults are the measured best)
+// LDS budget: THREE raster blocks per CU.  3 waves/SIMD from three independent work items is
+// worth far more than a tile that always holds a whole rectangle (0.327 -> 0.255 ms on C1; the
+// rectangles that no longer fit split into two row bands).  The CU grants LDS in 1 280-byte
+// steps: 11 520 pixels (45 KB) + the small arrays = 53 296 B is the largest block that still
+// fits three times (11 648 pixels does not).
 #ifndef RBS_TILE_PX
-#define RBS_TILE_PX 16384
+#define RBS_TILE_PX 11520
 #endif
 #ifndef RBS_COPY_UNROLL
 #define RBS_COPY_UNROLL 8
@@ -51,11 +56,14 @@ namespace rbs {
 #endif
 constexpr int kBlock = RBS_BLOCK;          // threads per raster block (a multiple of 64)
 constexpr int kTilePx = RBS_TILE_PX;       // LDS depth tile (u32 per pixel)
-constexpr int kBigCap = 1024;              // triangles deferred to the cooperative path per chunk
+#ifndef RBS_BIG_CAP
+#define RBS_BIG_CAP 256
+#endif
+constexpr int kBigCap = RBS_BIG_CAP;       // triangles deferred to the cooperative path per chunk
 constexpr int kBigThresh = RBS_BIG_THRESH; // bbox pixels above which a triangle is "big"
 constexpr int kCopyUnroll = RBS_COPY_UNROLL; // float4 loads in flight per lane in copy blocks
 constexpr int kEvalQueue = 128;             // per-wave queue of covered pixels awaiting evaluation
-constexpr int kRectAlign = 16;              // rectangle x-alignment in pixels (64 B)
+constexpr int kRectAlign = 16;              // whole planes: rectangle x-alignment in pixels (64 B)
 constexpr float kSnapTau = 0x1p-18f;         // background snap of the occlusion process (oracle ORC_SNAP_TAU)
 constexpr unsigned kInfBits = 0x7f800000u;
 constexpr int kMaxBodies = 16;
@@ -74,6 +82,7 @@ struct DevParams {
                                    //   (min cos <= -1: never cull this cluster)
     int body_cull[kMaxBodies];     // 0: keep every triangle; +1/-1: the body is a closed, consistently
                                    //   oriented surface (sign of its signed volume): back faces may go
+    int rect_align;                // rectangle x-alignment in pixels: 16 whole planes, 4 windowed (float4)
     int tile_w, tile_h;            // work-item tile limits: width <= tile_w, pixels <= min(tile_w*tile_h, kTilePx)
     double fx, fy, cx, cy;
     double sphere[kMaxBodies][4];  // model-space bounding sphere: centre xyz, radius
@@ -203,8 +212,8 @@ __device__ inline Rect particle_rect(const DevParams& P, const double* __restric
         r.y0 = (int)fmin(fmax(floor(vmin) - 1.0, 0.0), H);
         r.y1 = (int)fmin(fmax(ceil(vmax) + 2.0, 0.0), H);
     }
-    r.x0 &= ~(kRectAlign - 1);
-    r.x1 = min(P.cols, (r.x1 + kRectAlign - 1) & ~(kRectAlign - 1));
+    r.x0 &= ~(P.rect_align - 1);
+    r.x1 = min(P.cols, (r.x1 + P.rect_align - 1) & ~(P.rect_align - 1));
     if (r.x1 <= r.x0 || r.y1 <= r.y0) { r.x0 = r.x1 = r.y0 = r.y1 = 0; }
     return r;
 }
@@ -476,10 +485,10 @@ __global__ void frame_aux_kernel(const float* __restrict__ frame, double* __rest
 // log-likelihood ratio of one covered, observed pixel + posterior occlusion.
 // Rounding points as in the oracle: a, b, p_bg -> float; a+b and the ratios in float; log in
 // double.
-__device__ inline double pixel_loglik(const DevParams& P, int gi, float o, float r, float prior,
-                                      float& posterior)
+__device__ inline double pixel_loglik(const DevParams& P, int gi, float r, float prior, float& posterior)
 {
     const size_t n = (size_t)P.npx;
+    const float o = P.frame[gi];   // finite: the pixel was queued because it is
     // the five per-frame terms of this pixel: one memory round trip
     const double inv_s2s = P.aux[(size_t)AUX_INV_S2S * n + gi];
     const double kk = P.aux[(size_t)AUX_K * n + gi];
@@ -518,7 +527,7 @@ __device__ inline double block_reduce_sum(double v, double* red)
 
 // ------------------------------------------------------------------ raster work item
 struct Smem {
-    unsigned* tile; int* big; double* red; int* nbig; int* item; int4* evalq;
+    unsigned* tile; int* big; double* red; int* nbig; int* item; int* evalq;
 };
 __device__ inline Smem carve(unsigned char* smem)
 {
@@ -528,7 +537,7 @@ __device__ inline Smem carve(unsigned char* smem)
     m.red = reinterpret_cast<double*>(smem + sizeof(unsigned) * kTilePx + sizeof(int) * kBigCap);
     m.nbig = reinterpret_cast<int*>(m.red + kBlock / 64);
     m.item = m.nbig + 1;
-    m.evalq = reinterpret_cast<int4*>(m.nbig + 4);   // 16 B aligned: all carve sizes are multiples of 16
+    m.evalq = m.nbig + 4;   // per wave: pixel index, depth bits, prior -- kEvalQueue ints each
     return m;
 }
 
@@ -568,7 +577,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     // Everything else (the occlusion process on uncovered pixels) is finished in the scan.
     double ll = 0.0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    int4* q = m.evalq + wave * kEvalQueue;
+    int* q = m.evalq + wave * 3 * kEvalQueue;   // q[0..), q[kEvalQueue..), q[2 kEvalQueue..)
     int qn = 0;
     // push this lane's pixel if `active`; evaluate 64 queued pixels as soon as there are 64
 #define RBS_PUSH_EVAL(active, gidx, depthbits, prior, obs)                                              \
@@ -578,21 +587,22 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
             if (active) {                                                                               \
                 const int pos_ = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask_ >> 32),                \
                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask_, 0));               \
-                q[pos_] = make_int4((gidx), (int)(depthbits), __float_as_int(prior), __float_as_int(obs)); \
+                q[pos_] = (gidx);                                                                       \
+                q[kEvalQueue + pos_] = (int)(depthbits);                                                \
+                q[2 * kEvalQueue + pos_] = __float_as_int(prior);                                       \
             }                                                                                           \
             qn += __popcll(mask_);                                                                      \
             if (qn >= 64) {                                                                             \
                 __builtin_amdgcn_wave_barrier();                                                        \
-                const int4 e_ = q[lane];                                                                \
+                const int eg_ = q[lane], ed_ = q[kEvalQueue + lane], ep_ = q[2 * kEvalQueue + lane];    \
                 float post_;                                                                            \
-                ll += pixel_loglik(P, e_.x, __int_as_float(e_.w), __uint_as_float((unsigned)e_.y),      \
-                                   __int_as_float(e_.z), post_);                                        \
-                if (UPDATE) dst[e_.x] = post_;                                                          \
+                ll += pixel_loglik(P, eg_, __uint_as_float((unsigned)ed_), __int_as_float(ep_), post_); \
+                if (UPDATE) dst[eg_] = post_;                                                           \
                 qn -= 64;                                                                               \
-                int4 carry_ = make_int4(0, 0, 0, 0);                                                    \
-                if (lane < qn) carry_ = q[64 + lane];                                                   \
+                int cg_ = 0, cd_ = 0, cp_ = 0;                                                          \
+                if (lane < qn) { cg_ = q[64 + lane]; cd_ = q[kEvalQueue + 64 + lane]; cp_ = q[2 * kEvalQueue + 64 + lane]; } \
                 __builtin_amdgcn_wave_barrier();                                                        \
-                if (lane < qn) q[lane] = carry_;                                                        \
+                if (lane < qn) { q[lane] = cg_; q[kEvalQueue + lane] = cd_; q[2 * kEvalQueue + lane] = cp_; } \
             }                                                                                           \
         }                                                                                               \
     } while (0)
@@ -665,11 +675,10 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
 #undef RBS_PUSH_EVAL
     __builtin_amdgcn_wave_barrier();
     if (lane < qn) {
-        const int4 e = q[lane];
+        const int eg = q[lane], ed = q[kEvalQueue + lane], ep = q[2 * kEvalQueue + lane];
         float post;
-        ll += pixel_loglik(P, e.x, __int_as_float(e.w), __uint_as_float((unsigned)e.y),
-                           __int_as_float(e.z), post);
-        if (UPDATE) dst[e.x] = post;
+        ll += pixel_loglik(P, eg, __uint_as_float((unsigned)ed), __int_as_float(ep), post);
+        if (UPDATE) dst[eg] = post;
     }
     RBS_TICK(3);
     const double total = block_reduce_sum(ll, m.red);
@@ -833,8 +842,7 @@ __global__ __launch_bounds__(1024) void rbs_scan_kernel(const int* __restrict__ 
     if (threadIdx.x == 0) *work_counter = 0;
 }
 
-// 3 waves/SIMD caps the raster kernel at 168 VGPRs (a 44-byte spill): leaves the copy kernel's
-// waves more of the register file; measured +1.5 % on the C1 call.
+// Three 4-wave blocks per CU = 3 waves/SIMD = 168 VGPRs (a few spilled dwords).
 #ifndef RBS_RASTER_MINWAVES
 #define RBS_RASTER_MINWAVES 3
 #endif
@@ -876,17 +884,21 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
         if (r.x1 > r.x0) part = raster_eval_tile<UPDATE>(P, particle, r, item - first, m);
         if (threadIdx.x == 0) {
             // the particle's log-likelihood: its only item's sum, or -- by whichever block
-            // finishes the particle's last item -- the items' sums added in item order
+            // finishes the particle's last item -- the items' sums added in item order.  The
+            // partial sums travel through device-scope atomics (performed at the memory side, so
+            // they need no fence: a release fence here would write the whole L2 back, and this
+            // kernel keeps the planes it is writing there); the exchange has returned before the
+            // counter is bumped.
             const int cnt = P.item_offset[particle + 1] - first;
             if (cnt == 1) {
                 P.out[particle] = part;
             } else {
-                P.partial[item] = part;
-                __threadfence();
-                if (atomicAdd(&P.done[particle], 1) == cnt - 1) {
-                    __threadfence();
+                unsigned long long* pp = reinterpret_cast<unsigned long long*>(P.partial);
+                const unsigned long long old = atomicExch(pp + item, (unsigned long long)__double_as_longlong(part));
+                const int bump = old == 0xfff8deadbeef0000ull ? 2 : 1;   // never 2: ties the counter to the returned value
+                if (atomicAdd(&P.done[particle], bump) == cnt - 1) {
                     double sum = 0.0;
-                    for (int k = 0; k < cnt; ++k) sum += __builtin_nontemporal_load(&P.partial[first + k]);
+                    for (int k = 0; k < cnt; ++k) sum += __longlong_as_double((long long)atomicOr(pp + first + k, 0ull));
                     P.out[particle] = sum;
                 }
             }
@@ -1099,6 +1111,6 @@ __global__ void rbs_fill_kernel(float* __restrict__ p, size_t n, float v)
 
 constexpr size_t kSmemBytes = sizeof(unsigned) * kTilePx + sizeof(int) * kBigCap +
                               sizeof(double) * (kBlock / 64) + 16 +
-                              sizeof(int4) * (kBlock / 64) * kEvalQueue;
+                              sizeof(int) * 3 * (kBlock / 64) * kEvalQueue;
 
 }  // namespace rbs

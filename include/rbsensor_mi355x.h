@@ -163,8 +163,10 @@ int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out);
 /* Device time in milliseconds of the most recent rbs_loglikes* call (HIP events recorded on the
  * launch stream around its kernels); blocks until it finished. */
 int32_t rbs_last_kernel_ms(rbs_handle* h, float* ms);
-/* Averages over the last min(last_n, 64) rbs_loglikes* calls, from HIP events the library
- * records on the streams the kernels run on: call_ms = the launch-stream part of a call
+/* Averages over the timed calls among the last last_n rbs_loglikes* calls (the library brackets
+ * every 8th call with HIP events -- RBS_TIMING_EVERY in the environment at rbs_create changes
+ * that -- and keeps the last 64 timed calls), from events recorded on the streams the kernels
+ * run on: call_ms = the launch-stream part of a call
  * (prep, scan, raster, reduce kernels); copy_kernel_ms = the copy kernel alone on its own
  * stream (updating calls only, 0 if none).  Blocks until those calls finished. */
 int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float* copy_kernel_ms,
