@@ -41,6 +41,8 @@ struct rbs_handle {
     float* d_occ[2] = {nullptr, nullptr};
     int cur = 0;
     int pending_frames = 0;     // set_observation calls since the last updating loglikes
+    const float* lazy_frame = nullptr;   // frame handed over by rbs_set_observation_device whose ingest
+    hipStream_t lazy_stream = nullptr;   //   kernel has not been launched yet (it rides on the next loglikes)
     double* d_poses = nullptr;
     int* d_indices = nullptr;
     double* d_out = nullptr;
@@ -51,12 +53,11 @@ struct rbs_handle {
     bool windowed = true;       // planes valid inside their window only (RBS_STATE=dense: whole plane)
     int smalln_target = 768;    // few particles: aim at about this many work items per call
     int rect_align = 4;         // windowed planes: rectangles move in float4 columns
-    int prep_fuse_max = 512;    // up to this many particles: rectangles + scan in one single-block launch
     int win_chunks = 8;         // row chunks (blocks) per particle of the windowed copy kernel
     float background = 0.f;     // never-covered occlusion level of the current buffer
-    int* d_tiles = nullptr;     // [max_particles] tiles per particle
-    int* d_item_offset = nullptr; // [max_particles+1]
-    int* d_work_counter = nullptr;
+    int2* d_item_range = nullptr;   // [max_particles] work items of each particle
+    int* d_item_particle = nullptr; // [partial_cap] owner of each work item
+    int* d_ctr = nullptr;           // [4] work-item counters of even / odd calls
     int* d_done = nullptr;      // [max_particles] finished work items per particle
     double* d_partial = nullptr; // [partial_cap] per-item partial sums
     unsigned long long* d_phase = nullptr;  // RBS_PHASE_TIMING builds
@@ -156,6 +157,24 @@ size_t tiles_upper_bound(int cols, int rows, int max_w, int cap_px)
     return worst;
 }
 
+// Launch the ingest of a frame rbs_set_observation_device left pending, on the stream it was
+// given for; `then` (if not that stream) is ordered after it.
+int32_t flush_lazy_frame(rbs_handle* h, hipStream_t then)
+{
+    if (!h->lazy_frame) return RBS_OK;
+    const size_t n = (size_t)h->npx;
+    hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->lazy_stream,
+                       h->lazy_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms, h->base.sf,
+                       h->base.lambda, h->d_frame);
+    RBS_HIP(h, hipGetLastError());
+    h->lazy_frame = nullptr;
+    if (then != h->lazy_stream) {
+        RBS_HIP(h, hipEventRecord(h->ev_fork, h->lazy_stream));
+        RBS_HIP(h, hipStreamWaitEvent(then, h->ev_fork, 0));
+    }
+    return RBS_OK;
+}
+
 int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indices, int n,
                          bool update, double* d_out, hipStream_t s)
 {
@@ -194,15 +213,20 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipStreamSynchronize(s));
         RBS_HIP(h, hipStreamSynchronize(h->copy_stream));
         (void)hipFree(h->d_partial);
+        (void)hipFree(h->d_item_particle);
         h->d_partial = nullptr;
+        h->d_item_particle = nullptr;
         h->partial_cap = 0;
         RBS_HIP(h, hipMalloc(&h->d_partial, sizeof(double) * need));
+        RBS_HIP(h, hipMalloc(&h->d_item_particle, sizeof(int) * need));
         h->partial_cap = need;
     }
     int* const d_rects = h->d_rects[h->calls & 1];
     P.rects = d_rects;
-    P.item_offset = h->d_item_offset;
-    P.work_counter = h->d_work_counter;
+    P.item_range = h->d_item_range;
+    P.item_particle = h->d_item_particle;
+    P.ctr_this = h->d_ctr + 2 * (int)(h->calls & 1);
+    P.ctr_next = h->d_ctr + 2 * (int)((h->calls + 1) & 1);
     P.done = h->d_done;
     P.partial = h->d_partial;
 #ifdef RBS_PHASE_TIMING
@@ -219,12 +243,15 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
         h->join_pending = -1;
     }
-    const bool fused_prep = n <= std::min(h->prep_fuse_max, rbs::kPrepScanMax);
-    if (fused_prep)
-        hipLaunchKernelGGL(rbs::rbs_prep_scan_kernel, dim3(1), dim3(1024), 0, s, P, d_rects, h->d_item_offset,
-                           h->d_work_counter, update ? 1 : 0);
-    else
-        hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(256), 0, s, P, d_rects, h->d_tiles, update ? 1 : 0);
+    if (h->lazy_frame && h->lazy_stream == s) {
+        const int aux_blocks = (h->npx + 255) / 256;
+        hipLaunchKernelGGL(rbs::rbs_frame_prep_kernel, dim3((unsigned)(aux_blocks + (n + 255) / 256)), dim3(256), 0, s, P,
+                           d_rects, update ? 1 : 0, h->lazy_frame, h->d_aux, h->d_pbg, h->d_frame, aux_blocks);
+        h->lazy_frame = nullptr;
+    } else {
+        if (int32_t rc = flush_lazy_frame(h, s)) return rc;
+        hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(256), 0, s, P, d_rects, update ? 1 : 0);
+    }
     RBS_HIP(h, hipGetLastError());
     if (update) {
         // fork: the copy kernel runs on the handle's second stream, concurrently with the
@@ -243,11 +270,6 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_stop[tslot], h->copy_stream));
             RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
         }
-    }
-    if (!fused_prep) {
-        hipLaunchKernelGGL(rbs::rbs_scan_kernel, dim3(1), dim3(1024), 0, s, h->d_tiles, h->d_item_offset, n,
-                           h->d_work_counter);
-        RBS_HIP(h, hipGetLastError());
     }
     // deferred join: the raster kernel reads planes the previous updating call's copy kernel
     // may still be writing; everything before this point overlapped with that copy's tail
@@ -322,6 +344,7 @@ int32_t materialize(rbs_handle* h, int slot, hipStream_t s)
 // Make stream `s` (and the host, if sync) see the planes of the last updating call complete.
 int32_t drain(rbs_handle* h, bool host_sync)
 {
+    if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     if (h->join_pending >= 0) {
         RBS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[h->join_pending], 0));
         if (host_sync) RBS_HIP(h, hipEventSynchronize(h->ev_join[h->join_pending]));
@@ -354,9 +377,9 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_win[0]);
     (void)hipFree(h->d_win[1]);
     (void)hipFree(h->d_win_used);
-    (void)hipFree(h->d_tiles);
-    (void)hipFree(h->d_item_offset);
-    (void)hipFree(h->d_work_counter);
+    (void)hipFree(h->d_item_range);
+    (void)hipFree(h->d_item_particle);
+    (void)hipFree(h->d_ctr);
     (void)hipFree(h->d_done);
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_cluster_sphere);
@@ -658,7 +681,6 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         if (const char* m = std::getenv("RBS_SMALLN_TARGET")) h->smalln_target = std::max(1, std::atoi(m));
         if (const char* m = std::getenv("RBS_RECT_ALIGN")) h->rect_align = std::atoi(m) >= 16 ? 16 : (std::atoi(m) >= 8 ? 8 : 4);
         if (const char* m = std::getenv("RBS_TIMING_EVERY")) h->timing_every = std::max(1, std::atoi(m));
-        if (const char* m = std::getenv("RBS_PREP_FUSE_MAX")) h->prep_fuse_max = std::atoi(m);
         if (const char* m = std::getenv("RBS_WIN_CHUNKS")) h->win_chunks = std::min(1024, std::max(1, std::atoi(m)));
         if (h->cols & 3) h->windowed = false;   // windows move whole float4s
         h->base.rect_align = h->windowed ? h->rect_align : rbs::kRectAlign;
@@ -680,9 +702,9 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMalloc(&h->d_win[0], sizeof(int4) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_win[1], sizeof(int4) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_win_used, sizeof(int4) * (size_t)h->max_particles));
-    RBS_HIP(h, hipMalloc(&h->d_tiles, sizeof(int) * (size_t)h->max_particles));
-    RBS_HIP(h, hipMalloc(&h->d_item_offset, sizeof(int) * ((size_t)h->max_particles + 1)));
-    RBS_HIP(h, hipMalloc(&h->d_work_counter, sizeof(int)));
+    RBS_HIP(h, hipMalloc(&h->d_item_range, sizeof(int2) * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_ctr, sizeof(int) * 4));
+    RBS_HIP(h, hipMemset(h->d_ctr, 0, sizeof(int) * 4));
     RBS_HIP(h, hipMalloc(&h->d_done, sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_cluster_sphere, sizeof(float) * cluster_sphere.size()));
     RBS_HIP(h, hipMemcpy(h->d_cluster_sphere, cluster_sphere.data(), sizeof(float) * cluster_sphere.size(),
@@ -709,6 +731,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
             need = std::max(need, (size_t)std::min(2 * nn, h->max_particles) * tiles_upper_bound(h->cols, h->rows, 256, 256 * th));
         }
         RBS_HIP(h, hipMalloc(&h->d_partial, sizeof(double) * need));
+        RBS_HIP(h, hipMalloc(&h->d_item_particle, sizeof(int) * need));
         h->partial_cap = need;
     }
     // HIP creates a stream's hardware queue at its first submission: do that now, not inside the
@@ -799,6 +822,7 @@ int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("set_observation: expected %d pixels, got %zu", h->npx, n));
     RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     RBS_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer reuse
     for (size_t p = 0; p < n; ++p) h->h_frame[p] = (float)depth[p];
     if (int32_t rc = upload_frame(h)) return rc;
@@ -813,6 +837,7 @@ int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("set_observation_f32: expected %d pixels, got %zu", h->npx, n));
     RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     RBS_HIP(h, hipStreamSynchronize(h->stream));
     std::memcpy(h->h_frame, depth, n * sizeof(float));
     if (int32_t rc = upload_frame(h)) return rc;
@@ -829,6 +854,7 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
                     fmt("set_observation_native: %dx%d / %d does not give the evaluated %dx%d", width,
                         height, f, h->cols, h->rows));
     RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     RBS_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer reuse
     const size_t n = (size_t)width * height;
     if (n > h->native_cap) {
@@ -858,12 +884,12 @@ int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* st
     if (!d_depth) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_observation_device: null pointer");
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
-    const size_t n = (size_t)h->npx;
-    // one kernel: copy the frame into the handle's buffer and derive the per-pixel model terms
-    hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                       d_depth, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms, h->base.sf,
-                       h->base.lambda, h->d_frame);
-    RBS_HIP(h, hipGetLastError());
+    // the ingest kernel (copy into the handle's buffer + per-pixel model terms) is not launched
+    // here: it shares a launch with the next rbs_loglikes* call's rectangles kernel when that
+    // call comes on the same stream, and is launched on `s` by whatever needs the frame otherwise
+    if (int32_t rc = flush_lazy_frame(h, s)) return rc;   // an earlier frame nobody evaluated
+    h->lazy_frame = d_depth;
+    h->lazy_stream = s;
     h->pending_frames += 1;
     return RBS_OK;
 }
@@ -873,6 +899,7 @@ int32_t rbs_get_observation(rbs_handle* h, float* out)
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
     if (!out) return fail(h, RBS_ERR_INVALID_ARGUMENT, "get_observation: null pointer");
     RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     RBS_HIP(h, hipStreamSynchronize(h->stream));
     RBS_HIP(h, hipMemcpy(out, h->d_frame, sizeof(float) * h->npx, hipMemcpyDeviceToHost));
     return RBS_OK;

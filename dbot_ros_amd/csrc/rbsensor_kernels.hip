@@ -107,8 +107,10 @@ struct DevParams {
     int n;
     int bands, band_rows;          // copy blocks per particle, rows per band
     const int* rects;              // [n][4] screen rectangles (rbs_prep_kernel)
-    const int* item_offset;        // [n+1] exclusive scan of tiles per particle
-    int* work_counter;             // atomic queue head over the (particle, tile) items
+    int2* item_range;              // [n] (first work item, number of work items) of each particle
+    int* item_particle;            // [items] owner of each work item
+    int* ctr_this;                 // [2] this call's (items allotted, items taken) counters ...
+    int* ctr_next;                 // [2] ... and the next call's, zeroed by this call's raster kernel
     double* partial;               // [items] partial log-likelihood per work item
     int* done;                     // [n] finished work items per particle (the last one sums them)
 #ifdef RBS_PHASE_TIMING
@@ -464,12 +466,10 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
 enum { AUX_INV_S2S = 0, AUX_K = 1, AUX_CV = 2, AUX_EO = 3, AUX_PLANES = 4 };
 
 // keep != nullptr: `frame` is the caller's buffer and is also copied into the handle's own.
-__global__ void frame_aux_kernel(const float* __restrict__ frame, double* __restrict__ aux,
-                                 float* __restrict__ pbg, int npx, double tw, double ms, double sf,
-                                 double lam, float* __restrict__ keep)
+__device__ inline void frame_aux_pixel(int i, const float* __restrict__ frame, double* __restrict__ aux,
+                                       float* __restrict__ pbg, int npx, double tw, double ms, double sf,
+                                       double lam, float* __restrict__ keep)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npx) return;
     const float of = frame[i];
     if (keep) keep[i] = of;
     const double o = (double)of;
@@ -480,6 +480,14 @@ __global__ void frame_aux_kernel(const float* __restrict__ frame, double* __rest
     aux[(size_t)AUX_CV * npx + i] = (1.0 - tw) / (sqrt(2.0 * M_PI) * sigma);
     aux[(size_t)AUX_EO * npx + i] = 0.5 * (1.0 - tw) * lam * eo;
     pbg[i] = (float)(tw / kMaxDepth + (1.0 - tw) * lam * eo);
+}
+
+__global__ void frame_aux_kernel(const float* __restrict__ frame, double* __restrict__ aux,
+                                 float* __restrict__ pbg, int npx, double tw, double ms, double sf,
+                                 double lam, float* __restrict__ keep)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npx) frame_aux_pixel(i, frame, aux, pbg, npx, tw, ms, sf, lam, keep);
 }
 
 // log-likelihood ratio of one covered, observed pixel + posterior occlusion.
@@ -759,12 +767,18 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
 // bounding box of the parent's window and the rectangle -- and seeds the child's window with the
 // rectangle (the copy kernel grows it over every value it writes that differs from the
 // background).  An empty window is (cols, rows, 0, 0), so unions are plain min/max.
-__device__ inline int prep_particle(const DevParams& P, int i, int* __restrict__ rects, int update)
+__device__ inline void prep_particle(const DevParams& P, int i, int* __restrict__ rects, int update)
 {
     const Rect r = particle_rect(P, P.poses + (size_t)i * 12 * P.n_bodies);
     reinterpret_cast<int4*>(rects)[i] = make_int4(r.x0, r.y0, r.x1, r.y1);
     const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, kTilePx));
     P.done[i] = 0;
+    {   // work items: any free range will do -- a particle's items are summed in their own order
+        const int cnt = r.x1 > r.x0 ? tg.nx * tg.ny : 1;   // an empty rectangle still owns one (empty) item
+        const int first = atomicAdd(&P.ctr_this[0], cnt);
+        P.item_range[i] = make_int2(first, cnt);
+        for (int k = 0; k < cnt; ++k) P.item_particle[first + k] = i;
+    }
     if (update && P.windowed) {
         const int4 rw = r.x1 > r.x0 ? make_int4(r.x0, r.y0, r.x1, r.y1) : make_int4(P.cols, P.rows, 0, 0);
         const int parent = P.indices[i];
@@ -773,73 +787,28 @@ __device__ inline int prep_particle(const DevParams& P, int i, int* __restrict__
         P.win_used[i] = make_int4(min(pw.x, rw.x), min(pw.y, rw.y), max(pw.z, rw.z), max(pw.w, rw.w));
         P.win_dst[i] = rw;
     }
-    return r.x1 > r.x0 ? tg.nx * tg.ny : 1;   // an empty rectangle still owns one (empty) item
 }
 
-__global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int* __restrict__ tiles,
-                                int update)
+__global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int update)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
-    tiles[i] = prep_particle(P, i, rects, update);
+    prep_particle(P, i, rects, update);
 }
 
-// Up to 4096 particles: rectangles AND the scan in one single-block launch (each thread owns up
-// to four consecutive particles) -- one kernel and one launch gap less on the per-frame chain.
-constexpr int kPrepScanMax = 4096;
-__global__ __launch_bounds__(1024) void rbs_prep_scan_kernel(const DevParams P, int* __restrict__ rects,
-                                                              int* __restrict__ offset,
-                                                              int* __restrict__ work_counter, int update)
+// A frame handed over on the device right before this call: its per-pixel terms (the first
+// aux_blocks blocks) and the particles' rectangles (the rest) are independent, one launch.
+__global__ void rbs_frame_prep_kernel(const DevParams P, int* __restrict__ rects, int update,
+                                      const float* __restrict__ frame_src, double* __restrict__ aux,
+                                      float* __restrict__ pbg, float* __restrict__ keep, int aux_blocks)
 {
-    __shared__ int part[1024];
-    const int n = P.n;
-    const int per = (n + 1023) / 1024;
-    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
-    int cnt[kPrepScanMax / 1024];
-    int sum = 0;
-#pragma unroll
-    for (int k = 0; k < kPrepScanMax / 1024; ++k) {
-        cnt[k] = 0;
-        if (lo + k < hi) { cnt[k] = prep_particle(P, lo + k, rects, update); sum += cnt[k]; }
+    if ((int)blockIdx.x < aux_blocks) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < P.npx) frame_aux_pixel(i, frame_src, aux, pbg, P.npx, P.tw, P.ms, P.sf, P.lambda, keep);
+    } else {
+        const int i = ((int)blockIdx.x - aux_blocks) * blockDim.x + threadIdx.x;
+        if (i < P.n) prep_particle(P, i, rects, update);
     }
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
-        const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-#pragma unroll
-    for (int k = 0; k < kPrepScanMax / 1024; ++k)
-        if (lo + k < hi) { offset[lo + k] = run; run += cnt[k]; }
-    if (threadIdx.x == 1023) offset[n] = part[1023];
-    if (threadIdx.x == 0) *work_counter = 0;
-}
-
-// Single block: exclusive scan tiles[0..n) -> offset[0..n]; resets the work queue.
-__global__ __launch_bounds__(1024) void rbs_scan_kernel(const int* __restrict__ tiles,
-                                                         int* __restrict__ offset, int n,
-                                                         int* __restrict__ work_counter)
-{
-    __shared__ int part[1024];
-    const int per = (n + 1023) / 1024;
-    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += tiles[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
-        const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-    for (int i = lo; i < hi; ++i) { offset[i] = run; run += tiles[i]; }
-    if (threadIdx.x == 1023) offset[n] = part[1023];
-    if (threadIdx.x == 0) *work_counter = 0;
 }
 
 // Three 4-wave blocks per CU = 3 waves/SIMD = 168 VGPRs (a few spilled dwords).
@@ -854,32 +823,23 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Smem m = carve(smem);
-    const int total = P.item_offset[P.n];
+    const int total = P.ctr_this[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr_next[0] = 0; P.ctr_next[1] = 0; }
 #ifdef RBS_PHASE_TIMING
     const unsigned long long c0_ = clock64(), w0_ = wall_clock64();
 #endif
     for (;;) {
-        if (threadIdx.x == 0) *m.item = atomicAdd(P.work_counter, 1);
+        if (threadIdx.x == 0) *m.item = atomicAdd(&P.ctr_this[1], 1);
         __syncthreads();
         const int item = __builtin_amdgcn_readfirstlane(*m.item);
         if (item >= total) break;
-        // particle owning this item: largest i with item_offset[i] <= item (64-ary search, wave-parallel)
-        int lo = 0, hi = P.n;
-        const int lane = threadIdx.x & 63;
-        while (hi - lo > 1) {
-            const int step = (hi - lo + 63) >> 6;
-            const int idx = lo + lane * step;
-            const bool le = idx < hi && P.item_offset[idx] <= item;
-            const int k = __popcll(__ballot(le));   // probes are sorted: the first k lanes are true
-            lo = lo + (k - 1) * step;
-            hi = min(hi, lo + step);
-        }
-        // wave-uniform by construction: tell the compiler, so the pose / rectangle / parent index
-        // become scalar loads held in SGPRs instead of per-lane vector loads in every loop
-        const int particle = __builtin_amdgcn_readfirstlane(lo);
+        // wave-uniform: tell the compiler, so the pose / rectangle / parent index become scalar
+        // loads held in SGPRs instead of per-lane vector loads in every loop
+        const int particle = __builtin_amdgcn_readfirstlane(P.item_particle[item]);
         const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
         const Rect r = {q.x, q.y, q.z, q.w};
-        const int first = P.item_offset[particle];
+        const int2 range = P.item_range[particle];
+        const int first = range.x;
         double part = 0.0;
         if (r.x1 > r.x0) part = raster_eval_tile<UPDATE>(P, particle, r, item - first, m);
         if (threadIdx.x == 0) {
@@ -889,7 +849,7 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
             // they need no fence: a release fence here would write the whole L2 back, and this
             // kernel keeps the planes it is writing there); the exchange has returned before the
             // counter is bumped.
-            const int cnt = P.item_offset[particle + 1] - first;
+            const int cnt = range.y;
             if (cnt == 1) {
                 P.out[particle] = part;
             } else {

@@ -100,8 +100,10 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
                                        int32_t height, int32_t downsampling_factor);
 /* The same from DEVICE memory on the handle's device (float[rows*cols], evaluated resolution):
  * for frames that are already on the GPU (a driver / preprocessing stage there, or a caller
- * replaying a resident sequence).  Enqueued on `stream` (NULL = the handle's own stream), no
- * host synchronisation; the caller keeps `d_depth` alive until that work has run. */
+ * replaying a resident sequence).  Ordered on `stream` (NULL = the handle's own stream), no
+ * host synchronisation.  The ingest kernel is launched by the next rbs_* call that needs the
+ * frame (it shares a launch with the next rbs_loglikes_device on the same stream): the caller
+ * keeps `d_depth` alive and unchanged until that call's work has run. */
 int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* stream);
 /* Current evaluated observation -> host float[rows*cols] (inspection). */
 int32_t rbs_get_observation(rbs_handle* h, float* out);

@@ -680,3 +680,48 @@ def test_many_particles_and_many_tiles(gpu_lib):
             assert_planes_match(g.get_occlusion(47), eager.get_occlusion(47))
             runs.append(np.concatenate(lls))
     assert np.array_equal(runs[0], runs[1])
+
+
+def test_device_resident_frames(gpu_lib):
+    """rbs_set_observation_device: frames already in HBM give exactly what the host-pointer
+    ingest gives -- through the asynchronous device-pointer loglikes (where the ingest shares a
+    launch with the call), through the host-pointer loglikes, with a frame nobody evaluated in
+    between, and rbs_get_observation sees the pending frame."""
+    import torch
+    n, cols, rows = 40, 160, 120
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    o = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    rng = np.random.default_rng(9)
+    truths = [synth.truth_pose(1, frame=k) for k in range(5)]
+    frames = [synth.make_frame(o.render_depth(t), rows, cols, rng).astype(np.float32) for t in truths]
+    poses = [synth.particle_poses(t, n, rng) for t in truths]
+    dev = torch.device("cuda", 0)
+    d_frames = [torch.from_numpy(f).to(dev) for f in frames]
+    stream = torch.cuda.Stream(device=dev)
+    with RbSensor(om, cam, P, max_particles=n) as a, RbSensor(om, cam, P, max_particles=n) as b:
+        ia, ib = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for k in range(5):
+            a.set_observation(frames[k])
+            if k == 2:                       # a frame that is never evaluated: time still advances
+                a.set_observation(frames[k])
+                b.set_observation_device(d_frames[k - 1].data_ptr(), stream.cuda_stream)
+            b.set_observation_device(d_frames[k].data_ptr(), stream.cuda_stream)
+            if k == 1:
+                assert np.array_equal(b.get_observation(), frames[k], equal_nan=True)
+            la = a.loglikes_poses(poses[k], ia, update=True)
+            if k % 2 == 0:                   # host-pointer call picks the pending frame up
+                lb = b.loglikes_poses(poses[k], ib, update=True)
+            else:                            # device-pointer call on the frame's stream
+                dp = torch.from_numpy(poses[k].reshape(n, -1)).to(dev)
+                di = torch.from_numpy(ib).to(dev)
+                do = torch.empty(n, dtype=torch.float64, device=dev)
+                torch.cuda.synchronize()
+                b.loglikes_device(dp.data_ptr(), di.data_ptr(), n, True, do.data_ptr(), stream.cuda_stream)
+                b.synchronize()
+                torch.cuda.synchronize()
+                lb = do.cpu().numpy()
+                ib[:] = np.arange(n)
+            assert np.array_equal(la, lb)
+            par = rng.permutation(n).astype(np.int32)
+            ia, ib = par.copy(), par.copy()
+        assert np.array_equal(a.get_occlusion(3), b.get_occlusion(3))
