@@ -684,6 +684,9 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         if (const char* m = std::getenv("RBS_WIN_CHUNKS")) h->win_chunks = std::min(1024, std::max(1, std::atoi(m)));
         if (h->cols & 3) h->windowed = false;   // windows move whole float4s
         h->base.rect_align = h->windowed ? h->rect_align : rbs::kRectAlign;
+        // whole planes: the big copy kernel must run BESIDE the raster kernel, and three raster
+        // blocks per CU hold 504 of a SIMD's 512 VGPRs -- two leave room for the copy waves
+        if (!h->windowed && !std::getenv("RBS_RASTER_BLOCKS")) h->raster_blocks = 2 * std::max(1, prop.multiProcessorCount);
     }
     RBS_HIP(h, hipMalloc(&h->d_soup, soup.size() * sizeof(double)));
     RBS_HIP(h, hipMemcpy(h->d_soup, soup.data(), soup.size() * sizeof(double), hipMemcpyHostToDevice));

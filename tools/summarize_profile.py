@@ -60,7 +60,7 @@ if os.path.exists(cal_f):
                               "fetch_correction": fetch_scale, "write_correction": write_scale}
 total = 0.0
 for (k, c), v in sorted(fetch.items()):
-    if any(t in k for t in ("rbs_copy_kernel", "rbs_copy_rows_kernel", "rbs_copy_window_kernel", "rbs_raster_kernel", "rbs_prep_kernel",
+    if any(t in k for t in ("rbs_copy_kernel", "rbs_copy_rows_kernel", "rbs_copy_window_kernel", "rbs_raster_kernel", "rbs_prep_kernel", "rbs_frame_prep_kernel",
                                 "rbs_scan_kernel", "rbs_reduce_kernel", "frame_aux_kernel")):
         wv = write.get((k, "WRITE_SIZE"), 0.0)
         # the x2 fetch correction is calibrated for 16 B/lane streams (the copy kernel); the raster
