@@ -725,3 +725,47 @@ def test_device_resident_frames(gpu_lib):
             par = rng.permutation(n).astype(np.int32)
             ia, ib = par.copy(), par.copy()
         assert np.array_equal(a.get_occlusion(3), b.get_occlusion(3))
+
+
+def test_layouts_agree_through_the_device_tracker(gpu_lib, monkeypatch):
+    """The whole filter loop (transition, loglikes, weights, resampling on the device) run on
+    windowed planes and on whole planes from the same seed: bitwise identical estimates, frame
+    after frame, with an occluder passing through -- the layout changes bytes moved, never a
+    number."""
+    from dbot_ros_amd import CameraData, ObjectModel, RbSensorBuilder, pose
+    from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
+    n, cols, rows = 192, 160, 120
+    v, f = synth.mesh_m1(level=2)
+    om = ObjectModel([v], [f])
+    cam = CameraData(synth.camera_matrix(cols, rows), rows, cols)
+    P = RbSensorBuilder.Parameters(sample_count=n)
+
+    def truth_state(k):
+        Rt = synth.truth_pose(1, frame=k)[0]
+        st = np.zeros(12)
+        st[3:6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+        st[0:3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0]
+        return st
+
+    out = {}
+    for layout in ("window", "dense"):
+        monkeypatch.setenv("RBS_STATE", layout)
+        with RbSensor(om, cam, P, max_particles=n) as s:
+            tr = DeviceParticleTracker(ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters()).build(), s, om,
+                                       ParticleTrackerBuilder.Parameters(evaluation_count=n), device_rng=True, seed=3)
+            tr.initialize([truth_state(0)])
+            rng = np.random.default_rng(0)
+            ests = []
+            for k in range(1, 121):
+                kk = k % 40 if k % 40 < 20 else 40 - (k % 40)
+                fr = synth.make_frame(s.render_depth(synth.truth_pose(1, frame=kk)), rows, cols, rng,
+                                      occluder=(k % 50 > 35))
+                ests.append(tr.track(fr).copy())
+            w = s.get_window(0)
+            out[layout] = (np.array(ests), w)
+            tr.close()
+    assert np.array_equal(out["window"][0], out["dense"][0])
+    assert np.isfinite(out["window"][0]).all()
+    ww = out["window"][1]
+    assert (ww[2] - ww[0]) * (ww[3] - ww[1]) < cols * rows // 2
+    assert out["dense"][1] == (0, 0, cols, rows)

@@ -28,4 +28,4 @@ with RbSensor(om, cam, P, max_particles=n) as s:
         tot = c[1:5].sum()
         print("rep", rep, "ms", "%.3f" % s.last_kernel_ms(), {names[k]: "%.1f%%" % (100 * c[k] / tot) for k in range(1, 5)},
               "wave0 cycles per item: %.0f" % (tot / n),
-              "| block lifetime: %.0f cycles, %.1f us wall -> %.2f GHz shader clock" % (c[5] / 512, c[6] / 512 / 100.0, c[5] / max(c[6], 1) * 0.1))
+              "| block lifetime: %.0f cycles, %.1f us wall -> %.2f GHz shader clock" % (c[5] / 768, c[6] / 768 / 100.0, c[5] / max(c[6], 1) * 0.1))
