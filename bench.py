@@ -247,6 +247,21 @@ def main():
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # what bounds the dominant kernel when it is not HBM: VALU issue, from the committed SQ
+        # counter summary of this same command (tools/profile_round.sh); live: measured HBM rate
+        valu = None
+        sqf = os.path.join(ROOT, "profiles", "r01_raster_sq.json" if layout == "window" else "r01_dense_raster_sq.json")
+        if os.path.exists(sqf) and kernel_name == "rbs_raster_kernel":
+            try:
+                j = json.load(open(sqf))
+                per = j["per_dispatch"]
+                valu = {"valu_wave_instructions_per_launch": per["SQ_INSTS_VALU"],
+                        "issue_rate_G_per_s": per["SQ_INSTS_VALU"] / (kernel_ms * 1e-3) / 1e9,
+                        "peak_issue_rate_G_per_s": 256 * 4 * 2.4 / 4.0 * 1.0,   # 1 024 SIMDs, one wave64 VALU op per 4 cycles, 2.4 GHz
+                        "source": os.path.relpath(sqf, ROOT)}
+                valu["frac"] = valu["issue_rate_G_per_s"] / valu["peak_issue_rate_G_per_s"]
+            except Exception:
+                valu = None
         out = {
             "metric": "particle-likelihoods/sec @640x480" if (a.cols, a.rows) == (640, 480)
                       else f"particle-likelihoods/sec @{a.cols}x{a.rows}",
@@ -267,6 +282,8 @@ def main():
                          "kernel_ms": kernel_ms, "kernel_launches_averaged": n_used,
                          "raster_kernel_ms": raster_ms, "copy_kernel_ms": copy_ms,
                          "state_layout": layout, "stored_window_fraction_of_plane": win_frac,
+                         "measured_hbm_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+                         "valu_issue": valu,
                          "call_ms_launch_stream": call_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }

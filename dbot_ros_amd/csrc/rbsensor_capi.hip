@@ -5,6 +5,7 @@
 //   soup      9 * n_tri doubles, SoA triangle soup                     (368 KB @5 120 tris)
 //   frame     rows*cols float, current observation                     (1.2 MB)
 //   occ[2]    2 * N * rows*cols float, double-buffered occlusion planes (2.46 MB * N)
+//   win[2]    2 * N int4 + one float: a plane is explicit inside its window, the background elsewhere
 //   poses / indices / out   per-call staging for the host-pointer API
 // There is no CPU path in this library.
 #include "rbsensor_kernels.hip"
