@@ -510,14 +510,28 @@ __device__ inline double pixel_loglik(const DevParams& P, int gi, float r, float
 #endif
     const double w = ((double)r - (double)o) * inv_s2s;
     const double twD = P.tw / kMaxDepth;
-    const double pv = twD + cv * exp(-(w * w));
-    const double E1 = exp((double)r * P.lambda);
-    const double po = twD + eo * (E1 / (E1 - 1.0)) * (1.0 + erf(w + kk));
+#if defined(RBS_EXP_NOERF)      // profiling builds: what each transcendental costs (finite stand-ins)
+#define RBS_ERF_(x) (fabs(x) * 1e-3)
+#else
+#define RBS_ERF_(x) erf(x)
+#endif
+#if defined(RBS_EXP_NOEXP)
+#define RBS_EXP_(x) (2.0 + fabs(x))
+#else
+#define RBS_EXP_(x) exp(x)
+#endif
+    const double pv = twD + cv * RBS_EXP_(-(w * w));
+    const double E1 = RBS_EXP_((double)r * P.lambda);
+    const double po = twD + eo * (E1 / (E1 - 1.0)) * (1.0 + RBS_ERF_(w + kk));
     const float a = (float)(pv * (1.0 - (double)prior));
     const float b = (float)(po * (double)prior);
     const float sum = a + b;
     posterior = b / sum;
+#if defined(RBS_EXP_NOLOG)
+    return (double)(sum / pbg);
+#else
     return log((double)(sum / pbg));
+#endif
 }
 
 __device__ inline double block_reduce_sum(double v, double* red)
