@@ -166,7 +166,7 @@ int32_t flush_lazy_frame(rbs_handle* h, hipStream_t then)
     const size_t n = (size_t)h->npx;
     hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->lazy_stream,
                        h->lazy_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms, h->base.sf,
-                       h->base.lambda, h->d_frame);
+                       h->base.lambda, h->lazy_frame == h->d_frame ? (float*)nullptr : h->d_frame);
     RBS_HIP(h, hipGetLastError());
     h->lazy_frame = nullptr;
     if (then != h->lazy_stream) {
@@ -247,7 +247,8 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     if (h->lazy_frame && h->lazy_stream == s) {
         const int aux_blocks = (h->npx + 255) / 256;
         hipLaunchKernelGGL(rbs::rbs_frame_prep_kernel, dim3((unsigned)(aux_blocks + (n + 255) / 256)), dim3(256), 0, s, P,
-                           d_rects, update ? 1 : 0, h->lazy_frame, h->d_aux, h->d_pbg, h->d_frame, aux_blocks);
+                           d_rects, update ? 1 : 0, h->lazy_frame, h->d_aux, h->d_pbg,
+                           h->lazy_frame == h->d_frame ? (float*)nullptr : h->d_frame, aux_blocks);
         h->lazy_frame = nullptr;
     } else {
         if (int32_t rc = flush_lazy_frame(h, s)) return rc;
@@ -410,10 +411,9 @@ int32_t upload_frame(rbs_handle* h)
     const size_t n = (size_t)h->npx;
     RBS_HIP(h, hipMemcpyAsync(h->d_frame, h->h_frame, n * sizeof(float), hipMemcpyHostToDevice,
                               h->stream));
-    hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       h->stream, h->d_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms,
-                       h->base.sf, h->base.lambda, (float*)nullptr);
-    RBS_HIP(h, hipGetLastError());
+    // the per-pixel terms kernel rides on the next loglikes launch (flush_lazy_frame otherwise)
+    h->lazy_frame = h->d_frame;
+    h->lazy_stream = h->stream;
     return RBS_OK;
 }
 
@@ -874,10 +874,8 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
     hipLaunchKernelGGL(rbs::rbs_subsample_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0,
                        h->stream, h->d_native, width, f, h->d_frame, h->rows, h->cols);
     RBS_HIP(h, hipGetLastError());
-    hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0,
-                       h->stream, h->d_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms,
-                       h->base.sf, h->base.lambda, (float*)nullptr);
-    RBS_HIP(h, hipGetLastError());
+    h->lazy_frame = h->d_frame;   // per-pixel terms: with the next loglikes launch
+    h->lazy_stream = h->stream;
     h->pending_frames += 1;
     return RBS_OK;
 }
