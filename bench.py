@@ -33,8 +33,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", type=int, default=2000, help="particles per GPU")
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--rows", type=int, default=480)
@@ -300,7 +300,7 @@ def main():
             for _ in range(a.warmup):
                 launch(dense)
             torch.cuda.synchronize()
-            dsteps = min(a.steps, 60)
+            dsteps = min(a.steps, 120)
             td = time.perf_counter()
             for _ in range(dsteps):
                 launch(dense)
