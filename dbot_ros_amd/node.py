@@ -59,3 +59,29 @@ def to_eigen_vector(native_image, downsampling_factor):
     f = int(downsampling_factor)
     rows, cols = img.shape[0] // f, img.shape[1] // f
     return np.ascontiguousarray(img[: rows * f: f, : cols * f: f]).ravel()
+
+
+def replay_dataset(params, dataset, mesh_package_path, initial_states, device_id=0, seed=0, max_frames=None):
+    """Run the tracker over a recorded TrackingDataset (dbot_ros_amd.dataset) the way
+    the node runs over live topics: K from the bag's camera_info (frame 0, as GetCameraMatrix does,
+    R:source/dbot_ros/util/tracking_dataset.cpp:157-164), every depth image sub-sampled by
+    `downsampling_factor` (R:source/dbot_ros/util/ros_interface.h:152-168) and handed to
+    tracker.track (R:source/dbot_ros/object_tracker_ros.hpp:44-49).
+    Returns (estimates [frames, parts*12], wall seconds of the tracking loop)."""
+    import time
+    tracker, object_model, camera_data, _ = build_particle_tracker(params, dataset.get_camera_matrix(0),
+                                                                   mesh_package_path, device_id=device_id, seed=seed)
+    f = int(params["downsampling_factor"])
+    try:
+        tracker.initialize(initial_states)
+        n = dataset.size() if max_frames is None else min(max_frames, dataset.size())
+        frames = [dataset.frame_vector(i, f) for i in range(n)]      # host decode outside the timed loop
+        ests = []
+        t0 = time.perf_counter()
+        for fr in frames:
+            ests.append(tracker.track(fr))
+        wall = time.perf_counter() - t0
+    finally:
+        tracker.close()
+        tracker.sensor.close()
+    return np.array(ests), wall

@@ -103,3 +103,43 @@ def test_node_assembly_tracks_at_the_reference_operating_point(tmp_path, gpu_lib
     assert max(errs[-5:]) < 0.025, errs   # 80x60: one pixel is 8.8 mm at 0.7 m -> a few pixels
     tracker.close()
     sensor.close()
+
+
+@pytest.mark.gpu
+def test_replay_of_a_recorded_dataset(tmp_path, gpu_lib):
+    """SURVEY 8 f4 end to end: a recorded dataset directory (measurements.bag + ground_truth.txt,
+    written here by the ROS-free writer from native 640x480 frames) is loaded back and tracked
+    through the node assembly at the reference's operating point; the estimates follow the
+    recorded ground truth."""
+    from dbot_ros_amd import CameraData, RbSensor, RbSensorBuilder
+    from dbot_ros_amd import dataset as ds
+    paths = _write(tmp_path)
+    tree = node.load_rosparams(*paths)
+    K = synth.camera_matrix(640, 480)
+    vs, ts = objloader.SimpleWavefrontObjectModelLoader(
+        objloader.ObjectResourceIdentifier(str(tmp_path), "object_models", ["part.obj"])).load()
+    from dbot_ros_amd import ObjectModel
+    om = ObjectModel(vs, ts, center=True)
+
+    def truth_state(k):
+        Rt = synth.truth_pose(1, frame=k)[0]
+        s = np.zeros(12)
+        s[3:6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+        s[0:3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0]
+        return s
+
+    rng = np.random.default_rng(0)
+    rec = ds.TrackingDataset(tmp_path / "recording", load=False)
+    with RbSensor(om, CameraData(K, 480, 640), RbSensorBuilder.Parameters(sample_count=1), max_particles=1) as full:
+        for k in range(1, 13):
+            native = synth.make_frame(full.render_depth(synth.truth_pose(1, frame=k)), 480, 640, rng, occluder=False)
+            stamp = ds.Stamp.from_sec(1500000000.0 + k / 30.0)
+            rec.add_frame(ds.Image(native.reshape(480, 640), stamp, seq=k), ds.CameraInfo(K, 480, 640, stamp, seq=k),
+                          ground_truth=truth_state(k))
+    rec.store()
+    data = ds.TrackingDataset(tmp_path / "recording")
+    assert data.size() == 12 and np.array_equal(data.get_camera_matrix(5), K)
+    ests, wall = node.replay_dataset(tree, data, str(tmp_path), [truth_state(0)], seed=3)
+    assert ests.shape == (12, 12) and wall > 0
+    err = [np.linalg.norm(ests[i, 0:3] - data.get_ground_truth(i)[0:3]) for i in range(12)]
+    assert max(err[-4:]) < 0.025, err
