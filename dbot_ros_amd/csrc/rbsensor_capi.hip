@@ -199,7 +199,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.out = d_out;
     P.n = n;
     const int slot = (int)(h->calls % rbs_handle::kRing);          // ev_join
-    const bool timed = h->timing_every <= 1 || h->calls % h->timing_every == 0;
+    const bool timed = h->timing_every <= 1 || h->calls < 4 || h->calls % h->timing_every == 0;   // and the first few, so short sessions have a warm sample
     const int tslot = (int)(h->timed_calls % rbs_handle::kRing);    // timing events
     if (timed) h->ring_update[tslot] = update;
     // tile limits: as large as the LDS tile allows (a particle's rectangle is then usually ONE
