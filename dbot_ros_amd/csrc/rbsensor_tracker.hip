@@ -273,11 +273,33 @@ __global__ __launch_bounds__(1024) void mean_kernel(const TrackerDev T)
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 1024) s += exp(T.logw[i] - m);
     const double S = block_sum(s, sh);
-    for (int d = 0; d < T.D; ++d) {
-        double a = 0.0;
-        for (int i = threadIdx.x; i < n; i += 1024) a += (exp(T.logw[i] - m) / S) * T.part_new[(size_t)i * T.D + d];
-        a = block_sum(a, sh);
-        if (threadIdx.x == 0) T.mean[d] = a;
+    // the twelve components of a body are reduced together: each one's additions are exactly
+    // those of block_sum (same per-thread order, same shuffle tree, same order over the waves),
+    // with two barriers per body instead of twenty-four
+    __shared__ double shb[16][kBody];
+    for (int b = 0; b < T.parts; ++b) {
+        double a[kBody];
+#pragma unroll
+        for (int k = 0; k < kBody; ++k) a[k] = 0.0;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const double w = exp(T.logw[i] - m) / S;
+            const double* p = T.part_new + (size_t)i * T.D + b * kBody;
+#pragma unroll
+            for (int k = 0; k < kBody; ++k) a[k] += w * p[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kBody; ++k)
+            for (int off = 32; off > 0; off >>= 1) a[k] += __shfl_down(a[k], off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int k = 0; k < kBody; ++k) shb[threadIdx.x >> 6][k] = a[k];
+        __syncthreads();
+        if ((int)threadIdx.x < kBody) {
+            double sum = 0.0;
+            for (int w = 0; w < 16; ++w) sum += shb[w][threadIdx.x];
+            T.mean[b * kBody + threadIdx.x] = sum;
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x < T.parts) {
