@@ -536,6 +536,13 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
             std::map<std::pair<int, int>, int> edges;
             double vol6 = 0.0, avol6 = 0.0;
             bool ok = true;
+            // connected components (shells) over the welded vertices: every shell must be wound the
+            // same way -- an inside-out shell beside an outward one would pass the edge test and
+            // still show the camera its "back" faces first
+            std::vector<int> comp(weld.size());
+            for (size_t i = 0; i < comp.size(); ++i) comp[i] = (int)i;
+            auto find = [&](int x) { while (comp[x] != x) { comp[x] = comp[comp[x]]; x = comp[x]; } return x; };
+            std::vector<double> tri_vol(nt, 0.0);
             for (int t = 0; t < nt && ok; ++t) {
                 const int a = wid[T[3 * t]], bb = wid[T[3 * t + 1]], c3 = wid[T[3 * t + 2]];
                 if (a == bb || bb == c3 || a == c3) continue;
@@ -547,6 +554,20 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
                                  (p0[2] - ctr[2]) * ((p1[0] - ctr[0]) * (p2[1] - ctr[1]) - (p1[1] - ctr[1]) * (p2[0] - ctr[0]));
                 vol6 += d;
                 avol6 += std::fabs(d);
+                tri_vol[t] = d;
+                comp[find(a)] = find(bb);
+                comp[find(bb)] = find(c3);
+            }
+            if (ok) {
+                std::map<int, std::pair<double, double>> shell;   // root -> (signed, absolute) volume * 6
+                for (int t = 0; t < nt; ++t) {
+                    if (tri_vol[t] == 0.0) continue;
+                    auto& sv = shell[find(wid[T[3 * t]])];
+                    sv.first += tri_vol[t];
+                    sv.second += std::fabs(tri_vol[t]);
+                }
+                for (const auto& sv : shell)
+                    if (!(std::fabs(sv.second.first) > 1e-6 * sv.second.second) || (sv.second.first > 0.0) != (vol6 > 0.0)) ok = false;
             }
             if (ok)
                 for (const auto& e : edges)

@@ -366,8 +366,9 @@ __device__ inline bool cluster_faces_away(const double* __restrict__ Rt, const f
     return lhs > 1e-3f * (D + rho) + 1e-4f;
 }
 
-// Back-face culling.  A body whose mesh is a closed, consistently oriented surface (checked at
-// create time) and whose bounding sphere lies wholly in front of the camera plane (so no
+// Back-face culling.  A body whose mesh is a closed, consistently oriented surface, every shell
+// of it wound the same way (checked at create time; the surface is taken to be embedded, i.e.
+// not passing through itself inside-out) and whose bounding sphere lies wholly in front of the camera plane (so no
 // triangle is dropped by the Z <= 0 rule and the camera is outside it) cannot show a back face:
 // the ray through a sample enters the solid through a front face no farther than any back face
 // it meets, so the z-min -- the only thing the tile keeps -- is decided by front faces alone.

@@ -622,12 +622,14 @@ def _mesh_variants():
     shells_t = np.concatenate([t, t + len(v)])
     soup_v = v[t].reshape(-1, 3)                      # every triangle owns its three vertices
     soup_t = np.arange(len(soup_v), dtype=np.int32).reshape(-1, 3)
+    inside_out_t = np.concatenate([t, flipped + len(v)])      # second shell wound the other way
     return {"closed": (v, t), "closed_inward": (v, flipped), "with_holes": (v, holes),
-            "mixed_winding": (v, mixed), "two_shells": (shells_v, shells_t), "unwelded": (soup_v, soup_t)}
+            "mixed_winding": (v, mixed), "two_shells": (shells_v, shells_t), "unwelded": (soup_v, soup_t),
+            "one_shell_inside_out": (shells_v, inside_out_t)}
 
 
 @pytest.mark.parametrize("variant", ["closed", "closed_inward", "with_holes", "mixed_winding", "two_shells",
-                                     "unwelded"])
+                                     "unwelded", "one_shell_inside_out"])
 def test_backface_culling_never_changes_a_depth(gpu_lib, variant):
     """Back faces are dropped only where that is exact: closed, consistently oriented bodies
     wholly in front of the camera.  Whatever the mesh -- inward winding, holes that show the
