@@ -476,10 +476,12 @@ __device__ inline void frame_aux_pixel(int i, const float* __restrict__ frame, d
     const double o = (double)of;
     const double sigma = ms + sf * o * o;
     const double eo = exp(0.5 * lam * (-2.0 * o + lam * sigma * sigma));
-    aux[(size_t)AUX_INV_S2S * npx + i] = 1.0 / (sqrt(2.0) * sigma);
-    aux[(size_t)AUX_K * npx + i] = lam * sigma / sqrt(2.0);
-    aux[(size_t)AUX_CV * npx + i] = (1.0 - tw) / (sqrt(2.0 * M_PI) * sigma);
-    aux[(size_t)AUX_EO * npx + i] = 0.5 * (1.0 - tw) * lam * eo;
+    // the four terms of a pixel side by side (32 B): one cache line per evaluated pixel, not four
+    double* a4 = aux + (size_t)AUX_PLANES * i;
+    a4[AUX_INV_S2S] = 1.0 / (sqrt(2.0) * sigma);
+    a4[AUX_K] = lam * sigma / sqrt(2.0);
+    a4[AUX_CV] = (1.0 - tw) / (sqrt(2.0 * M_PI) * sigma);
+    a4[AUX_EO] = 0.5 * (1.0 - tw) * lam * eo;
     pbg[i] = (float)(tw / kMaxDepth + (1.0 - tw) * lam * eo);
 }
 
@@ -496,14 +498,16 @@ __global__ void frame_aux_kernel(const float* __restrict__ frame, double* __rest
 // double.
 __device__ inline double pixel_loglik(const DevParams& P, int gi, float r, float prior, float& posterior)
 {
-    const size_t n = (size_t)P.npx;
     const float o = P.frame[gi];   // finite: the pixel was queued because it is
     // the five per-frame terms of this pixel: one memory round trip
-    const double inv_s2s = P.aux[(size_t)AUX_INV_S2S * n + gi];
-    const double kk = P.aux[(size_t)AUX_K * n + gi];
-    const double cv = P.aux[(size_t)AUX_CV * n + gi];
-    const double eo = P.aux[(size_t)AUX_EO * n + gi];
-    const float pbg = P.pbg[gi];
+    typedef double doublex2 __attribute__((ext_vector_type(2)));
+    const doublex2* a4 = reinterpret_cast<const doublex2*>(P.aux + (size_t)AUX_PLANES * gi);
+    const doublex2 a01 = a4[0], a23 = a4[1];
+    const double inv_s2s = a01.x, kk = a01.y, cv = a23.x, eo = a23.y;
+    // p_bg = tw/D + (1-tw) lam e, and the stored e_o is exactly half of the second term (a
+    // power-of-two scaling commutes with every rounding): the same double, hence the same float,
+    // as frame_aux_pixel's pbg -- without a fifth load
+    const float pbg = (float)(P.tw / kMaxDepth + 2.0 * eo);
     __builtin_amdgcn_sched_barrier(0);
 #ifdef RBS_EXP_SKIP_EVAL     // profiling builds: the loads, none of the transcendental work
     posterior = prior;
