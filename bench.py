@@ -43,6 +43,9 @@ def parse():
                     choices=["permutation", "identity", "resampled", "peaked", "peaked_unsorted"])
     ap.add_argument("--update", type=int, default=1, help="0: read-only evaluation (non-final blocks)")
     ap.add_argument("--sequence", type=int, default=30, help="frames in the moving-object sequence (0: one static frame)")
+    ap.add_argument("--fill-planes", type=float, default=None,
+                    help="start from planes that differ from the background everywhere (windows = whole frame): "
+                         "the windowed layout's worst case")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the whole-plane (RBS_STATE=dense) comparison run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -154,6 +157,10 @@ def main():
     d_out = torch.empty(n, dtype=torch.float64, device=dev)
     d_all = torch.empty(n * world, dtype=torch.float64, device=dev) if world > 1 else None
     sensor.reset()
+    if a.fill_planes is not None:
+        plane = np.full(a.rows * a.cols, a.fill_planes, dtype=np.float32)
+        for slot in range(n):
+            sensor.set_occlusion(slot, plane)
     sensor.set_observation(frame)
     sensor.synchronize()
     # a non-default torch stream: the kernel, the timing events and the RCCL all-gather all

@@ -52,6 +52,18 @@ struct rbs_handle {
     int4* d_win[2] = {nullptr, nullptr};   // [max_particles] window of each plane, per buffer
     int4* d_win_used = nullptr; // [max_particles] region the copy kernel writes this call
     bool windowed = true;       // planes valid inside their window only (RBS_STATE=dense: whole plane)
+    // windowed planes whose windows have grown to a large part of the frame are served like whole
+    // planes (streaming copy kernel beside two raster blocks per CU); the stored area is sampled
+    // on the device every timing_every-th updating call and read back without blocking
+    unsigned char* d_wide_flags = nullptr;   // [max_particles][copy blocks per plane], allocated on first use
+    unsigned long long* d_area = nullptr;
+    unsigned long long* h_area = nullptr;   // pinned
+    hipEvent_t ev_area = nullptr;
+    bool area_pending = false;
+    int area_n = 0;
+    bool wide = false;
+    double wide_enter = 0.70, wide_leave = 0.50;   // measured break-even of the two copy kernels: ~0.74 of the frame
+    int cu_count = 256;
     int smalln_target = 768;    // few particles: aim at about this many work items per call
     int rect_align = 4;         // windowed planes: rectangles move in float4 columns
     int win_chunks = 8;         // row chunks (blocks) per particle of the windowed copy kernel
@@ -244,6 +256,19 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
         h->join_pending = -1;
     }
+    bool sample_area = false;
+    if (h->windowed && update) {
+        if (h->area_pending && hipEventQuery(h->ev_area) == hipSuccess) {
+            const double frac = (double)*h->h_area / ((double)h->area_n * (double)h->npx);
+            if (frac > h->wide_enter) h->wide = true;
+            else if (frac < h->wide_leave) h->wide = false;
+            h->area_pending = false;
+        }
+        sample_area = timed && !h->area_pending;
+        if (sample_area) RBS_HIP(h, hipMemsetAsync(h->d_area, 0, sizeof(unsigned long long), s));
+    }
+    P.area_sum = sample_area ? h->d_area : nullptr;
+    const bool wide = h->windowed && update && h->wide;
     if (h->lazy_frame && h->lazy_stream == s) {
         const int aux_blocks = (h->npx + 255) / 256;
         hipLaunchKernelGGL(rbs::rbs_frame_prep_kernel, dim3((unsigned)(aux_blocks + (n + 255) / 256)), dim3(256), 0, s, P,
@@ -255,12 +280,18 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(256), 0, s, P, d_rects, update ? 1 : 0);
     }
     RBS_HIP(h, hipGetLastError());
+    if (sample_area) {
+        RBS_HIP(h, hipMemcpyAsync(h->h_area, h->d_area, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        RBS_HIP(h, hipEventRecord(h->ev_area, s));
+        h->area_pending = true;
+        h->area_n = n;
+    }
     if (update) {
         // fork: the copy kernel runs on the handle's second stream, concurrently with the
         // persistent raster kernel; it needs this call's rectangles only
         RBS_HIP(h, hipEventRecord(h->ev_fork, s));
         RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
-        if (h->windowed) {
+        if (h->windowed && !wide) {
             // the windowed copy is small and the raster blocks leave it no registers once they
             // are resident (3 x 168 VGPRs per SIMD): it goes first, under the scan kernel and the
             // raster kernel's ramp-up
@@ -279,16 +310,28 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
         h->join_pending = -1;
     }
-    const dim3 rgrid((unsigned)h->raster_blocks);
+    // wide windows: two raster blocks per CU leave the streaming copy its registers
+    const dim3 rgrid((unsigned)(wide ? std::min(h->raster_blocks, 2 * h->cu_count) : h->raster_blocks));
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
     if (update) {
         hipLaunchKernelGGL((rbs::rbs_raster_kernel<true>), rgrid, block, rbs::kSmemBytes, s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
-        if (timed && !h->windowed) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
-        if (h->windowed) {
+        if (timed && (!h->windowed || wide)) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
+        if (h->windowed && !wide) {
             // launched above, ahead of the raster kernel
+        } else if (wide) {
+            const int W4 = P.cols >> 2;
+            const int nseg = (W4 + 63) / 64;
+            const int ny = std::min(n, 32768);
+            const dim3 rg((unsigned)(((P.rows + 1) / 2) * nseg), (unsigned)ny, (unsigned)((n + ny - 1) / ny));
+            const int nblk = ((P.rows + 1) / 2) * nseg;
+            if (!h->d_wide_flags)
+                RBS_HIP(h, hipMalloc(&h->d_wide_flags, (size_t)h->max_particles * nblk));
+            P.wide_flags = h->d_wide_flags;
+            hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<2, true>), rg, dim3(64), 0, h->copy_stream, P, nseg);
+            hipLaunchKernelGGL(rbs::rbs_wide_window_kernel, dim3((unsigned)n), dim3(64), 0, h->copy_stream, P, nseg, nblk);
         } else if ((P.cols & 3) == 0 && h->copy_rows > 0) {
             const int W4 = P.cols >> 2;
             const int tpb = h->copy_tpb > 0 ? h->copy_tpb : std::min(1024, (W4 + 63) / 64 * 64);
@@ -298,17 +341,17 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             const dim3 rg((unsigned)(((P.rows + h->copy_rows - 1) / h->copy_rows) * nseg), (unsigned)ny,
                           (unsigned)((n + ny - 1) / ny));
             switch (h->copy_rows) {
-                case 1: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<1>), rg, rblock, 0, h->copy_stream, P, nseg); break;
-                case 2: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<2>), rg, rblock, 0, h->copy_stream, P, nseg); break;
-                case 4: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<4>), rg, rblock, 0, h->copy_stream, P, nseg); break;
-                default: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<8>), rg, rblock, 0, h->copy_stream, P, nseg); break;
+                case 1: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<1, false>), rg, rblock, 0, h->copy_stream, P, nseg); break;
+                case 2: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<2, false>), rg, rblock, 0, h->copy_stream, P, nseg); break;
+                case 4: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<4, false>), rg, rblock, 0, h->copy_stream, P, nseg); break;
+                default: hipLaunchKernelGGL((rbs::rbs_copy_rows_kernel<8, false>), rg, rblock, 0, h->copy_stream, P, nseg); break;
             }
         } else if ((P.cols & 3) == 0)
             hipLaunchKernelGGL((rbs::rbs_copy_kernel<4>), cgrid, block, 0, h->copy_stream, P);
         else
             hipLaunchKernelGGL((rbs::rbs_copy_kernel<1>), cgrid, block, 0, h->copy_stream, P);
         RBS_HIP(h, hipGetLastError());
-        if (!h->windowed) {
+        if (!h->windowed || wide) {
             if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_stop[tslot], h->copy_stream));
             RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
         }
@@ -382,6 +425,10 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_item_range);
     (void)hipFree(h->d_item_particle);
     (void)hipFree(h->d_ctr);
+    (void)hipFree(h->d_area);
+    (void)hipFree(h->d_wide_flags);
+    if (h->h_area) (void)hipHostFree(h->h_area);
+    if (h->ev_area) (void)hipEventDestroy(h->ev_area);
     (void)hipFree(h->d_done);
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_cluster_sphere);
@@ -692,7 +739,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     {
         hipDeviceProp_t prop;
         RBS_HIP(h, hipGetDeviceProperties(&prop, h->device));
-        h->raster_blocks = 3 * std::max(1, prop.multiProcessorCount);
+        h->cu_count = std::max(1, prop.multiProcessorCount);
+        h->raster_blocks = 3 * h->cu_count;
         // tuning overrides (defaults are the measured best on MI355X)
         if (const char* m = std::getenv("RBS_RASTER_BLOCKS")) h->raster_blocks = std::max(1, std::atoi(m));
         h->tile_override = std::getenv("RBS_TILE");
@@ -701,6 +749,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         if (const char* m = std::getenv("RBS_STATE")) h->windowed = std::strcmp(m, "dense") != 0;
         h->smalln_target = 2 * std::max(1, prop.multiProcessorCount);   // measured best at 64..500 particles
         if (const char* m = std::getenv("RBS_SMALLN_TARGET")) h->smalln_target = std::max(1, std::atoi(m));
+        if (const char* m = std::getenv("RBS_WIDE_ENTER")) { h->wide_enter = std::atof(m); h->wide_leave = h->wide_enter * 0.67; }
         if (const char* m = std::getenv("RBS_RECT_ALIGN")) h->rect_align = std::atoi(m) >= 16 ? 16 : (std::atoi(m) >= 8 ? 8 : 4);
         if (const char* m = std::getenv("RBS_TIMING_EVERY")) h->timing_every = std::max(1, std::atoi(m));
         if (const char* m = std::getenv("RBS_WIN_CHUNKS")) h->win_chunks = std::min(1024, std::max(1, std::atoi(m)));
@@ -728,6 +777,9 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMalloc(&h->d_win[1], sizeof(int4) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_win_used, sizeof(int4) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_item_range, sizeof(int2) * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_area, sizeof(unsigned long long)));
+    RBS_HIP(h, hipHostMalloc(&h->h_area, sizeof(unsigned long long), hipHostMallocDefault));
+    RBS_HIP(h, hipEventCreateWithFlags(&h->ev_area, hipEventDisableTiming));
     RBS_HIP(h, hipMalloc(&h->d_ctr, sizeof(int) * 4));
     RBS_HIP(h, hipMemset(h->d_ctr, 0, sizeof(int) * 4));
     RBS_HIP(h, hipMalloc(&h->d_done, sizeof(int) * (size_t)h->max_particles));

@@ -98,6 +98,8 @@ struct DevParams {
     const int4* win_src;           // [slots] window of each parent plane (x0,y0,x1,y1)
     int4* win_dst;                 // [slots] window of each child plane: tight bbox, grown atomically
     int4* win_used;                // [n] region the copy kernel writes: bbox(parent window, rect)
+    unsigned long long* area_sum;  // sampled calls: sum over particles of |win_used| in pixels (else null)
+    unsigned char* wide_flags;     // wide windows: [n][blocks per plane] "this copy block wrote a non-background value"
     const float* occ_src;          // [slots][npx]
     float* occ_dst;                // [slots][npx]
     const double* poses;           // [n][n_bodies][12]
@@ -803,8 +805,11 @@ __device__ inline void prep_particle(const DevParams& P, int i, int* __restrict_
         const int parent = P.indices[i];
         int4 pw = make_int4(P.cols, P.rows, 0, 0);
         if ((unsigned)parent < (unsigned)P.slots) pw = P.win_src[parent];
-        P.win_used[i] = make_int4(min(pw.x, rw.x), min(pw.y, rw.y), max(pw.z, rw.z), max(pw.w, rw.w));
+        const int4 u = make_int4(min(pw.x, rw.x), min(pw.y, rw.y), max(pw.z, rw.z), max(pw.w, rw.w));
+        P.win_used[i] = u;
         P.win_dst[i] = rw;
+        if (P.area_sum && u.z > u.x && u.w > u.y)
+            atomicAdd(P.area_sum, (unsigned long long)(u.z - u.x) * (unsigned long long)(u.w - u.y));
     }
 }
 
@@ -911,7 +916,12 @@ __global__ __launch_bounds__(kBlock) void rbs_copy_kernel(const DevParams P)
 // address order (x = segment, then row group fastest), which keeps
 // the chip-wide HBM access stream nearly sequential -- measured 6.2-6.6 TB/s for a plain copy
 // of this shape vs 5.3-5.8 TB/s for 32-64 KB per block (tools/copybench2.hip).
-template <int ROWS>
+// WIN: the planes are windowed but the windows have grown to a large part of the frame, where
+// this streaming shape beats rbs_copy_window_kernel: a float4 outside the parent's window is the
+// background instead of a load, and every block leaves a flag "wrote something that differs from
+// the background" from which rbs_wide_window_kernel rebuilds the child's window afterwards (a
+// million atomics on the windows themselves serialise: 19 ms).
+template <int ROWS, bool WIN>
 __global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, int nseg)
 {
     const int particle = (int)blockIdx.y + (int)blockIdx.z * (int)gridDim.y;
@@ -920,6 +930,8 @@ __global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, 
     const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
     const int parent = P.indices[particle];
     if ((unsigned)parent >= (unsigned)P.slots) return;
+    int4 pw = make_int4(0, 0, P.cols, P.rows);
+    if (WIN) pw = P.win_src[parent];
     // blockIdx.x = row group * nseg + column segment (segment fastest: address order)
     const int rg = (int)blockIdx.x / nseg;
     const int seg = (int)blockIdx.x - rg * nseg;
@@ -937,8 +949,11 @@ __global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, 
     for (int k = 0; k < ROWS; ++k) {
         const int row = r0 + k;
         ok[k] = row < P.rows && !(in_cols && row >= q.y && row < q.w);
-        if (ok[k]) v[k] = __builtin_nontemporal_load(&s4[(size_t)row * W4 + c4]);
+        const bool stored = !WIN || (col >= pw.x && col < pw.z && row >= pw.y && row < pw.w);
+        v[k].x = v[k].y = v[k].z = v[k].w = P.bg_old;
+        if (ok[k] && stored) v[k] = __builtin_nontemporal_load(&s4[(size_t)row * W4 + c4]);
     }
+    int by0 = P.rows, by1 = 0;
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         if (!ok[k]) continue;
@@ -948,6 +963,40 @@ __global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, 
         w.z = occ_step(alpha, beta, v[k].z, bg_new);
         w.w = occ_step(alpha, beta, v[k].w, bg_new);
         __builtin_nontemporal_store(w, &d4[(size_t)(r0 + k) * W4 + c4]);
+        if (WIN && (w.x != bg_new || w.y != bg_new || w.z != bg_new || w.w != bg_new)) {
+            by0 = min(by0, r0 + k);
+            by1 = max(by1, r0 + k + 1);
+        }
+    }
+    if (WIN) {
+        const unsigned long long any = __ballot(by1 > by0);
+        if ((threadIdx.x & 63) == 0)
+            P.wide_flags[(size_t)particle * gridDim.x + blockIdx.x] = any ? 1 : 0;
+    }
+}
+
+// After a wide-window copy: the child's window = its rectangle (seeded by the rectangles kernel)
+// grown over the flagged copy blocks (2 rows x 256 columns each).  One wave per particle.
+__global__ __launch_bounds__(64) void rbs_wide_window_kernel(const DevParams P, int nseg, int nblk)
+{
+    const int i = (int)blockIdx.x;
+    if (i >= P.n) return;
+    const unsigned char* f = P.wide_flags + (size_t)i * nblk;
+    int x0 = P.cols, y0 = P.rows, x1 = 0, y1 = 0;
+    for (int b = (int)threadIdx.x; b < nblk; b += 64) {
+        if (!f[b]) continue;
+        const int rg = b / nseg, seg = b - rg * nseg;
+        x0 = min(x0, seg * 256); x1 = max(x1, min(P.cols, seg * 256 + 256));
+        y0 = min(y0, rg * 2);    y1 = max(y1, min(P.rows, rg * 2 + 2));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
+        x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
+    }
+    if (threadIdx.x == 0 && x1 > x0) {
+        const int4 w = P.win_dst[i];
+        P.win_dst[i] = make_int4(min(w.x, x0), min(w.y, y0), max(w.z, x1), max(w.w, y1));
     }
 }
 

@@ -140,6 +140,11 @@ class Oracle:
         fn(self._h, int(slot), out.ctypes.data_as(C.POINTER(C.c_float)))
         return out
 
+    def set_occlusion(self, slot, plane):
+        buf = np.ascontiguousarray(plane, dtype=np.float32).ravel()
+        assert buf.size == self.rows * self.cols
+        self._lib.orc_set_occlusion(self._h, int(slot), buf.ctypes.data_as(C.POINTER(C.c_float)))
+
     def render_depth(self, pose):
         pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(self.n_bodies * 12)
         out = np.empty(self.rows * self.cols, dtype=np.float32)

@@ -771,3 +771,43 @@ def test_layouts_agree_through_the_device_tracker(gpu_lib, monkeypatch):
     ww = out["window"][1]
     assert (ww[2] - ww[0]) * (ww[3] - ww[1]) < cols * rows // 2
     assert out["dense"][1] == (0, 0, cols, rows)
+
+
+def test_wide_windows_take_the_streaming_path(gpu_lib, monkeypatch, state_layout):
+    """Windowed planes whose windows cover most of the frame are copied by the whole-plane
+    streaming kernel (window-aware) and re-tightened from per-block flags: same numbers, and the
+    windows come back down once the planes have decayed."""
+    if state_layout != "window":
+        pytest.skip("windowed layout only")
+    monkeypatch.setenv("RBS_WIDE_ENTER", "0.0")      # always take the wide path
+    monkeypatch.setenv("RBS_TIMING_EVERY", "1")      # sample the stored area on every call
+    n, cols, rows = 10, 160, 120
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    P.delta_time = 0.5
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    rng = np.random.default_rng(8)
+    full = np.full(rows * cols, 0.8, np.float32)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        for slot in range(n):
+            g.set_occlusion(slot, full)
+            eager.set_occlusion(slot, full)
+        ig, io = np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32)
+        areas = []
+        for k in range(70):
+            truth = synth.truth_pose(1, frame=k % 10)
+            frame = synth.make_frame(eager.render_depth(truth), rows, cols, rng)
+            poses = synth.particle_poses(truth, n, rng, scale=2.0)
+            g.set_observation(frame)
+            eager.set_observation(frame)
+            lg = g.loglikes_poses(poses, ig, update=True)
+            lo = eager.loglikes_poses(poses, io, update=True)
+            assert rel_err(lg, lo).max() <= TOL_EAGER
+            w = g.get_window(3)
+            areas.append((w[2] - w[0]) * (w[3] - w[1]))
+            if k in (0, 20, 69):
+                for slot in (0, 3, 9):
+                    assert_planes_match(g.get_occlusion(slot), eager.get_occlusion(slot))
+            par = rng.permutation(n).astype(np.int32)
+            ig, io = par.copy(), par.copy()
+    assert areas[0] == cols * rows            # everything differs from the background at first
+    assert areas[-1] < cols * rows // 3       # ... and the block flags let the window shrink again
