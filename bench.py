@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--fill-planes", type=float, default=None,
                     help="start from planes that differ from the background everywhere (windows = whole frame): "
                          "the windowed layout's worst case")
+    ap.add_argument("--fill-fraction", type=float, default=1.0,
+                    help="with --fill-planes: only a central rectangle of this fraction of the frame")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the whole-plane (RBS_STATE=dense) comparison run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -158,7 +160,11 @@ def main():
     d_all = torch.empty(n * world, dtype=torch.float64, device=dev) if world > 1 else None
     sensor.reset()
     if a.fill_planes is not None:
-        plane = np.full(a.rows * a.cols, a.fill_planes, dtype=np.float32)
+        plane = np.full((a.rows, a.cols), np.float32(0.1), dtype=np.float32)      # = the background after reset
+        fr = float(np.sqrt(min(1.0, max(0.0, a.fill_fraction))))
+        r0, c0 = int(a.rows * (1 - fr) / 2), int(a.cols * (1 - fr) / 2)
+        plane[r0:a.rows - r0, c0:a.cols - c0] = a.fill_planes
+        plane = plane.ravel()
         for slot in range(n):
             sensor.set_occlusion(slot, plane)
     sensor.set_observation(frame)

@@ -62,7 +62,9 @@ struct rbs_handle {
     bool area_pending = false;
     int area_n = 0;
     bool wide = false;
-    double wide_enter = 0.70, wide_leave = 0.50;   // measured break-even of the two copy kernels: ~0.74 of the frame
+    double area_frac = 0.0;     // last sampled stored-window area / frame area
+    double mid_enter = 0.15;    // above it: two raster blocks per CU, so the windowed copy runs beside them
+    double wide_enter = 0.50, wide_leave = 0.35;   // measured: the streaming copy wins from about half the frame
     int cu_count = 256;
     int smalln_target = 768;    // few particles: aim at about this many work items per call
     int rect_align = 4;         // windowed planes: rectangles move in float4 columns
@@ -260,6 +262,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     if (h->windowed && update) {
         if (h->area_pending && hipEventQuery(h->ev_area) == hipSuccess) {
             const double frac = (double)*h->h_area / ((double)h->area_n * (double)h->npx);
+            h->area_frac = frac;
             if (frac > h->wide_enter) h->wide = true;
             else if (frac < h->wide_leave) h->wide = false;
             h->area_pending = false;
@@ -311,7 +314,8 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         h->join_pending = -1;
     }
     // wide windows: two raster blocks per CU leave the streaming copy its registers
-    const dim3 rgrid((unsigned)(wide ? std::min(h->raster_blocks, 2 * h->cu_count) : h->raster_blocks));
+    const bool mid = h->windowed && update && !wide && h->area_frac > h->mid_enter;
+    const dim3 rgrid((unsigned)(wide || mid ? std::min(h->raster_blocks, 2 * h->cu_count) : h->raster_blocks));
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
     if (update) {
         hipLaunchKernelGGL((rbs::rbs_raster_kernel<true>), rgrid, block, rbs::kSmemBytes, s, P);
@@ -749,6 +753,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         if (const char* m = std::getenv("RBS_STATE")) h->windowed = std::strcmp(m, "dense") != 0;
         h->smalln_target = 2 * std::max(1, prop.multiProcessorCount);   // measured best at 64..500 particles
         if (const char* m = std::getenv("RBS_SMALLN_TARGET")) h->smalln_target = std::max(1, std::atoi(m));
+        if (const char* m = std::getenv("RBS_MID_ENTER")) h->mid_enter = std::atof(m);
         if (const char* m = std::getenv("RBS_WIDE_ENTER")) { h->wide_enter = std::atof(m); h->wide_leave = h->wide_enter * 0.67; }
         if (const char* m = std::getenv("RBS_RECT_ALIGN")) h->rect_align = std::atoi(m) >= 16 ? 16 : (std::atoi(m) >= 8 ? 8 : 4);
         if (const char* m = std::getenv("RBS_TIMING_EVERY")) h->timing_every = std::max(1, std::atoi(m));
