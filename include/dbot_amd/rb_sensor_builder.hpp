@@ -232,6 +232,14 @@ public:
         check(rbs_set_observation(handle_, image.data(), image.size()));
     }
 
+    /// The driver's float pixels directly (no double round trip), or a frame that already lives
+    /// on the sensor's GPU (`stream`: a hipStream_t, nullptr = the sensor's own).
+    void set_observation_f32(const float* depth, size_t n) { check(rbs_set_observation_f32(handle_, depth, n)); }
+    void set_observation_device(const float* d_depth, void* stream = nullptr)
+    {
+        check(rbs_set_observation_device(handle_, d_depth, stream));
+    }
+
     /// deltas: state deltas around integrated_poses(); indices: occlusion slot each particle
     /// inherits from, set to identity when update is true.  Returns log-likelihoods.
     RealArray loglikes(const StateArray& deltas, IntArray& indices, const bool& update = false)
