@@ -820,18 +820,21 @@ __global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int 
     prep_particle(P, i, rects, update);
 }
 
-// A frame handed over on the device right before this call: its per-pixel terms (the first
-// aux_blocks blocks) and the particles' rectangles (the rest) are independent, one launch.
+// A frame handed over right before this call: its per-pixel terms (aux_blocks blocks) and the
+// particles' rectangles (the other blocks) are independent, one launch.
 __global__ void rbs_frame_prep_kernel(const DevParams P, int* __restrict__ rects, int update,
                                       const float* __restrict__ frame_src, double* __restrict__ aux,
                                       float* __restrict__ pbg, float* __restrict__ keep, int aux_blocks)
 {
-    if ((int)blockIdx.x < aux_blocks) {
+    // the rectangle blocks come first: their threads run a long serial FP64 chain and should start
+    // at once, the short per-pixel blocks fill in around them
+    const int prep_blocks = (int)gridDim.x - aux_blocks;
+    if ((int)blockIdx.x < prep_blocks) {
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        if (i < P.npx) frame_aux_pixel(i, frame_src, aux, pbg, P.npx, P.tw, P.ms, P.sf, P.lambda, keep);
-    } else {
-        const int i = ((int)blockIdx.x - aux_blocks) * blockDim.x + threadIdx.x;
         if (i < P.n) prep_particle(P, i, rects, update);
+    } else {
+        const int i = ((int)blockIdx.x - prep_blocks) * blockDim.x + threadIdx.x;
+        if (i < P.npx) frame_aux_pixel(i, frame_src, aux, pbg, P.npx, P.tw, P.ms, P.sf, P.lambda, keep);
     }
 }
 
