@@ -811,3 +811,37 @@ def test_wide_windows_take_the_streaming_path(gpu_lib, monkeypatch, state_layout
             ig, io = par.copy(), par.copy()
     assert areas[0] == cols * rows            # everything differs from the background at first
     assert areas[-1] < cols * rows // 3       # ... and the block flags let the window shrink again
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_varying_particle_counts_and_call_patterns(gpu_lib, seed):
+    """Twenty frames with the number of particles changing from call to call, read-only calls,
+    skipped frames and an object that wanders: parents always index slots the latest updating
+    call wrote.  Log-likelihoods and every live plane as the oracle (device rule)."""
+    rng = np.random.default_rng(70 + seed)
+    nmax, cols, rows = 24, 160, 120
+    om, cam, P = sc.make_scene(("m1_l2", "box12")[: 1 + seed % 2], cols, rows, max_particles=nmax)
+    nb = 1 + seed % 2
+    eager = ob.Oracle(om, cam, P, max_particles=nmax, mode=ob.EAGER)
+    with RbSensor(om, cam, P, max_particles=nmax) as g:
+        live = 1                                  # after reset every slot holds the initial plane
+        parents_ok = nmax
+        for k in range(20):
+            truth = synth.truth_pose(nb, frame=int(rng.integers(0, 40)), z=float(rng.uniform(0.5, 0.9)))
+            frame = synth.make_frame(eager.render_depth(truth), rows, cols, rng)
+            for _ in range(int(rng.integers(1, 3))):          # sometimes a frame nobody evaluates
+                g.set_observation(frame)
+                eager.set_observation(frame)
+            n = int(rng.integers(1, nmax + 1))
+            poses = synth.particle_poses(truth, n, rng, scale=float(rng.uniform(0.5, 4.0)))
+            par = rng.integers(0, parents_ok, n).astype(np.int32)
+            upd = bool(rng.random() < 0.7)
+            ig, io = par.copy(), par.copy()
+            lg = g.loglikes_poses(poses, ig, update=upd)
+            lo = eager.loglikes_poses(poses, io, update=upd)
+            assert rel_err(lg, lo).max() <= TOL_EAGER, (k, n, upd)
+            if upd:
+                parents_ok = live = n
+                for slot in rng.choice(n, size=min(n, 3), replace=False):
+                    assert_planes_match(g.get_occlusion(int(slot)), eager.get_occlusion(int(slot)))
+        assert live >= 1
