@@ -845,3 +845,27 @@ def test_varying_particle_counts_and_call_patterns(gpu_lib, seed):
                 for slot in rng.choice(n, size=min(n, 3), replace=False):
                     assert_planes_match(g.get_occlusion(int(slot)), eager.get_occlusion(int(slot)))
         assert live >= 1
+
+
+def test_stress_config_against_the_oracle(gpu_lib):
+    """BASELINE C4's shape (50 880-triangle mesh at 1280x960, rectangles of many tiles whose
+    partial sums several blocks add up) on a handful of particles over three frames."""
+    n = 6
+    om, cam, P = sc.make_scene(("m4",), 1280, 960, max_particles=n)
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    rng = np.random.default_rng(4)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        ig, io = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for k in range(3):
+            truth = synth.truth_pose(1, z=0.5, frame=2 * k)
+            frame = synth.make_frame(eager.render_depth(truth), 960, 1280, rng)
+            poses = synth.particle_poses(truth, n, rng, scale=1.5)
+            g.set_observation(frame)
+            eager.set_observation(frame)
+            lg = g.loglikes_poses(poses, ig, update=True)
+            lo = eager.loglikes_poses(poses, io, update=True)
+            assert rel_err(lg, lo).max() <= TOL_EAGER
+            par = rng.integers(0, n, n).astype(np.int32)
+            ig, io = par.copy(), par.copy()
+        for slot in (0, n - 1):
+            assert_planes_match(g.get_occlusion(slot), eager.get_occlusion(slot))
