@@ -3,24 +3,27 @@
 // One RbSensor::loglikes(deltas, indices, update) call (made once per sampling block inside
 // tracker_->track, R:source/dbot_ros/object_tracker_ros.hpp:49) is:
 //
-//   rbs_prep_kernel     per particle: conservative screen rectangle of the bodies (bounding
-//                       spheres, x-aligned to 128 B) and its split into <=128x128-px tiles;
-//                       exclusive scan of the tile counts -> (particle, tile) work items.
-//   rbs_raster_kernel   PERSISTENT, 2 blocks per CU, pulling work items from an atomic queue:
+//   rbs_frame_prep_kernel  two independent jobs in one launch: the per-pixel model terms of a
+//                       newly handed-over frame, and per particle the conservative screen
+//                       rectangle of the bodies, its work items (one per <= 11 520-px tile,
+//                       allotted by atomicAdd) and, on windowed planes, the region the copy
+//                       kernel writes.  (rbs_prep_kernel: the rectangles alone.)
+//   rbs_raster_kernel   PERSISTENT, 3 blocks per CU, pulling work items from an atomic queue:
 //                       software depth rasterizer (wave64 = one 64-triangle cluster, culled
-//                       against the tile frustum; triangles -> LDS depth tile, ds_min_u32
-//                       z-min), then the per-pixel Kinect likelihood + occlusion posterior
-//                       over the tile, wave64 shuffle reduce -> one partial sum per item.
-//                       FP64 VALU bound.
-//   rbs_reduce_kernel   per particle: ordered sum of its tiles' partial sums -> out[i].
-//   rbs_copy_kernel     (update only, second stream, concurrent with the raster kernel) one
-//                       small block per (particle, row band): streams the parent's occlusion
-//                       plane into the child's slot outside the rectangle, advancing every
-//                       pixel by the occlusion process occ' = fma(alpha, occ, beta).
-//                       HBM bound: 2*4*rows*cols bytes per particle-likelihood.
+//                       against the tile frustum and, for closed bodies, by its normal cone;
+//                       triangles -> LDS depth tile, ds_min_u32 z-min), then the per-pixel
+//                       Kinect likelihood + occlusion posterior over the tile, block reduce ->
+//                       the particle's log-likelihood.  VALU (FP64) bound.
+//   rbs_copy_window_kernel  (update only, second stream) the child's window outside its
+//                       rectangle: the parent's values advanced by the occlusion process
+//                       occ' = snap(fma(alpha, occ, beta)), the background where the parent
+//                       stores nothing; re-tightens the child's window.
+//   rbs_copy_rows_kernel  whole planes (RBS_STATE=dense, or windows grown past half the frame):
+//                       streams the parent's plane into the child's slot outside the
+//                       rectangle.  HBM bound: 2*4*rows*cols bytes per particle-likelihood.
 //
-// The raster kernel holds a fixed LDS/VGPR share of every CU for the whole call, the many
-// light copy blocks stream through the rest, so FP64 work and HBM streaming overlap.
+// Occlusion planes are stored as a window + a background level: the
+// numbers are those of whole planes, only the bytes moved differ.
 //
 // Arithmetic contract (tests/ compare against oracle/): the geometry is individually rounded
 // binary64 in a fixed operation order (compile with -ffp-contract=off), the stored depth is
