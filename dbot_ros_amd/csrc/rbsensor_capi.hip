@@ -219,10 +219,23 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     // tile limits: as large as the LDS tile allows (a particle's rectangle is then usually ONE
     // work item, whatever its aspect); with fewer particles than persistent blocks the pixel
     // budget is divided so that a rectangle splits into about blocks/n row bands
+    if (h->windowed && update && h->area_pending && hipEventQuery(h->ev_area) == hipSuccess) {
+        const double frac = (double)*h->h_area / ((double)h->area_n * (double)h->npx);   // sampled a few calls ago
+        h->area_frac = frac;
+        if (frac > h->wide_enter) h->wide = true;
+        else if (frac < h->wide_leave) h->wide = false;
+        h->area_pending = false;
+    }
+    // the whole-plane layout always runs two raster blocks per CU and can afford the larger LDS
+    // tile (fewer rectangles split into two work items).  Windowed planes keep ONE tile size
+    // whatever the number of blocks of a call: the split decides the order in which a
+    // particle's partial sums are added, and the switch between the modes depends on when an
+    // asynchronous read-back lands -- results must not.
+    P.tile_px = !h->windowed && h->raster_blocks <= 2 * h->cu_count ? rbs::kTilePxBig : rbs::kTilePx;
     P.tile_w = 256;
-    P.tile_h = std::max(4, rbs::kTilePx / 256 / std::max(1, h->smalln_target / std::max(1, n)));
+    P.tile_h = std::max(4, P.tile_px / 256 / std::max(1, h->smalln_target / std::max(1, n)));
     if (const char* m = h->tile_override) { P.tile_w = std::max(16, std::atoi(m) / 16 * 16); P.tile_h = std::max(1, std::atoi(m)); }
-    const size_t tiles_max = tiles_upper_bound(h->cols, h->rows, P.tile_w, std::min(P.tile_w * P.tile_h, rbs::kTilePx));
+    const size_t tiles_max = tiles_upper_bound(h->cols, h->rows, P.tile_w, std::min(P.tile_w * P.tile_h, P.tile_px));
     const size_t need = (size_t)n * tiles_max;
     if (need > h->partial_cap) {
         RBS_HIP(h, hipStreamSynchronize(s));
@@ -260,13 +273,6 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     }
     bool sample_area = false;
     if (h->windowed && update) {
-        if (h->area_pending && hipEventQuery(h->ev_area) == hipSuccess) {
-            const double frac = (double)*h->h_area / ((double)h->area_n * (double)h->npx);
-            h->area_frac = frac;
-            if (frac > h->wide_enter) h->wide = true;
-            else if (frac < h->wide_leave) h->wide = false;
-            h->area_pending = false;
-        }
         sample_area = timed && !h->area_pending;
         if (sample_area) RBS_HIP(h, hipMemsetAsync(h->d_area, 0, sizeof(unsigned long long), s));
     }
@@ -318,7 +324,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     const dim3 rgrid((unsigned)(wide || mid ? std::min(h->raster_blocks, 2 * h->cu_count) : h->raster_blocks));
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
     if (update) {
-        hipLaunchKernelGGL((rbs::rbs_raster_kernel<true>), rgrid, block, rbs::kSmemBytes, s, P);
+        hipLaunchKernelGGL((rbs::rbs_raster_kernel<true>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
@@ -360,7 +366,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
         }
     } else {
-        hipLaunchKernelGGL((rbs::rbs_raster_kernel<false>), rgrid, block, rbs::kSmemBytes, s, P);
+        hipLaunchKernelGGL((rbs::rbs_raster_kernel<false>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
     }
@@ -800,11 +806,11 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
 
     // the raster / render kernels carve the LDS depth tile from dynamic shared memory
     RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
     RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
     RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_render_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::kSmemBytes));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
 
     {   // per-item partial sums: sized for the default tiling so no call ever allocates
         size_t need = (size_t)h->max_particles * tiles_upper_bound(h->cols, h->rows, 256, rbs::kTilePx);
@@ -1139,8 +1145,9 @@ int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out)
     P.poses = h->d_poses;
     P.n = 1;
     P.tile_w = 256;
-    P.tile_h = rbs::kTilePx / 256;
-    hipLaunchKernelGGL(rbs::rbs_render_kernel, dim3(1), dim3(rbs::kBlock), rbs::kSmemBytes,
+    P.tile_px = rbs::kTilePxBig;
+    P.tile_h = P.tile_px / 256;
+    hipLaunchKernelGGL(rbs::rbs_render_kernel, dim3(1), dim3(rbs::kBlock), rbs::smem_bytes(P.tile_px),
                        h->stream, P, h->d_render);
     RBS_HIP(h, hipGetLastError());
     RBS_HIP(h, hipMemcpyAsync(out, h->d_render, sizeof(float) * h->npx, hipMemcpyDeviceToHost,

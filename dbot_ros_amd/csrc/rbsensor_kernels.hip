@@ -58,7 +58,8 @@ namespace rbs {
 #define RBS_BLOCK 256
 #endif
 constexpr int kBlock = RBS_BLOCK;          // threads per raster block (a multiple of 64)
-constexpr int kTilePx = RBS_TILE_PX;       // LDS depth tile (u32 per pixel)
+constexpr int kTilePx = RBS_TILE_PX;       // LDS depth tile (u32 per pixel) of a launch with 3 blocks per CU
+constexpr int kTilePxBig = 16384;          // ... of a launch with 2 blocks per CU (whole planes / wide windows)
 #ifndef RBS_BIG_CAP
 #define RBS_BIG_CAP 256
 #endif
@@ -85,6 +86,7 @@ struct DevParams {
                                    //   (min cos <= -1: never cull this cluster)
     int body_cull[kMaxBodies];     // 0: keep every triangle; +1/-1: the body is a closed, consistently
                                    //   oriented surface (sign of its signed volume): back faces may go
+    int tile_px;                   // pixels of this launch's LDS depth tile (its dynamic shared memory is sized for it)
     int rect_align;                // rectangle x-alignment in pixels: 16 whole planes, 4 windowed (float4)
     int tile_w, tile_h;            // work-item tile limits: width <= tile_w, pixels <= min(tile_w*tile_h, kTilePx)
     double fx, fy, cx, cy;
@@ -561,7 +563,7 @@ __device__ inline double block_reduce_sum(double v, double* red)
 struct Smem {
     unsigned* tile; int* big; double* red; int* nbig; int* item; int* evalq;
 };
-__device__ inline Smem carve(unsigned char* smem)
+__device__ inline Smem carve(unsigned char* smem, int kTilePx)
 {
     Smem m;
     m.tile = reinterpret_cast<unsigned*>(smem);
@@ -579,7 +581,7 @@ template <bool UPDATE>
 __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect r, int tile_id,
                                           const Smem& m)
 {
-    const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, kTilePx));
+    const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
     const int ty = tile_id / tg.nx, tx = tile_id - ty * tg.nx;
     const int wx0 = r.x0 + tx * tg.tw, wy0 = r.y0 + ty * tg.th;
     const int wx1 = min(r.x1, wx0 + tg.tw), wy1 = min(r.y1, wy0 + tg.th);
@@ -795,7 +797,7 @@ __device__ inline void prep_particle(const DevParams& P, int i, int* __restrict_
 {
     const Rect r = particle_rect(P, P.poses + (size_t)i * 12 * P.n_bodies);
     reinterpret_cast<int4*>(rects)[i] = make_int4(r.x0, r.y0, r.x1, r.y1);
-    const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, kTilePx));
+    const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
     P.done[i] = 0;
     {   // work items: any free range will do -- a particle's items are summed in their own order
         const int cnt = r.x1 > r.x0 ? tg.nx * tg.ny : 1;   // an empty rectangle still owns one (empty) item
@@ -852,7 +854,7 @@ template <bool UPDATE>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel(const DevParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Smem m = carve(smem);
+    const Smem m = carve(smem, P.tile_px);
     const int total = P.ctr_this[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr_next[0] = 0; P.ctr_next[1] = 0; }
 #ifdef RBS_PHASE_TIMING
@@ -1108,10 +1110,10 @@ __global__ void rbs_set_window_kernel(int4* __restrict__ win, int n, int4 value)
 __global__ __launch_bounds__(kBlock) void rbs_render_kernel(const DevParams P, float* out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Smem m = carve(smem);
+    const Smem m = carve(smem, P.tile_px);
     const Rect r = particle_rect(P, P.poses);
     if (r.x1 <= r.x0) return;
-    const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, kTilePx));
+    const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
     for (int wy0 = r.y0; wy0 < r.y1; wy0 += tg.th)
         for (int wx0 = r.x0; wx0 < r.x1; wx0 += tg.tw) {
             const int wx1 = min(r.x1, wx0 + tg.tw), wy1 = min(r.y1, wy0 + tg.th);
@@ -1143,8 +1145,9 @@ __global__ void rbs_fill_kernel(float* __restrict__ p, size_t n, float v)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
-constexpr size_t kSmemBytes = sizeof(unsigned) * kTilePx + sizeof(int) * kBigCap +
-                              sizeof(double) * (kBlock / 64) + 16 +
-                              sizeof(int) * 3 * (kBlock / 64) * kEvalQueue;
-
+constexpr size_t smem_bytes(int tile_px)
+{
+    return sizeof(unsigned) * (size_t)tile_px + sizeof(int) * kBigCap + sizeof(double) * (kBlock / 64) + 16 +
+           sizeof(int) * 3 * (kBlock / 64) * kEvalQueue;
+}
 }  // namespace rbs
