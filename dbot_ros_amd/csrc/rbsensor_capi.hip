@@ -1365,14 +1365,20 @@ int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* norm
     }
     T.seed = seed;
     const dim3 g256((unsigned)((T.n + 255) / 256)), b256(256);
+    const char* nf = std::getenv("RBS_TRACKER_FUSED");
+    const bool fused = T.n <= rbt::kFusedFilterMax && !(nf && std::atoi(nf) == 0);
     for (int b = 0; b < T.parts; ++b) {
         const bool last = b == T.parts - 1;
         hipLaunchKernelGGL(rbt::propagate_kernel, g256, b256, 0, s, T, b);
         RBT_HIP(t, hipGetLastError());
         if (int32_t rc = enqueue_loglikes(h, T.poses, T.idx, T.n, last, T.ll_new, s)) return rc;
-        hipLaunchKernelGGL(rbt::weights_kernel, dim3(1), dim3(1024), 0, s, T, last ? 1 : 0);
-        hipLaunchKernelGGL(rbt::resample_kernel, g256, b256, 0, s, T, b);
-        hipLaunchKernelGGL(rbt::gather_kernel, dim3((unsigned)T.n), dim3(64), 0, s, T);
+        if (fused) {
+            hipLaunchKernelGGL(rbt::filter_step_kernel, dim3(1), dim3(1024), 0, s, T, b, last ? 1 : 0, last ? 1 : 0);
+        } else {
+            hipLaunchKernelGGL(rbt::weights_kernel, dim3(1), dim3(1024), 0, s, T, last ? 1 : 0);
+            hipLaunchKernelGGL(rbt::resample_kernel, g256, b256, 0, s, T, b);
+            hipLaunchKernelGGL(rbt::gather_kernel, dim3((unsigned)T.n), dim3(64), 0, s, T);
+        }
         RBT_HIP(t, hipGetLastError());
         std::swap(T.part_old, T.part_old2);
         std::swap(T.part_new, T.part_new2);
@@ -1380,8 +1386,10 @@ int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* norm
         std::swap(T.ll, T.ll2);
         std::swap(T.idx, T.idx2);
     }
-    hipLaunchKernelGGL(rbt::mean_kernel, dim3(1), dim3(1024), 0, s, T);
-    hipLaunchKernelGGL(rbt::recentre_kernel, g256, b256, 0, s, T);
+    if (!fused) {
+        hipLaunchKernelGGL(rbt::mean_kernel, dim3(1), dim3(1024), 0, s, T);
+        hipLaunchKernelGGL(rbt::recentre_kernel, g256, b256, 0, s, T);
+    }
     RBT_HIP(t, hipGetLastError());
     std::swap(T.part_old, T.part_new);   // this frame's particles are the next frame's old ones
     RBT_HIP(t, hipMemcpyAsync(out_state, T.deflt, sizeof(double) * T.D, hipMemcpyDeviceToHost, s));
