@@ -43,6 +43,8 @@ def parse():
                     choices=["permutation", "identity", "resampled", "peaked", "peaked_unsorted"])
     ap.add_argument("--update", type=int, default=1, help="0: read-only evaluation (non-final blocks)")
     ap.add_argument("--sequence", type=int, default=30, help="frames in the moving-object sequence (0: one static frame)")
+    ap.add_argument("--config", default=None, choices=["c1", "c1_readonly", "c2", "c3_slice", "c4_slice", "default_res"],
+                    help="a row of BASELINE.md section 3 (sets mesh / particles / resolution / steps; c1 = no flags)")
     ap.add_argument("--fill-planes", type=float, default=None,
                     help="start from planes that differ from the background everywhere (windows = whole frame): "
                          "the windowed layout's worst case")
@@ -51,7 +53,15 @@ def parse():
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the whole-plane (RBS_STATE=dense) comparison run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    a = ap.parse_args()
+    presets = {"c1": {}, "c1_readonly": {"update": 0},
+               "c2": {"mesh": "m1,m2,m3", "particles": 6666, "steps": 50},
+               "c3_slice": {"particles": 25000, "steps": 20, "warmup": 3},
+               "c4_slice": {"mesh": "m4", "cols": 1280, "rows": 960, "particles": 6250, "steps": 5, "warmup": 2},
+               "default_res": {"cols": 80, "rows": 60}}
+    for k, v in presets.get(a.config, {}).items():
+        setattr(a, k, v)
+    return a
 
 
 def cpu_baseline(om, cam, P, truth, frame, seconds):
