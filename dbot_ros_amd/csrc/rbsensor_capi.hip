@@ -126,6 +126,7 @@ std::string fmt(const char* f, ...)
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \
         if (e_ != hipSuccess) {                                                               \
+            (void)hipGetLastError(); /* HIP's last error is sticky: it must not fail a later call */ \
             (h)->err = fmt("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,   \
                            __LINE__);                                                         \
             return e_ == hipErrorOutOfMemory ? RBS_ERR_OUT_OF_MEMORY : RBS_ERR_HIP;           \
@@ -499,6 +500,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
                     "need 0 < p_occluded_occluded - p_occluded_visible < 1");
     if (!(cfg->delta_time > 0.0)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "delta_time must be > 0");
 
+    (void)hipGetLastError();   // a stale error left by somebody else on this thread is not ours
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, RBS_ERR_NO_DEVICE,
@@ -1263,9 +1265,11 @@ int32_t tfail(rbs_tracker* t, int32_t code, const std::string& msg) { t->err = m
 #define RBT_HIP(t, call)                                                                       \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
-        if (e_ != hipSuccess)                                                                  \
+        if (e_ != hipSuccess) {                                                                \
+            (void)hipGetLastError();                                                           \
             return tfail(t, e_ == hipErrorOutOfMemory ? RBS_ERR_OUT_OF_MEMORY : RBS_ERR_HIP,   \
                          fmt("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); \
+        }                                                                                      \
     } while (0)
 
 template <typename X>

@@ -869,3 +869,22 @@ def test_stress_config_against_the_oracle(gpu_lib):
             ig, io = par.copy(), par.copy()
         for slot in (0, n - 1):
             assert_planes_match(g.get_occlusion(slot), eager.get_occlusion(slot))
+
+
+def test_out_of_device_memory_is_an_error_not_a_wreck(gpu_lib, state_layout):
+    """More occlusion slots than the GPU has memory for: rbs_create reports RBS_ERR_OUT_OF_MEMORY,
+    gives back what it had allocated, and leaves no sticky HIP error behind -- the next handle
+    works."""
+    if state_layout != "window":
+        pytest.skip("layout-independent")
+    import torch
+    from dbot_ros_amd import _capi
+    om, cam, P = sc.make_scene(("m1_l2",), 640, 480, max_particles=4)
+    free0 = torch.cuda.mem_get_info()[0]
+    too_many = int(free0 // (640 * 480 * 4)) // 2 + 2000      # two buffers of this many planes do not fit
+    with pytest.raises(RbSensorError) as e:
+        RbSensor(om, cam, P, max_particles=too_many)
+    assert e.value.code == _capi.RBS_ERR_OUT_OF_MEMORY
+    assert torch.cuda.mem_get_info()[0] > 0.9 * free0
+    with RbSensor(om, cam, P, max_particles=4) as g:
+        assert np.isfinite(g.render_depth(synth.truth_pose(1))).any()
