@@ -888,3 +888,44 @@ def test_out_of_device_memory_is_an_error_not_a_wreck(gpu_lib, state_layout):
     assert torch.cuda.mem_get_info()[0] > 0.9 * free0
     with RbSensor(om, cam, P, max_particles=4) as g:
         assert np.isfinite(g.render_depth(synth.truth_pose(1))).any()
+
+
+def test_hostile_inputs_match_the_oracle(gpu_lib):
+    """NaN / infinite / astronomically large poses, a body without triangles, a frame of
+    infinities: nothing crashes, nothing hangs, and the numbers are the oracle's."""
+    from dbot_ros_amd import CameraData, ObjectModel, RbSensorBuilder
+    v, t = synth.mesh_m1(level=2)
+    empty_t = np.zeros((0, 3), np.int32)
+    om = ObjectModel([v, v[:3] * 0.5], [t, empty_t], center=True)
+    cols, rows, n = 96, 64, 8
+    cam = CameraData(synth.camera_matrix(cols, rows), rows, cols)
+    P = RbSensorBuilder.Parameters(sample_count=n)
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    rng = np.random.default_rng(2)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        ig, io = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for k in range(4):
+            truth = synth.truth_pose(2, frame=k)
+            poses = synth.particle_poses(truth, n, rng, scale=2.0)
+            poses[1, 0, 9] = np.nan                  # NaN translation
+            poses[2, 0, 0] = np.inf                  # infinite rotation entry
+            poses[3, 0, 11] = 1e300                  # astronomically far
+            poses[4, 0, 9:12] = (1e-300, -1e-300, 1e-310)   # at the camera centre, denormal depth
+            poses[5, 0, :9] = 0.0                    # collapsed rotation: every triangle degenerate
+            frame = synth.make_frame(eager.render_depth(truth), rows, cols, rng)
+            if k == 2:
+                frame[:] = np.inf
+            g.set_observation(frame)
+            eager.set_observation(frame)
+            lg = g.loglikes_poses(poses, ig, update=True)
+            lo = eager.loglikes_poses(poses, io, update=True)
+            same_nan = np.isnan(lg) == np.isnan(lo)
+            assert same_nan.all(), (lg, lo)
+            ok = ~np.isnan(lo)
+            assert rel_err(lg[ok], lo[ok]).max() <= TOL_EAGER
+            par = rng.integers(0, n, n).astype(np.int32)
+            ig, io = par.copy(), par.copy()
+        for slot in range(n):
+            a, b = g.get_occlusion(slot), eager.get_occlusion(slot)
+            assert np.array_equal(np.isnan(a), np.isnan(b))
+            assert_planes_match(np.nan_to_num(a, nan=0.5), np.nan_to_num(b, nan=0.5))
