@@ -97,7 +97,15 @@ def cpu_baseline(om, cam, P, truth, frame, seconds):
     cores = os.cpu_count() or 1
     threads = min(cores, n)
     done_mt, el_mt = run(threads, max(3.0, seconds / 3))
-    return {"value": done / el, "unit": "particle-likelihoods/s", "cores": 1, "kind": "port",
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": done / el, "unit": "particle-likelihoods/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": cores,
             "sample": f"{done} particle-likelihoods = {done // n} loglikes(update=true) calls x {n} "
                       f"particles, {cam.cols}x{cam.rows}, {tris} triangles, {el:.1f} s on 1 of {cores} host cores",
             "all_cores": {"value": done_mt / el_mt, "cores": threads,
