@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
 """Soak: the device tracker over a long back-and-forth sequence with intermittent occluders, once
-per occlusion-state layout (windowed planes / whole planes).  Both layouts hold the same numbers,
-so with the same seed the two runs must produce bitwise identical estimates; prints tracking
-error, the stored window sizes along the way and the final plane range.
-usage: python tools/soak_tracker.py [frames=1500] [particles=2000]"""
+per occlusion-state layout (windowed planes / whole planes).  Both layouts hold the same planes;
+log-likelihoods agree to the order of their additions (1e-15 relative), so while the filter
+tracks, the two runs give the same estimates; prints tracking error, the stored window sizes
+along the way and the final plane range.
+usage: python tools/soak_tracker.py [frames=1500] [particles=2000] [speed=1]
+speed > 1 makes the object sweep the image (speed x 2 mm per frame): the windows grow through the
+mid-size and wide regimes and back.  (Once the filter has lost the object its weights are
+degenerate and last-bit differences decide resampling draws: the runs then part ways, which is
+chaos, not an error -- tools/_diff-style plane comparisons are the layout check there.)"""
 import os
 import sys
 import time
@@ -16,6 +21,7 @@ from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder,
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+speed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 cols, rows = 640, 480
 v, f = synth.mesh_m3()
 om = ObjectModel([v], [f])
@@ -42,7 +48,7 @@ def run(layout):
         errs, wins = [], []
         t0 = time.time()
         for k in range(1, frames + 1):
-            kk = k % 120 if k % 120 < 60 else 120 - (k % 120)      # back and forth within 60 frames
+            kk = (k % 120 if k % 120 < 60 else 120 - (k % 120)) * speed - 30 * (speed - 1)   # back and forth within 60 frames
             fr = synth.make_frame(s.render_depth(synth.truth_pose(1, frame=kk)), rows, cols, rng,
                                   occluder=(k % 200 > 150))
             est = tr.track(fr)
@@ -65,8 +71,8 @@ def run(layout):
 
 a = run("window")
 b = run("dense")
-print("estimates bitwise identical across layouts:", bool(np.array_equal(a, b)))
-if not np.array_equal(a, b):
-    d = np.abs(a - b).max(axis=1)
-    print("first differing frame", int(np.argmax(d > 0)) + 1, "max |diff|", float(d.max()))
+d = np.abs(a - b).max(axis=1)
+print("estimates across layouts: max |difference| %.3e (bitwise identical: %s)" % (float(d.max()), bool(np.array_equal(a, b))))
+if d.max() > 1e-6:
+    print("first frame differing by more than 1e-6:", int(np.argmax(d > 1e-6)) + 1)
     sys.exit(1)
