@@ -930,3 +930,55 @@ def test_hostile_inputs_match_the_oracle(gpu_lib):
             a, b = g.get_occlusion(slot), eager.get_occlusion(slot)
             assert np.array_equal(np.isnan(a), np.isnan(b))
             assert_planes_match(np.nan_to_num(a, nan=0.5), np.nan_to_num(b, nan=0.5))
+
+
+def test_layouts_hold_the_same_planes_under_stress(gpu_lib, monkeypatch, state_layout):
+    """Differential test of the two layouts on identical inputs: random poses (some at or behind
+    the camera plane, some far off screen), dense random frames, read-only calls, everybody
+    inheriting one parent now and then.  Planes bit for bit; log-likelihoods to 1e-12 relative
+    (the rectangles are aligned differently, so the additions come in a different order)."""
+    if state_layout != "window":
+        pytest.skip("runs both layouts itself")
+    from dbot_ros_amd.pose import pack_Rt, rotvec_to_matrix
+    n, cols, rows = 48, 160, 120
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    monkeypatch.setenv("RBS_TIMING_EVERY", "1")
+    monkeypatch.setenv("RBS_STATE", "window")
+    a = RbSensor(om, cam, P, max_particles=n)
+    monkeypatch.setenv("RBS_STATE", "dense")
+    b = RbSensor(om, cam, P, max_particles=n)
+    try:
+        rng = np.random.default_rng(12)
+        ia, ib = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        center = np.array([0.0, 0.0, 0.7])
+        for k in range(80):
+            center = center + rng.normal(0, 0.03, 3)
+            center[2] = abs(center[2])
+            R = rotvec_to_matrix(rng.normal(size=(n, 1, 3)))
+            tt = center[None, None, :] + rng.normal(0, 0.05, (n, 1, 3))
+            if k % 7 == 3:
+                tt[:8, 0, 2] = rng.uniform(-0.05, 0.05, 8)
+            if k % 5 == 2:
+                tt[8:16, 0, 0] += 3.0
+            poses = pack_Rt(R, tt)
+            frame = rng.uniform(0.3, 1.5, rows * cols).astype(np.float32)
+            frame[rng.random(frame.size) < 0.05] = np.nan
+            a.set_observation(frame)
+            b.set_observation(frame)
+            upd = bool(rng.random() < 0.8)
+            la = a.loglikes_poses(poses, ia, update=upd)
+            lb = b.loglikes_poses(poses, ib, update=upd)
+            assert np.array_equal(np.isnan(la), np.isnan(lb))
+            ok = ~np.isnan(lb)
+            assert rel_err(la[ok], lb[ok]).max() <= 1e-12
+            if upd:
+                par = rng.integers(0, n, n).astype(np.int32)
+                if k % 3 == 0:
+                    par[:] = par[0]
+                ia, ib = par.copy(), par.copy()
+                if k % 10 == 0:
+                    for slot in (0, n // 2, n - 1):
+                        assert np.array_equal(a.get_occlusion(slot), b.get_occlusion(slot))
+    finally:
+        a.close()
+        b.close()
