@@ -169,7 +169,7 @@ int32_t rbs_last_kernel_ms(rbs_handle* h, float* ms);
  * every 8th call with HIP events -- RBS_TIMING_EVERY in the environment at rbs_create changes
  * that -- and keeps the last 64 timed calls), from events recorded on the streams the kernels
  * run on: call_ms = the launch-stream part of a call
- * (prep, scan, raster, reduce kernels); copy_kernel_ms = the copy kernel alone on its own
+ * (frame terms + rectangles kernel, raster kernel); copy_kernel_ms = the copy kernel alone on its own
  * stream (updating calls only, 0 if none).  Blocks until those calls finished. */
 int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float* copy_kernel_ms,
                            int32_t* n_used);
