@@ -160,3 +160,49 @@ class ShardedSensor:
             slots[k] = g - self.lo if owner[j] == self.rank else staging[g][0]
         self.local_parent_slots = slots
         return moves
+
+
+class ShardedRbSensor:
+    """A ShardedSensor behind the single-sensor interface the trackers drive
+    (set_observation / loglikes_poses(poses, indices, update) / reset), so that
+    `ParticleTracker(transition, ShardedRbSensor(...), ...)` run identically on every rank
+    (same seed) is the particle-sharded tracker: every rank holds all particle STATES (they are
+    96 bytes each), evaluates its shard, all-gathers the log-likelihoods and migrates planes.
+
+    `indices[i]` is, as for a single sensor, the plane particle i inherits, named by the id the
+    plane's particle had at the last updating call; it is translated into the incremental
+    resampling the ShardedSensor lays the planes out by."""
+
+    def __init__(self, sensor, n_total, group=None, device=None):
+        self.ss = ShardedSensor(sensor, n_total, group, device)
+        self.n = n_total
+        self.rows, self.cols = sensor.rows, sensor.cols
+        self.applied = np.arange(n_total, dtype=np.int64)   # plane (by last-update id) each particle holds now
+        self.moves = 0
+
+    def reset(self):
+        self.ss.reset()
+        self.applied = np.arange(self.n, dtype=np.int64)
+
+    def set_observation(self, image):
+        self.ss.set_observation(image)
+
+    def loglikes_poses(self, poses, indices, update=False):
+        want = np.asarray(indices, dtype=np.int64)
+        if len(want) != self.n:
+            raise ValueError("a sharded sensor evaluates all particles in every call")
+        if not np.array_equal(want, self.applied):
+            holder = {}
+            for k, plane in enumerate(self.applied):       # some particle that holds each live plane
+                holder.setdefault(int(plane), k)
+            parents = np.array([holder[int(p)] for p in want], dtype=np.int64)
+            self.moves += len(self.ss.resample(parents))
+            self.applied = want.copy()
+        ll = self.ss.loglikes(poses, update)
+        if update:
+            self.applied = np.arange(self.n, dtype=np.int64)
+            indices[:] = np.arange(self.n, dtype=indices.dtype)
+        return ll
+
+    def close(self):
+        self.ss.sensor.close()

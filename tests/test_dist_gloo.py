@@ -110,3 +110,64 @@ def test_two_rank_sharded_run_matches_single_process():
             # same particles (poses are indexed by global child id), same inherited planes
             assert np.abs(ll - ll_ref).max() <= 1e-9 * max(1.0, np.abs(ll_ref).max())
             assert np.array_equal(par, par_ref)
+
+
+# ---------------------------------------------------------------- the sharded TRACKER
+def _tracker_run(sensor, om, frames, n, two_bodies=False):
+    from dbot_ros_amd import pose
+    from dbot_ros_amd.tracker import ObjectTransitionBuilder, ParticleTracker, ParticleTrackerBuilder
+    parts = om.count_parts
+    trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=parts)).build()
+    tr = ParticleTracker(trans, sensor, om, ParticleTrackerBuilder.Parameters(evaluation_count=n * parts),
+                         np.random.default_rng(5))
+    init = np.zeros(12 * parts)
+    for b in range(parts):
+        Rt = frames[0][0][b]
+        init[12 * b + 3:12 * b + 6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+        init[12 * b:12 * b + 3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[b]
+    tr.initialize([init])
+    return np.array([tr.track(f) for _, f in frames]), tr.n_resamplings
+
+
+def _tracker_inputs(parts):
+    meshes = ("m1_l2", "box12")[:parts]
+    om, cam, P = sc.make_scene(meshes, 80, 60, max_particles=2 * N)
+    o = ob.Oracle(om, cam, P, max_particles=1)
+    return om, cam, P, sc.make_frames(o, parts, 5, seed=8)
+
+
+def _tracker_worker(rank, world, port, parts, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        om, cam, P, frames = _tracker_inputs(parts)
+        shard = int(np.diff(rdist.shard_bounds(N, world)).max())
+        o = _OracleWithImport(om, cam, P, max_particles=2 * shard, mode=ob.EAGER)
+        ss = rdist.ShardedRbSensor(o, N)
+        ests, nres = _tracker_run(ss, om, frames, N)
+        q.put((rank, ests, nres, ss.moves))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("parts", [1, 2])
+def test_two_rank_sharded_tracker_matches_single_process(parts):
+    """ParticleTracker over a ShardedRbSensor on two gloo ranks (oracle evaluators) against the same
+    tracker over one oracle: identical estimates -- with two bodies there are two sampling blocks
+    per frame, i.e. read-only calls and resampling between them."""
+    om, cam, P, frames = _tracker_inputs(parts)
+    ref, nres_ref = _tracker_run(ob.Oracle(om, cam, P, max_particles=N, mode=ob.EAGER), om, frames, N)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 27500 + (os.getpid() % 2000) + parts
+    procs = [ctx.Process(target=_tracker_worker, args=(r, 2, port, parts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, ests, nres, moves in got:
+        assert nres == nres_ref and nres > 0
+        assert np.abs(ests - ref).max() <= 1e-9, np.abs(ests - ref).max()
+    assert got[0][3] == got[1][3] and got[0][3] > 0, "no plane migrated"

@@ -982,3 +982,28 @@ def test_layouts_hold_the_same_planes_under_stress(gpu_lib, monkeypatch, state_l
     finally:
         a.close()
         b.close()
+
+
+def test_sharded_tracker_matches_the_single_gpu_tracker(gpu_lib, state_layout):
+    """tools/tracker_fps_dist.py with two ranks (gloo rendezvous, both on cuda:0) against the
+    same tracker on one rank: every particle's log-likelihood comes from the same device code
+    whatever rank evaluates it, so the estimates are identical -- and planes did migrate."""
+    if state_layout != "window":
+        pytest.skip("layout-independent")
+    import json
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tracker_fps_dist.py")
+    env = dict(os.environ, RBS_BENCH_BACKEND="gloo")
+    out = {}
+    for world in (1, 2):
+        port = 29300 + (os.getpid() + world) % 600
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), tool, "96", "6"],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        out[world] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out[1]["estimate_digest"] == out[2]["estimate_digest"]
+    assert out[2]["planes_migrated"] > 0 and out[1]["planes_migrated"] == 0
+    assert out[2]["final_position_error_m"] < 0.01
