@@ -42,26 +42,30 @@ def place_children(parents, bounds):
     the other ranks in rank order."""
     parents = np.asarray(parents, dtype=np.int64)
     world = len(bounds) - 1
+    n = len(parents)
     cap = np.diff(bounds).astype(np.int64)
     owner = np.searchsorted(bounds, parents, side="right") - 1
-    child_rank = np.full(len(parents), -1, dtype=np.int64)
-    child_slot = np.full(len(parents), -1, dtype=np.int64)
-    used = np.zeros(world, dtype=np.int64)
+    child_rank = np.full(n, -1, dtype=np.int64)
+    child_slot = np.full(n, -1, dtype=np.int64)
+    # children in parent order (stable); the owners are then non-decreasing, so each rank's
+    # children are one contiguous run: its first cap[r] stay, the rest are surplus
     order = np.argsort(parents, kind="stable")
-    surplus = []
-    for j in order:
-        r = owner[j]
-        if used[r] < cap[r]:
-            child_rank[j], child_slot[j] = r, used[r]
-            used[r] += 1
-        else:
-            surplus.append(j)
-    r = 0
-    for j in surplus:
-        while used[r] >= cap[r]:
-            r += 1
-        child_rank[j], child_slot[j] = r, used[r]
-        used[r] += 1
+    o_owner = owner[order]
+    counts = np.bincount(o_owner, minlength=world).astype(np.int64)
+    starts = np.cumsum(counts) - counts
+    pos = np.arange(n, dtype=np.int64) - starts[o_owner]
+    keep = pos < cap[o_owner]
+    child_rank[order[keep]] = o_owner[keep]
+    child_slot[order[keep]] = pos[keep]
+    used = np.minimum(counts, cap)
+    surplus = order[~keep]
+    if len(surplus):
+        free = cap - used
+        ranks = np.repeat(np.arange(world, dtype=np.int64), free)
+        first = np.cumsum(free) - free
+        slots = np.arange(int(free.sum()), dtype=np.int64) - np.repeat(first, free) + np.repeat(used, free)
+        child_rank[surplus] = ranks[: len(surplus)]
+        child_slot[surplus] = slots[: len(surplus)]
     return child_rank, child_slot
 
 
@@ -122,8 +126,10 @@ class ShardedSensor:
         pslot = slot_of[parents]                      # global slot holding each child's parent plane
         child_rank, child_slot = place_children(pslot, self.bounds)
         owner = np.searchsorted(self.bounds, pslot, side="right") - 1
-        moves = sorted({(int(owner[j]), int(child_rank[j]), int(pslot[j]))
-                        for j in range(len(parents)) if owner[j] != child_rank[j]})
+        away = owner != child_rank
+        moves = [tuple(int(x) for x in row)
+                 for row in np.unique(np.stack([owner[away], child_rank[away], pslot[away]], axis=1), axis=0)] \
+            if away.any() else []
         staging, ops, keep = {}, [], []
         npx = self.sensor.rows * self.sensor.cols
         on_device = self.device is not None and hasattr(self.sensor, "export_plane")
@@ -154,10 +160,14 @@ class ShardedSensor:
         new_layout = np.empty(self.n_total, dtype=np.int64)
         new_layout[self.bounds[child_rank] + child_slot] = np.arange(self.n_total)
         self.layout = new_layout
-        slots = np.empty(self.shard, dtype=np.int32)
-        for k, j in enumerate(self.owned):
-            g = int(pslot[j])
-            slots[k] = g - self.lo if owner[j] == self.rank else staging[g][0]
+        mine = self.owned
+        g = pslot[mine]
+        slots = (g - self.lo).astype(np.int32)
+        remote = owner[mine] != self.rank
+        if remote.any():
+            keys = np.array(sorted(staging), dtype=np.int64)
+            vals = np.array([staging[k][0] for k in keys], dtype=np.int32)
+            slots[remote] = vals[np.searchsorted(keys, g[remote])]
         self.local_parent_slots = slots
         return moves
 
@@ -192,10 +202,8 @@ class ShardedRbSensor:
         if len(want) != self.n:
             raise ValueError("a sharded sensor evaluates all particles in every call")
         if not np.array_equal(want, self.applied):
-            holder = {}
-            for k, plane in enumerate(self.applied):       # some particle that holds each live plane
-                holder.setdefault(int(plane), k)
-            parents = np.array([holder[int(p)] for p in want], dtype=np.int64)
+            live, holder = np.unique(self.applied, return_index=True)   # the first particle holding each live plane
+            parents = holder[np.searchsorted(live, want)].astype(np.int64)
             self.moves += len(self.ss.resample(parents))
             self.applied = want.copy()
         ll = self.ss.loglikes(poses, update)
