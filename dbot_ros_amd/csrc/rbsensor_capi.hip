@@ -49,6 +49,7 @@ struct rbs_handle {
     double* d_out = nullptr;
     int* d_rects[2] = {nullptr, nullptr};  // [max_particles][4], alternating per call: the previous
                                 // call's copy kernel may still be reading its rectangles
+    int* d_parents[2] = {nullptr, nullptr};   // [max_particles] snapshot of the caller's indices, alternating like d_rects
     int4* d_win[2] = {nullptr, nullptr};   // [max_particles] window of each plane, per buffer
     int4* d_win_used = nullptr; // [max_particles] region the copy kernel writes this call
     bool windowed = true;       // planes valid inside their window only (RBS_STATE=dense: whole plane)
@@ -252,6 +253,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     }
     int* const d_rects = h->d_rects[h->calls & 1];
     P.rects = d_rects;
+    P.parents = h->d_parents[h->calls & 1];
     P.item_range = h->d_item_range;
     P.item_particle = h->d_item_particle;
     P.ctr_this = h->d_ctr + 2 * (int)(h->calls & 1);
@@ -430,6 +432,8 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_out);
     (void)hipFree(h->d_rects[0]);
     (void)hipFree(h->d_rects[1]);
+    (void)hipFree(h->d_parents[0]);
+    (void)hipFree(h->d_parents[1]);
     (void)hipFree(h->d_win[0]);
     (void)hipFree(h->d_win[1]);
     (void)hipFree(h->d_win_used);
@@ -786,6 +790,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMalloc(&h->d_out, sizeof(double) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_rects[0], sizeof(int) * 4 * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_rects[1], sizeof(int) * 4 * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_parents[0], sizeof(int) * (size_t)h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_parents[1], sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_win[0], sizeof(int4) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_win[1], sizeof(int4) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_win_used, sizeof(int4) * (size_t)h->max_particles));

@@ -108,7 +108,10 @@ struct DevParams {
     const float* occ_src;          // [slots][npx]
     float* occ_dst;                // [slots][npx]
     const double* poses;           // [n][n_bodies][12]
-    const int* indices;            // [n] parent slot
+    const int* indices;            // [n] parent slot as the caller passed it: read by the rectangles kernel ONLY,
+                                   //   in the caller's stream order (the caller may rewrite it right after the call)
+    int* parents;                  // [n] the rectangles kernel's snapshot of `indices`, double-buffered across calls
+                                   //   like `rects`: what the raster and the (side-stream) copy kernels read
     int slots;                     // occlusion slots allocated (valid parents: 0..slots-1)
     double* out;                   // [n]
     int n;
@@ -589,7 +592,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     const bool whole = (wx0 == r.x0 && wy0 == r.y0 && wx1 == r.x1 && wy1 == r.y1);
 
     const double* pose = P.poses + (size_t)particle * 12 * P.n_bodies;
-    const int parent = P.indices[particle];
+    const int parent = P.parents[particle];
     // a parent slot outside the allocation (only possible through the unchecked device-pointer
     // API) must not turn into a wild read: the particle's likelihood becomes NaN instead
     if ((unsigned)parent >= (unsigned)P.slots) return NAN;
@@ -729,7 +732,7 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
     const int row0 = band * P.band_rows;
     const int row1 = min(P.rows, row0 + P.band_rows);
     if (row0 >= row1) return;
-    const int parent = P.indices[particle];
+    const int parent = P.parents[particle];
     if ((unsigned)parent >= (unsigned)P.slots) return;
     const float* __restrict__ src = P.occ_src + (size_t)parent * P.npx + (size_t)row0 * P.cols;
     float* __restrict__ dst = P.occ_dst + (size_t)particle * P.npx + (size_t)row0 * P.cols;
@@ -799,6 +802,8 @@ __device__ inline void prep_particle(const DevParams& P, int i, int* __restrict_
     reinterpret_cast<int4*>(rects)[i] = make_int4(r.x0, r.y0, r.x1, r.y1);
     const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
     P.done[i] = 0;
+    const int parent = P.indices[i];
+    P.parents[i] = parent;
     {   // work items: any free range will do -- a particle's items are summed in their own order
         const int cnt = r.x1 > r.x0 ? tg.nx * tg.ny : 1;   // an empty rectangle still owns one (empty) item
         const int first = atomicAdd(&P.ctr_this[0], cnt);
@@ -807,7 +812,6 @@ __device__ inline void prep_particle(const DevParams& P, int i, int* __restrict_
     }
     if (update && P.windowed) {
         const int4 rw = r.x1 > r.x0 ? make_int4(r.x0, r.y0, r.x1, r.y1) : make_int4(P.cols, P.rows, 0, 0);
-        const int parent = P.indices[i];
         int4 pw = make_int4(P.cols, P.rows, 0, 0);
         if ((unsigned)parent < (unsigned)P.slots) pw = P.win_src[parent];
         const int4 u = make_int4(min(pw.x, rw.x), min(pw.y, rw.y), max(pw.z, rw.z), max(pw.w, rw.w));
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, 
     if (particle >= P.n) return;
     const int W4 = P.cols >> 2;
     const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
-    const int parent = P.indices[particle];
+    const int parent = P.parents[particle];
     if ((unsigned)parent >= (unsigned)P.slots) return;
     int4 pw = make_int4(0, 0, P.cols, P.rows);
     if (WIN) pw = P.win_src[parent];
@@ -1020,7 +1024,7 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
 {
     const int particle = (int)blockIdx.y + (int)blockIdx.z * (int)gridDim.y;
     if (particle >= P.n) return;
-    const int parent = P.indices[particle];
+    const int parent = P.parents[particle];
     if ((unsigned)parent >= (unsigned)P.slots) return;
     const int4 u = P.win_used[particle];
     if (u.z <= u.x || u.w <= u.y) return;

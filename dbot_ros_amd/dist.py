@@ -73,9 +73,20 @@ class ShardedSensor:
     """Drives one rank's sensor inside a particle-sharded filter.
 
     Particles keep their GLOBAL ids (0..N-1: the row of the pose / weight arrays every rank
-    holds identically).  `layout[g]` is the particle id stored at global slot g (rank-major:
-    rank r owns global slots bounds[r]..bounds[r+1]); it is recomputed identically on every
-    rank after each resampling, so no rank ever needs to ask where a plane lives."""
+    holds identically).  Two maps are kept apart (they differ whenever a resampling is not
+    followed at once by an updating call, e.g. between the sampling blocks of a multi-body
+    tracker):
+
+      layout[g]   the particle id EVALUATED at global slot g (rank-major: rank r owns global
+                  slots bounds[r]..bounds[r+1]); recomputed identically on every rank after
+                  each resampling, so no rank ever needs to ask where a particle is evaluated;
+      inherit[j]  the PHYSICAL global slot holding the plane particle j inherits.  Planes only
+                  move physically in an updating call (child j's posterior is written to the
+                  slot j is evaluated at); between updating calls the own slots [0, shard) of
+                  every rank are immutable, resamplings only compose `inherit`, and the planes a
+                  rank needs from elsewhere are copies in its staging slots [stage0, 2*stage0),
+                  remembered in `staged` (per destination rank, identical on every rank) until
+                  the next updating call invalidates them."""
 
     def __init__(self, sensor, n_total, group=None, device=None):
         self.sensor, self.group, self.device = sensor, group, device
@@ -85,9 +96,16 @@ class ShardedSensor:
         self.bounds = shard_bounds(n_total, self.world)
         self.lo, self.hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
         self.shard = self.hi - self.lo
-        self.stage0 = int(np.diff(self.bounds).max())        # first staging slot
-        self.layout = np.arange(n_total, dtype=np.int64)
+        self.stage0 = int(np.diff(self.bounds).max())        # first staging slot; also the staging capacity
+        self._fresh()
+
+    def _fresh(self):
+        self.layout = np.arange(self.n_total, dtype=np.int64)
+        self.inherit = np.zeros(self.n_total, dtype=np.int64)   # after reset every particle inherits slot 0 ...
+        self.slot_at_update = np.zeros(self.n_total, dtype=np.int64)
+        self.staged = [dict() for _ in range(self.world)]
         self.local_parent_slots = np.zeros(self.shard, dtype=np.int32)
+        self._after_reset = True     # ... of its OWN rank (reset fills every plane alike): no migration
 
     @property
     def owned(self):
@@ -96,8 +114,7 @@ class ShardedSensor:
 
     def reset(self):
         self.sensor.reset()
-        self.layout = np.arange(self.n_total, dtype=np.int64)
-        self.local_parent_slots[:] = 0
+        self._fresh()
 
     def set_observation(self, image):
         self.sensor.set_observation(image)
@@ -109,7 +126,14 @@ class ShardedSensor:
         idx = self.local_parent_slots.copy()
         ll = self.sensor.loglikes_poses(np.asarray(poses_all)[self.owned], idx, update=update)
         if update:
-            self.local_parent_slots = idx  # identity: slot k now holds particle owned[k]
+            # slot k of this rank now physically holds the plane of particle owned[k]
+            self.local_parent_slots = np.arange(self.shard, dtype=np.int32)
+            slot_of = np.empty(self.n_total, dtype=np.int64)
+            slot_of[self.layout] = np.arange(self.n_total)
+            self.inherit = slot_of
+            self.slot_at_update = slot_of.copy()
+            self.staged = [dict() for _ in range(self.world)]
+            self._after_reset = False
         by_slot = gather_loglikes(ll, self.bounds, self.group, self.device)
         out = np.empty(self.n_total)
         out[self.layout] = by_slot
@@ -117,20 +141,43 @@ class ShardedSensor:
 
     def resample(self, parents):
         """parents[j] = global id of the particle child j inherits from (identical on all
-        ranks).  Places the children parent-affine, migrates the planes of parents whose
-        children landed on another rank into that rank's staging slots, and updates the
-        layout: afterwards particle j is evaluated where its plane is."""
-        parents = np.asarray(parents, dtype=np.int64)
-        slot_of = np.empty(self.n_total, dtype=np.int64)
-        slot_of[self.layout] = np.arange(self.n_total)
-        pslot = slot_of[parents]                      # global slot holding each child's parent plane
+        ranks).  Returns the planes moved between ranks as (src, dst, global slot) triples."""
+        return self._apply(self.inherit[np.asarray(parents, dtype=np.int64)])
+
+    def set_inheritance(self, plane_ids):
+        """plane_ids[j] = id, AT THE LAST UPDATING CALL, of the particle whose plane particle j
+        inherits (the meaning of RbSensor::loglikes' `indices`)."""
+        return self._apply(self.slot_at_update[np.asarray(plane_ids, dtype=np.int64)])
+
+    def _apply(self, inherit):
+        """Places the particles parent-affine for the physical slots `inherit`, copies the planes
+        of parents whose children landed on another rank into that rank's staging slots (unless
+        a copy made since the last updating call is still there), and updates the layout:
+        afterwards particle j is evaluated where (a copy of) its plane is."""
+        self.inherit = inherit
+        if self._after_reset:
+            # every plane of every rank is the initial plane: particles stay where they are and
+            # inherit the first slot of their own rank
+            self.local_parent_slots = np.zeros(self.shard, dtype=np.int32)
+            return []
+        pslot = inherit
         child_rank, child_slot = place_children(pslot, self.bounds)
         owner = np.searchsorted(self.bounds, pslot, side="right") - 1
         away = owner != child_rank
-        moves = [tuple(int(x) for x in row)
-                 for row in np.unique(np.stack([owner[away], child_rank[away], pslot[away]], axis=1), axis=0)] \
-            if away.any() else []
-        staging, ops, keep = {}, [], []
+        moves = []
+        if away.any():
+            need = np.unique(np.stack([owner[away], child_rank[away], pslot[away]], axis=1), axis=0)
+            for dst in np.unique(need[:, 1]):
+                rows = need[need[:, 1] == dst]
+                cache = self.staged[int(dst)]
+                new = [r for r in rows if int(r[2]) not in cache]
+                if len(cache) + len(new) > self.stage0:     # staging full: start over with what is needed now
+                    cache.clear()
+                    new = list(rows)
+                for r in new:
+                    cache[int(r[2])] = self.stage0 + len(cache)
+                    moves.append((int(r[0]), int(dst), int(r[2])))
+        ops, keep, landed = [], [], []
         npx = self.sensor.rows * self.sensor.cols
         on_device = self.device is not None and hasattr(self.sensor, "export_plane")
         stream = torch.cuda.current_stream().cuda_stream if on_device else None
@@ -146,16 +193,16 @@ class ShardedSensor:
             elif dst == self.rank:
                 t = torch.empty(npx, dtype=torch.float32, device=self.device if on_device else None)
                 ops.append(dist.P2POp(dist.irecv, t, src, group=self.group))
-                staging[g] = (self.stage0 + len(staging), t)
+                landed.append((self.staged[self.rank][g], t))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        for g, (slot, t) in staging.items():
+        for slot, t in landed:
             if on_device:
                 self.sensor.import_plane(slot, t.data_ptr(), stream)
             else:
                 self.sensor.set_occlusion(slot, t.cpu().numpy())
-        if on_device and staging:
+        if on_device and landed:
             torch.cuda.current_stream().synchronize()   # staging tensors die with this scope
         new_layout = np.empty(self.n_total, dtype=np.int64)
         new_layout[self.bounds[child_rank] + child_slot] = np.arange(self.n_total)
@@ -165,9 +212,8 @@ class ShardedSensor:
         slots = (g - self.lo).astype(np.int32)
         remote = owner[mine] != self.rank
         if remote.any():
-            keys = np.array(sorted(staging), dtype=np.int64)
-            vals = np.array([staging[k][0] for k in keys], dtype=np.int32)
-            slots[remote] = vals[np.searchsorted(keys, g[remote])]
+            cache = self.staged[self.rank]
+            slots[remote] = np.array([cache[int(x)] for x in g[remote]], dtype=np.int32)
         self.local_parent_slots = slots
         return moves
 
@@ -180,8 +226,7 @@ class ShardedRbSensor:
     96 bytes each), evaluates its shard, all-gathers the log-likelihoods and migrates planes.
 
     `indices[i]` is, as for a single sensor, the plane particle i inherits, named by the id the
-    plane's particle had at the last updating call; it is translated into the incremental
-    resampling the ShardedSensor lays the planes out by."""
+    plane's particle had at the last updating call."""
 
     def __init__(self, sensor, n_total, group=None, device=None):
         self.ss = ShardedSensor(sensor, n_total, group, device)
@@ -202,9 +247,7 @@ class ShardedRbSensor:
         if len(want) != self.n:
             raise ValueError("a sharded sensor evaluates all particles in every call")
         if not np.array_equal(want, self.applied):
-            live, holder = np.unique(self.applied, return_index=True)   # the first particle holding each live plane
-            parents = holder[np.searchsorted(live, want)].astype(np.int64)
-            self.moves += len(self.ss.resample(parents))
+            self.moves += len(self.ss.set_inheritance(want))
             self.applied = want.copy()
         ll = self.ss.loglikes(poses, update)
         if update:

@@ -207,7 +207,11 @@ def _rotvecs(R):
     cs = 0.5 * (np.trace(R, axis1=1, axis2=2) - 1.0)
     ang = np.arctan2(sn, cs)
     k = np.where(sn > 1e-8, ang / np.where(sn > 1e-8, sn, 1.0), 1.0)
-    return s * k[:, None]
+    out = s * k[:, None]
+    flip = (sn <= 1e-8) & (cs <= 0.0)      # angle ~ pi: axis from the symmetric part (pose.matrix_to_rotvec)
+    for i in np.nonzero(flip)[0]:
+        out[i] = matrix_to_rotvec(R[i])
+    return out
 
 
 class DeviceParticleTracker(ParticleTracker):

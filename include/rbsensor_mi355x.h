@@ -118,8 +118,10 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
 
 /* Device-pointer variant: poses/indices/out_loglik are device memory on the handle's device,
  * work is enqueued on `stream` (a hipStream_t, NULL = the handle's own stream) and the call
- * returns without synchronising.  indices is read-only; with update != 0 the caller must
- * treat the slot map as identity afterwards.  d_out_loglik is complete in `stream` order.  The
+ * returns without synchronising.  indices is read-only and read in `stream` order only (the
+ * first kernel snapshots it for the library's second stream): the caller may overwrite it by work
+ * enqueued on `stream` right after the call.  With update != 0 the caller must treat the slot
+ * map as identity afterwards.  d_out_loglik is complete in `stream` order.  The
  * occlusion planes an updating call writes are finished by a second, internal stream: every
  * later rbs_* call on the handle orders itself after them (so back-to-back calls pipeline), and
  * rbs_synchronize / rbs_occlusion_*_device_ptr / any host-pointer entry point waits for them. */

@@ -46,8 +46,21 @@ static void matrix_to_rotvec(const double* R, double* rv)
     const double sn = sqrt(sx * sx + sy * sy + sz * sz);
     const double cs = 0.5 * ((R[0] + R[4] + R[8]) - 1.0);
     const double ang = atan2(sn, cs);
-    const double k = sn > 1e-8 ? ang / sn : 1.0;
-    rv[0] = sx * k; rv[1] = sy * k; rv[2] = sz * k;
+    if (sn > 1e-8 || cs > 0.0) {
+        const double k = sn > 1e-8 ? ang / sn : 1.0;
+        rv[0] = sx * k; rv[1] = sy * k; rv[2] = sz * k;
+        return;
+    }
+    /* angle ~ pi: the antisymmetric part vanishes, the axis comes from the symmetric part
+     * (column i of R + e_i is parallel to the axis; i = the largest diagonal entry), as in
+     * dbot_ros_amd/pose.py matrix_to_rotvec */
+    double d[3];
+    for (int k = 0; k < 3; ++k) d[k] = sqrt(fmax((R[4 * k] + 1.0) * 0.5, 0.0));
+    const int i = d[0] >= d[1] ? (d[0] >= d[2] ? 0 : 2) : (d[1] >= d[2] ? 1 : 2);
+    double a[3];
+    for (int k = 0; k < 3; ++k) a[k] = (R[3 * k + i] + (k == i ? 1.0 : 0.0)) / (2.0 * d[i]);
+    const double an = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    for (int k = 0; k < 3; ++k) rv[k] = a[k] / an * ang;
 }
 
 static void matmul3(const double* A, const double* B, double* C)

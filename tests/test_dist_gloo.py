@@ -112,6 +112,72 @@ def test_two_rank_sharded_run_matches_single_process():
             assert np.array_equal(par, par_ref)
 
 
+# ------------------------------------------------- resamplings that no updating call follows
+def _double_resample_script():
+    """update, then per frame: two resamplings each followed by a READ-ONLY evaluation, then an
+    updating evaluation under a third resampling -- the call pattern of a three-body tracker
+    whose first two sampling blocks both resample."""
+    om, cam, P, frames, poses, uniforms = _inputs()
+    rng = np.random.default_rng(77)
+    steps = []
+    for k in range(len(frames)):
+        steps.append([rng.integers(0, N, N) for _ in range(3)])
+    return om, cam, P, frames, poses, steps
+
+
+def _double_resample_single():
+    om, cam, P, frames, poses, steps = _double_resample_script()
+    o = ob.Oracle(om, cam, P, max_particles=N, mode=ob.EAGER)
+    o.reset()
+    idx = np.zeros(N, np.int32)
+    out = []
+    for k, (_, frame) in enumerate(frames):
+        o.set_observation(frame)
+        for j, parents in enumerate(steps[k]):
+            idx = idx[parents].copy()
+            out.append(o.loglikes_poses(poses[k], idx, update=(j == 2)).copy())
+    return out
+
+
+def _double_resample_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        om, cam, P, frames, poses, steps = _double_resample_script()
+        shard = int(np.diff(rdist.shard_bounds(N, world)).max())
+        o = _OracleWithImport(om, cam, P, max_particles=2 * shard, mode=ob.EAGER)
+        ss = rdist.ShardedSensor(o, N)
+        ss.reset()
+        out, moves = [], 0
+        for k, (_, frame) in enumerate(frames):
+            ss.set_observation(frame)
+            for j, parents in enumerate(steps[k]):
+                moves += len(ss.resample(parents))
+                out.append(ss.loglikes(poses[k], update=(j == 2)).copy())
+        q.put((rank, out, moves))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_resampling_twice_without_update(world):
+    ref = _double_resample_single()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 25500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_double_resample_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, out, moves in got:
+        assert (moves > 0) == (world > 1)
+        for a, b in zip(out, ref):
+            assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+
+
 # ---------------------------------------------------------------- the sharded TRACKER
 def _tracker_run(sensor, om, frames, n, two_bodies=False):
     from dbot_ros_amd import pose
@@ -130,7 +196,7 @@ def _tracker_run(sensor, om, frames, n, two_bodies=False):
 
 
 def _tracker_inputs(parts):
-    meshes = ("m1_l2", "box12")[:parts]
+    meshes = ("m1_l2", "box12", "m1_l2")[:parts]
     om, cam, P = sc.make_scene(meshes, 80, 60, max_particles=2 * N)
     o = ob.Oracle(om, cam, P, max_particles=1)
     return om, cam, P, sc.make_frames(o, parts, 5, seed=8)
@@ -150,7 +216,7 @@ def _tracker_worker(rank, world, port, parts, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("parts", [1, 2])
+@pytest.mark.parametrize("parts", [1, 2, 3])
 def test_two_rank_sharded_tracker_matches_single_process(parts):
     """ParticleTracker over a ShardedRbSensor on two gloo ranks (oracle evaluators) against the same
     tracker over one oracle: identical estimates -- with two bodies there are two sampling blocks
