@@ -50,6 +50,7 @@ def parse():
                          "the windowed layout's worst case")
     ap.add_argument("--fill-fraction", type=float, default=1.0,
                     help="with --fill-planes: only a central rectangle of this fraction of the frame")
+    ap.add_argument("--precision", default=None, choices=["f64", "f32"], help="likelihood precision (default: the library's)")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the whole-plane (RBS_STATE=dense) comparison run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -146,7 +147,7 @@ def main():
     cam = CameraData(synth.camera_matrix(a.cols, a.rows), a.rows, a.cols)
     n = a.particles
     P = RbSensorBuilder.Parameters(sample_count=n)
-    sensor = RbSensor(om, cam, P, device_id=local, max_particles=n)
+    sensor = RbSensor(om, cam, P, device_id=local, max_particles=n, precision=a.precision)
 
     # synthetic frame: the product's own render hook supplies the object's depth
     rng = np.random.default_rng(0)

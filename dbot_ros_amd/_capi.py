@@ -11,13 +11,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RBS_LIB_PATH selects an alternative build of the SAME library (kernel tuning experiments)
 LIB_PATH = os.environ.get("RBS_LIB_PATH") or os.path.join(_HERE, "lib", "librbsensor_mi355x.so")
 
-RBS_ABI_VERSION = 1
+RBS_ABI_VERSION = 2
 RBS_OK = 0
 RBS_ERR_INVALID_ARGUMENT = -1
 RBS_ERR_NO_DEVICE = -2
 RBS_ERR_OUT_OF_MEMORY = -3
 RBS_ERR_HIP = -4
 RBS_ERR_UNSUPPORTED = -5
+RBS_PRECISION_DEFAULT, RBS_PRECISION_F64, RBS_PRECISION_F32 = 0, 1, 2
+RBS_STATE_DEFAULT, RBS_STATE_WINDOWED, RBS_STATE_DENSE = 0, 1, 2
+PRECISIONS = {None: 0, "default": 0, "f64": 1, "f32": 2}
+LAYOUTS = {None: 0, "default": 0, "window": 1, "windowed": 1, "dense": 2}
 
 # every symbol include/rbsensor_mi355x.h declares
 EXPORTS = (
@@ -64,6 +68,10 @@ class RbsConfig(C.Structure):
         ("model_sigma", C.c_double),
         ("sigma_factor", C.c_double),
         ("delta_time", C.c_double),
+        ("likelihood_precision", C.c_int32),
+        ("state_layout", C.c_int32),
+        ("n_devices", C.c_int32),
+        ("device_ids", C.POINTER(C.c_int32)),
     ]
 
 

@@ -80,6 +80,10 @@ struct rbs_handle {
     size_t partial_cap = 0;
     float* d_cluster_sphere = nullptr;
     float* d_cluster_cone = nullptr;
+    float* d_vtx = nullptr;         // [sum of vertex counts][4] float32 vertices (screen rectangles)
+    float* d_tri_plane = nullptr;   // [n_tri][4] model-space plane of each triangle (float32 pre-cull)
+    float* d_auxf = nullptr;        // [npx][4] per-frame-pixel terms in float (likelihood precision F32)
+    int precision = RBS_PRECISION_F64;
     float* d_render = nullptr;
     float* h_frame = nullptr;   // pinned staging
     float* h_native = nullptr;  // pinned staging for full-resolution frames
@@ -182,7 +186,8 @@ int32_t flush_lazy_frame(rbs_handle* h, hipStream_t then)
     const size_t n = (size_t)h->npx;
     hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->lazy_stream,
                        h->lazy_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms, h->base.sf,
-                       h->base.lambda, h->lazy_frame == h->d_frame ? (float*)nullptr : h->d_frame);
+                       h->base.lambda, h->lazy_frame == h->d_frame ? (float*)nullptr : h->d_frame,
+                       reinterpret_cast<rbs::floatx4*>(h->d_auxf));
     RBS_HIP(h, hipGetLastError());
     h->lazy_frame = nullptr;
     if (then != h->lazy_stream) {
@@ -266,7 +271,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
 #endif
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_start[tslot], s));
     const dim3 block(rbs::kBlock);
-    const dim3 pgrid((unsigned)((n + 255) / 256));
+    const dim3 pgrid((unsigned)((n + rbs::kPrepPerBlock - 1) / rbs::kPrepPerBlock));
     // dense planes: prep + scan read only the poses and run ahead of the previous call's copy
     // kernel (which reads the other rectangle buffer); windowed planes: prep reads the windows
     // that copy kernel is still growing, so the join comes first (that copy is short)
@@ -282,14 +287,15 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.area_sum = sample_area ? h->d_area : nullptr;
     const bool wide = h->windowed && update && h->wide;
     if (h->lazy_frame && h->lazy_stream == s) {
-        const int aux_blocks = (h->npx + 255) / 256;
-        hipLaunchKernelGGL(rbs::rbs_frame_prep_kernel, dim3((unsigned)(aux_blocks + (n + 255) / 256)), dim3(256), 0, s, P,
+        constexpr int ptb = 64 * rbs::kPrepPerBlock;
+        const int aux_blocks = (h->npx + ptb - 1) / ptb;
+        hipLaunchKernelGGL(rbs::rbs_frame_prep_kernel, dim3((unsigned)(aux_blocks + (n + rbs::kPrepPerBlock - 1) / rbs::kPrepPerBlock)), dim3(ptb), 0, s, P,
                            d_rects, update ? 1 : 0, h->lazy_frame, h->d_aux, h->d_pbg,
                            h->lazy_frame == h->d_frame ? (float*)nullptr : h->d_frame, aux_blocks);
         h->lazy_frame = nullptr;
     } else {
         if (int32_t rc = flush_lazy_frame(h, s)) return rc;
-        hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(256), 0, s, P, d_rects, update ? 1 : 0);
+        hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(64 * rbs::kPrepPerBlock), 0, s, P, d_rects, update ? 1 : 0);
     }
     RBS_HIP(h, hipGetLastError());
     if (sample_area) {
@@ -327,7 +333,10 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     const dim3 rgrid((unsigned)(wide || mid ? std::min(h->raster_blocks, 2 * h->cu_count) : h->raster_blocks));
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
     if (update) {
-        hipLaunchKernelGGL((rbs::rbs_raster_kernel<true>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
+        if (h->precision == RBS_PRECISION_F32)
+            hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 1>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
+        else
+            hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 0>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
@@ -369,7 +378,10 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
         }
     } else {
-        hipLaunchKernelGGL((rbs::rbs_raster_kernel<false>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
+        if (h->precision == RBS_PRECISION_F32)
+            hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 1>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
+        else
+            hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 0>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
     }
@@ -448,6 +460,9 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_cluster_sphere);
     (void)hipFree(h->d_cluster_cone);
+    (void)hipFree(h->d_tri_plane);
+    (void)hipFree(h->d_vtx);
+    (void)hipFree(h->d_auxf);
     (void)hipFree(h->d_render);
     if (h->h_frame) (void)hipHostFree(h->h_frame);
     if (h->h_native) (void)hipHostFree(h->h_native);
@@ -523,6 +538,13 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     h->p_oo = cfg->p_occluded_occluded;
     h->init_occ = cfg->initial_occlusion_prob;
     h->delta_time = cfg->delta_time;
+    switch (cfg->likelihood_precision) {
+        case RBS_PRECISION_DEFAULT: h->precision = RBS_PRECISION_LIBRARY_DEFAULT; break;
+        case RBS_PRECISION_F64: case RBS_PRECISION_F32: h->precision = cfg->likelihood_precision; break;
+        default: return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("likelihood_precision %d", cfg->likelihood_precision));
+    }
+    if (cfg->state_layout < RBS_STATE_DEFAULT || cfg->state_layout > RBS_STATE_DENSE)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("state_layout %d", cfg->state_layout));
 
     DevParams& B = h->base;
     B.rows = h->rows; B.cols = h->cols; B.npx = h->npx;
@@ -545,12 +567,14 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         B.tri_begin[b + 1] = (int)n_tri;
     }
     for (int b = h->n_bodies; b < rbs::kMaxBodies; ++b) B.tri_begin[b + 1] = (int)n_tri;
+    for (int b = 0; b < rbs::kMaxBodies; ++b) B.tri_end[b] = B.tri_begin[b];
     if (n_tri > (1L << 30)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "too many triangles");
     B.n_tri = (int)n_tri;
     const size_t n_alloc = (size_t)(n_tri > 0 ? n_tri : 64);
     std::vector<double> soup((size_t)9 * n_alloc, std::nan(""));
     std::vector<float> cluster_sphere(4 * (n_alloc / 64), 0.f);
     std::vector<float> cluster_cone(4 * (n_alloc / 64), -2.f);   // min cos -2: never culled
+    std::vector<float> tri_plane(4 * n_alloc, std::nanf(""));    // NaN: never pre-culled
     const bool allow_cull = !(std::getenv("RBS_NO_CULL") && std::atoi(std::getenv("RBS_NO_CULL")));
     size_t voff = 0, toff = 0;
     for (int b = 0; b < h->n_bodies; ++b) {
@@ -574,11 +598,6 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         }
         B.sphere[b][0] = ctr[0]; B.sphere[b][1] = ctr[1]; B.sphere[b][2] = ctr[2];
         B.sphere[b][3] = std::sqrt(r2) * (1.0 + 1e-9) + 1e-12;
-        for (int c3 = 0; c3 < 3; ++c3) {   // bounding box, padded so rounding can never shave a vertex off
-            const double pad = 1e-9 * (hi[c3] - lo[c3]) + 1e-12;
-            B.aabb[b][c3] = lo[c3] - pad;
-            B.aabb[b][3 + c3] = hi[c3] + pad;
-        }
         for (int t = 0; t < nt; ++t)
             for (int k = 0; k < 3; ++k)
                 if (T[3 * t + k] < 0 || T[3 * t + k] >= nv)
@@ -688,6 +707,24 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
                 for (int c3 = 0; c3 < 3; ++c3)
                     soup[(size_t)(3 * k + c3) * n_alloc + base + j] = V[3 * T[3 * t + k] + c3];
         }
+        B.tri_end[b] = (int)base + nt;
+        // model-space plane of each triangle, unit normal of its winding (float32 pre-cull only)
+        for (int j = 0; j < nt; ++j) {
+            double p[3][3];
+            for (int k = 0; k < 3; ++k)
+                for (int c3 = 0; c3 < 3; ++c3) p[k][c3] = soup[(size_t)(3 * k + c3) * n_alloc + base + j];
+            const double e1[3] = {p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]};
+            const double e2[3] = {p[2][0] - p[0][0], p[2][1] - p[0][1], p[2][2] - p[0][2]};
+            const double n3[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            const double len = std::sqrt(n3[0] * n3[0] + n3[1] * n3[1] + n3[2] * n3[2]);
+            if (!(len > 0.0) || !std::isfinite(len)) continue;   // zero area: stays NaN = kept (the setup rejects it)
+            // offset from the triangle's centroid (the three vertices give the same plane up to rounding)
+            const double cx3 = (p[0][0] + p[1][0] + p[2][0]) / 3.0, cy3 = (p[0][1] + p[1][1] + p[2][1]) / 3.0,
+                         cz3 = (p[0][2] + p[1][2] + p[2][2]) / 3.0;
+            float* pl = &tri_plane[4 * (base + j)];
+            pl[0] = (float)(n3[0] / len); pl[1] = (float)(n3[1] / len); pl[2] = (float)(n3[2] / len);
+            pl[3] = (float)(-(n3[0] * cx3 + n3[1] * cy3 + n3[2] * cz3) / len);
+        }
         // bounding sphere of each cluster of 64 (centre = bbox centre of its vertices)
         for (size_t c = base / 64; c < (size_t)B.tri_begin[b + 1] / 64; ++c) {
             double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
@@ -762,7 +799,11 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         h->tile_override = std::getenv("RBS_TILE");
         if (const char* m = std::getenv("RBS_COPY_ROWS")) h->copy_rows = std::atoi(m);
         if (const char* m = std::getenv("RBS_COPY_TPB")) h->copy_tpb = std::max(64, std::atoi(m) / 64 * 64);
-        if (const char* m = std::getenv("RBS_STATE")) h->windowed = std::strcmp(m, "dense") != 0;
+        // the layout is the caller's choice (rbs_config.state_layout); the environment is consulted
+        // only when the caller leaves it open (tools comparing both layouts of an unchanged caller)
+        if (cfg->state_layout == RBS_STATE_DENSE) h->windowed = false;
+        else if (cfg->state_layout == RBS_STATE_DEFAULT)
+            if (const char* m = std::getenv("RBS_STATE")) h->windowed = std::strcmp(m, "dense") != 0;
         h->smalln_target = 2 * std::max(1, prop.multiProcessorCount);   // measured best at 64..500 particles
         if (const char* m = std::getenv("RBS_SMALLN_TARGET")) h->smalln_target = std::max(1, std::atoi(m));
         if (const char* m = std::getenv("RBS_MID_ENTER")) h->mid_enter = std::atof(m);
@@ -810,12 +851,38 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMemcpy(h->d_cluster_cone, cluster_cone.data(), sizeof(float) * cluster_cone.size(),
                          hipMemcpyHostToDevice));
     B.cluster_cone = h->d_cluster_cone;
+    RBS_HIP(h, hipMalloc(&h->d_tri_plane, sizeof(float) * tri_plane.size()));
+    RBS_HIP(h, hipMemcpy(h->d_tri_plane, tri_plane.data(), sizeof(float) * tri_plane.size(), hipMemcpyHostToDevice));
+    B.tri_plane = reinterpret_cast<const rbs::floatx4*>(h->d_tri_plane);
+    {   // float32 copy of the vertices, per body (screen rectangles)
+        std::vector<float> vtx;
+        size_t vo = 0;
+        B.vtx_begin[0] = 0;
+        for (int b = 0; b < h->n_bodies; ++b) {
+            for (int i = 0; i < cfg->vertex_counts[b]; ++i) {
+                for (int c3 = 0; c3 < 3; ++c3) vtx.push_back((float)cfg->vertices[3 * (vo + i) + c3]);
+                vtx.push_back(0.f);
+            }
+            vo += (size_t)cfg->vertex_counts[b];
+            B.vtx_begin[b + 1] = (int)vo;
+        }
+        for (int b = h->n_bodies; b < rbs::kMaxBodies; ++b) B.vtx_begin[b + 1] = (int)vo;
+        RBS_HIP(h, hipMalloc(&h->d_vtx, sizeof(float) * std::max<size_t>(vtx.size(), 4)));
+        RBS_HIP(h, hipMemcpy(h->d_vtx, vtx.data(), sizeof(float) * vtx.size(), hipMemcpyHostToDevice));
+        B.vtx = reinterpret_cast<const rbs::floatx4*>(h->d_vtx);
+    }
+    if (h->precision == RBS_PRECISION_F32) RBS_HIP(h, hipMalloc(&h->d_auxf, sizeof(float) * 4 * (size_t)h->npx));
+    B.auxf = reinterpret_cast<const rbs::floatx4*>(h->d_auxf);
     RBS_HIP(h, hipHostMalloc(&h->h_frame, plane, hipHostMallocDefault));
 
     // the raster / render kernels carve the LDS depth tile from dynamic shared memory
-    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true>),
+    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
-    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false>),
+    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
+    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
+    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
     RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_render_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));

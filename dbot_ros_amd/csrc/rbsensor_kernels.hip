@@ -66,21 +66,29 @@ constexpr int kTilePxBig = 16384;          // ... of a launch with 2 blocks per 
 constexpr int kBigCap = RBS_BIG_CAP;       // triangles deferred to the cooperative path per chunk
 constexpr int kBigThresh = RBS_BIG_THRESH; // bbox pixels above which a triangle is "big"
 constexpr int kCopyUnroll = RBS_COPY_UNROLL; // float4 loads in flight per lane in copy blocks
+#ifndef RBS_SCAN_UNROLL
+#define RBS_SCAN_UNROLL 4
+#endif
+constexpr int kScanUnroll = RBS_SCAN_UNROLL;  // quads per lane whose loads are in flight together in the pixel pass
 constexpr int kEvalQueue = 128;             // per-wave queue of covered pixels awaiting evaluation
 constexpr int kRectAlign = 16;              // whole planes: rectangle x-alignment in pixels (64 B)
 constexpr float kSnapTau = 0x1p-18f;         // background snap of the occlusion process (oracle ORC_SNAP_TAU)
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kInfBits = 0x7f800000u;
 constexpr int kMaxBodies = 16;
 constexpr double kMaxDepth = 6.0;    // KinectPixelModel max_depth
 constexpr double kHalfLifeDepth = 1.0;
-
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 struct DevParams {
     int rows, cols, npx;
     int n_bodies;
     int n_tri;                     // soup length: every body padded to a multiple of 64
     int tri_begin[kMaxBodies + 1]; // triangle range per body (multiples of 64)
+    int tri_end[kMaxBodies];       // end of the body's REAL triangles (the rest of its last cluster is NaN padding)
+    const floatx4* tri_plane;      // [n_tri] model-space plane of each triangle: unit normal of its winding, offset
+                                   //   (n.x + d = signed distance of x from the plane); NaN for padding
+    const floatx4* vtx;            // vertices of every body (x, y, z, 0), float32: the screen rectangle only
+    int vtx_begin[kMaxBodies + 1]; // vertex range per body
     const float* cluster_sphere;   // [n_tri/64][4] model-space bounding sphere of each cluster
     const float* cluster_cone;     // [n_tri/64][4] outward-normal cone of each cluster: unit axis, min cos
                                    //   (min cos <= -1: never cull this cluster)
@@ -91,10 +99,10 @@ struct DevParams {
     int tile_w, tile_h;            // work-item tile limits: width <= tile_w, pixels <= min(tile_w*tile_h, kTilePx)
     double fx, fy, cx, cy;
     double sphere[kMaxBodies][4];  // model-space bounding sphere: centre xyz, radius
-    double aabb[kMaxBodies][6];    // model-space bounding box: lo xyz, hi xyz
     const double* soup;            // SoA [9][n_tri]: v0.xyz v1.xyz v2.xyz
     const float* frame;            // observation, float metres
-    const double* aux;             // per-frame-pixel terms, SoA [4][npx] (frame_aux_kernel)
+    const double* aux;             // per-frame-pixel terms, [npx][4] binary64 (frame_aux_kernel)
+    const floatx4* auxf;           // the same four terms rounded to float (likelihood precision F32)
     const float* pbg;              // per-frame-pixel background density, rounded to float
     double tw, ms, sf, lambda;     // tail_weight, model_sigma, sigma_factor, ln2/half_life
     float alpha, beta;             // occlusion process over the elapsed frames
@@ -166,63 +174,73 @@ __device__ inline float occ_step(float alpha, float beta, float v, float bg_new)
 }
 
 // ------------------------------------------------------------------ screen rectangle
-// Conservative pixel rectangle containing every pixel the particle's bodies can cover, from
-// the bodies' bounding spheres intersected with the projection of their model-space bounding
-// boxes (8 corners; a convex hull projects inside the hull of its projected corners when it is
-// entirely in front of the camera); x-aligned to kRectAlign pixels so raster and copy blocks
-// split rows at 64-byte boundaries.  Result only decides WHO writes a pixel, never its value.
+// Pixel rectangle containing every pixel the particle's bodies can cover: the bounding box of the
+// projected VERTICES (a triangle wholly in front of the camera projects inside the hull of its
+// projected vertices), computed by one wave per particle, lanes striding over the vertices, in
+// float32 with a margin that covers the float rounding (a few 1e-3 px) -- the rasterizer's own
+// binary64 bounding boxes therefore lie inside it.  x-aligned to rect_align pixels so raster and
+// copy blocks split rows at float4 / 64-byte boundaries.  The result only decides WHO writes a
+// pixel, never its value.  (Up to round 1 the rectangle came from the bounding sphere and the
+// corners of the bounding box: 9 200 px for the 5 120-triangle ellipsoid at 0.7 m where this
+// one has 5 700 -- the pixel pass, the tile and the stored windows shrink by as much.)
+// Called by all 64 lanes of a wave; every lane returns the same rectangle.
 __device__ inline Rect particle_rect(const DevParams& P, const double* __restrict__ pose)
 {
-    double umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
-    bool full = false;
+    const int lane = threadIdx.x & 63, stride = 64;
+    const float fx = (float)P.fx, fy = (float)P.fy, cx = (float)P.cx, cy = (float)P.cy;
+    float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY, zmin = INFINITY, tabs = 0.f;
     for (int b = 0; b < P.n_bodies; ++b) {
         const double* Rt = pose + 12 * b;
-        const double sx = P.sphere[b][0], sy = P.sphere[b][1], sz = P.sphere[b][2];
-        const double rho = P.sphere[b][3];
-        const double X = ((Rt[0] * sx + Rt[1] * sy) + Rt[2] * sz) + Rt[9];
-        const double Y = ((Rt[3] * sx + Rt[4] * sy) + Rt[5] * sz) + Rt[10];
-        const double Z = ((Rt[6] * sx + Rt[7] * sy) + Rt[8] * sz) + Rt[11];
-        const double zmin = Z - rho, zmax = Z + rho;
-        if (!(zmin > 1e-6)) { full = true; continue; }
-        const double xl = X - rho, xr = X + rho, yl = Y - rho, yr = Y + rho;
-        umax = fmax(umax, P.fx * (xr >= 0.0 ? xr / zmin : xr / zmax) + P.cx);
-        umin = fmin(umin, P.fx * (xl >= 0.0 ? xl / zmax : xl / zmin) + P.cx);
-        vmax = fmax(vmax, P.fy * (yr >= 0.0 ? yr / zmin : yr / zmax) + P.cy);
-        vmin = fmin(vmin, P.fy * (yl >= 0.0 ? yl / zmax : yl / zmin) + P.cy);
-    }
-    if (!full) {
-        // tighter bound: the 8 corners of every body's bounding box (all are in front of the
-        // camera here because the enclosing sphere is)
-        double bumin = INFINITY, bumax = -INFINITY, bvmin = INFINITY, bvmax = -INFINITY;
-        bool ok = true;
-        for (int b = 0; b < P.n_bodies; ++b) {
-            const double* Rt = pose + 12 * b;
-            for (int c = 0; c < 8; ++c) {
-                const double x = P.aabb[b][(c & 1) ? 3 : 0], y = P.aabb[b][(c & 2) ? 4 : 1],
-                             z = P.aabb[b][(c & 4) ? 5 : 2];
-                const double X = ((Rt[0] * x + Rt[1] * y) + Rt[2] * z) + Rt[9];
-                const double Y = ((Rt[3] * x + Rt[4] * y) + Rt[5] * z) + Rt[10];
-                const double Z = ((Rt[6] * x + Rt[7] * y) + Rt[8] * z) + Rt[11];
-                if (!(Z > 1e-6)) { ok = false; continue; }
-                const double u = P.fx * (X / Z) + P.cx, v = P.fy * (Y / Z) + P.cy;
-                bumin = fmin(bumin, u); bumax = fmax(bumax, u);
-                bvmin = fmin(bvmin, v); bvmax = fmax(bvmax, v);
+        const float r0 = (float)Rt[0], r1 = (float)Rt[1], r2 = (float)Rt[2], r3 = (float)Rt[3], r4 = (float)Rt[4],
+                    r5 = (float)Rt[5], r6 = (float)Rt[6], r7 = (float)Rt[7], r8 = (float)Rt[8];
+        const float tx = (float)Rt[9], ty = (float)Rt[10], tz = (float)Rt[11];
+        tabs = fmaxf(tabs, fabsf(tx) + fabsf(ty) + fabsf(tz));
+        // eight vertex loads in flight per lane (the vertices sit in L2; one dependent load per
+        // trip would leave this kernel, which the raster kernel waits for, latency bound)
+        constexpr int kV = 8;
+        const int v1 = P.vtx_begin[b + 1];
+        for (int i0 = P.vtx_begin[b] + lane; i0 < v1; i0 += stride * kV) {
+            floatx4 pv[kV];
+#pragma unroll
+            for (int k = 0; k < kV; ++k) pv[k] = P.vtx[min(i0 + stride * k, v1 - 1)];   // the tail repeats the last vertex
+#pragma unroll
+            for (int k = 0; k < kV; ++k) {
+                const floatx4 p = pv[k];
+                const float X = fmaf(r0, p.x, fmaf(r1, p.y, fmaf(r2, p.z, tx)));
+                const float Y = fmaf(r3, p.x, fmaf(r4, p.y, fmaf(r5, p.z, ty)));
+                const float Z = fmaf(r6, p.x, fmaf(r7, p.y, fmaf(r8, p.z, tz)));
+                const float iz = __builtin_amdgcn_rcpf(Z);
+                const float u = fmaf(fx, X * iz, cx), v = fmaf(fy, Y * iz, cy);
+                zmin = fminf(zmin, Z);     // NaN poses: fminf/fmaxf drop the NaN, zmin stays +inf ...
+                umin = fminf(umin, u); umax = fmaxf(umax, u);
+                vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
             }
         }
-        if (ok) {
-            umin = fmax(umin, bumin); umax = fmin(umax, bumax);
-            vmin = fmax(vmin, bvmin); vmax = fmin(vmax, bvmax);
-        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        umin = fminf(umin, __shfl_xor(umin, off)); umax = fmaxf(umax, __shfl_xor(umax, off));
+        vmin = fminf(vmin, __shfl_xor(vmin, off)); vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+        zmin = fminf(zmin, __shfl_xor(zmin, off));
+        tabs = fmaxf(tabs, __shfl_xor(tabs, off));
     }
     Rect r;
+    // a vertex at or behind the camera plane (the rasterizer drops such triangles, but their
+    // neighbours may project anywhere), or a pose that is not finite: the whole frame
+    const bool full = !(zmin > 1e-4f) || !(zmin < INFINITY) || !(tabs < INFINITY) ||
+                      !(umax - umin < INFINITY) || !(vmax - vmin < INFINITY);   // ... and the extents are -inf
     if (full) {
         r.x0 = 0; r.y0 = 0; r.x1 = P.cols; r.y1 = P.rows;
     } else {
-        const double W = (double)P.cols, H = (double)P.rows;
-        r.x0 = (int)fmin(fmax(floor(umin) - 1.0, 0.0), W);
-        r.x1 = (int)fmin(fmax(ceil(umax) + 2.0, 0.0), W);
-        r.y0 = (int)fmin(fmax(floor(vmin) - 1.0, 0.0), H);
-        r.y1 = (int)fmin(fmax(ceil(vmax) + 2.0, 0.0), H);
+        // float rounding of X, Y, Z (inputs rounded to float + three fmas each), of the reciprocal
+        // (1 ulp) and of the projection
+        const float mx = 4e-6f * fx * (tabs + 1.0f) / zmin + 3e-7f * (fabsf(umin - cx) + fabsf(umax - cx)) + 1e-3f;
+        const float my = 4e-6f * fy * (tabs + 1.0f) / zmin + 3e-7f * (fabsf(vmin - cy) + fabsf(vmax - cy)) + 1e-3f;
+        const float W = (float)P.cols, H = (float)P.rows;
+        r.x0 = (int)fminf(fmaxf(floorf(umin - mx), 0.0f), W);
+        r.x1 = (int)fminf(fmaxf(ceilf(umax + mx) + 1.0f, 0.0f), W);
+        r.y0 = (int)fminf(fmaxf(floorf(vmin - my), 0.0f), H);
+        r.y1 = (int)fminf(fmaxf(ceilf(vmax + my) + 1.0f, 0.0f), H);
     }
     r.x0 &= ~(P.rect_align - 1);
     r.x1 = min(P.cols, (r.x1 + P.rect_align - 1) & ~(P.rect_align - 1));
@@ -394,16 +412,45 @@ __device__ inline int body_cullsign(const DevParams& P, const double* __restrict
     return (Z - P.sphere[b][3] > 1e-6) ? P.body_cull[b] : 0;
 }
 
+// One lane's triangle: setup, then its sample points (or the cooperative queue when it is big).
+__device__ inline void raster_lane_triangle(const DevParams& P, int t, const double* __restrict__ Rt, int wx0,
+                                            int wy0, int wx1, int wy1, int cullsign, unsigned* tile, int tw,
+                                            int* big, int* nbig)
+{
+    Tri T;
+    if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, cullsign, T)) return;
+#ifdef RBS_EXP_SKIP_PIXELS   // profiling builds (tools/phase_timing.py): triangle setup only
+    if (T.nv0 != 12345.678) return;
+#endif
+    const int bw = T.xhi - T.xlo + 1, bh = T.yhi - T.ylo + 1;
+    if (bw * bh > kBigThresh) {
+        const int slot = atomicAdd(nbig, 1);
+        if (slot < kBigCap) { big[slot] = t; return; }
+    }
+    for (int row = T.ylo; row <= T.yhi; ++row)
+        for (int col = T.xlo; col <= T.xhi; ++col)
+            tri_pixel(T, col, row, tile, tw, wx0, wy0);
+}
+
 // Rasterize every body of one particle into the LDS tile covering window
 // [wx0,wx1) x [wy0,wy1).  One wave takes one 64-triangle cluster at a time (triangles were
-// ordered along a space-filling curve at create time, so a cluster is a compact surface
-// patch): wave-uniform frustum cull, then one lane per triangle.  Small triangles are
-// rasterized by their lane; triangles whose clipped bbox exceeds kBigThresh pixels are queued
-// in LDS and rasterized by the whole block, pixel-parallel.
+// grouped into compact surface patches at create time): wave-uniform frustum / normal-cone cull
+// of whole clusters, then one lane per triangle.
+// Triangle compaction: the expensive part -- binary64 transform, three divisions, projection,
+// plane setup, the per-sample loops -- runs in lockstep, so a lane whose triangle turns out to
+// face away idles through all of it.  For bodies that may be culled (closed, oriented, in front
+// of the camera) a float32 test of the camera centre against the triangle's model-space plane
+// (four floats, three FMAs) drops the triangles that CLEARLY face away before the setup, and the
+// survivors' indices are compacted through a per-wave LDS queue (tq) and set up 64 at a time with
+// full lanes.  The pre-test only removes triangles the exact projected-area test inside
+// tri_setup would remove as well (it keeps everything within 10 um + 1e-5 |eye| of edge-on), so
+// depths are unchanged bit for bit.
+// Small triangles are rasterized by their lane; triangles whose clipped bbox exceeds kBigThresh
+// pixels are queued in LDS and rasterized by the whole block, pixel-parallel.
 // Caller has cleared the tile and synchronised; on return the tile is complete and synchronised.
 __device__ inline void raster_window(const DevParams& P, const double* __restrict__ pose,
                                      int wx0, int wy0, int wx1, int wy1, bool cull, unsigned* tile,
-                                     int* big, int* nbig)
+                                     int* big, int* nbig, int* tq)
 {
     const int tw = wx1 - wx0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -415,7 +462,16 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
     for (int b = 0; b < P.n_bodies; ++b) {
         const double* Rt = pose + 12 * b;
         const int c0 = P.tri_begin[b] >> 6, c1 = P.tri_begin[b + 1] >> 6;
+        const int t_end = P.tri_end[b];
         const int cullsign = body_cullsign(P, Rt, b);
+        // camera centre in model coordinates, e = -R^T t (float32: only the conservative pre-test uses it)
+        const float tx = (float)Rt[9], ty = (float)Rt[10], tz = (float)Rt[11];
+        const float ex = -((float)Rt[0] * tx + (float)Rt[3] * ty + (float)Rt[6] * tz);
+        const float ey = -((float)Rt[1] * tx + (float)Rt[4] * ty + (float)Rt[7] * tz);
+        const float ez = -((float)Rt[2] * tx + (float)Rt[5] * ty + (float)Rt[8] * tz);
+        const float eps = 1e-5f * (1.0f + sqrtf(ex * ex + ey * ey + ez * ez));
+        const float fsign = (float)cullsign;
+        int qh = 0, qn = 0;   // ring queue of surviving triangle indices: head, count (wave-uniform)
         for (int base = c0; base < c1; base += 64) {
             // 64 clusters culled at once, one per lane (every wave computes the same mask)
             const int ci = base + lane;
@@ -429,20 +485,39 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
                 mask &= mask - 1;
                 if ((taken++) % (kBlock / 64) != wave) continue;
                 const int t = ((base + bit) << 6) + lane;
-                Tri T;
-                if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, cullsign, T)) continue;
-#ifdef RBS_EXP_SKIP_PIXELS   // profiling builds (tools/phase_timing.py): triangle setup only
-                if (T.nv0 != 12345.678) continue;
-#endif
-                const int bw = T.xhi - T.xlo + 1, bh = T.yhi - T.ylo + 1;
-                if (bw * bh > kBigThresh) {
-                    const int slot = atomicAdd(nbig, 1);
-                    if (slot < kBigCap) { big[slot] = t; continue; }
+                if (cullsign == 0) {   // nothing to pre-test: the cluster's lanes go straight to the setup
+                    raster_lane_triangle(P, t, Rt, wx0, wy0, wx1, wy1, 0, tile, tw, big, nbig);
+                    continue;
                 }
-                for (int row = T.ylo; row <= T.yhi; ++row)
-                    for (int col = T.xlo; col <= T.xhi; ++col)
-                        tri_pixel(T, col, row, tile, tw, wx0, wy0);
+                bool keep = t < t_end;
+                if (keep) {
+                    const floatx4 pl = P.tri_plane[t];
+                    const float sd = pl.x * ex + pl.y * ey + pl.z * ez + pl.w;   // eye's signed distance, winding side
+                    keep = !(fsign * sd < -eps);   // outward normal = cullsign * winding normal; NaN keeps
+                }
+                const unsigned long long km = __ballot(keep);
+                if (keep) {
+                    const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0));
+                    tq[(qh + pos) & 127] = t;
+                }
+                qn += __popcll(km);
+                if (qn >= 64) {
+                    __builtin_amdgcn_wave_barrier();
+                    const int tt = tq[(qh + lane) & 127];
+                    __builtin_amdgcn_wave_barrier();
+                    qh = (qh + 64) & 127;
+                    qn -= 64;
+                    raster_lane_triangle(P, tt, Rt, wx0, wy0, wx1, wy1, cullsign, tile, tw, big, nbig);
+                }
             }
+        }
+        if (qn > 0) {   // the body's last, partly filled batch
+            __builtin_amdgcn_wave_barrier();
+            if (lane < qn) {
+                const int tt = tq[(qh + lane) & 127];
+                raster_lane_triangle(P, tt, Rt, wx0, wy0, wx1, wy1, cullsign, tile, tw, big, nbig);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
@@ -479,7 +554,7 @@ enum { AUX_INV_S2S = 0, AUX_K = 1, AUX_CV = 2, AUX_EO = 3, AUX_PLANES = 4 };
 // keep != nullptr: `frame` is the caller's buffer and is also copied into the handle's own.
 __device__ inline void frame_aux_pixel(int i, const float* __restrict__ frame, double* __restrict__ aux,
                                        float* __restrict__ pbg, int npx, double tw, double ms, double sf,
-                                       double lam, float* __restrict__ keep)
+                                       double lam, float* __restrict__ keep, floatx4* __restrict__ auxf)
 {
     const float of = frame[i];
     if (keep) keep[i] = of;
@@ -493,14 +568,19 @@ __device__ inline void frame_aux_pixel(int i, const float* __restrict__ frame, d
     a4[AUX_CV] = (1.0 - tw) / (sqrt(2.0 * M_PI) * sigma);
     a4[AUX_EO] = 0.5 * (1.0 - tw) * lam * eo;
     pbg[i] = (float)(tw / kMaxDepth + (1.0 - tw) * lam * eo);
+    if (auxf) {   // likelihood precision F32: the same terms, each rounded once to float
+        floatx4 f;
+        f.x = (float)a4[AUX_INV_S2S]; f.y = (float)a4[AUX_K]; f.z = (float)a4[AUX_CV]; f.w = (float)a4[AUX_EO];
+        auxf[i] = f;
+    }
 }
 
 __global__ void frame_aux_kernel(const float* __restrict__ frame, double* __restrict__ aux,
                                  float* __restrict__ pbg, int npx, double tw, double ms, double sf,
-                                 double lam, float* __restrict__ keep)
+                                 double lam, float* __restrict__ keep, floatx4* __restrict__ auxf)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npx) frame_aux_pixel(i, frame, aux, pbg, npx, tw, ms, sf, lam, keep);
+    if (i < npx) frame_aux_pixel(i, frame, aux, pbg, npx, tw, ms, sf, lam, keep, auxf);
 }
 
 // log-likelihood ratio of one covered, observed pixel + posterior occlusion.
@@ -549,6 +629,31 @@ __device__ inline double pixel_loglik(const DevParams& P, int gi, float r, float
 #endif
 }
 
+// Likelihood precision F32 (rbs_config.likelihood_precision = RBS_PRECISION_F32): the same model
+// with the per-pixel transcendental work in float32 -- coverage, depth and the occlusion process
+// are untouched (binary64 geometry, float state), only exp / erf / log and the mixture algebra
+// change.  Written for relative accuracy: 1 + erf(x) as erfc(-x) (no cancellation in the lower
+// tail), E1/(E1-1) as 1/(1 - exp(-lam r)).  Per-pixel error of the log term <~ 5e-7; the
+// particle's sum is accumulated in binary64.  tests/: <= 1e-5 relative against the
+// reference-semantics (LAZY) oracle, the north_star tolerance.
+__device__ inline double pixel_loglik_f32(const DevParams& P, int gi, float r, float prior, float& posterior)
+{
+    const float o = P.frame[gi];
+    const floatx4 a = P.auxf[gi];          // 1/(sqrt2 sigma), lam sigma/sqrt2, c_v, e_o
+    const float pbg = P.pbg[gi];
+    __builtin_amdgcn_sched_barrier(0);
+    const float twD = (float)(P.tw / kMaxDepth);
+    const float w = (r - o) * a.x;
+    const float pv = twD + a.z * expf(-(w * w));
+    const float ratio = 1.0f / (1.0f - expf(-(r * (float)P.lambda)));
+    const float po = twD + a.w * ratio * erfcf(-(w + a.y));
+    const float av = pv * (1.0f - prior);
+    const float bv = po * prior;
+    const float sum = av + bv;
+    posterior = bv / sum;
+    return (double)logf(sum / pbg);
+}
+
 __device__ inline double block_reduce_sum(double v, double* red)
 {
 #pragma unroll
@@ -580,7 +685,7 @@ __device__ inline Smem carve(unsigned char* smem, int kTilePx)
 
 // One (particle, tile) work item: rasterize the tile window, evaluate its pixels, return the
 // block-reduced partial log-likelihood (valid in thread 0).
-template <bool UPDATE>
+template <bool UPDATE, int PREC>
 __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect r, int tile_id,
                                           const Smem& m)
 {
@@ -605,7 +710,8 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     __syncthreads();
     RBS_TICK(1);
     // a rectangle that is a single tile was sized from the same spheres: nothing to cull
-    raster_window(P, pose, wx0, wy0, wx1, wy1, !whole || P.n_bodies > 1, m.tile, m.big, m.nbig);
+    raster_window(P, pose, wx0, wy0, wx1, wy1, !whole || P.n_bodies > 1, m.tile, m.big, m.nbig,
+                  m.evalq + (threadIdx.x >> 6) * 3 * kEvalQueue);   // the eval queue is idle during the raster phase
     RBS_TICK(2);
 
     // Pixel pass.  Only ~1/3 of a tile's pixels are covered by the object, in runs that leave
@@ -633,7 +739,8 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                 __builtin_amdgcn_wave_barrier();                                                        \
                 const int eg_ = q[lane], ed_ = q[kEvalQueue + lane], ep_ = q[2 * kEvalQueue + lane];    \
                 float post_;                                                                            \
-                ll += pixel_loglik(P, eg_, __uint_as_float((unsigned)ed_), __int_as_float(ep_), post_); \
+                ll += PREC ? pixel_loglik_f32(P, eg_, __uint_as_float((unsigned)ed_), __int_as_float(ep_), post_)              \
+                           : pixel_loglik(P, eg_, __uint_as_float((unsigned)ed_), __int_as_float(ep_), post_); \
                 if (UPDATE) dst[eg_] = post_;                                                           \
                 qn -= 64;                                                                               \
                 int cg_ = 0, cd_ = 0, cp_ = 0;                                                          \
@@ -655,36 +762,57 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
         int lr = (int)threadIdx.x / tq;
         int qc = (int)threadIdx.x - lr * tq;
         const uint4* __restrict__ tile4 = reinterpret_cast<const uint4*>(m.tile);
-        for (int q0 = wave * 64; q0 < nq; q0 += kBlock) {
-            const int qd = q0 + lane;
-            const bool valid = qd < nq;
-            uint4 d4 = make_uint4(kInfBits, kInfBits, kInfBits, kInfBits);
-            floatx4 s4 = {P.bg_old, P.bg_old, P.bg_old, P.bg_old};
-            floatx4 o4 = {0.f, 0.f, 0.f, 0.f};
-            int gbase = 0;
-            bool anyc = false;
-            if (valid) {
-                const int gy = wy0 + lr, gx = wx0 + (qc << 2);
-                gbase = gy * P.cols + gx;
-                d4 = tile4[qd];
-                anyc = (d4.x & d4.y & d4.z & d4.w) != kInfBits;   // a finite depth lacks an exponent bit
-                const bool stored = gx >= pw.x && gx < pw.z && gy >= pw.y && gy < pw.w;
-                if (stored && (UPDATE || anyc)) s4 = *reinterpret_cast<const floatx4*>(src + gbase);
-                if (anyc) o4 = *reinterpret_cast<const floatx4*>(P.frame + gbase);
+        // kScanUnroll quads per lane per trip: all their loads (the parent's values come from HBM --
+        // another call wrote them -- and a dependent load per trip left the phase latency bound:
+        // 13 % of the kernel) are issued before the first is used
+        for (int q0 = wave * 64; q0 < nq; q0 += kBlock * kScanUnroll) {
+            uint4 d4[kScanUnroll];
+            floatx4 s4[kScanUnroll], o4[kScanUnroll];
+            int gb[kScanUnroll];
+            bool vl[kScanUnroll], ac[kScanUnroll];
+#pragma unroll
+            for (int u = 0; u < kScanUnroll; ++u) {
+                const int qd = q0 + u * kBlock + lane;
+                vl[u] = qd < nq;
+                d4[u] = make_uint4(kInfBits, kInfBits, kInfBits, kInfBits);
+                s4[u] = floatx4{P.bg_old, P.bg_old, P.bg_old, P.bg_old};
+                o4[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+                gb[u] = 0;
+                ac[u] = false;
+                if (vl[u]) {
+                    const int gy = wy0 + lr, gx = wx0 + (qc << 2);
+                    gb[u] = gy * P.cols + gx;
+                    d4[u] = tile4[qd];
+                    ac[u] = (d4[u].x & d4[u].y & d4[u].z & d4[u].w) != kInfBits;   // a finite depth lacks an exponent bit
+                    const bool stored = gx >= pw.x && gx < pw.z && gy >= pw.y && gy < pw.w;
+#ifndef RBS_EXP_NO_SRCLOAD
+                    if (stored && (UPDATE || ac[u])) s4[u] = *reinterpret_cast<const floatx4*>(src + gb[u]);
+#endif
+                    if (ac[u]) o4[u] = *reinterpret_cast<const floatx4*>(P.frame + gb[u]);
+                }
+                qc += rstep; lr += qstep;
+                if (qc >= tq) { qc -= tq; ++lr; }
             }
-            qc += rstep; lr += qstep;
-            if (qc >= tq) { qc -= tq; ++lr; }
-            floatx4 pr;
-            pr.x = occ_step(P.alpha, P.beta, s4.x, P.bg_new);
-            pr.y = occ_step(P.alpha, P.beta, s4.y, P.bg_new);
-            pr.z = occ_step(P.alpha, P.beta, s4.z, P.bg_new);
-            pr.w = occ_step(P.alpha, P.beta, s4.w, P.bg_new);
-            if (UPDATE && valid) *reinterpret_cast<floatx4*>(dst + gbase) = pr;
-            if (__ballot(anyc) == 0) continue;   // wave-uniform: nothing of the object in these 256 pixels
-            RBS_PUSH_EVAL(d4.x != kInfBits && isfinite(o4.x), gbase + 0, d4.x, pr.x, o4.x);
-            RBS_PUSH_EVAL(d4.y != kInfBits && isfinite(o4.y), gbase + 1, d4.y, pr.y, o4.y);
-            RBS_PUSH_EVAL(d4.z != kInfBits && isfinite(o4.z), gbase + 2, d4.z, pr.z, o4.z);
-            RBS_PUSH_EVAL(d4.w != kInfBits && isfinite(o4.w), gbase + 3, d4.w, pr.w, o4.w);
+#pragma unroll
+            for (int u = 0; u < kScanUnroll; ++u) {
+                if (q0 + u * kBlock >= nq) break;   // wave-uniform
+                floatx4 pr;
+                pr.x = occ_step(P.alpha, P.beta, s4[u].x, P.bg_new);
+                pr.y = occ_step(P.alpha, P.beta, s4[u].y, P.bg_new);
+                pr.z = occ_step(P.alpha, P.beta, s4[u].z, P.bg_new);
+                pr.w = occ_step(P.alpha, P.beta, s4[u].w, P.bg_new);
+#ifndef RBS_EXP_NO_DSTSTORE
+                if (UPDATE && vl[u]) *reinterpret_cast<floatx4*>(dst + gb[u]) = pr;
+#endif
+#ifdef RBS_EXP_NO_PUSH
+                continue;
+#endif
+                if (__ballot(ac[u]) == 0) continue;   // wave-uniform: nothing of the object in these 256 pixels
+                RBS_PUSH_EVAL(d4[u].x != kInfBits && isfinite(o4[u].x), gb[u] + 0, d4[u].x, pr.x, o4[u].x);
+                RBS_PUSH_EVAL(d4[u].y != kInfBits && isfinite(o4[u].y), gb[u] + 1, d4[u].y, pr.y, o4[u].y);
+                RBS_PUSH_EVAL(d4[u].z != kInfBits && isfinite(o4[u].z), gb[u] + 2, d4[u].z, pr.z, o4[u].z);
+                RBS_PUSH_EVAL(d4[u].w != kInfBits && isfinite(o4[u].w), gb[u] + 3, d4[u].w, pr.w, o4[u].w);
+            }
         }
     } else {
         // any width: one pixel per lane
@@ -714,7 +842,8 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     if (lane < qn) {
         const int eg = q[lane], ed = q[kEvalQueue + lane], ep = q[2 * kEvalQueue + lane];
         float post;
-        ll += pixel_loglik(P, eg, __uint_as_float((unsigned)ed), __int_as_float(ep), post);
+        ll += PREC ? pixel_loglik_f32(P, eg, __uint_as_float((unsigned)ed), __int_as_float(ep), post)
+                   : pixel_loglik(P, eg, __uint_as_float((unsigned)ed), __int_as_float(ep), post);
         if (UPDATE) dst[eg] = post;
     }
     RBS_TICK(3);
@@ -796,20 +925,41 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
 // bounding box of the parent's window and the rectangle -- and seeds the child's window with the
 // rectangle (the copy kernel grows it over every value it writes that differs from the
 // background).  An empty window is (cols, rows, 0, 0), so unions are plain min/max.
-__device__ inline void prep_particle(const DevParams& P, int i, int* __restrict__ rects, int update)
+constexpr int kPrepPerBlock = 8;   // particles (= waves) per block of the rectangles kernel
+
+// One wave per particle, kPrepPerBlock particles per block.  The work items of the block's
+// particles are allotted with ONE atomicAdd per block (any free range will do: a particle's
+// items are summed in their own order, so no scan kernel is needed -- but two thousand blocks
+// bumping one counter serialise at 11-13 ns each, 26 us at 2 000 particles).
+__device__ inline void prep_particles(const DevParams& P, int block, int* __restrict__ rects, int update)
 {
-    const Rect r = particle_rect(P, P.poses + (size_t)i * 12 * P.n_bodies);
+    __shared__ int cnts[kPrepPerBlock + 1];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = block * kPrepPerBlock + w;
+    const bool live = i < P.n;
+    Rect r = {0, 0, 0, 0};
+    int cnt = 0;
+    if (live) {
+        r = particle_rect(P, P.poses + (size_t)i * 12 * P.n_bodies);
+        const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
+        cnt = r.x1 > r.x0 ? tg.nx * tg.ny : 1;   // an empty rectangle still owns one (empty) item
+    }
+    if (lane == 0) cnts[w] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int k = 0; k < kPrepPerBlock; ++k) { const int c = cnts[k]; cnts[k] = total; total += c; }
+        cnts[kPrepPerBlock] = total ? atomicAdd(&P.ctr_this[0], total) : 0;
+    }
+    __syncthreads();
+    if (!live || lane != 0) return;
     reinterpret_cast<int4*>(rects)[i] = make_int4(r.x0, r.y0, r.x1, r.y1);
-    const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
     P.done[i] = 0;
     const int parent = P.indices[i];
     P.parents[i] = parent;
-    {   // work items: any free range will do -- a particle's items are summed in their own order
-        const int cnt = r.x1 > r.x0 ? tg.nx * tg.ny : 1;   // an empty rectangle still owns one (empty) item
-        const int first = atomicAdd(&P.ctr_this[0], cnt);
-        P.item_range[i] = make_int2(first, cnt);
-        for (int k = 0; k < cnt; ++k) P.item_particle[first + k] = i;
-    }
+    const int first = cnts[kPrepPerBlock] + cnts[w];
+    P.item_range[i] = make_int2(first, cnt);
+    for (int k = 0; k < cnt; ++k) P.item_particle[first + k] = i;
     if (update && P.windowed) {
         const int4 rw = r.x1 > r.x0 ? make_int4(r.x0, r.y0, r.x1, r.y1) : make_int4(P.cols, P.rows, 0, 0);
         int4 pw = make_int4(P.cols, P.rows, 0, 0);
@@ -822,16 +972,15 @@ __device__ inline void prep_particle(const DevParams& P, int i, int* __restrict_
     }
 }
 
-__global__ void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int update)
+
+__global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int update)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
-    prep_particle(P, i, rects, update);
+    prep_particles(P, (int)blockIdx.x, rects, update);
 }
 
 // A frame handed over right before this call: its per-pixel terms (aux_blocks blocks) and the
 // particles' rectangles (the other blocks) are independent, one launch.
-__global__ void rbs_frame_prep_kernel(const DevParams P, int* __restrict__ rects, int update,
+__global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_frame_prep_kernel(const DevParams P, int* __restrict__ rects, int update,
                                       const float* __restrict__ frame_src, double* __restrict__ aux,
                                       float* __restrict__ pbg, float* __restrict__ keep, int aux_blocks)
 {
@@ -839,11 +988,11 @@ __global__ void rbs_frame_prep_kernel(const DevParams P, int* __restrict__ rects
     // at once, the short per-pixel blocks fill in around them
     const int prep_blocks = (int)gridDim.x - aux_blocks;
     if ((int)blockIdx.x < prep_blocks) {
-        const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        if (i < P.n) prep_particle(P, i, rects, update);
+        prep_particles(P, (int)blockIdx.x, rects, update);
     } else {
-        const int i = ((int)blockIdx.x - prep_blocks) * blockDim.x + threadIdx.x;
-        if (i < P.npx) frame_aux_pixel(i, frame_src, aux, pbg, P.npx, P.tw, P.ms, P.sf, P.lambda, keep);
+        const int i = ((int)blockIdx.x - prep_blocks) * (int)blockDim.x + (int)threadIdx.x;
+        if (i < P.npx) frame_aux_pixel(i, frame_src, aux, pbg, P.npx, P.tw, P.ms, P.sf, P.lambda, keep,
+                                       const_cast<floatx4*>(P.auxf));
     }
 }
 
@@ -854,7 +1003,7 @@ __global__ void rbs_frame_prep_kernel(const DevParams P, int* __restrict__ rects
 // Persistent: a fixed number of raster blocks per CU keeps its LDS/VGPR share for the whole
 // launch (never starved by the many small copy blocks) and pulls (particle, tile) items from
 // an atomic queue.
-template <bool UPDATE>
+template <bool UPDATE, int PREC>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel(const DevParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -877,7 +1026,7 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
         const int2 range = P.item_range[particle];
         const int first = range.x;
         double part = 0.0;
-        if (r.x1 > r.x0) part = raster_eval_tile<UPDATE>(P, particle, r, item - first, m);
+        if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC>(P, particle, r, item - first, m);
         if (threadIdx.x == 0) {
             // the particle's log-likelihood: its only item's sum, or -- by whichever block
             // finishes the particle's last item -- the items' sums added in item order.  The
@@ -1124,7 +1273,8 @@ __global__ __launch_bounds__(kBlock) void rbs_render_kernel(const DevParams P, f
             const int tw = wx1 - wx0, npx = tw * (wy1 - wy0);
             for (int p = threadIdx.x; p < npx; p += kBlock) m.tile[p] = kInfBits;
             __syncthreads();
-            raster_window(P, P.poses, wx0, wy0, wx1, wy1, true, m.tile, m.big, m.nbig);
+            raster_window(P, P.poses, wx0, wy0, wx1, wy1, true, m.tile, m.big, m.nbig,
+                          m.evalq + (threadIdx.x >> 6) * 3 * kEvalQueue);
             for (int p = threadIdx.x; p < npx; p += kBlock) {
                 const int lr = p / tw;
                 out[(wy0 + lr) * P.cols + wx0 + (p - lr * tw)] = __uint_as_float(m.tile[p]);

@@ -133,7 +133,11 @@ class RbSensorBuilder:
 class RbSensor:
     """dbot RbSensor mirror over the C-ABI handle."""
 
-    def __init__(self, object_model, camera_data, params, device_id=0, max_particles=None):
+    def __init__(self, object_model, camera_data, params, device_id=0, max_particles=None,
+                 precision=None, state_layout=None, device_ids=None):
+        """precision: None (library default) | "f64" | "f32" (rbs_config.likelihood_precision);
+        state_layout: None | "window" | "dense"; device_ids: several HIP ordinals = particle
+        sharding inside the handle (max_particles is then the total)."""
         self._lib = _capi.load()
         self._h = C.c_void_p()
         self.n_bodies = object_model.count_parts
@@ -163,6 +167,17 @@ class RbSensor:
         cfg.model_sigma = params.kinect.model_sigma
         cfg.sigma_factor = params.kinect.sigma_factor
         cfg.delta_time = params.delta_time
+        cfg.likelihood_precision = _capi.PRECISIONS[precision]
+        cfg.state_layout = _capi.LAYOUTS[state_layout]
+        if device_ids is not None and len(device_ids) > 1:
+            ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+            cfg.n_devices = len(ids)
+            cfg.device_ids = ids.ctypes.data_as(C.POINTER(C.c_int32))
+        else:
+            cfg.n_devices = 0
+            cfg.device_ids = None
+            if device_ids is not None and len(device_ids) == 1:
+                cfg.device_id = int(device_ids[0])
         rc = self._lib.rbs_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             msg = self._lib.rbs_last_error(None).decode()

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RBS_ABI_VERSION 1
+#define RBS_ABI_VERSION 2
 
 enum {
     RBS_OK = 0,
@@ -47,6 +47,20 @@ enum {
     RBS_ERR_HIP = -4,
     RBS_ERR_UNSUPPORTED = -5
 };
+
+/* rbs_config.likelihood_precision: the arithmetic of the per-pixel Kinect likelihood (exp / erf /
+ * log and the mixture algebra).  Coverage, depth and the occlusion process do not depend on it:
+ * geometry is binary64, depth and occlusion state are float, the per-particle sum is binary64.
+ *   F64  binary64 with the reference CPU path's float rounding points: agrees with
+ *        the device-rule oracle to ~1e-15 and with the reference-semantics oracle to ~5e-9.
+ *   F32  float32 transcendentals: ~2x faster raster kernel, agrees with the reference-semantics
+ *        oracle to <= 1e-5 relative (BASELINE.json north_star's tolerance; measured ~1e-7).
+ * DEFAULT = the library's default, RBS_PRECISION_LIBRARY_DEFAULT. */
+enum { RBS_PRECISION_DEFAULT = 0, RBS_PRECISION_F64 = 1, RBS_PRECISION_F32 = 2 };
+#define RBS_PRECISION_LIBRARY_DEFAULT RBS_PRECISION_F64
+/* rbs_config.state_layout: how occlusion planes are stored ("occlusion state layout" below).
+ * DEFAULT = windowed (RBS_STATE=dense in the environment overrides DEFAULT only: tooling). */
+enum { RBS_STATE_DEFAULT = 0, RBS_STATE_WINDOWED = 1, RBS_STATE_DENSE = 2 };
 
 typedef struct rbs_handle rbs_handle;
 
@@ -72,6 +86,15 @@ typedef struct rbs_config {
     double model_sigma;
     double sigma_factor;
     double delta_time;
+    /* --- ABI version 2 --- */
+    int32_t likelihood_precision;   /* RBS_PRECISION_*                                         */
+    int32_t state_layout;           /* RBS_STATE_*                                             */
+    /* Particle sharding over several devices of one node inside ONE handle (the reference's
+     * tracker node is one process, R:source/dbot_ros/tracker/particle_tracker_node.cpp:277-284):
+     * n_devices <= 1 -> device_id alone.  n_devices > 1 -> device_ids[n_devices] HIP ordinals;
+     * max_particles is the TOTAL over all devices.  See "several devices" below. */
+    int32_t n_devices;
+    const int32_t* device_ids;
 } rbs_config;
 
 int32_t rbs_abi_version(void);
