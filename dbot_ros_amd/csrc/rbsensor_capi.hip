@@ -82,7 +82,6 @@ struct rbs_handle {
     float* d_cluster_cone = nullptr;
     float* d_vtx = nullptr;         // [sum of vertex counts][4] float32 vertices (screen rectangles)
     float* d_tri_plane = nullptr;   // [n_tri][4] model-space plane of each triangle (float32 pre-cull)
-    float* d_auxf = nullptr;        // [npx][4] per-frame-pixel terms in float (likelihood precision F32)
     int precision = RBS_PRECISION_F64;
     float* d_render = nullptr;
     float* h_frame = nullptr;   // pinned staging
@@ -184,10 +183,11 @@ int32_t flush_lazy_frame(rbs_handle* h, hipStream_t then)
 {
     if (!h->lazy_frame) return RBS_OK;
     const size_t n = (size_t)h->npx;
+    // (precision F32 keeps no per-pixel terms: a frame already in the handle's buffer needs nothing)
+    if (h->d_aux || h->lazy_frame != h->d_frame)
     hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->lazy_stream,
                        h->lazy_frame, h->d_aux, h->d_pbg, h->npx, h->base.tw, h->base.ms, h->base.sf,
-                       h->base.lambda, h->lazy_frame == h->d_frame ? (float*)nullptr : h->d_frame,
-                       reinterpret_cast<rbs::floatx4*>(h->d_auxf));
+                       h->base.lambda, h->lazy_frame == h->d_frame ? (float*)nullptr : h->d_frame);
     RBS_HIP(h, hipGetLastError());
     h->lazy_frame = nullptr;
     if (then != h->lazy_stream) {
@@ -288,7 +288,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     const bool wide = h->windowed && update && h->wide;
     if (h->lazy_frame && h->lazy_stream == s) {
         constexpr int ptb = 64 * rbs::kPrepPerBlock;
-        const int aux_blocks = (h->npx + ptb - 1) / ptb;
+        const int aux_blocks = (h->d_aux || h->lazy_frame != h->d_frame) ? (h->npx + ptb - 1) / ptb : 0;
         hipLaunchKernelGGL(rbs::rbs_frame_prep_kernel, dim3((unsigned)(aux_blocks + (n + rbs::kPrepPerBlock - 1) / rbs::kPrepPerBlock)), dim3(ptb), 0, s, P,
                            d_rects, update ? 1 : 0, h->lazy_frame, h->d_aux, h->d_pbg,
                            h->lazy_frame == h->d_frame ? (float*)nullptr : h->d_frame, aux_blocks);
@@ -462,7 +462,6 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_cluster_cone);
     (void)hipFree(h->d_tri_plane);
     (void)hipFree(h->d_vtx);
-    (void)hipFree(h->d_auxf);
     (void)hipFree(h->d_render);
     if (h->h_frame) (void)hipHostFree(h->h_frame);
     if (h->h_native) (void)hipHostFree(h->h_native);
@@ -821,8 +820,10 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMemcpy(h->d_soup, soup.data(), soup.size() * sizeof(double), hipMemcpyHostToDevice));
     B.soup = h->d_soup;
     RBS_HIP(h, hipMalloc(&h->d_frame, plane));
-    RBS_HIP(h, hipMalloc(&h->d_aux, sizeof(double) * rbs::AUX_PLANES * (size_t)h->npx));
-    RBS_HIP(h, hipMalloc(&h->d_pbg, plane));
+    if (h->precision == RBS_PRECISION_F64) {   // F32 derives the per-pixel terms from the observation on the fly
+        RBS_HIP(h, hipMalloc(&h->d_aux, sizeof(double) * rbs::AUX_PLANES * (size_t)h->npx));
+        RBS_HIP(h, hipMalloc(&h->d_pbg, plane));
+    }
     RBS_HIP(h, hipMalloc(&h->d_render, plane));
     RBS_HIP(h, hipMalloc(&h->d_occ[0], plane * h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_occ[1], plane * h->max_particles));
@@ -871,8 +872,6 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         RBS_HIP(h, hipMemcpy(h->d_vtx, vtx.data(), sizeof(float) * vtx.size(), hipMemcpyHostToDevice));
         B.vtx = reinterpret_cast<const rbs::floatx4*>(h->d_vtx);
     }
-    if (h->precision == RBS_PRECISION_F32) RBS_HIP(h, hipMalloc(&h->d_auxf, sizeof(float) * 4 * (size_t)h->npx));
-    B.auxf = reinterpret_cast<const rbs::floatx4*>(h->d_auxf);
     RBS_HIP(h, hipHostMalloc(&h->h_frame, plane, hipHostMallocDefault));
 
     // the raster / render kernels carve the LDS depth tile from dynamic shared memory

@@ -42,7 +42,7 @@ namespace rbs {
 // steps: 11 520 pixels (45 KB) + the small arrays = 53 296 B is the largest block that still
 // fits three times (11 648 pixels does not).
 #ifndef RBS_TILE_PX
-#define RBS_TILE_PX 11520
+#define RBS_TILE_PX 11008
 #endif
 #ifndef RBS_COPY_UNROLL
 #define RBS_COPY_UNROLL 8
@@ -67,10 +67,10 @@ constexpr int kBigCap = RBS_BIG_CAP;       // triangles deferred to the cooperat
 constexpr int kBigThresh = RBS_BIG_THRESH; // bbox pixels above which a triangle is "big"
 constexpr int kCopyUnroll = RBS_COPY_UNROLL; // float4 loads in flight per lane in copy blocks
 #ifndef RBS_SCAN_UNROLL
-#define RBS_SCAN_UNROLL 4
+#define RBS_SCAN_UNROLL 2
 #endif
-constexpr int kScanUnroll = RBS_SCAN_UNROLL;  // quads per lane whose loads are in flight together in the pixel pass
-constexpr int kEvalQueue = 128;             // per-wave queue of covered pixels awaiting evaluation
+constexpr int kEvalQueue = 128;             // per-wave ring of covered pixels awaiting evaluation (a power of two)
+constexpr int kQPlanes = 4;                 // ints per queued pixel: index, depth, prior, observation (F32 precision)
 constexpr int kRectAlign = 16;              // whole planes: rectangle x-alignment in pixels (64 B)
 constexpr float kSnapTau = 0x1p-18f;         // background snap of the occlusion process (oracle ORC_SNAP_TAU)
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -102,7 +102,6 @@ struct DevParams {
     const double* soup;            // SoA [9][n_tri]: v0.xyz v1.xyz v2.xyz
     const float* frame;            // observation, float metres
     const double* aux;             // per-frame-pixel terms, [npx][4] binary64 (frame_aux_kernel)
-    const floatx4* auxf;           // the same four terms rounded to float (likelihood precision F32)
     const float* pbg;              // per-frame-pixel background density, rounded to float
     double tw, ms, sf, lambda;     // tail_weight, model_sigma, sigma_factor, ln2/half_life
     float alpha, beta;             // occlusion process over the elapsed frames
@@ -554,10 +553,11 @@ enum { AUX_INV_S2S = 0, AUX_K = 1, AUX_CV = 2, AUX_EO = 3, AUX_PLANES = 4 };
 // keep != nullptr: `frame` is the caller's buffer and is also copied into the handle's own.
 __device__ inline void frame_aux_pixel(int i, const float* __restrict__ frame, double* __restrict__ aux,
                                        float* __restrict__ pbg, int npx, double tw, double ms, double sf,
-                                       double lam, float* __restrict__ keep, floatx4* __restrict__ auxf)
+                                       double lam, float* __restrict__ keep)
 {
     const float of = frame[i];
     if (keep) keep[i] = of;
+    if (!aux) return;   // likelihood precision F32 derives these terms from the observation on the fly
     const double o = (double)of;
     const double sigma = ms + sf * o * o;
     const double eo = exp(0.5 * lam * (-2.0 * o + lam * sigma * sigma));
@@ -568,19 +568,14 @@ __device__ inline void frame_aux_pixel(int i, const float* __restrict__ frame, d
     a4[AUX_CV] = (1.0 - tw) / (sqrt(2.0 * M_PI) * sigma);
     a4[AUX_EO] = 0.5 * (1.0 - tw) * lam * eo;
     pbg[i] = (float)(tw / kMaxDepth + (1.0 - tw) * lam * eo);
-    if (auxf) {   // likelihood precision F32: the same terms, each rounded once to float
-        floatx4 f;
-        f.x = (float)a4[AUX_INV_S2S]; f.y = (float)a4[AUX_K]; f.z = (float)a4[AUX_CV]; f.w = (float)a4[AUX_EO];
-        auxf[i] = f;
-    }
 }
 
 __global__ void frame_aux_kernel(const float* __restrict__ frame, double* __restrict__ aux,
                                  float* __restrict__ pbg, int npx, double tw, double ms, double sf,
-                                 double lam, float* __restrict__ keep, floatx4* __restrict__ auxf)
+                                 double lam, float* __restrict__ keep)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npx) frame_aux_pixel(i, frame, aux, pbg, npx, tw, ms, sf, lam, keep, auxf);
+    if (i < npx) frame_aux_pixel(i, frame, aux, pbg, npx, tw, ms, sf, lam, keep);
 }
 
 // log-likelihood ratio of one covered, observed pixel + posterior occlusion.
@@ -630,28 +625,74 @@ __device__ inline double pixel_loglik(const DevParams& P, int gi, float r, float
 }
 
 // Likelihood precision F32 (rbs_config.likelihood_precision = RBS_PRECISION_F32): the same model
-// with the per-pixel transcendental work in float32 -- coverage, depth and the occlusion process
-// are untouched (binary64 geometry, float state), only exp / erf / log and the mixture algebra
-// change.  Written for relative accuracy: 1 + erf(x) as erfc(-x) (no cancellation in the lower
-// tail), E1/(E1-1) as 1/(1 - exp(-lam r)).  Per-pixel error of the log term <~ 5e-7; the
-// particle's sum is accumulated in binary64.  tests/: <= 1e-5 relative against the
+// with the per-pixel transcendental work in float32 on the hardware's exp2 / log2 / rcp units --
+// coverage, depth and the occlusion process are untouched (binary64 geometry, float state), only
+// exp / erf / log and the mixture algebra change.  Written for RELATIVE accuracy: 1 + erf(x) as
+// erfc(-x) (no cancellation in the lower tail) through t exp(-z^2 + poly(t)), t = 1/(1 + z/2)
+// (Numerical Recipes' erfcc, fractional error 1.2e-7 everywhere); E1/(E1-1) as
+// 1/(1 - exp(-lam r)); log(sum / p_bg) as log(sum) - log(p_bg) with log(p_bg) computed once per
+// frame pixel in binary64.  About 50 VALU instructions per 64 pixels instead of 125 (ocml's
+// expf / erfcf / logf and correctly rounded divisions) or 250 (binary64).  Per-pixel error of
+// the log term: 1.3e-7 mean, 1.7e-6 max, bias -3e-8 (numpy float32 emulation over 4e5 random
+// pixels); the particle's sum is accumulated in binary64.  tests/: <= 1e-5 relative against the
 // reference-semantics (LAZY) oracle, the north_star tolerance.
-__device__ inline double pixel_loglik_f32(const DevParams& P, int gi, float r, float prior, float& posterior)
+#ifndef RBS_F32_EXP
+#define RBS_F32_EXP 0
+#endif
+#ifndef RBS_F32_LOG
+#define RBS_F32_LOG 0
+#endif
+#ifndef RBS_F32_DIV
+#define RBS_F32_DIV 0
+#endif
+__device__ inline float fast_exp(float x) { return RBS_F32_EXP ? expf(x) : __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ inline float fast_log(float x) { return RBS_F32_LOG ? logf(x) : 0.6931471805599453f * __builtin_amdgcn_logf(x); }
+// hardware reciprocal (1 ulp) + one Newton step: half an ulp for operands in the normal range
+__device__ inline float fast_rcp(float x)
 {
-    const float o = P.frame[gi];
-    const floatx4 a = P.auxf[gi];          // 1/(sqrt2 sigma), lam sigma/sqrt2, c_v, e_o
-    const float pbg = P.pbg[gi];
-    __builtin_amdgcn_sched_barrier(0);
-    const float twD = (float)(P.tw / kMaxDepth);
-    const float w = (r - o) * a.x;
-    const float pv = twD + a.z * expf(-(w * w));
-    const float ratio = 1.0f / (1.0f - expf(-(r * (float)P.lambda)));
-    const float po = twD + a.w * ratio * erfcf(-(w + a.y));
+    if (RBS_F32_DIV) return 1.0f / x;
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(r, fmaf(-x, r, 1.0f), r);
+}
+__device__ inline float fast_erfc(float x)
+{
+    const float z = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, z, 1.0f));
+    float p = 0.17087277f;
+    p = fmaf(p, t, -0.82215223f); p = fmaf(p, t, 1.48851587f); p = fmaf(p, t, -1.13520398f);
+    p = fmaf(p, t, 0.27886807f);  p = fmaf(p, t, -0.18628806f); p = fmaf(p, t, 0.09678418f);
+    p = fmaf(p, t, 0.37409196f);  p = fmaf(p, t, 1.00002368f);  p = fmaf(p, t, -1.26551223f);
+    const float a = t * fast_exp(p - z * z);
+    return x >= 0.0f ? a : 2.0f - a;
+}
+// Everything the likelihood needs beyond (rendered depth, prior, observation) is a function of
+// the observation: recomputing those terms costs about 15 float instructions per pixel, fetching
+// them (per-frame planes, as the binary64 path does) costs two gathers whose latency three waves
+// per SIMD do not hide.  No memory access at all here.
+__device__ inline double pixel_loglik_f32(const DevParams& P, float r, float prior, float o, float& posterior)
+{
+    const float lam = (float)P.lambda, twD = (float)(P.tw / kMaxDepth), omt = (float)(1.0 - P.tw);
+    const float sigma = fmaf((float)P.sf * o, o, (float)P.ms);
+    const float is = fast_rcp(sigma);
+    const float inv_s2s = 0.7071067811865476f * is;                       // 1/(sqrt2 sigma)
+    const float kk = (0.7071067811865476f * lam) * sigma;                 // lam sigma/sqrt2
+    const float cv = (0.3989422804014327f * omt) * is;                    // (1-tw)/(sqrt(2 pi) sigma)
+    const float eo = (0.5f * omt * lam) * fast_exp((0.5f * lam) * fmaf(lam * sigma, sigma, -2.0f * o));
+    const float lpbg = fast_log(fmaf(2.0f, eo, twD));
+    const float w = (r - o) * inv_s2s;
+    const float pv = fmaf(cv, fast_exp(-(w * w)), twD);
+    const float ratio = fast_rcp(1.0f - fast_exp(-(r * lam)));
+    const float po = fmaf(eo * ratio, fast_erfc(-(w + kk)), twD);
     const float av = pv * (1.0f - prior);
     const float bv = po * prior;
     const float sum = av + bv;
-    posterior = bv / sum;
-    return (double)logf(sum / pbg);
+    // the posterior is STATE (its error is carried into the next frames): one Newton step on the
+    // reciprocal and a residual correction of the quotient -- within half an ulp of bv / sum for
+    // these operands (normal range), 6 instructions instead of the IEEE division's 12
+    const float rs = fast_rcp(sum);
+    const float qd = bv * rs;
+    posterior = fmaf(rs, fmaf(-qd, sum, bv), qd);
+    return (double)(fast_log(sum) - lpbg);
 }
 
 __device__ inline double block_reduce_sum(double v, double* red)
@@ -679,7 +720,7 @@ __device__ inline Smem carve(unsigned char* smem, int kTilePx)
     m.red = reinterpret_cast<double*>(smem + sizeof(unsigned) * kTilePx + sizeof(int) * kBigCap);
     m.nbig = reinterpret_cast<int*>(m.red + kBlock / 64);
     m.item = m.nbig + 1;
-    m.evalq = m.nbig + 4;   // per wave: pixel index, depth bits, prior -- kEvalQueue ints each
+    m.evalq = m.nbig + 4;   // per wave: kQPlanes planes of kEvalQueue ints
     return m;
 }
 
@@ -711,7 +752,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     RBS_TICK(1);
     // a rectangle that is a single tile was sized from the same spheres: nothing to cull
     raster_window(P, pose, wx0, wy0, wx1, wy1, !whole || P.n_bodies > 1, m.tile, m.big, m.nbig,
-                  m.evalq + (threadIdx.x >> 6) * 3 * kEvalQueue);   // the eval queue is idle during the raster phase
+                  m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue);   // the eval queue is idle during the raster phase
     RBS_TICK(2);
 
     // Pixel pass.  Only ~1/3 of a tile's pixels are covered by the object, in runs that leave
@@ -720,33 +761,41 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     // Everything else (the occlusion process on uncovered pixels) is finished in the scan.
     double ll = 0.0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    int* q = m.evalq + wave * 3 * kEvalQueue;   // q[0..), q[kEvalQueue..), q[2 kEvalQueue..)
-    int qn = 0;
+    int* q = m.evalq + wave * kQPlanes * kEvalQueue;   // planes: pixel index, depth bits, prior, observation
+    int qh = 0, qn = 0;                                // ring: head, count (wave-uniform)
+    // evaluate the 64 (or, at the end, `cnt_`) oldest queued pixels
+#define RBS_EVAL_BATCH(cnt_)                                                                            \
+    do {                                                                                                \
+        if (lane < (cnt_)) {                                                                            \
+            const int at_ = (qh + lane) & (kEvalQueue - 1);                                             \
+            const int eg_ = q[at_];                                                                     \
+            const float ed_ = __int_as_float(q[kEvalQueue + at_]), ep_ = __int_as_float(q[2 * kEvalQueue + at_]); \
+            float post_;                                                                                \
+            if (PREC) ll += pixel_loglik_f32(P, ed_, ep_, __int_as_float(q[3 * kEvalQueue + at_]), post_); \
+            else ll += pixel_loglik(P, eg_, ed_, ep_, post_);                                           \
+            if (UPDATE) dst[eg_] = post_;                                                               \
+        }                                                                                               \
+    } while (0)
     // push this lane's pixel if `active`; evaluate 64 queued pixels as soon as there are 64
 #define RBS_PUSH_EVAL(active, gidx, depthbits, prior, obs)                                              \
     do {                                                                                                \
         const unsigned long long mask_ = __ballot(active);                                              \
         if (mask_) {                                                                                    \
             if (active) {                                                                               \
-                const int pos_ = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask_ >> 32),                \
-                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask_, 0));               \
+                const int pos_ = (qh + qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask_ >> 32),          \
+                                                __builtin_amdgcn_mbcnt_lo((unsigned)mask_, 0))) & (kEvalQueue - 1); \
                 q[pos_] = (gidx);                                                                       \
                 q[kEvalQueue + pos_] = (int)(depthbits);                                                \
                 q[2 * kEvalQueue + pos_] = __float_as_int(prior);                                       \
+                if (PREC) q[3 * kEvalQueue + pos_] = __float_as_int(obs);                               \
             }                                                                                           \
             qn += __popcll(mask_);                                                                      \
             if (qn >= 64) {                                                                             \
                 __builtin_amdgcn_wave_barrier();                                                        \
-                const int eg_ = q[lane], ed_ = q[kEvalQueue + lane], ep_ = q[2 * kEvalQueue + lane];    \
-                float post_;                                                                            \
-                ll += PREC ? pixel_loglik_f32(P, eg_, __uint_as_float((unsigned)ed_), __int_as_float(ep_), post_)              \
-                           : pixel_loglik(P, eg_, __uint_as_float((unsigned)ed_), __int_as_float(ep_), post_); \
-                if (UPDATE) dst[eg_] = post_;                                                           \
-                qn -= 64;                                                                               \
-                int cg_ = 0, cd_ = 0, cp_ = 0;                                                          \
-                if (lane < qn) { cg_ = q[64 + lane]; cd_ = q[kEvalQueue + 64 + lane]; cp_ = q[2 * kEvalQueue + 64 + lane]; } \
+                RBS_EVAL_BATCH(64);                                                                     \
                 __builtin_amdgcn_wave_barrier();                                                        \
-                if (lane < qn) { q[lane] = cg_; q[kEvalQueue + lane] = cd_; q[2 * kEvalQueue + lane] = cp_; } \
+                qh = (qh + 64) & (kEvalQueue - 1);                                                      \
+                qn -= 64;                                                                               \
             }                                                                                           \
         }                                                                                               \
     } while (0)
@@ -765,6 +814,8 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
         // kScanUnroll quads per lane per trip: all their loads (the parent's values come from HBM --
         // another call wrote them -- and a dependent load per trip left the phase latency bound:
         // 13 % of the kernel) are issued before the first is used
+        // (binary64 likelihood: the kernel is at its register limit, one quad per trip)
+        constexpr int kScanUnroll = PREC ? RBS_SCAN_UNROLL : 1;
         for (int q0 = wave * 64; q0 < nq; q0 += kBlock * kScanUnroll) {
             uint4 d4[kScanUnroll];
             floatx4 s4[kScanUnroll], o4[kScanUnroll];
@@ -839,13 +890,8 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     }
 #undef RBS_PUSH_EVAL
     __builtin_amdgcn_wave_barrier();
-    if (lane < qn) {
-        const int eg = q[lane], ed = q[kEvalQueue + lane], ep = q[2 * kEvalQueue + lane];
-        float post;
-        ll += PREC ? pixel_loglik_f32(P, eg, __uint_as_float((unsigned)ed), __int_as_float(ep), post)
-                   : pixel_loglik(P, eg, __uint_as_float((unsigned)ed), __int_as_float(ep), post);
-        if (UPDATE) dst[eg] = post;
-    }
+    RBS_EVAL_BATCH(qn);
+#undef RBS_EVAL_BATCH
     RBS_TICK(3);
     const double total = block_reduce_sum(ll, m.red);
     RBS_TICK(4);
@@ -991,8 +1037,7 @@ __global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_frame_prep_kernel(cons
         prep_particles(P, (int)blockIdx.x, rects, update);
     } else {
         const int i = ((int)blockIdx.x - prep_blocks) * (int)blockDim.x + (int)threadIdx.x;
-        if (i < P.npx) frame_aux_pixel(i, frame_src, aux, pbg, P.npx, P.tw, P.ms, P.sf, P.lambda, keep,
-                                       const_cast<floatx4*>(P.auxf));
+        if (i < P.npx) frame_aux_pixel(i, frame_src, aux, pbg, P.npx, P.tw, P.ms, P.sf, P.lambda, keep);
     }
 }
 
@@ -1274,7 +1319,7 @@ __global__ __launch_bounds__(kBlock) void rbs_render_kernel(const DevParams P, f
             for (int p = threadIdx.x; p < npx; p += kBlock) m.tile[p] = kInfBits;
             __syncthreads();
             raster_window(P, P.poses, wx0, wy0, wx1, wy1, true, m.tile, m.big, m.nbig,
-                          m.evalq + (threadIdx.x >> 6) * 3 * kEvalQueue);
+                          m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue);
             for (int p = threadIdx.x; p < npx; p += kBlock) {
                 const int lr = p / tw;
                 out[(wy0 + lr) * P.cols + wx0 + (p - lr * tw)] = __uint_as_float(m.tile[p]);
@@ -1302,6 +1347,6 @@ __global__ void rbs_fill_kernel(float* __restrict__ p, size_t n, float v)
 constexpr size_t smem_bytes(int tile_px)
 {
     return sizeof(unsigned) * (size_t)tile_px + sizeof(int) * kBigCap + sizeof(double) * (kBlock / 64) + 16 +
-           sizeof(int) * 3 * (kBlock / 64) * kEvalQueue;
+           sizeof(int) * kQPlanes * (kBlock / 64) * kEvalQueue;
 }
 }  // namespace rbs

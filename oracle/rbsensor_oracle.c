@@ -13,6 +13,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORC_MAX_DEPTH 6.0       /* hard-coded max_depth        */
 #define ORC_HALF_LIFE_DEPTH 1.0 /* hard-coded half_life_depth  */
@@ -34,6 +37,11 @@ struct orc_sensor {
     /* scratch */
     float* depth;        /* [npx] */
     int32_t* covered;    /* [npx] list of covered pixel ids */
+    /* per-thread scratch of the multi-threaded baseline: allocated once, kept */
+    int n_scratch;
+    float** tdepth;
+    int32_t** tcov;
+    double* abs_sum;     /* [max_particles] sum of |per-pixel log term| of the last loglikes call */
     double lambda;       /* ln 2 / half_life_depth */
 };
 
@@ -226,6 +234,7 @@ orc_sensor* orc_create(const orc_config* cfg)
     s->frame = (float*)malloc(sizeof(float) * s->npx);
     s->depth = (float*)malloc(sizeof(float) * s->npx);
     s->covered = (int32_t*)malloc(sizeof(int32_t) * s->npx);
+    s->abs_sum = (double*)calloc((size_t)cfg->max_particles, sizeof(double));
     for (int k = 0; k < 2; ++k) {
         s->occ[k] = (float*)malloc(sizeof(float) * plane);
         s->stamp[k] = cfg->occlusion_mode == ORC_OCC_LAZY
@@ -251,6 +260,13 @@ void orc_destroy(orc_sensor* s)
     free(s->frame);
     free(s->depth);
     free(s->covered);
+    free(s->abs_sum);
+    for (int t = 0; t < s->n_scratch; ++t) {
+        free(s->tdepth[t]);
+        free(s->tcov[t]);
+    }
+    free(s->tdepth);
+    free(s->tcov);
     for (int k = 0; k < 2; ++k) {
         free(s->occ[k]);
         free(s->stamp[k]);
@@ -260,16 +276,30 @@ void orc_destroy(orc_sensor* s)
 
 /* RbSensor::reset(), triggered by tracker->initialize at
  * R:source/dbot_ros/tracker/particle_tracker_node.cpp:252 (SURVEY A.4 last line). */
-void orc_reset(orc_sensor* s)
+void orc_reset(orc_sensor* s) { orc_reset_mt(s, 1); }
+
+/* n_threads > 1 (the multi-threaded baseline): every slot of BOTH buffers is first touched by
+ * the thread that will evaluate it under schedule(static), so its pages land on that thread's
+ * NUMA node instead of all on the creating thread's. */
+void orc_reset_mt(orc_sensor* s, int32_t n_threads)
 {
-    const size_t plane = s->npx * (size_t)s->cfg.max_particles;
     const float init = (float)s->cfg.initial_occlusion_prob;
+    const int32_t slots = s->cfg.max_particles;
     s->cur = 0;
     s->clock = 0;
     s->last_update_clock = 0;
     s->background = init;
-    for (size_t p = 0; p < plane; ++p) s->occ[0][p] = init;
-    if (s->stamp[0]) memset(s->stamp[0], 0, sizeof(int32_t) * plane);
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads > 1 ? n_threads : 1)
+#endif
+    for (int32_t i = 0; i < slots; ++i) {
+        for (int k = 0; k < (n_threads > 1 ? 2 : 1); ++k) {
+            float* o = s->occ[k] + (size_t)i * s->npx;
+            for (size_t p = 0; p < s->npx; ++p) o[p] = init;
+            if (s->stamp[k]) memset(s->stamp[k] + (size_t)i * s->npx, 0, sizeof(int32_t) * s->npx);
+        }
+    }
 }
 
 /* RbSensor::set_observation -- frame layout per R:source/dbot_ros/util/ros_interface.h:161-165;
@@ -308,7 +338,7 @@ static double loglik_one(orc_sensor* s, const double* pose, int32_t parent, int3
 
     const int32_t ncov = render_into(s, pose, depth, covered);
 
-    double ll = 0.0;
+    double ll = 0.0, abs_ll = 0.0;
     for (int32_t k = 0; k < ncov; ++k) {
         const size_t p = (size_t)covered[k];
         const float r = depth[p];
@@ -326,12 +356,15 @@ static double loglik_one(orc_sensor* s, const double* pose, int32_t parent, int3
         const float b = (float)(orc_prob_occluded(s, (double)o, (double)r) * (double)occ);
         const float pbg = (float)orc_prob_occluded(s, (double)o, INFINITY);
         const float sum = a + b;
-        ll += log((double)(sum / pbg));
+        const double term = log((double)(sum / pbg));
+        ll += term;
+        abs_ll += fabs(term);
         if (update) {
             cocc[p] = b / sum;
             if (lazy) cstamp[p] = s->clock;
         }
     }
+    s->abs_sum[child] = abs_ll;
     return ll;
 }
 
@@ -358,17 +391,30 @@ void orc_loglikes_mt(orc_sensor* s, const double* poses, int32_t* indices, int32
                                        bg_now, s->depth, s->covered);
     } else {
 #ifdef _OPENMP
+        /* per-thread scratch lives in the sensor: allocated (and first touched by its thread)
+         * once, not mmap'ed and unmapped in every call */
+        if (s->n_scratch < n_threads) {
+            s->tdepth = (float**)realloc(s->tdepth, sizeof(float*) * (size_t)n_threads);
+            s->tcov = (int32_t**)realloc(s->tcov, sizeof(int32_t*) * (size_t)n_threads);
+            for (int t = s->n_scratch; t < n_threads; ++t) { s->tdepth[t] = NULL; s->tcov[t] = NULL; }
+            s->n_scratch = n_threads;
+        }
 #pragma omp parallel num_threads(n_threads)
         {
-            float* depth = (float*)malloc(sizeof(float) * s->npx);
-            int32_t* covered = (int32_t*)malloc(sizeof(int32_t) * s->npx);
-            for (size_t p = 0; p < s->npx; ++p) depth[p] = INFINITY;
-#pragma omp for schedule(dynamic, 1)
+            const int t = omp_get_thread_num();
+            if (!s->tdepth[t]) {
+                s->tdepth[t] = (float*)malloc(sizeof(float) * s->npx);
+                s->tcov[t] = (int32_t*)malloc(sizeof(int32_t) * s->npx);
+                for (size_t p = 0; p < s->npx; ++p) s->tdepth[t][p] = INFINITY;
+            }
+            float* depth = s->tdepth[t];
+            int32_t* covered = s->tcov[t];
+            /* static: particle i is always evaluated by the same thread, whose NUMA node holds
+             * slot i of both buffers (orc_reset_mt) */
+#pragma omp for schedule(static)
             for (int32_t i = 0; i < n; ++i)
                 out_loglik[i] = loglik_one(s, poses + (size_t)i * pstride, indices[i], i, update, alpha,
                                            beta, bg_now, depth, covered);
-            free(depth);
-            free(covered);
         }
 #else
         for (int32_t i = 0; i < n; ++i)
@@ -421,3 +467,8 @@ void orc_get_occlusion_now(const orc_sensor* s, int32_t slot, float* out)
 }
 
 float orc_background(const orc_sensor* s) { return s->background; }
+
+void orc_last_abs_sums(const orc_sensor* s, double* out, int32_t n)
+{
+    memcpy(out, s->abs_sum, sizeof(double) * (size_t)n);
+}

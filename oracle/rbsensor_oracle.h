@@ -102,6 +102,12 @@ double orc_propagate(const orc_sensor* s, double occ, double dt);
 void orc_eager_coeffs(const orc_sensor* s, int32_t n_frames, float* alpha, float* beta);
 float orc_eager_prior(float alpha, float beta, float occ, float bg_now);
 float orc_background(const orc_sensor* s);  /* EAGER: never-covered level at the last updating call */
+/* Per particle of the last orc_loglikes* call: the sum of the MAGNITUDES of the per-pixel log
+ * terms its log-likelihood adds up -- the conditioning of that sum, against which a float32
+ * implementation's error is bounded (tests/test_gpu_f32.py). */
+void orc_last_abs_sums(const orc_sensor* s, double* out, int32_t n);
+/* orc_reset with NUMA-aware first touch for the n_threads baseline (see the .c file). */
+void orc_reset_mt(orc_sensor* s, int32_t n_threads);
 
 /* ---- tracker_oracle.c: transition + RBC filter step + tracker mean ---- */
 typedef struct orc_tracker orc_tracker;

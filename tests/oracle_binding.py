@@ -49,6 +49,8 @@ def load():
         lib.orc_create.argtypes = [C.POINTER(OrcConfig)]
         lib.orc_destroy.argtypes = [H]
         lib.orc_reset.argtypes = [H]
+        lib.orc_reset_mt.argtypes = [H, C.c_int32]
+        lib.orc_last_abs_sums.argtypes = [H, dp, C.c_int32]
         lib.orc_set_observation.argtypes = [H, dp]
         lib.orc_loglikes.argtypes = [H, dp, ip, C.c_int32, C.c_int32, dp]
         lib.orc_loglikes_mt.argtypes = [H, dp, ip, C.c_int32, C.c_int32, dp, C.c_int32]
@@ -116,8 +118,19 @@ class Oracle:
     def __del__(self):
         self.close()
 
-    def reset(self):
-        self._lib.orc_reset(self._h)
+    def reset(self, threads=1):
+        """threads > 1: NUMA-aware first touch for the multi-threaded baseline (bench.py)."""
+        if threads > 1:
+            self._lib.orc_reset_mt(self._h, int(threads))
+        else:
+            self._lib.orc_reset(self._h)
+
+    def last_abs_sums(self, n):
+        """Per particle of the last loglikes call: sum of |per-pixel log term| (the conditioning of
+        the log-likelihood sum)."""
+        out = np.empty(n, dtype=np.float64)
+        self._lib.orc_last_abs_sums(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), int(n))
+        return out
 
     def set_observation(self, image):
         a = np.ascontiguousarray(image, dtype=np.float64).ravel()

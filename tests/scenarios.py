@@ -27,7 +27,7 @@ def make_frames(oracle, n_bodies, n_frames, seed=0, z=0.7, **kw):
     return out
 
 
-def run_sequence(sensor, frames, n, seed=1, n_bodies=1, update_every=True, permute=True):
+def run_sequence(sensor, frames, n, seed=1, n_bodies=1, update_every=True, permute=True, abs_sums=None):
     """Drive a sensor (oracle or product: same method names) through a frame sequence the way
     the filter does: set_observation, loglikes(update=True), resample-like index shuffle.
     Returns per-frame log-likelihood arrays."""
@@ -40,6 +40,8 @@ def run_sequence(sensor, frames, n, seed=1, n_bodies=1, update_every=True, permu
         poses = synth.particle_poses(truth, n, rng, scale=1.0 + 0.5 * k)
         ll = sensor.loglikes_poses(poses, indices, update=True)
         lls.append(ll)
+        if abs_sums is not None:     # oracle only: the conditioning of each particle's sum
+            abs_sums.append(sensor.last_abs_sums(n))
         assert (indices == np.arange(n)).all()
         if permute:
             # children inherit from parents drawn with replacement (multinomial resampling)
