@@ -84,7 +84,18 @@ struct rbs_handle {
     float* d_tri_plane = nullptr;   // [n_tri][4] model-space plane of each triangle (float32 pre-cull)
     int precision = RBS_PRECISION_F64;
     float* d_render = nullptr;
-    float* h_frame = nullptr;   // pinned staging
+    // pinned staging of the host-pointer API: poses | indices in one block (one H2D copy), the
+    // log-likelihoods in another, and the event the caller waits on (the out copy alone -- the
+    // planes' copy kernel on the second stream is joined by the next call, as in the device API)
+    unsigned char* h_in = nullptr;
+    double* h_out = nullptr;
+    unsigned char* d_in = nullptr;     // device image of h_in
+    size_t in_idx_off = 0;             // byte offset of the indices inside h_in / d_in
+    hipEvent_t ev_out = nullptr;
+    float* h_frames[2] = {nullptr, nullptr};   // pinned frame staging, alternating
+    hipEvent_t ev_frame[2] = {nullptr, nullptr};
+    int frame_slot = 0;
+    float* h_frame = nullptr;   // = h_frames[frame_slot]
     float* h_native = nullptr;  // pinned staging for full-resolution frames
     float* d_native = nullptr;
     size_t native_cap = 0;
@@ -463,7 +474,14 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_tri_plane);
     (void)hipFree(h->d_vtx);
     (void)hipFree(h->d_render);
-    if (h->h_frame) (void)hipHostFree(h->h_frame);
+    for (int k = 0; k < 2; ++k) {
+        if (h->h_frames[k]) (void)hipHostFree(h->h_frames[k]);
+        if (h->ev_frame[k]) (void)hipEventDestroy(h->ev_frame[k]);
+    }
+    if (h->h_in) (void)hipHostFree(h->h_in);
+    if (h->h_out) (void)hipHostFree(h->h_out);
+    (void)hipFree(h->d_in);
+    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     if (h->h_native) (void)hipHostFree(h->h_native);
     (void)hipFree(h->d_native);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -487,9 +505,20 @@ int32_t upload_frame(rbs_handle* h)
     const size_t n = (size_t)h->npx;
     RBS_HIP(h, hipMemcpyAsync(h->d_frame, h->h_frame, n * sizeof(float), hipMemcpyHostToDevice,
                               h->stream));
+    RBS_HIP(h, hipEventRecord(h->ev_frame[h->frame_slot], h->stream));
     // the per-pixel terms kernel rides on the next loglikes launch (flush_lazy_frame otherwise)
     h->lazy_frame = h->d_frame;
     h->lazy_stream = h->stream;
+    return RBS_OK;
+}
+
+// The pinned frame buffer the next host frame is staged in: the other one of the two, once the
+// upload that last used it has finished (two frames ago: in practice never a wait).
+int32_t next_frame_staging(rbs_handle* h)
+{
+    h->frame_slot ^= 1;
+    h->h_frame = h->h_frames[h->frame_slot];
+    RBS_HIP(h, hipEventSynchronize(h->ev_frame[h->frame_slot]));
     return RBS_OK;
 }
 
@@ -538,7 +567,15 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     h->init_occ = cfg->initial_occlusion_prob;
     h->delta_time = cfg->delta_time;
     switch (cfg->likelihood_precision) {
-        case RBS_PRECISION_DEFAULT: h->precision = RBS_PRECISION_LIBRARY_DEFAULT; break;
+        case RBS_PRECISION_DEFAULT:
+            // the caller leaves it open: the library's default, unless the environment names one
+            // (the exactness test-suites of an unchanged caller pin F64 this way)
+            h->precision = RBS_PRECISION_LIBRARY_DEFAULT;
+            if (const char* m = std::getenv("RBS_PRECISION")) {
+                if (!std::strcmp(m, "f64")) h->precision = RBS_PRECISION_F64;
+                else if (!std::strcmp(m, "f32")) h->precision = RBS_PRECISION_F32;
+            }
+            break;
         case RBS_PRECISION_F64: case RBS_PRECISION_F32: h->precision = cfg->likelihood_precision; break;
         default: return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("likelihood_precision %d", cfg->likelihood_precision));
     }
@@ -872,7 +909,20 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         RBS_HIP(h, hipMemcpy(h->d_vtx, vtx.data(), sizeof(float) * vtx.size(), hipMemcpyHostToDevice));
         B.vtx = reinterpret_cast<const rbs::floatx4*>(h->d_vtx);
     }
-    RBS_HIP(h, hipHostMalloc(&h->h_frame, plane, hipHostMallocDefault));
+    for (int k = 0; k < 2; ++k) {
+        RBS_HIP(h, hipHostMalloc(&h->h_frames[k], plane, hipHostMallocDefault));
+        RBS_HIP(h, hipEventCreateWithFlags(&h->ev_frame[k], hipEventDisableTiming));
+    }
+    h->h_frame = h->h_frames[0];
+    {
+        const size_t pose_bytes = sizeof(double) * 12 * h->n_bodies * (size_t)h->max_particles;
+        h->in_idx_off = pose_bytes;
+        const size_t in_bytes = pose_bytes + sizeof(int) * (size_t)h->max_particles;
+        RBS_HIP(h, hipHostMalloc(&h->h_in, in_bytes, hipHostMallocDefault));
+        RBS_HIP(h, hipHostMalloc(&h->h_out, sizeof(double) * (size_t)h->max_particles, hipHostMallocDefault));
+        RBS_HIP(h, hipMalloc(&h->d_in, in_bytes));
+        RBS_HIP(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+    }
 
     // the raster / render kernels carve the LDS depth tile from dynamic shared memory
     RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 0>),
@@ -985,7 +1035,7 @@ int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n)
                     fmt("set_observation: expected %d pixels, got %zu", h->npx, n));
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
-    RBS_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer reuse
+    if (int32_t rc = next_frame_staging(h)) return rc;
     for (size_t p = 0; p < n; ++p) h->h_frame[p] = (float)depth[p];
     if (int32_t rc = upload_frame(h)) return rc;
     h->pending_frames += 1;
@@ -1000,7 +1050,7 @@ int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n)
                     fmt("set_observation_f32: expected %d pixels, got %zu", h->npx, n));
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
-    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    if (int32_t rc = next_frame_staging(h)) return rc;
     std::memcpy(h->h_frame, depth, n * sizeof(float));
     if (int32_t rc = upload_frame(h)) return rc;
     h->pending_frames += 1;
@@ -1081,15 +1131,27 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
                         fmt("loglikes: indices[%d] = %d outside 0..%d", i, indices[i],
                             h->max_particles - 1));
     RBS_HIP(h, hipSetDevice(h->device));
+    // pinned staging (a copy from pageable memory is staged by the runtime anyway, synchronously):
+    // poses and indices travel in ONE H2D copy; the call waits for the log-likelihoods' D2H copy
+    // only -- the occlusion planes are finished by the second stream and joined by the next call
     const size_t pose_bytes = sizeof(double) * 12 * h->n_bodies * (size_t)n;
-    RBS_HIP(h, hipMemcpyAsync(h->d_poses, poses, pose_bytes, hipMemcpyHostToDevice, h->stream));
-    RBS_HIP(h, hipMemcpyAsync(h->d_indices, indices, sizeof(int) * (size_t)n, hipMemcpyHostToDevice,
-                              h->stream));
-    const int32_t rc = enqueue_loglikes(h, h->d_poses, h->d_indices, n, update != 0, h->d_out, h->stream);
+    std::memcpy(h->h_in, poses, pose_bytes);
+    std::memcpy(h->h_in + h->in_idx_off, indices, sizeof(int) * (size_t)n);
+    if (pose_bytes == h->in_idx_off) {
+        RBS_HIP(h, hipMemcpyAsync(h->d_in, h->h_in, pose_bytes + sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    } else {
+        RBS_HIP(h, hipMemcpyAsync(h->d_in, h->h_in, pose_bytes, hipMemcpyHostToDevice, h->stream));
+        RBS_HIP(h, hipMemcpyAsync(h->d_in + h->in_idx_off, h->h_in + h->in_idx_off, sizeof(int) * (size_t)n,
+                                  hipMemcpyHostToDevice, h->stream));
+    }
+    const int32_t rc = enqueue_loglikes(h, reinterpret_cast<const double*>(h->d_in),
+                                        reinterpret_cast<const int*>(h->d_in + h->in_idx_off), n, update != 0,
+                                        h->d_out, h->stream);
     if (rc != RBS_OK) return rc;
-    RBS_HIP(h, hipMemcpyAsync(out_loglik, h->d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
-                              h->stream));
-    if (int32_t rc = drain(h, true)) return rc;
+    RBS_HIP(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    RBS_HIP(h, hipEventRecord(h->ev_out, h->stream));
+    RBS_HIP(h, hipEventSynchronize(h->ev_out));
+    std::memcpy(out_loglik, h->h_out, sizeof(double) * (size_t)n);
     if (update)
         for (int32_t i = 0; i < n; ++i) indices[i] = i;
     return RBS_OK;

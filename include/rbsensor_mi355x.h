@@ -53,11 +53,16 @@ enum {
  * geometry is binary64, depth and occlusion state are float, the per-particle sum is binary64.
  *   F64  binary64 with the reference CPU path's float rounding points: agrees with
  *        the device-rule oracle to ~1e-15 and with the reference-semantics oracle to ~5e-9.
- *   F32  float32 transcendentals: ~2x faster raster kernel, agrees with the reference-semantics
- *        oracle to <= 1e-5 relative (BASELINE.json north_star's tolerance; measured ~1e-7).
- * DEFAULT = the library's default, RBS_PRECISION_LIBRARY_DEFAULT. */
+ *   F32  float32 likelihood on the exp2 / log2 / rcp units, per-pixel terms derived from the
+ *        observation on the fly (no per-frame planes): raster kernel 1.5x faster; agrees with the
+ *        reference-semantics oracle to <= 1e-5 relative (BASELINE.json north_star's tolerance;
+ *        measured <= 7e-7) for every particle whose sum is well conditioned, and to <= 1e-6 of
+ *        the sum of the magnitudes of the per-pixel terms for all (measured 7e-8): float32-level
+ *        agreement, ~5e-4 absolute on log-likelihoods of magnitude 1e4.
+ * DEFAULT = the library's default, RBS_PRECISION_LIBRARY_DEFAULT (RBS_PRECISION=f64|f32 in the
+ * environment overrides DEFAULT only). */
 enum { RBS_PRECISION_DEFAULT = 0, RBS_PRECISION_F64 = 1, RBS_PRECISION_F32 = 2 };
-#define RBS_PRECISION_LIBRARY_DEFAULT RBS_PRECISION_F64
+#define RBS_PRECISION_LIBRARY_DEFAULT RBS_PRECISION_F32
 /* rbs_config.state_layout: how occlusion planes are stored ("occlusion state layout" below).
  * DEFAULT = windowed (RBS_STATE=dense in the environment overrides DEFAULT only: tooling). */
 enum { RBS_STATE_DEFAULT = 0, RBS_STATE_WINDOWED = 1, RBS_STATE_DENSE = 2 };

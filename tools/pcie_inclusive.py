@@ -2,7 +2,8 @@ import sys, os, time, numpy as np
 sys.path.insert(0, os.getcwd())
 from dbot_ros_amd import CameraData, ObjectModel, RbSensor, RbSensorBuilder, synth
 n=2000; v,f=synth.mesh_m1(); om=ObjectModel([v],[f]); cam=CameraData(synth.camera_matrix(),480,640)
-with RbSensor(om,cam,RbSensorBuilder.Parameters(sample_count=n),max_particles=n) as s:
+prec=sys.argv[1] if len(sys.argv)>1 else None
+with RbSensor(om,cam,RbSensorBuilder.Parameters(sample_count=n),max_particles=n,precision=prec) as s:
     rng=np.random.default_rng(0); truth=synth.truth_pose(1)
     frame=synth.make_frame(s.render_depth(truth),480,640,rng).astype(np.float32)
     poses=synth.particle_poses(truth,n,rng); idx=rng.permutation(n).astype(np.int32)
