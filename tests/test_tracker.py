@@ -173,8 +173,9 @@ def test_host_tracker_mirror_matches_the_c_oracle_tracker(meshes, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-9), ("f32", 1e-6)])
 @pytest.mark.parametrize("meshes,n,cols,rows", [(("m1_l2",), 64, 160, 120), (("m1_l2", "box12"), 96, 160, 120)])
-def test_device_tracker_matches_the_c_oracle_tracker(gpu_lib, meshes, n, cols, rows):
+def test_device_tracker_matches_the_c_oracle_tracker(gpu_lib, meshes, n, cols, rows, precision, tol):
     """rbs_tracker_* on the GPU against oracle/tracker_oracle.c over the oracle sensor (device
     rule), same host-supplied randomness: the checker is entirely under oracle/."""
     from dbot_ros_amd.tracker import DeviceParticleTracker
@@ -185,7 +186,7 @@ def test_device_tracker_matches_the_c_oracle_tracker(gpu_lib, meshes, n, cols, r
     orc = ob.Oracle(om, cam, P, max_particles=per, mode=ob.EAGER)
     trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=nb)).build()
     ref = ob.OracleTracker(orc, per, trans.sigma, trans.vf, tp.max_kl_divergence)
-    with RbSensor(om, cam, P, max_particles=per) as s:
+    with RbSensor(om, cam, P, max_particles=per, precision=precision) as s:
         dev = DeviceParticleTracker(trans, s, om, tp, np.random.default_rng(2))
         init = _model_init(om, nb)
         dev.initialize([init])
@@ -196,9 +197,10 @@ def test_device_tracker_matches_the_c_oracle_tracker(gpu_lib, meshes, n, cols, r
             normals, uniforms = dev.draw_randomness()
             ed = dev.track(frame, normals, uniforms)
             er, nres = ref.track(frame, normals, uniforms)
-            assert np.abs(ed - er).max() <= 1e-9, (k, np.abs(ed - er).max())
+            assert np.abs(ed - er).max() <= tol, (k, np.abs(ed - er).max())
             pd, wd, idd = dev.get_state()
             pr, wr, idr = ref.get_state()
-            assert np.abs(pd - pr).max() <= 1e-9 and np.array_equal(idd, idr) and dev.n_resamplings == nres
+            # (F32: the same parents as long as no uniform falls within ~1e-7 of a cdf step)
+            assert np.abs(pd - pr).max() <= tol and np.array_equal(idd, idr) and dev.n_resamplings == nres
         assert nres >= 1
         dev.close()
