@@ -1,24 +1,44 @@
 #!/usr/bin/env python3
-"""bench.py -- particle-likelihoods/s of the RbSensor hot path on MI355X.
+"""bench.py -- particle-likelihoods/s of the RbSensor hot path on MI355X (BASELINE.json metric).
 
 A "step" is one frame of BASELINE.json config C1 on one GPU: set_observation(frame k) +
 RbSensor::loglikes(update=true) over 2 000 particles, one 5 120-triangle mesh (M1), 640x480
 synthetic frames of SURVEY 8d's sequence (the object translates 2 mm and turns 1 degree per
 frame; 30 frames played forwards and backwards), every child inheriting from a distinct random
 parent slot (permutation: no occlusion plane is read twice, the worst case for HBM traffic).
-Inputs (frames, poses, parent indices, occlusion planes) are resident in HBM before the timed
-region.  --sequence 0 replays one frame and one pose set for ever (a resting object).  With --gpus N each
-rank evaluates its own 2 000-particle shard (weak scaling) and the per-particle
-log-likelihoods are all-gathered over RCCL every step (the weight exchange before resampling).
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      algorithmic bytes (2*4*W*H per particle-likelihood) / live kernel time
-  cpu_baseline  the CPU oracle (reference CPU-path semantics) timed on this host, 1 thread
+`value` (the contract's number): inputs (frames, poses, parent indices, occlusion planes) resident
+in HBM before the timed region, device-pointer API.  The same JSON line carries, as flat keys,
+
+  host_api_*      the SAME steps through the host-pointer API the reference's filter would call:
+                  frame upload, pose upload and log-likelihood download inside the clock
+                  (SURVEY 8d's definition of the metric)
+  tracker_fps_*   frames/s of the full per-frame step (frame upload + transition + loglikes +
+                  weights + KL + resampling + mean) at 200 / 2 000 / 20 000 particles
+  f64_*           the same resident steps with likelihood precision F64
+  roofline        dominant kernel of the headline run (windowed planes: the raster kernel, bound by
+                  VALU issue): achieved = VALU wave-instructions/s from a LIVE rocprofv3 PMC pass
+                  of this very command (child process) / live HIP-event kernel time; frac <= 1;
+                  plus the measured HBM traffic (PMC, separate passes, gfx950 corrections) and the
+                  algorithmic-bytes figure of SURVEY 8d for comparison
+  dense_*         the same steps on whole planes (state_layout=dense), where the copy kernel is
+                  dominant and HBM bound: algorithmic bytes / its live duration vs 8 TB/s
+  cpu_baseline    the CPU oracle (reference CPU-path semantics) on this host: 1 thread (as dbot's
+                  CPU model runs) and all cores
+
+With `torch.distributed.run` (--gpus N, one rank per GPU) each rank evaluates its own 2 000-particle
+shard (weak scaling) and the per-particle log-likelihoods are all-gathered over RCCL every step
+(the weight exchange before resampling); only the headline is measured then.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,7 +47,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # 1 024 SIMDs x one wave64 VALU instruction per 4 cycles x 2.4 GHz = 614.4 G/s
+WORKLOAD_FLAGS = ("particles", "cols", "rows", "mesh", "parents", "update", "sequence", "precision", "layout")
 
 
 def parse():
@@ -50,10 +72,17 @@ def parse():
                          "the windowed layout's worst case")
     ap.add_argument("--fill-fraction", type=float, default=1.0,
                     help="with --fill-planes: only a central rectangle of this fraction of the frame")
-    ap.add_argument("--precision", default=None, choices=["f64", "f32"], help="likelihood precision (default: the library's)")
-    ap.add_argument("--no-dense-leg", action="store_true", help="skip the whole-plane (RBS_STATE=dense) comparison run")
+    ap.add_argument("--precision", default="f32", choices=["f64", "f32"], help="likelihood precision of the headline run")
+    ap.add_argument("--layout", default="window", choices=["window", "dense"], help="occlusion state layout of the headline run")
+    ap.add_argument("--quick", action="store_true", help="headline only: no dense / f64 / host / tracker / cpu / pmc legs")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the whole-plane (state_layout=dense) comparison run")
+    ap.add_argument("--no-f64-leg", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true")
+    ap.add_argument("--no-tracker-fps", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="no live rocprofv3 counter passes (roofline falls back to profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the process rocprofv3 wraps
     a = ap.parse_args()
     presets = {"c1": {}, "c1_readonly": {"update": 0},
                "c2": {"mesh": "m1,m2,m3", "particles": 6666, "steps": 50},
@@ -62,26 +91,233 @@ def parse():
                "default_res": {"cols": 80, "rows": 60}}
     for k, v in presets.get(a.config, {}).items():
         setattr(a, k, v)
+    if a.quick or a.config not in (None, "c1"):
+        a.no_dense_leg = a.no_f64_leg = a.no_host_leg = a.no_tracker_fps = a.no_cpu_baseline = True
+        a.no_pmc = a.no_pmc or a.quick
     return a
+
+
+# --------------------------------------------------------------------------------- scene
+def build_scene(a):
+    from dbot_ros_amd import CameraData, ObjectModel, RbSensorBuilder, synth
+    mesh_fns = {"m1": synth.mesh_m1, "m2": synth.mesh_m2, "m3": synth.mesh_m3, "m4": synth.mesh_m4,
+                "box12": synth.mesh_box12}
+    meshes = [mesh_fns[m]() for m in a.mesh.split(",")]
+    om = ObjectModel([v for v, _ in meshes], [t for _, t in meshes], center=True)
+    cam = CameraData(synth.camera_matrix(a.cols, a.rows), a.rows, a.cols)
+    P = RbSensorBuilder.Parameters(sample_count=a.particles)
+    return om, cam, P, sum(len(t) for _, t in meshes), len(meshes)
+
+
+class Workload:
+    """Frames, poses and parent indices of the moving-object sequence, on the host and in HBM."""
+
+    def __init__(self, a, om, cam, P, nb, device, rank):
+        from dbot_ros_amd import RbSensor, synth
+        n = a.particles
+        rng = np.random.default_rng(0)
+        prng = np.random.default_rng(1 + rank)
+        F = max(1, a.sequence)
+        self.truths = [synth.truth_pose(nb, frame=k) for k in range(F)]
+        with RbSensor(om, cam, P, device_id=device.index, max_particles=1) as r:   # the product's own render hook
+            self.frames = np.stack([synth.make_frame(r.render_depth(t), a.rows, a.cols, rng) for t in self.truths]).astype(np.float32)
+        self.poses = np.stack([synth.particle_poses(t, n, prng).reshape(n, -1) for t in self.truths])
+        self.order = list(range(F)) + list(range(F - 2, 0, -1))      # forwards, then backwards
+        if a.parents == "permutation":
+            parents = synth.resample_like_indices(n, prng)
+        elif a.parents == "identity":
+            parents = np.arange(n, dtype=np.int32)
+        elif a.parents == "resampled":
+            parents = synth.resample_like_indices(n, prng, concentration=1.0)
+        else:  # a tracker's usual regime: few survivors, many siblings
+            parents = synth.resample_like_indices(n, prng, concentration=0.02)
+            if a.parents == "peaked_unsorted":
+                parents = prng.permutation(parents).astype(np.int32)
+        self.parents = parents
+        self.d_poses = torch.from_numpy(self.poses).to(device)             # [F][n][12*bodies]
+        self.d_frames = torch.from_numpy(self.frames).to(device)           # [F][rows*cols]
+        self.d_idx = torch.from_numpy(parents).to(device)
+        self.pose_bytes = self.d_poses[0].numel() * 8
+        self.frame_bytes = self.d_frames[0].numel() * 4
+
+
+def fill_planes(sensor, a):
+    plane = np.full((a.rows, a.cols), np.float32(0.1), dtype=np.float32)      # = the background after reset
+    fr = float(np.sqrt(min(1.0, max(0.0, a.fill_fraction))))
+    r0, c0 = int(a.rows * (1 - fr) / 2), int(a.cols * (1 - fr) / 2)
+    plane[r0:a.rows - r0, c0:a.cols - c0] = a.fill_planes
+    for slot in range(a.particles):
+        sensor.set_occlusion(slot, plane.ravel())
+
+
+class ResidentRun:
+    """set_observation_device + loglikes_device on a caller-owned stream, everything in HBM."""
+
+    def __init__(self, a, W, sensor, stream, d_out):
+        self.a, self.W, self.sensor, self.stream, self.d_out = a, W, sensor, stream, d_out
+        self.count = 0
+
+    def launch(self):
+        a, W = self.a, self.W
+        k = W.order[self.count % len(W.order)]
+        self.count += 1
+        if a.sequence > 0:
+            self.sensor.set_observation_device(W.d_frames.data_ptr() + k * W.frame_bytes, self.stream.cuda_stream)
+        self.sensor.loglikes_device(W.d_poses.data_ptr() + k * W.pose_bytes, W.d_idx.data_ptr(), a.particles,
+                                    bool(a.update), self.d_out.data_ptr(), self.stream.cuda_stream)
+
+    def timed(self, steps, warmup, after=None, barrier=None):
+        for _ in range(warmup):
+            self.launch()
+            if after:
+                after()
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.launch()
+            if after:
+                after()
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def kernel_times(self, launches=512):
+        """Average kernel durations over >= 200 launches, from the HIP events the library records
+        on the streams its kernels run on (every 2nd call carries events in this pass)."""
+        self.sensor.set_timing_every(2)
+        for _ in range(launches):
+            self.launch()
+        torch.cuda.synchronize()
+        call_ms, copy_ms, n_used = self.sensor.timing_summary(launches)
+        raster_ms = self.sensor.raster_kernel_ms(launches)
+        self.sensor.set_timing_every(8)
+        return raster_ms, copy_ms, call_ms, n_used
+
+
+def make_sensor(a, om, cam, P, device, precision=None, layout=None, n=None):
+    from dbot_ros_amd import RbSensor
+    return RbSensor(om, cam, P, device_id=device.index, max_particles=n or a.particles,
+                    precision=precision or a.precision, state_layout=layout or a.layout)
+
+
+def prime(sensor, a, W):
+    sensor.reset()
+    if a.fill_planes is not None:
+        fill_planes(sensor, a)
+    sensor.set_observation(W.frames[0])
+    sensor.synchronize()
+
+
+# --------------------------------------------------------------------------------- PMC child passes
+def pmc_pass(a, counters, layout, timeout=150):
+    """One rocprofv3 --pmc pass over a short child run of this same command (same workload
+    flags).  Returns {kernel short name: {counter: mean value per dispatch}} or None."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="rbs_pmc_", dir="/tmp")
+    flags = []
+    for f in WORKLOAD_FLAGS:
+        v = layout if f == "layout" else getattr(a, f)
+        flags += ["--" + f, str(v)]
+    cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "12", "--warmup", "3", *flags]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        acc = {}
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                name = row["Kernel_Name"]
+                short = next((k for k in ("rbs_raster_kernel", "rbs_copy_window_kernel", "rbs_copy_rows_kernel",
+                                          "rbs_frame_prep_kernel", "rbs_prep_kernel", "rbs_wide_window_kernel") if k in name), None)
+                if short is None:
+                    continue
+                d = acc.setdefault(short, {}).setdefault(row["Counter_Name"], {})
+                d[row["Dispatch_Id"]] = d.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+        res = {}
+        for k, cs in acc.items():
+            res[k] = {}
+            for c, per in cs.items():
+                v = [per[d] for d in sorted(per, key=int)]
+                v = v[len(v) // 4:]            # drop the warm-up dispatches
+                res[k][c] = float(np.mean(v))
+        return res or None
+    except Exception as e:                     # noqa: BLE001 -- the bench must survive a box without counters
+        print(f"# pmc pass {counters} failed: {e}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def hbm_bytes(fetch, write, kernel):
+    """FETCH_SIZE / WRITE_SIZE are KiB; gfx950's FETCH_SIZE reports half the bytes of wide
+    coalesced reads (MI355X_MICROARCH.md, HBM section; calibrated on a float4 stream copy in
+    profiles/r01_pmc_hbm.json: x1.99995 and x0.99996)."""
+    if not fetch or not write or kernel not in fetch or kernel not in write:
+        return None
+    return fetch[kernel].get("FETCH_SIZE", 0.0) * 1024.0 * 2.0 + write[kernel].get("WRITE_SIZE", 0.0) * 1024.0
+
+
+# --------------------------------------------------------------------------------- CPU baseline
+def usable_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota
+    (cpu.max).  On the GPU boxes of this pool the host reports 256 hardware threads but the
+    container's quota is 16 CPUs: a thread team sized by os.cpu_count() spends its time being
+    throttled (round 1's 'all cores' figure was slower than one thread for that reason)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, period = open(path).read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(period)
+        except (OSError, ValueError):
+            pass
+    if quota is None:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota)))
+    return n, quota
 
 
 def cpu_baseline(om, cam, P, truth, frame, seconds):
     """The oracle in reference-CPU-semantics mode (LAZY) on a bounded sample of the same
-    workload: config C0's 200 particles per call, repeated frame after frame (update=true,
-    permuted parents) until `seconds` elapse.  Headline = single thread, as dbot's CPU model
-    runs; `all_cores` = the same loop with OpenMP over particles on every host core."""
+    workload.  Headline = single thread, config C0's 200 particles per call, as dbot's CPU model
+    runs; all_cores = C1's 2 000 particles per call with OpenMP over particles on every host core
+    (persistent thread team, per-thread scratch kept, every slot first touched by the thread that
+    evaluates it)."""
+    os.environ.setdefault("OMP_PROC_BIND", "false")    # a quota-limited container: let the scheduler place the team
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     from dbot_ros_amd import synth
-    n = 200
     tris = sum(len(t) for t in om.triangles)
 
-    def run(threads, budget):
+    def run(n, threads, budget):
         orc = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
         rng = np.random.default_rng(1)
         poses = synth.particle_poses(truth, n, rng)
         idx = np.zeros(n, dtype=np.int32)
-        orc.reset()
+        orc.reset(threads=threads)
+        if threads > 1:                      # thread team + scratch: set-up, not the baseline
+            orc.set_observation(frame)
+            orc.loglikes_poses(poses, idx, update=True, threads=threads)
         done, t0 = 0, time.perf_counter()
         while True:
             orc.set_observation(frame)
@@ -94,10 +330,10 @@ def cpu_baseline(om, cam, P, truth, frame, seconds):
         orc.close()
         return done, el
 
-    done, el = run(1, seconds)
+    n1 = 200
+    done, el = run(n1, 1, seconds)
     cores = os.cpu_count() or 1
-    threads = min(cores, n)
-    done_mt, el_mt = run(threads, max(3.0, seconds / 3))
+    usable, quota = usable_cores()
     model = "unknown CPU"
     try:
         for line in open("/proc/cpuinfo"):
@@ -106,13 +342,65 @@ def cpu_baseline(om, cam, P, truth, frame, seconds):
                 break
     except OSError:
         pass
-    return {"value": done / el, "unit": "particle-likelihoods/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": cores,
-            "sample": f"{done} particle-likelihoods = {done // n} loglikes(update=true) calls x {n} "
-                      f"particles, {cam.cols}x{cam.rows}, {tris} triangles, {el:.1f} s on 1 of {cores} host cores",
-            "all_cores": {"value": done_mt / el_mt, "cores": threads,
-                          "sample": f"{done_mt} particle-likelihoods in {el_mt:.1f} s, OpenMP over particles"}}
+    out = {"value": done / el, "unit": "particle-likelihoods/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": cores,
+           "sample": f"{done} particle-likelihoods = {done // n1} loglikes(update=true) calls x {n1} "
+                     f"particles, {cam.cols}x{cam.rows}, {tris} triangles, {el:.1f} s on 1 of {cores} host cores"}
+    out["usable_cores"] = usable
+    out["cgroup_cpu_quota"] = quota
+    if usable > 1:
+        nm = 2000
+        threads = min(usable, nm)
+        done_mt, el_mt = run(nm, threads, max(3.0, seconds / 3))
+        out["all_cores_value"] = done_mt / el_mt
+        out["all_cores_threads"] = threads
+        out["all_cores_speedup"] = (done_mt / el_mt) / (done / el)
+        out["all_cores_sample"] = (f"{done_mt} particle-likelihoods = {done_mt // nm} calls x {nm} particles in {el_mt:.1f} s, "
+                                   f"OpenMP over particles, {threads} threads = every CPU this container may use "
+                                   f"({cores} hardware threads on the host" + (f", cgroup quota {quota:g} CPUs)" if quota else ")"))
+        if out["all_cores_speedup"] < 0.5 * threads and out["all_cores_speedup"] < 10.0:
+            out["all_cores_note"] = "below half-linear scaling: the host is shared with other tenants (see /proc/loadavg)"
+    return out
 
 
+# --------------------------------------------------------------------------------- tracker FPS
+def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30):
+    """Frames/s of the device tracker (rbs_tracker_*: transition, weights, KL, resampling and mean
+    on the GPU, device RNG, one host sync per frame; the frame is uploaded from host memory every
+    frame) on the 30-frame sequence.  Second half of BASELINE.json's metric."""
+    from dbot_ros_amd import RbSensor, RbSensorBuilder, pose, synth
+    from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
+    nb = om.count_parts
+    out = {}
+    frames = None
+    for n in counts:
+        P = RbSensorBuilder.Parameters(sample_count=n)
+        with RbSensor(om, cam, P, device_id=device.index, max_particles=max(1, n // nb)) as s:
+            if frames is None:
+                rng = np.random.default_rng(0)
+                frames = [synth.make_frame(s.render_depth(synth.truth_pose(nb, frame=k)), cam.rows, cam.cols, rng,
+                                           occluder=False).astype(np.float32) for k in range(n_frames + 1)]
+            trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=nb)).build()
+            tr = DeviceParticleTracker(trans, s, om, ParticleTrackerBuilder.Parameters(evaluation_count=n), device_rng=True, seed=1)
+            init = np.zeros(12 * nb)
+            for b in range(nb):
+                Rt = synth.truth_pose(nb, frame=0)[b]
+                init[12 * b + 3:12 * b + 6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+                init[12 * b:12 * b + 3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[b]
+            tr.initialize([init])
+            tr.track(frames[0])  # warm-up
+            t0 = time.perf_counter()
+            for k in range(1, n_frames + 1):
+                est = tr.track(frames[k])
+            dt = time.perf_counter() - t0
+            Rt = synth.truth_pose(nb, frame=n_frames)[0]
+            err = float(np.linalg.norm(est[0:3] - (Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0])))
+            out[n] = {"fps": n_frames / dt, "ms_per_frame": dt / n_frames * 1e3, "resamplings": tr.n_resamplings,
+                      "final_position_error_m": err}
+            tr.close()
+    return out
+
+
+# --------------------------------------------------------------------------------- main
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,63 +425,29 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from dbot_ros_amd import CameraData, ObjectModel, RbSensor, RbSensorBuilder, synth
-    mesh_fns = {"m1": synth.mesh_m1, "m2": synth.mesh_m2, "m3": synth.mesh_m3, "m4": synth.mesh_m4,
-                "box12": synth.mesh_box12}
-    meshes = [mesh_fns[m]() for m in a.mesh.split(",")]
-    nb = len(meshes)
-    f = np.concatenate([t for _, t in meshes])
-    om = ObjectModel([v for v, _ in meshes], [t for _, t in meshes], center=True)
-    cam = CameraData(synth.camera_matrix(a.cols, a.rows), a.rows, a.cols)
+    om, cam, P, n_tri, nb = build_scene(a)
     n = a.particles
-    P = RbSensorBuilder.Parameters(sample_count=n)
-    sensor = RbSensor(om, cam, P, device_id=local, max_particles=n, precision=a.precision)
-
-    # synthetic frame: the product's own render hook supplies the object's depth
-    rng = np.random.default_rng(0)
-    prng = np.random.default_rng(1 + rank)
-    F = max(1, a.sequence)
-    truths = [synth.truth_pose(nb, frame=k) for k in range(F)]
-    frames = np.stack([synth.make_frame(sensor.render_depth(t), a.rows, a.cols, rng) for t in truths])
-    poses_seq = np.stack([synth.particle_poses(t, n, prng).reshape(n, -1) for t in truths])
-    order = list(range(F)) + list(range(F - 2, 0, -1))      # forwards, then backwards
-    truth, frame = truths[0], frames[0]
-    if a.parents == "permutation":
-        parents = synth.resample_like_indices(n, prng)
-    elif a.parents == "identity":
-        parents = np.arange(n, dtype=np.int32)
-    elif a.parents == "resampled":
-        parents = synth.resample_like_indices(n, prng, concentration=1.0)
-    else:  # a tracker's usual regime: few survivors, many siblings
-        parents = synth.resample_like_indices(n, prng, concentration=0.02)
-        if a.parents == "peaked_unsorted":
-            parents = prng.permutation(parents).astype(np.int32)
-    if rank == 0:
-        print(f"# parents={a.parents}: {len(np.unique(parents))} distinct of {n}", file=sys.stderr)
-
     dev = torch.device("cuda", local)
-    d_poses = torch.from_numpy(poses_seq).to(dev)                       # [F][n][12*bodies]
-    d_frames = torch.from_numpy(frames.astype(np.float32)).to(dev)     # [F][rows*cols]
-    d_idx = torch.from_numpy(parents).to(dev)
-    d_out = torch.empty(n, dtype=torch.float64, device=dev)
-    d_all = torch.empty(n * world, dtype=torch.float64, device=dev) if world > 1 else None
-    sensor.reset()
-    if a.fill_planes is not None:
-        plane = np.full((a.rows, a.cols), np.float32(0.1), dtype=np.float32)      # = the background after reset
-        fr = float(np.sqrt(min(1.0, max(0.0, a.fill_fraction))))
-        r0, c0 = int(a.rows * (1 - fr) / 2), int(a.cols * (1 - fr) / 2)
-        plane[r0:a.rows - r0, c0:a.cols - c0] = a.fill_planes
-        plane = plane.ravel()
-        for slot in range(n):
-            sensor.set_occlusion(slot, plane)
-    sensor.set_observation(frame)
-    sensor.synchronize()
-    # a non-default torch stream: the kernel, the timing events and the RCCL all-gather all
-    # live on it (a NULL stream would select the handle's private stream instead)
+    W = Workload(a, om, cam, P, nb, dev, rank)
+    if rank == 0 and not a.pmc_child:
+        print(f"# parents={a.parents}: {len(np.unique(W.parents))} distinct of {n}", file=sys.stderr)
+    # a non-default torch stream: the kernels, the timing events and the RCCL all-gather all live
+    # on it (a NULL stream would select the handle's private stream instead)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
+    d_out = torch.empty(n, dtype=torch.float64, device=dev)
+    d_all = torch.empty(n * world, dtype=torch.float64, device=dev) if world > 1 else None
     d_out.zero_()                  # first submission creates the stream's hardware queue: setup, not a step
     torch.cuda.synchronize()
+
+    sensor = make_sensor(a, om, cam, P, dev)
+    prime(sensor, a, W)
+    run = ResidentRun(a, W, sensor, stream, d_out)
+
+    if a.pmc_child:                # wrapped by rocprofv3: a few steps, no output
+        run.timed(a.steps, a.warmup)
+        sensor.close()
+        return
 
     def exchange():
         # the weight exchange before resampling: every rank gets all N*world log-likelihoods
@@ -204,47 +458,8 @@ def main():
             dist.all_gather(host, d_out.cpu())
             d_all.copy_(torch.cat(host))
 
-    pose_bytes = d_poses[0].numel() * 8
-    frame_bytes = d_frames[0].numel() * 4
-    counter = [0]
-
-    def launch(sn):
-        k = order[counter[0] % len(order)]
-        counter[0] += 1
-        if a.sequence > 0:
-            sn.set_observation_device(d_frames.data_ptr() + k * frame_bytes, stream.cuda_stream)
-        sn.loglikes_device(d_poses.data_ptr() + k * pose_bytes, d_idx.data_ptr(), n, bool(a.update),
-                           d_out.data_ptr(), stream.cuda_stream)
-
-    def step():
-        launch(sensor)
-        if world > 1:
-            exchange()
-
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # events are packets the stream retires between kernels: bracket every 4th step only (the
-    # library samples its own kernel timing events the same way)
-    k_ev = []
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        if i % 4 == 0:
-            k_ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
-            k_ev[-1][0].record(stream)
-        launch(sensor)
-        if i % 4 == 0:
-            k_ev[-1][1].record(stream)
-        if world > 1:
-            exchange()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = run.timed(a.steps, a.warmup, after=exchange if world > 1 else None,
+                        barrier=dist.barrier if world > 1 else None)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -253,102 +468,160 @@ def main():
         ref = d_all.view(world, n)[rank].cpu().numpy()
         if not np.array_equal(ref, d_out.cpu().numpy()):
             raise SystemExit("all-gather returned the wrong shard")
-    call_ms = float(np.mean([s.elapsed_time(e) for s, e in k_ev]))
-    # the dominant kernel (rbs_copy_kernel) runs on the library's second stream: its duration
-    # comes from the HIP events the library records on THAT stream, averaged over the timed steps
-    lib_call_ms, copy_ms, n_used = sensor.timing_summary(a.steps)
-    raster_ms = sensor.raster_kernel_ms(a.steps)
-    # the dominant kernel: the raster kernel on windowed planes, the copy kernel on whole planes
-    kernel_name, kernel_ms = ("rbs_copy_kernel", copy_ms) if (a.update and copy_ms > raster_ms) else ("rbs_raster_kernel", raster_ms)
-    windows = np.array([sensor.get_window(s_) for s_ in range(0, n, max(1, n // 64))])
-    win_frac = float(np.mean(np.maximum(0, windows[:, 2] - windows[:, 0]) * np.maximum(0, windows[:, 3] - windows[:, 1]))) / (a.rows * a.cols)
     ll = d_out.cpu().numpy()
     if not np.isfinite(ll).all():
         raise SystemExit("non-finite log-likelihoods in the timed run")
+    # dominant-kernel durations: a separate pass of 512 launches, 256 of them bracketed by events
+    raster_ms, copy_ms, call_ms, n_used = run.kernel_times(512)
+    windows = np.array([sensor.get_window(s_) for s_ in range(0, n, max(1, n // 64))])
+    win_frac = float(np.mean(np.maximum(0, windows[:, 2] - windows[:, 0]) * np.maximum(0, windows[:, 3] - windows[:, 1]))) / (a.rows * a.cols)
 
-    if rank == 0:
-        alg_bytes = (2.0 if a.update else 1.0) * 4.0 * a.rows * a.cols * n  # per launch, SURVEY 8d
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        layout = "dense" if os.environ.get("RBS_STATE") == "dense" else "window"
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                j = json.load(open(pmc))
-                if j.get("state_layout", "dense") == layout:
-                    traffic = j.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # what bounds the dominant kernel when it is not HBM: VALU issue, from the committed SQ
-        # counter summary of this same command (tools/profile_round.sh); live: measured HBM rate
-        valu = None
-        sqf = os.path.join(ROOT, "profiles", "r01_raster_sq.json" if layout == "window" else "r01_dense_raster_sq.json")
-        if os.path.exists(sqf) and kernel_name == "rbs_raster_kernel":
-            try:
-                j = json.load(open(sqf))
-                per = j["per_dispatch"]
-                valu = {"valu_wave_instructions_per_launch": per["SQ_INSTS_VALU"],
-                        "issue_rate_G_per_s": per["SQ_INSTS_VALU"] / (kernel_ms * 1e-3) / 1e9,
-                        "peak_issue_rate_G_per_s": 256 * 4 * 2.4 / 4.0 * 1.0,   # 1 024 SIMDs, one wave64 VALU op per 4 cycles, 2.4 GHz
-                        "source": os.path.relpath(sqf, ROOT)}
-                valu["frac"] = valu["issue_rate_G_per_s"] / valu["peak_issue_rate_G_per_s"]
-            except Exception:
-                valu = None
-        out = {
-            "metric": "particle-likelihoods/sec @640x480" if (a.cols, a.rows) == (640, 480)
-                      else f"particle-likelihoods/sec @{a.cols}x{a.rows}",
-            "value": n * world * a.steps / elapsed,
-            "unit": "particle-likelihoods/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C1: {n} particles/GPU x loglikes(update={'true' if a.update else 'false'}), {a.cols}x{a.rows} "
-                                   f"synthetic depth frame, mesh {a.mesh} ({len(f)} triangles), "
-                                   f"parents={a.parents}, " + (f"{F}-frame moving-object sequence" if a.sequence > 0 else "one static frame"),
-                       "particles_per_gpu": n, "resolution": [a.cols, a.rows], "triangles": int(len(f)),
-                       "sharding": f"particles/{world}" + (" + RCCL all-gather of log-likelihoods" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": kernel_name,
-                         "kernel_ms": kernel_ms, "kernel_launches_averaged": n_used,
-                         "raster_kernel_ms": raster_ms, "copy_kernel_ms": copy_ms,
-                         "state_layout": layout, "stored_window_fraction_of_plane": win_frac,
-                         "measured_hbm_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
-                         "valu_issue": valu,
-                         "call_ms_launch_stream": call_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
-        }
-        if world == 1 and a.update and layout == "window" and not a.no_dense_leg:
-            # the same steps on whole planes (every updating call copies every plane in full):
-            # what the windowed layout falls back to when windows grow to the whole frame
-            os.environ["RBS_STATE"] = "dense"
-            dense = RbSensor(om, cam, P, device_id=local, max_particles=n)
-            os.environ.pop("RBS_STATE")
-            dense.reset()
-            dense.set_observation(frame)
-            dense.synchronize()
-            counter[0] = 0
-            for _ in range(a.warmup):
-                launch(dense)
-            torch.cuda.synchronize()
-            dsteps = min(a.steps, 120)
-            td = time.perf_counter()
-            for _ in range(dsteps):
-                launch(dense)
-            torch.cuda.synchronize()
-            td = time.perf_counter() - td
-            _, dcopy_ms, _ = dense.timing_summary(dsteps)
-            out["dense_state"] = {"value": n * dsteps / td, "unit": "particle-likelihoods/s", "steps": dsteps,
-                                  "ms_per_step": td / dsteps * 1e3,
-                                  "roofline": {"bound": "hbm", "kernel": "rbs_copy_rows_kernel", "kernel_ms": dcopy_ms,
-                                               "achieved": alg_bytes / (dcopy_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                                               "unit": "GB/s", "frac": alg_bytes / (dcopy_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
-            dense.close()
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(om, cam, P, truth, frame, a.cpu_seconds)
-        print(json.dumps(out), flush=True)
+    if rank != 0:
+        sensor.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    alg_bytes = (2.0 if a.update else 1.0) * 4.0 * a.rows * a.cols * n  # per launch, SURVEY 8d
+    copy_dominant = bool(a.update) and copy_ms > raster_ms
+    out = {
+        "metric": "particle-likelihoods/sec @640x480" if (a.cols, a.rows) == (640, 480)
+                  else f"particle-likelihoods/sec @{a.cols}x{a.rows}",
+        "value": n * world * a.steps / elapsed,
+        "unit": "particle-likelihoods/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 geometry + f32 likelihood (precision F32)" if a.precision == "f32" else "f64",
+        "data": "synthetic",
+        "config": {"workload": f"C1: {n} particles/GPU x loglikes(update={'true' if a.update else 'false'}), {a.cols}x{a.rows} "
+                               f"synthetic depth frame, mesh {a.mesh} ({n_tri} triangles), "
+                               f"parents={a.parents}, " + (f"{max(1, a.sequence)}-frame moving-object sequence" if a.sequence > 0 else "one static frame")
+                               + f", likelihood precision {a.precision}, {a.layout} planes, inputs resident in HBM",
+                   "particles_per_gpu": n, "resolution": [a.cols, a.rows], "triangles": int(n_tri),
+                   "sharding": f"particles/{world}" + (" + RCCL all-gather of log-likelihoods" if world > 1 else "")},
+    }
+    single = world == 1
+    # ---- live counter passes of this same command (child processes under rocprofv3)
+    sq = fetch = write = None
+    if single and not a.no_pmc:
+        sq = pmc_pass(a, ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "SQ_WAVES"], a.layout)
+        fetch = pmc_pass(a, ["FETCH_SIZE"], a.layout)
+        write = pmc_pass(a, ["WRITE_SIZE"], a.layout)
+    pmc_live = sq is not None and "rbs_raster_kernel" in sq
+    if not pmc_live:               # a box without counters: the committed summary of this command
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", "r02_raster_sq.json")))
+            if j.get("precision") == a.precision and j.get("state_layout") == a.layout:
+                sq = {"rbs_raster_kernel": j["per_dispatch"]}
+        except Exception:           # noqa: BLE001
+            sq = None
+    rsq = (sq or {}).get("rbs_raster_kernel", {})
+    valu = rsq.get("SQ_INSTS_VALU")
+    raster_traffic = hbm_bytes(fetch, write, "rbs_raster_kernel")
+    copy_kernel = "rbs_copy_window_kernel" if a.layout == "window" else "rbs_copy_rows_kernel"
+    copy_traffic = hbm_bytes(fetch, write, copy_kernel)
+    if copy_dominant:
+        achieved = alg_bytes / (copy_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": copy_traffic, "kernel": copy_kernel, "kernel_ms": copy_ms}
+    else:
+        # windowed planes: the raster kernel is dominant and bound by VALU issue (every wave64 VALU
+        # instruction, float32 or binary64, holds a SIMD's issue port ~4 cycles: measured 4.1-4.2)
+        ginst = (valu / (raster_ms * 1e-3) / 1e9) if valu else None
+        roof = {"bound": "valu_issue", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                "frac": (ginst / VALU_PEAK_GINST) if ginst else None,
+                "traffic": raster_traffic, "kernel": "rbs_raster_kernel", "kernel_ms": raster_ms,
+                "valu_wave_instructions_per_launch": valu,
+                "valu_wave_instructions_per_particle": (valu / n) if valu else None,
+                "valu_busy_frac_of_simd_time": (rsq["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (raster_ms * 1e-3 * 2.4e9)) if rsq.get("SQ_ACTIVE_INST_VALU") else None,
+                "wave_time_waiting_frac": (rsq["SQ_WAIT_ANY"] / rsq["SQ_WAVE_CYCLES"]) if rsq.get("SQ_WAVE_CYCLES") else None,
+                "hbm_actual_GBps": (raster_traffic / (raster_ms * 1e-3) / 1e9) if raster_traffic else None,
+                "hbm_actual_frac": (raster_traffic / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if raster_traffic else None,
+                "algorithmic_equiv_GBps": alg_bytes / (raster_ms * 1e-3) / 1e9}
+    roof.update({"counters_live": bool(pmc_live), "kernel_launches_averaged": n_used,
+                 "raster_kernel_ms": raster_ms, "copy_kernel_ms": copy_ms, "call_ms_launch_stream": call_ms,
+                 "copy_kernel_hbm_bytes_per_launch": copy_traffic,
+                 "state_layout": a.layout, "stored_window_fraction_of_plane": win_frac,
+                 "algorithmic_bytes_per_launch": alg_bytes})
+    out["roofline"] = roof
     sensor.close()
+
+    # ---- the same steps on whole planes: the copy kernel is dominant there and HBM bound
+    if single and a.update and a.layout == "window" and not a.no_dense_leg:
+        dense = make_sensor(a, om, cam, P, dev, layout="dense")
+        prime(dense, a, W)
+        drun = ResidentRun(a, W, dense, stream, d_out)
+        dsteps = min(a.steps, 200)
+        td = drun.timed(dsteps, a.warmup)
+        d_raster_ms, d_copy_ms, _, d_used = drun.kernel_times(400)
+        dense.close()
+        dfetch = dwrite = None
+        if not a.no_pmc:
+            dfetch = pmc_pass(a, ["FETCH_SIZE"], "dense")
+            dwrite = pmc_pass(a, ["WRITE_SIZE"], "dense")
+        dtraffic = hbm_bytes(dfetch, dwrite, "rbs_copy_rows_kernel")
+        dach = alg_bytes / (d_copy_ms * 1e-3) / 1e9
+        out["dense_value"] = n * dsteps / td
+        out["dense_ms_per_step"] = td / dsteps * 1e3
+        out["roofline"].update({"dense_bound": "hbm", "dense_kernel": "rbs_copy_rows_kernel", "dense_kernel_ms": d_copy_ms,
+                                "dense_achieved_GBps": dach, "dense_frac": dach / HBM_PEAK_GBPS,
+                                "dense_traffic": dtraffic,
+                                "dense_traffic_over_algorithmic": (dtraffic / alg_bytes) if dtraffic else None,
+                                "dense_kernel_launches_averaged": d_used, "dense_raster_kernel_ms": d_raster_ms})
+    # ---- likelihood precision F64, same steps
+    if single and a.precision == "f32" and not a.no_f64_leg:
+        s64 = make_sensor(a, om, cam, P, dev, precision="f64")
+        prime(s64, a, W)
+        r64 = ResidentRun(a, W, s64, stream, d_out)
+        s_ = min(a.steps, 300)
+        t64 = r64.timed(s_, a.warmup)
+        k64 = r64.kernel_times(400)
+        s64.close()
+        out["f64_value"] = n * s_ / t64
+        out["f64_ms_per_step"] = t64 / s_ * 1e3
+        out["f64_raster_kernel_ms"] = k64[0]
+    # ---- host-pointer API: frame upload + pose upload + log-likelihood download inside the clock
+    if single and not a.no_host_leg:
+        hs = make_sensor(a, om, cam, P, dev)
+        prime(hs, a, W)
+        hsteps = min(a.steps, 300)
+
+        def host_step(i, with_frame=True):
+            k = W.order[i % len(W.order)]
+            if with_frame:
+                hs.set_observation(W.frames[k])
+            idx = W.parents.copy()
+            return hs.loglikes_poses(W.poses[k], idx, update=bool(a.update))
+
+        for i in range(10):
+            host_step(i)
+        t0 = time.perf_counter()
+        for i in range(hsteps):
+            host_step(i)
+        th = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for i in range(hsteps):
+            host_step(i, with_frame=False)
+        tl = time.perf_counter() - t0
+        hs.close()
+        out["host_api_value"] = n * hsteps / th
+        out["host_api_ms_per_step"] = th / hsteps * 1e3
+        out["host_api_loglikes_only_value"] = n * hsteps / tl
+        out["host_api_note"] = ("rbs_set_observation_f32 (1.2 MB frame from host memory) + rbs_loglikes (poses + parent indices "
+                                "from host memory, log-likelihoods back to host memory, synchronous), called through ctypes")
+    # ---- tracker FPS, the second half of the metric
+    if single and not a.no_tracker_fps:
+        fps = tracker_fps(om, cam, dev)
+        for k, v in fps.items():
+            out[f"tracker_fps_{k}"] = v["fps"]
+            out[f"tracker_ms_per_frame_{k}"] = v["ms_per_frame"]
+        out["tracker_fps_note"] = ("device tracker (rbs_tracker_*), one object (M1), 640x480, 30-frame sequence, frame uploaded "
+                                   "from host memory every frame, precision F32; resamplings " +
+                                   "/".join(str(v["resamplings"]) for v in fps.values()))
+    if single and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(om, cam, P, W.truths[0], W.frames[0], a.cpu_seconds)
+    print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -30,7 +30,7 @@ EXPORTS = (
     "rbs_set_observation_native_f32", "rbs_set_observation_device", "rbs_get_observation", "rbs_loglikes",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_export_plane", "rbs_import_plane",
-    "rbs_get_window", "rbs_get_background", "rbs_raster_kernel_ms",
+    "rbs_get_window", "rbs_get_background", "rbs_raster_kernel_ms", "rbs_set_timing_every",
     "rbs_render_depth",
     "rbs_last_kernel_ms", "rbs_timing_summary",
     "rbs_tracker_create", "rbs_tracker_destroy", "rbs_tracker_initialize", "rbs_tracker_track",
@@ -140,6 +140,8 @@ def load():
     lib.rbs_get_background.argtypes = [H, C.POINTER(C.c_float)]
     lib.rbs_raster_kernel_ms.restype = C.c_int32
     lib.rbs_raster_kernel_ms.argtypes = [H, C.c_int32, C.POINTER(C.c_float)]
+    lib.rbs_set_timing_every.restype = C.c_int32
+    lib.rbs_set_timing_every.argtypes = [H, C.c_int32]
     lib.rbs_export_plane.restype = C.c_int32
     lib.rbs_export_plane.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rbs_import_plane.restype = C.c_int32

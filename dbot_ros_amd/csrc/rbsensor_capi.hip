@@ -109,7 +109,7 @@ struct rbs_handle {
     const char* tile_override = nullptr;  // RBS_TILE env (tuning)
     // timing ring: HIP events around the whole call (on the launch stream) and around the copy
     // kernel (on the copy stream) for the last kRing loglikes calls
-    static constexpr int kRing = 64;
+    static constexpr int kRing = 256;
     hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {}, ev_copy_start[kRing] = {}, ev_join[kRing] = {};
     hipEvent_t ev_raster_start[kRing] = {}, ev_raster_stop[kRing] = {}, ev_copy_stop[kRing] = {};
     bool ring_update[kRing] = {};
@@ -1339,6 +1339,14 @@ int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float*
     *call_ms = (float)(tot / (double)n);
     *copy_kernel_ms = n_copy ? (float)(cpy / n_copy) : 0.f;
     *n_used = (int32_t)n;
+    return RBS_OK;
+}
+
+int32_t rbs_set_timing_every(rbs_handle* h, int32_t every)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (every < 1) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_timing_every: every must be >= 1");
+    h->timing_every = every;
     return RBS_OK;
 }
 

@@ -308,6 +308,9 @@ class RbSensor:
         self._check(self._lib.rbs_get_background(self._h, C.byref(v)))
         return float(np.float32(v.value))
 
+    def set_timing_every(self, every):
+        self._check(self._lib.rbs_set_timing_every(self._h, int(every)))
+
     def raster_kernel_ms(self, last_n=64):
         v = C.c_float()
         self._check(self._lib.rbs_raster_kernel_ms(self._h, int(last_n), C.byref(v)))

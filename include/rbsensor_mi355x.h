@@ -196,13 +196,16 @@ int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out);
  * launch stream around its kernels); blocks until it finished. */
 int32_t rbs_last_kernel_ms(rbs_handle* h, float* ms);
 /* Averages over the timed calls among the last last_n rbs_loglikes* calls (the library brackets
- * every 8th call with HIP events -- RBS_TIMING_EVERY in the environment at rbs_create changes
- * that -- and keeps the last 64 timed calls), from events recorded on the streams the kernels
+ * every 8th call with HIP events -- rbs_set_timing_every changes that -- and keeps the last 256
+ * timed calls), from events recorded on the streams the kernels
  * run on: call_ms = the launch-stream part of a call
  * (frame terms + rectangles kernel, raster kernel); copy_kernel_ms = the copy kernel alone on its own
  * stream (updating calls only, 0 if none).  Blocks until those calls finished. */
 int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float* copy_kernel_ms,
                            int32_t* n_used);
+/* Bracket every `every`-th rbs_loglikes* call with timing events from now on (default 8; the
+ * library keeps the last 256 timed calls).  bench.py's kernel-timing pass uses 2. */
+int32_t rbs_set_timing_every(rbs_handle* h, int32_t every);
 /* Same window of calls: the raster kernel alone (HIP events around it on the launch stream). */
 int32_t rbs_raster_kernel_ms(rbs_handle* h, int32_t last_n, float* raster_kernel_ms);
 

@@ -3,7 +3,7 @@
 args=$1; shift
 for e in "$@"; do
   for rep in 1 2; do
-    env $e python bench.py --no-cpu-baseline $args 2>/dev/null | python -c "
+    env $e python bench.py --quick $args 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

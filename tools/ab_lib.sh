@@ -5,7 +5,7 @@ args=$1; shift
 for spec in "$@"; do
   v=${spec%%:*}; e=""; [[ "$spec" == *:* ]] && e=$(echo "${spec#*:}" | tr ',' ' ')
   lib=""; [ "$v" != base ] && lib="RBS_LIB_PATH=$PWD/build_variants/$v.so"
-  env $lib $e python bench.py --no-cpu-baseline --no-dense-leg $args 2>/dev/null | python -c "
+  env $lib $e python bench.py --quick $args 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/reproduce_baseline.sh -- every row of BASELINE.md section 3 on one MI355X (run on the GPU box)
 for c in c1 c1_readonly c2 c3_slice c4_slice default_res; do
-  python bench.py --config $c --no-cpu-baseline --no-dense-leg 2>/dev/null | python -c "
+  python bench.py --config $c --quick 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
@@ -9,7 +9,7 @@ for l in sys.stdin:
         print('%-12s %10.0f particle-likelihoods/s  %.4f ms/step  raster %.4f ms  windows %.3f of a plane' % ('$c', d['value'], d['ms_per_step'], r['raster_kernel_ms'], r['stored_window_fraction_of_plane']))
 "
 done
-RBS_STATE=dense python bench.py --no-cpu-baseline --no-dense-leg 2>/dev/null | python -c "
+python bench.py --quick --layout dense 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -4,7 +4,7 @@
 tag=${1:-sq}; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/sq_$tag; rm -rf $out; mkdir -p $out
-BENCH="python bench.py --no-cpu-baseline --no-dense-leg --steps 10 --warmup 3 $BENCH_ARGS"
+BENCH="python bench.py --quick --steps 10 --warmup 3 $BENCH_ARGS"
 i=0
 for grp in \
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" \

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/trace_split.sh "<env>" : kernel start/end timeline (us) of the last two calls
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/kt; env $1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -o kt -- python bench.py --no-cpu-baseline --steps 6 --warmup 2 > gpurun_out/kt.log 2>&1
+rm -rf gpurun_out/kt; env $1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -o kt -- python bench.py --quick --steps 6 --warmup 2 > gpurun_out/kt.log 2>&1
 python - <<PY
 import csv
 rows=[r for r in csv.DictReader(open("gpurun_out/kt/kt_kernel_trace.csv"))]
