@@ -13,6 +13,8 @@
 
 #include "../../include/rbsensor_mi355x.h"
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -121,6 +123,32 @@ struct rbs_handle {
     long calls = 0;
     int join_pending = -1;      // ring slot whose copy kernel later work on the planes must wait for
     std::string err;
+    // ---- several devices in one handle (rbs_config.n_devices > 1) ----
+    // A GROUP handle owns one single-device handle ("shard") per device; global slot g lives on
+    // shard g / shard_cap.  Every call is fanned out to the shards by the calling thread; a
+    // shard's kernels read parents that live on other shards in place (peer access).
+    std::vector<rbs_handle*> shards;   // group: its shards
+    rbs_handle* group = nullptr;       // shard: its group
+    int shard_index = 0;
+    int shard_cap = 0;                 // global slots per device
+    hipEvent_t ev_done = nullptr;      // shard: its last loglikes call has finished, planes included
+    struct Rccl* rccl = nullptr;       // group: communicators for the log-likelihood all-gather (device tracker)
+    const float* snap_occ[rbs::kMaxDevices] = {};   // group: every shard's CURRENT planes / windows as of the start
+    const int4* snap_win[rbs::kMaxDevices] = {};    //   of the call being fanned out (shards flip buffers one by one)
+};
+
+// RCCL, bound at run time (dlopen): a single-device handle never needs it, and a process that
+// already carries torch's copy of the library keeps exactly one.
+struct Rccl {
+    void* lib = nullptr;
+    typedef void* comm_t;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::vector<comm_t> comms;
 };
 
 namespace {
@@ -228,6 +256,18 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.poses = d_poses;
     P.indices = d_indices;
     P.slots = h->max_particles;
+    P.n_dev = 1;
+    P.shard_cap = h->max_particles;
+    if (h->group) {   // the planes and windows of every shard of the group: parents are global slots
+        rbs_handle* g = h->group;
+        P.n_dev = (int)g->shards.size();
+        P.shard_cap = g->shard_cap;
+        P.slots = P.n_dev * g->shard_cap;
+        for (int k = 0; k < P.n_dev; ++k) {
+            P.occ_src_dev[k] = g->snap_occ[k];
+            P.win_src_dev[k] = g->snap_win[k];
+        }
+    }
     P.out = d_out;
     P.n = n;
     const int slot = (int)(h->calls % rbs_handle::kRing);          // ev_join
@@ -398,6 +438,14 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     }
     if (timed) { RBS_HIP(h, hipEventRecord(h->ev_stop[tslot], s)); h->timed_calls += 1; }
     if (update) h->join_pending = slot;   // joined lazily: by the next call, or by drain()
+    if (h->group) {
+        // other shards read this shard's planes: one event that covers both streams of this call
+        if (h->join_pending >= 0) {
+            RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+            h->join_pending = -1;
+        }
+        RBS_HIP(h, hipEventRecord(h->ev_done, s));
+    }
     h->calls += 1;
     if (update) {
         h->cur = 1 - h->cur;
@@ -958,6 +1006,262 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     return rbs_reset(h);
 }
 
+
+// ----------------------------------------------------------------------------- several devices
+// Copy a shard's error message up to the group handle the caller holds.
+int32_t gfail(rbs_handle* g, rbs_handle* shard, int32_t rc)
+{
+    g->err = fmt("device %d: %s", shard->device, shard->err.c_str());
+    return rc;
+}
+
+// Every shard orders its next call after EVERY shard's previous one: a call reads parents from
+// the other shards' current planes (complete only when their previous updating call is) and
+// overwrites the buffer the other shards' previous call was still reading.  All waits are
+// issued before any shard enqueues (an event waited on is the one last recorded).
+int32_t group_begin_call(rbs_handle* g, hipStream_t const* streams)
+{
+    const int nd = (int)g->shards.size();
+    for (int k = 0; k < nd; ++k) {
+        g->snap_occ[k] = g->shards[k]->d_occ[g->shards[k]->cur];
+        g->snap_win[k] = g->shards[k]->d_win[g->shards[k]->cur];
+    }
+    for (int a = 0; a < nd; ++a) {
+        rbs_handle* A = g->shards[a];
+        RBS_HIP(g, hipSetDevice(A->device));
+        for (int b = 0; b < nd; ++b)
+            if (b != a) RBS_HIP(g, hipStreamWaitEvent(streams ? streams[a] : A->stream, g->shards[b]->ev_done, 0));
+    }
+    return RBS_OK;
+}
+
+// A shard that evaluates no particle in an updating call still moves its state on with the group.
+void advance_empty(rbs_handle* h, bool update)
+{
+    if (!update) return;
+    float alpha, beta;
+    occlusion_coeffs(h, h->pending_frames, &alpha, &beta);
+    h->background = std::fmaf(alpha, h->background, beta);
+    h->cur = 1 - h->cur;
+    h->pending_frames = 0;
+    h->calls += 1;
+}
+
+int32_t group_load_rccl(rbs_handle* g, const std::vector<int>& devs)
+{
+    Rccl* r = new Rccl;
+    g->rccl = r;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r->lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r->lib) break;
+    }
+    if (!r->lib) return fail(g, RBS_ERR_UNSUPPORTED, fmt("several devices need RCCL: dlopen(librccl.so.1) failed: %s", dlerror()));
+    r->CommInitAll = reinterpret_cast<decltype(r->CommInitAll)>(dlsym(r->lib, "ncclCommInitAll"));
+    r->CommDestroy = reinterpret_cast<decltype(r->CommDestroy)>(dlsym(r->lib, "ncclCommDestroy"));
+    r->GroupStart = reinterpret_cast<decltype(r->GroupStart)>(dlsym(r->lib, "ncclGroupStart"));
+    r->GroupEnd = reinterpret_cast<decltype(r->GroupEnd)>(dlsym(r->lib, "ncclGroupEnd"));
+    r->AllGather = reinterpret_cast<decltype(r->AllGather)>(dlsym(r->lib, "ncclAllGather"));
+    r->GetErrorString = reinterpret_cast<decltype(r->GetErrorString)>(dlsym(r->lib, "ncclGetErrorString"));
+    if (!r->CommInitAll || !r->CommDestroy || !r->GroupStart || !r->GroupEnd || !r->AllGather || !r->GetErrorString)
+        return fail(g, RBS_ERR_UNSUPPORTED, "librccl lacks an ncclCommInitAll / ncclAllGather / ncclGroup* symbol");
+    r->comms.assign(devs.size(), nullptr);
+    const int rc = r->CommInitAll(r->comms.data(), (int)devs.size(), devs.data());
+    if (rc != 0) {
+        const std::string msg = fmt("ncclCommInitAll over %zu devices failed: %s", devs.size(), r->GetErrorString(rc));
+        r->comms.clear();
+        return fail(g, RBS_ERR_HIP, msg);
+    }
+    return RBS_OK;
+}
+
+// Every shard gets every shard's `count` doubles: buf[k * count .. ) of shard k's buffer is what
+// shard k produced.  RCCL all-gather over xGMI when the devices are distinct (the exchange of the
+// log-likelihoods before resampling); plain device-to-device copies when a device appears twice
+// in the handle (RCCL refuses that: functional tests on a one-GPU box).
+int32_t group_allgather(rbs_handle* g, double* const* bufs, size_t count, hipStream_t const* streams)
+{
+    const int nd = (int)g->shards.size();
+    if (g->rccl && !g->rccl->comms.empty()) {
+        Rccl* r = g->rccl;
+        int rc = r->GroupStart();
+        for (int k = 0; k < nd && rc == 0; ++k)
+            rc = r->AllGather(bufs[k] + (size_t)k * count, bufs[k], count, /*ncclDouble*/ 8, r->comms[k], streams[k]);
+        const int rc2 = r->GroupEnd();
+        if (rc != 0 || rc2 != 0) return fail(g, RBS_ERR_HIP, fmt("ncclAllGather failed: %s", r->GetErrorString(rc ? rc : rc2)));
+        return RBS_OK;
+    }
+    // one event per producer, then every consumer copies every other shard's piece on its own stream
+    for (int k = 0; k < nd; ++k) {
+        RBS_HIP(g, hipSetDevice(g->shards[k]->device));
+        RBS_HIP(g, hipEventRecord(g->shards[k]->ev_fork, streams[k]));
+    }
+    for (int a = 0; a < nd; ++a) {
+        RBS_HIP(g, hipSetDevice(g->shards[a]->device));
+        for (int b = 0; b < nd; ++b) {
+            if (b == a) continue;
+            RBS_HIP(g, hipStreamWaitEvent(streams[a], g->shards[b]->ev_fork, 0));
+            RBS_HIP(g, hipMemcpyPeerAsync(bufs[a] + (size_t)b * count, g->shards[a]->device, bufs[b] + (size_t)b * count,
+                                          g->shards[b]->device, sizeof(double) * count, streams[a]));
+        }
+    }
+    return RBS_OK;
+}
+
+int32_t create_group(const rbs_config* cfg, rbs_handle* g)
+{
+    const int nd = cfg->n_devices;
+    if (nd > rbs::kMaxDevices) return fail(g, RBS_ERR_INVALID_ARGUMENT, fmt("n_devices %d > %d", nd, rbs::kMaxDevices));
+    if (!cfg->device_ids) return fail(g, RBS_ERR_INVALID_ARGUMENT, "n_devices > 1 but device_ids is NULL");
+    if (cfg->max_particles <= 0) return fail(g, RBS_ERR_INVALID_ARGUMENT, "max_particles must be positive");
+    g->max_particles = cfg->max_particles;
+    g->shard_cap = (cfg->max_particles + nd - 1) / nd;
+    g->rows = cfg->rows; g->cols = cfg->cols; g->npx = cfg->rows * cfg->cols;
+    g->n_bodies = cfg->n_objects;
+    g->device = cfg->device_ids[0];
+    std::vector<int> devs(cfg->device_ids, cfg->device_ids + nd);
+    bool distinct = true;
+    for (int a = 0; a < nd; ++a)
+        for (int b = a + 1; b < nd; ++b)
+            if (devs[a] == devs[b]) distinct = false;
+    for (int k = 0; k < nd; ++k) {
+        rbs_config sub = *cfg;
+        sub.device_id = devs[k];
+        sub.n_devices = 0;
+        sub.device_ids = nullptr;
+        sub.max_particles = g->shard_cap;
+        rbs_handle* sh = new (std::nothrow) rbs_handle;
+        if (!sh) return fail(g, RBS_ERR_OUT_OF_MEMORY, "out of host memory");
+        g->shards.push_back(sh);
+        sh->group = g;
+        sh->shard_index = k;
+        sh->shard_cap = g->shard_cap;
+        if (int32_t rc = create_impl(&sub, sh)) return gfail(g, sh, rc);
+        RBS_HIP(g, hipEventCreateWithFlags(&sh->ev_done, hipEventDisableTiming));
+        RBS_HIP(g, hipEventRecord(sh->ev_done, sh->stream));
+    }
+    g->windowed = g->shards[0]->windowed;
+    g->precision = g->shards[0]->precision;
+    // parents on another device are read in place
+    for (int a = 0; a < nd; ++a) {
+        RBS_HIP(g, hipSetDevice(devs[a]));
+        for (int b = 0; b < nd; ++b) {
+            if (devs[a] == devs[b]) continue;
+            int can = 0;
+            RBS_HIP(g, hipDeviceCanAccessPeer(&can, devs[a], devs[b]));
+            if (!can) return fail(g, RBS_ERR_UNSUPPORTED, fmt("device %d cannot access device %d's memory (peer access)", devs[a], devs[b]));
+            const hipError_t e = hipDeviceEnablePeerAccess(devs[b], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                (void)hipGetLastError();
+                return fail(g, RBS_ERR_HIP, fmt("hipDeviceEnablePeerAccess(%d -> %d): %s", devs[a], devs[b], hipGetErrorString(e)));
+            }
+            (void)hipGetLastError();
+        }
+    }
+    if (distinct)
+        if (int32_t rc = group_load_rccl(g, devs)) return rc;
+    return RBS_OK;
+}
+
+void release_group(rbs_handle* g)
+{
+    if (g->rccl) {
+        for (auto c : g->rccl->comms)
+            if (c) (void)g->rccl->CommDestroy(c);
+        // the library stays loaded: other handles (or torch) may be using it
+        delete g->rccl;
+        g->rccl = nullptr;
+    }
+    for (rbs_handle* sh : g->shards) {
+        if (sh->ev_done) { (void)hipSetDevice(sh->device); (void)hipStreamSynchronize(sh->stream); (void)hipEventDestroy(sh->ev_done); sh->ev_done = nullptr; }
+        release(sh);
+    }
+    g->shards.clear();
+    delete g;
+}
+
+// rbs_loglikes on a group: particle i is evaluated by shard i / shard_cap and (update) written
+// to global slot i; `indices` are global parent slots.
+int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int32_t n, int32_t update, double* out)
+{
+    const int nd = (int)g->shards.size();
+    const int cap = g->shard_cap;
+    for (int32_t i = 0; i < n; ++i)
+        if (indices[i] < 0 || indices[i] >= nd * cap)
+            return fail(g, RBS_ERR_INVALID_ARGUMENT, fmt("loglikes: indices[%d] = %d outside 0..%d", i, indices[i], nd * cap - 1));
+    if (int32_t rc = group_begin_call(g, nullptr)) return rc;
+    const size_t stride = (size_t)12 * g->n_bodies;
+    for (int k = 0; k < nd; ++k) {
+        rbs_handle* h = g->shards[k];
+        const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
+        RBS_HIP(g, hipSetDevice(h->device));
+        if (cnt <= 0) {
+            advance_empty(h, update != 0);
+            RBS_HIP(g, hipEventRecord(h->ev_done, h->stream));
+            continue;
+        }
+        const size_t pose_bytes = sizeof(double) * stride * (size_t)cnt;
+        std::memcpy(h->h_in, poses + stride * (size_t)lo, pose_bytes);
+        std::memcpy(h->h_in + h->in_idx_off, indices + lo, sizeof(int) * (size_t)cnt);
+        RBS_HIP(g, hipMemcpyAsync(h->d_in, h->h_in, pose_bytes, hipMemcpyHostToDevice, h->stream));
+        RBS_HIP(g, hipMemcpyAsync(h->d_in + h->in_idx_off, h->h_in + h->in_idx_off, sizeof(int) * (size_t)cnt,
+                                  hipMemcpyHostToDevice, h->stream));
+        if (int32_t rc = enqueue_loglikes(h, reinterpret_cast<const double*>(h->d_in),
+                                          reinterpret_cast<const int*>(h->d_in + h->in_idx_off), cnt, update != 0,
+                                          h->d_out, h->stream))
+            return gfail(g, h, rc);
+        RBS_HIP(g, hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
+        RBS_HIP(g, hipEventRecord(h->ev_out, h->stream));
+    }
+    for (int k = 0; k < nd; ++k) {
+        rbs_handle* h = g->shards[k];
+        const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
+        if (cnt <= 0) continue;
+        RBS_HIP(g, hipSetDevice(h->device));
+        RBS_HIP(g, hipEventSynchronize(h->ev_out));
+        std::memcpy(out + lo, h->h_out, sizeof(double) * (size_t)cnt);
+    }
+    if (update)
+        for (int32_t i = 0; i < n; ++i) indices[i] = i;
+    return RBS_OK;
+}
+
+// Route a global slot to its shard.
+rbs_handle* shard_of(rbs_handle* g, int32_t slot, int32_t* local)
+{
+    const int k = slot / g->shard_cap;
+    *local = slot - k * g->shard_cap;
+    return g->shards[k];
+}
+#define RBS_GROUP_SLOT(h, slot, call)                                                         \
+    do {                                                                                      \
+        if (!(h)->shards.empty()) {                                                           \
+            if ((slot) < 0 || (slot) >= (int)(h)->shards.size() * (h)->shard_cap)             \
+                return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("bad slot %d", (int)(slot)));    \
+            int32_t l_;                                                                       \
+            rbs_handle* sh_ = shard_of(h, slot, &l_);                                         \
+            const int32_t rc_ = call;                                                         \
+            return rc_ ? gfail(h, sh_, rc_) : RBS_OK;                                         \
+        }                                                                                     \
+    } while (0)
+#define RBS_GROUP_ALL(h, call)                                                                \
+    do {                                                                                      \
+        if (!(h)->shards.empty()) {                                                           \
+            for (rbs_handle* sh_ : (h)->shards) {                                             \
+                const int32_t rc_ = call;                                                     \
+                if (rc_) return gfail(h, sh_, rc_);                                           \
+            }                                                                                 \
+            return RBS_OK;                                                                    \
+        }                                                                                     \
+    } while (0)
+#define RBS_GROUP_FIRST(h, call)                                                              \
+    do {                                                                                      \
+        if (!(h)->shards.empty()) {                                                           \
+            rbs_handle* sh_ = (h)->shards[0];                                                 \
+            const int32_t rc_ = call;                                                         \
+            return rc_ ? gfail(h, sh_, rc_) : RBS_OK;                                         \
+        }                                                                                     \
+    } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -984,26 +1288,35 @@ int32_t rbs_create(const rbs_config* cfg, rbs_handle** out)
     rbs_handle* h = new (std::nothrow) rbs_handle;
     if (!h) { g_create_error = "rbs_create: out of host memory"; return RBS_ERR_OUT_OF_MEMORY; }
     int32_t rc;
+    const bool group = cfg->n_devices > 1 || (cfg->n_devices == 1 && cfg->device_ids && std::getenv("RBS_GROUP_SINGLE"));
     try {
-        rc = create_impl(cfg, h);
+        rc = group ? (cfg->abi_version != RBS_ABI_VERSION
+                          ? fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("abi_version %d, library is %d", cfg->abi_version, RBS_ABI_VERSION))
+                          : create_group(cfg, h))
+                   : create_impl(cfg, h);
     } catch (const std::exception& e) {
         h->err = std::string("rbs_create: ") + e.what();
         rc = RBS_ERR_OUT_OF_MEMORY;
     }
     if (rc != RBS_OK) {
         g_create_error = h->err;
-        release(h);
+        if (group) release_group(h); else release(h);
         return rc;
     }
     *out = h;
     return RBS_OK;
 }
 
-void rbs_destroy(rbs_handle* h) { release(h); }
+void rbs_destroy(rbs_handle* h)
+{
+    if (h && !h->shards.empty()) release_group(h);
+    else release(h);
+}
 
 int32_t rbs_reset(rbs_handle* h)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_ALL(h, rbs_reset(sh_));
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;   // no copy kernel may still be writing planes
     h->cur = 0;
@@ -1030,6 +1343,7 @@ int32_t rbs_reset(rbs_handle* h)
 int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_ALL(h, rbs_set_observation(sh_, depth, n));
     if (!depth || n != (size_t)h->npx)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("set_observation: expected %d pixels, got %zu", h->npx, n));
@@ -1045,6 +1359,7 @@ int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n)
 int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_ALL(h, rbs_set_observation_f32(sh_, depth, n));
     if (!depth || n != (size_t)h->npx)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("set_observation_f32: expected %d pixels, got %zu", h->npx, n));
@@ -1061,6 +1376,7 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
                                        int32_t height, int32_t f)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_ALL(h, rbs_set_observation_native_f32(sh_, native, width, height, f));
     if (!native || f <= 0 || width <= 0 || height <= 0 || height / f != h->rows || width / f != h->cols)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("set_observation_native: %dx%d / %d does not give the evaluated %dx%d", width,
@@ -1091,6 +1407,8 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
 int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* stream)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty())
+        return fail(h, RBS_ERR_UNSUPPORTED, "set_observation_device: a handle over several devices takes host frames (or drive it through rbs_tracker_*)");
     if (!d_depth) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_observation_device: null pointer");
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
@@ -1107,6 +1425,7 @@ int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* st
 int32_t rbs_get_observation(rbs_handle* h, float* out)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_FIRST(h, rbs_get_observation(sh_, out));
     if (!out) return fail(h, RBS_ERR_INVALID_ARGUMENT, "get_observation: null pointer");
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
@@ -1125,6 +1444,7 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
     if (n == 0) return RBS_OK;
     if (!poses || !indices || !out_loglik)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, "loglikes: null pointer");
+    if (!h->shards.empty()) return group_loglikes(h, poses, indices, n, update, out_loglik);
     for (int32_t i = 0; i < n; ++i)
         if (indices[i] < 0 || indices[i] >= h->max_particles)
             return fail(h, RBS_ERR_INVALID_ARGUMENT,
@@ -1161,6 +1481,8 @@ int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t*
                             int32_t n, int32_t update, double* d_out_loglik, void* stream)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty())
+        return fail(h, RBS_ERR_UNSUPPORTED, "loglikes_device: a handle over several devices is driven through rbs_loglikes or rbs_tracker_*");
     if (n < 0 || n > h->max_particles)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("loglikes_device: n = %d outside 0..max_particles = %d", n, h->max_particles));
@@ -1175,6 +1497,7 @@ int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t*
 int32_t rbs_synchronize(rbs_handle* h)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_ALL(h, rbs_synchronize(sh_));
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;
     return RBS_OK;
@@ -1183,6 +1506,7 @@ int32_t rbs_synchronize(rbs_handle* h)
 int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_SLOT(h, slot, rbs_get_occlusion(sh_, l_, out));
     if (slot < 0 || slot >= h->max_particles || !out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("get_occlusion: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
@@ -1197,6 +1521,7 @@ int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out)
 int32_t rbs_set_occlusion(rbs_handle* h, int32_t slot, const float* plane)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_SLOT(h, slot, rbs_set_occlusion(sh_, l_, plane));
     if (slot < 0 || slot >= h->max_particles || !plane)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("set_occlusion: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
@@ -1215,6 +1540,7 @@ int32_t rbs_set_occlusion(rbs_handle* h, int32_t slot, const float* plane)
 int32_t rbs_occlusion_device_ptr(rbs_handle* h, int32_t slot, void** out)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_SLOT(h, slot, rbs_occlusion_device_ptr(sh_, l_, out));
     if (slot < 0 || slot >= h->max_particles || !out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("occlusion_device_ptr: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
@@ -1228,6 +1554,7 @@ int32_t rbs_occlusion_device_ptr(rbs_handle* h, int32_t slot, void** out)
 int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_SLOT(h, slot, rbs_occlusion_next_device_ptr(sh_, l_, out));
     if (slot < 0 || slot >= h->max_particles || !out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("occlusion_next_device_ptr: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
@@ -1239,6 +1566,7 @@ int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out)
 int32_t rbs_export_plane(rbs_handle* h, int32_t slot, void* d_dst, void* stream)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_SLOT(h, slot, rbs_export_plane(sh_, l_, d_dst, stream));
     if (slot < 0 || slot >= h->max_particles || !d_dst)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("export_plane: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
@@ -1253,6 +1581,7 @@ int32_t rbs_export_plane(rbs_handle* h, int32_t slot, void* d_dst, void* stream)
 int32_t rbs_import_plane(rbs_handle* h, int32_t slot, const void* d_src, void* stream)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_SLOT(h, slot, rbs_import_plane(sh_, l_, d_src, stream));
     if (slot < 0 || slot >= h->max_particles || !d_src)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("import_plane: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
@@ -1271,6 +1600,7 @@ int32_t rbs_import_plane(rbs_handle* h, int32_t slot, const void* d_src, void* s
 int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_FIRST(h, rbs_render_depth(sh_, pose, out));
     if (!pose || !out) return fail(h, RBS_ERR_INVALID_ARGUMENT, "render_depth: null pointer");
     RBS_HIP(h, hipSetDevice(h->device));
     RBS_HIP(h, hipMemcpyAsync(h->d_poses, pose, sizeof(double) * 12 * h->n_bodies,
@@ -1314,6 +1644,7 @@ int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float*
                            int32_t* n_used)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_FIRST(h, rbs_timing_summary(sh_, last_n, call_ms, copy_kernel_ms, n_used));
     if (!call_ms || !copy_kernel_ms || !n_used || last_n <= 0)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, "timing_summary: bad argument");
     if (h->calls == 0) return fail(h, RBS_ERR_INVALID_ARGUMENT, "timing_summary: no loglikes launched yet");
@@ -1345,6 +1676,7 @@ int32_t rbs_timing_summary(rbs_handle* h, int32_t last_n, float* call_ms, float*
 int32_t rbs_set_timing_every(rbs_handle* h, int32_t every)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_ALL(h, rbs_set_timing_every(sh_, every));
     if (every < 1) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_timing_every: every must be >= 1");
     h->timing_every = every;
     return RBS_OK;
@@ -1353,6 +1685,7 @@ int32_t rbs_set_timing_every(rbs_handle* h, int32_t every)
 int32_t rbs_raster_kernel_ms(rbs_handle* h, int32_t last_n, float* raster_kernel_ms)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_FIRST(h, rbs_raster_kernel_ms(sh_, last_n, raster_kernel_ms));
     if (!raster_kernel_ms || last_n <= 0) return fail(h, RBS_ERR_INVALID_ARGUMENT, "raster_kernel_ms: bad argument");
     if (h->calls == 0) return fail(h, RBS_ERR_INVALID_ARGUMENT, "raster_kernel_ms: no loglikes launched yet");
     RBS_HIP(h, hipSetDevice(h->device));
@@ -1373,6 +1706,7 @@ int32_t rbs_raster_kernel_ms(rbs_handle* h, int32_t last_n, float* raster_kernel
 int32_t rbs_get_window(rbs_handle* h, int32_t slot, int32_t out[4])
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_SLOT(h, slot, rbs_get_window(sh_, l_, out));
     if (slot < 0 || slot >= h->max_particles || !out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("get_window: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
@@ -1384,6 +1718,7 @@ int32_t rbs_get_window(rbs_handle* h, int32_t slot, int32_t out[4])
 int32_t rbs_get_background(rbs_handle* h, float* out)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_FIRST(h, rbs_get_background(sh_, out));
     if (!out) return fail(h, RBS_ERR_INVALID_ARGUMENT, "get_background: null pointer");
     *out = h->background;
     return RBS_OK;
@@ -1399,6 +1734,9 @@ struct rbs_tracker {
     double* d_normals = nullptr;   // staging for host-supplied randomness
     double* d_uniforms = nullptr;
     std::string err;
+    // a sensor over several devices: one replica (all particle states + the filter's kernels) per
+    // shard; `s` is then the group handle and T is unused
+    std::vector<rbs_tracker*> reps;
 };
 
 namespace {
@@ -1423,14 +1761,12 @@ int32_t talloc(rbs_tracker* t, X** p, size_t count)
 }
 }  // namespace
 
-extern "C" {
+extern "C" void rbs_tracker_destroy(rbs_tracker* t);
 
-int32_t rbs_tracker_create(rbs_handle* sensor, const rbs_tracker_params* p, rbs_tracker** out)
+namespace {
+// One device's tracker state.  cap > 0: the sensor is a shard of a group with `cap` slots per device.
+int32_t tracker_create_one(rbs_handle* sensor, const rbs_tracker_params* p, int n_dev, int cap, rbs_tracker** out)
 {
-    if (!sensor || !out) return RBS_ERR_INVALID_ARGUMENT;
-    *out = nullptr;
-    if (!p || p->n_particles <= 0 || p->n_particles > sensor->max_particles)
-        return fail(sensor, RBS_ERR_INVALID_ARGUMENT, "tracker_create: n_particles outside 1..max_particles");
     RBS_HIP(sensor, hipSetDevice(sensor->device));
     rbs_tracker* t = new (std::nothrow) rbs_tracker;
     if (!t) return fail(sensor, RBS_ERR_OUT_OF_MEMORY, "tracker_create: out of host memory");
@@ -1452,7 +1788,9 @@ int32_t rbs_tracker_create(rbs_handle* sensor, const rbs_tracker_params* p, rbs_
         (rc = talloc(t, &T.parents, n)) || (rc = talloc(t, &T.cdf, n)) || (rc = talloc(t, &T.deflt, D)) ||
         (rc = talloc(t, &T.mean, D + (size_t)T.parts * 9)) || (rc = talloc(t, &T.poses, n * (size_t)T.parts * 12)) ||
         (rc = talloc(t, &T.flag, 2)) || (rc = talloc(t, &t->d_normals, n * P6)) ||
-        (rc = talloc(t, &t->d_uniforms, n * (size_t)T.parts))) {
+        (rc = talloc(t, &t->d_uniforms, n * (size_t)T.parts)) ||
+        (cap > 0 && ((rc = talloc(t, &T.layout, n)) || (rc = talloc(t, &T.ll_sorted, (size_t)n_dev * cap)) ||
+                     (rc = talloc(t, &T.poses_sorted, (size_t)cap * T.parts * 12)) || (rc = talloc(t, &T.idx_sorted, (size_t)cap))))) {
         rbs_tracker_destroy(t);
         return rc;
     }
@@ -1460,10 +1798,42 @@ int32_t rbs_tracker_create(rbs_handle* sensor, const rbs_tracker_params* p, rbs_
     *out = t;
     return RBS_OK;
 }
+}  // namespace
+
+extern "C" {
+
+int32_t rbs_tracker_create(rbs_handle* sensor, const rbs_tracker_params* p, rbs_tracker** out)
+{
+    if (!sensor || !out) return RBS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    const int total = sensor->shards.empty() ? sensor->max_particles : (int)sensor->shards.size() * sensor->shard_cap;
+    if (!p || p->n_particles <= 0 || p->n_particles > total)
+        return fail(sensor, RBS_ERR_INVALID_ARGUMENT, "tracker_create: n_particles outside 1..max_particles");
+    if (sensor->shards.empty()) return tracker_create_one(sensor, p, 1, 0, out);
+    rbs_tracker* g = new (std::nothrow) rbs_tracker;
+    if (!g) return fail(sensor, RBS_ERR_OUT_OF_MEMORY, "tracker_create: out of host memory");
+    g->s = sensor;
+    for (rbs_handle* sh : sensor->shards) {
+        rbs_tracker* r = nullptr;
+        if (int32_t rc = tracker_create_one(sh, p, (int)sensor->shards.size(), sensor->shard_cap, &r)) {
+            sensor->err = sh->err;
+            rbs_tracker_destroy(g);
+            return rc;
+        }
+        g->reps.push_back(r);
+    }
+    *out = g;
+    return RBS_OK;
+}
 
 void rbs_tracker_destroy(rbs_tracker* t)
 {
     if (!t) return;
+    if (!t->reps.empty() || !t->s->shards.empty()) {
+        for (rbs_tracker* r : t->reps) rbs_tracker_destroy(r);
+        delete t;
+        return;
+    }
     (void)hipSetDevice(t->s->device);
     (void)hipStreamSynchronize(t->s->stream);
     for (void* p : t->allocs) (void)hipFree(p);
@@ -1474,6 +1844,15 @@ int32_t rbs_tracker_initialize(rbs_tracker* t, const double* default_state)
 {
     if (!t) return RBS_ERR_INVALID_ARGUMENT;
     if (!default_state) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_initialize: null state");
+    if (!t->reps.empty()) {
+        for (rbs_tracker* r : t->reps)
+            if (int32_t rc = rbs_tracker_initialize(r, default_state)) { t->s->err = r->s->err; return rc; }
+        for (rbs_handle* sh : t->s->shards) {   // the shards' resets left their streams idle: a clean slate for the group's ordering
+            RBT_HIP(t, hipSetDevice(sh->device));
+            RBT_HIP(t, hipEventRecord(sh->ev_done, sh->stream));
+        }
+        return RBS_OK;
+    }
     rbt::TrackerDev& T = t->T;
     RBT_HIP(t, hipSetDevice(t->s->device));
     if (int32_t rc = rbs_reset(t->s)) return rc;
@@ -1486,12 +1865,121 @@ int32_t rbs_tracker_initialize(rbs_tracker* t, const double* default_state)
     return RBS_OK;
 }
 
+}  // extern "C" (group_tracker_track below needs C++ linkage)
+
+namespace {
+// One frame on a sensor over several devices.  Every device runs the whole filter on all the
+// particle states (identical inputs, identical code); the sensor call alone is sharded: device k
+// evaluates the particles laid out at slots [k cap, (k+1) cap) (layout_kernel), and the
+// log-likelihoods are exchanged with ONE all-gather per sampling block (RCCL over xGMI).
+int32_t group_tracker_track(rbs_tracker* t, const float* frame, const double* normals, const double* uniforms,
+                            uint64_t seed, double* out_state, int32_t* out_resamplings)
+{
+    rbs_handle* g = t->s;
+    const int nd = (int)g->shards.size(), cap = g->shard_cap;
+    if (frame)
+        if (int32_t rc = rbs_set_observation_f32(g, frame, (size_t)g->npx)) return rc;
+    std::vector<hipStream_t> streams(nd);
+    std::vector<double*> llbufs(nd);
+    for (int k = 0; k < nd; ++k) {
+        rbs_tracker* r = t->reps[k];
+        rbt::TrackerDev& T = r->T;
+        rbs_handle* h = r->s;
+        streams[k] = h->stream;
+        llbufs[k] = T.ll_sorted;
+        RBT_HIP(t, hipSetDevice(h->device));
+        const size_t n = (size_t)T.n;
+        T.normals = nullptr;
+        T.uniforms = nullptr;
+        if (normals) {
+            RBT_HIP(t, hipMemcpyAsync(r->d_normals, normals, sizeof(double) * n * T.parts * 6, hipMemcpyHostToDevice, h->stream));
+            T.normals = r->d_normals;
+        }
+        if (uniforms) {
+            RBT_HIP(t, hipMemcpyAsync(r->d_uniforms, uniforms, sizeof(double) * n * T.parts, hipMemcpyHostToDevice, h->stream));
+            T.uniforms = r->d_uniforms;
+        }
+        T.seed = seed;
+    }
+    const int parts = t->reps[0]->T.parts, n = t->reps[0]->T.n;
+    const dim3 g256((unsigned)((n + 255) / 256)), b256(256);
+    for (int b = 0; b < parts; ++b) {
+        const bool last = b == parts - 1;
+        for (int k = 0; k < nd; ++k) {
+            rbs_tracker* r = t->reps[k];
+            RBT_HIP(t, hipSetDevice(r->s->device));
+            hipLaunchKernelGGL(rbt::propagate_kernel, g256, b256, 0, streams[k], r->T, b);
+            hipLaunchKernelGGL(rbt::layout_kernel, dim3(1), dim3(1024), 0, streams[k], r->T, nd, cap);
+            const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
+            if (cnt > 0)
+                hipLaunchKernelGGL(rbt::shard_gather_kernel, dim3((unsigned)((cnt + 255) / 256)), b256, 0, streams[k], r->T, lo, cnt);
+            RBT_HIP(t, hipGetLastError());
+        }
+        if (int32_t rc = group_begin_call(g, nullptr)) return rc;
+        for (int k = 0; k < nd; ++k) {
+            rbs_tracker* r = t->reps[k];
+            rbs_handle* h = r->s;
+            RBT_HIP(t, hipSetDevice(h->device));
+            const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
+            if (cnt > 0) {
+                if (int32_t rc = enqueue_loglikes(h, r->T.poses_sorted, r->T.idx_sorted, cnt, last, r->T.ll_sorted + lo, h->stream))
+                    return gfail(g, h, rc);
+            } else {
+                advance_empty(h, last);
+                RBT_HIP(t, hipEventRecord(h->ev_done, h->stream));
+            }
+        }
+        if (int32_t rc = group_allgather(g, llbufs.data(), (size_t)cap, streams.data())) return rc;
+        for (int k = 0; k < nd; ++k) {
+            rbs_tracker* r = t->reps[k];
+            rbt::TrackerDev& T = r->T;
+            RBT_HIP(t, hipSetDevice(r->s->device));
+            hipStream_t s = streams[k];
+            hipLaunchKernelGGL(rbt::shard_scatter_kernel, g256, b256, 0, s, T, last ? 1 : 0);
+            hipLaunchKernelGGL(rbt::weights_kernel, dim3(1), dim3(1024), 0, s, T, 0);
+            hipLaunchKernelGGL(rbt::resample_kernel, g256, b256, 0, s, T, b);
+            hipLaunchKernelGGL(rbt::gather_kernel, dim3((unsigned)T.n), dim3(64), 0, s, T);
+            RBT_HIP(t, hipGetLastError());
+            std::swap(T.part_old, T.part_old2);
+            std::swap(T.part_new, T.part_new2);
+            std::swap(T.noise, T.noise2);
+            std::swap(T.ll, T.ll2);
+            std::swap(T.idx, T.idx2);
+        }
+    }
+    int flags[2] = {0, 0};
+    for (int k = 0; k < nd; ++k) {
+        rbs_tracker* r = t->reps[k];
+        rbt::TrackerDev& T = r->T;
+        RBT_HIP(t, hipSetDevice(r->s->device));
+        hipLaunchKernelGGL(rbt::mean_kernel, dim3(1), dim3(1024), 0, streams[k], T);
+        hipLaunchKernelGGL(rbt::recentre_kernel, g256, b256, 0, streams[k], T);
+        RBT_HIP(t, hipGetLastError());
+        std::swap(T.part_old, T.part_new);   // this frame's particles are the next frame's old ones
+        if (k == 0) {
+            RBT_HIP(t, hipMemcpyAsync(out_state, T.deflt, sizeof(double) * T.D, hipMemcpyDeviceToHost, streams[k]));
+            RBT_HIP(t, hipMemcpyAsync(flags, T.flag, sizeof(flags), hipMemcpyDeviceToHost, streams[k]));
+        }
+        T.frame += 1;
+    }
+    for (int k = 0; k < nd; ++k) {   // the host frame / randomness buffers may be reused after this call
+        RBT_HIP(t, hipSetDevice(t->reps[k]->s->device));
+        RBT_HIP(t, hipStreamSynchronize(streams[k]));
+    }
+    if (out_resamplings) *out_resamplings = flags[1];
+    return RBS_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* normals,
                           const double* uniforms, uint64_t seed, double* out_state,
                           int32_t* out_resamplings)
 {
     if (!t) return RBS_ERR_INVALID_ARGUMENT;
     if (!out_state) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_track: null output");
+    if (!t->reps.empty()) return group_tracker_track(t, frame, normals, uniforms, seed, out_state, out_resamplings);
     rbt::TrackerDev& T = t->T;
     rbs_handle* h = t->s;
     RBT_HIP(t, hipSetDevice(h->device));
@@ -1550,6 +2038,10 @@ int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* norm
 int32_t rbs_tracker_get(rbs_tracker* t, double* particles, double* log_weights, int32_t* indices)
 {
     if (!t) return RBS_ERR_INVALID_ARGUMENT;
+    if (!t->reps.empty()) {
+        for (rbs_tracker* r : t->reps) { RBT_HIP(t, hipSetDevice(r->s->device)); RBT_HIP(t, hipStreamSynchronize(r->s->stream)); }
+        return rbs_tracker_get(t->reps[0], particles, log_weights, indices);
+    }
     rbt::TrackerDev& T = t->T;
     RBT_HIP(t, hipSetDevice(t->s->device));
     RBT_HIP(t, hipStreamSynchronize(t->s->stream));

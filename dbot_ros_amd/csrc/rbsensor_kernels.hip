@@ -76,6 +76,7 @@ constexpr float kSnapTau = 0x1p-18f;         // background snap of the occlusion
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kInfBits = 0x7f800000u;
 constexpr int kMaxBodies = 16;
+constexpr int kMaxDevices = 8;
 constexpr double kMaxDepth = 6.0;    // KinectPixelModel max_depth
 constexpr double kHalfLifeDepth = 1.0;
 
@@ -112,6 +113,13 @@ struct DevParams {
     int4* win_used;                // [n] region the copy kernel writes: bbox(parent window, rect)
     unsigned long long* area_sum;  // sampled calls: sum over particles of |win_used| in pixels (else null)
     unsigned char* wide_flags;     // wide windows: [n][blocks per plane] "this copy block wrote a non-background value"
+    // Several devices in one handle (rbs_config.n_devices > 1): parent slots are GLOBAL, slot g lives
+    // on device g / shard_cap at local slot g % shard_cap, and a parent on another device is read
+    // in place over xGMI (peer access) -- its window's ~4 % of a plane, once.  n_dev <= 1: the
+    // tables are unused.
+    int n_dev, shard_cap;
+    const float* occ_src_dev[kMaxDevices];   // current planes of every device of the handle
+    const int4* win_src_dev[kMaxDevices];    // ... and their windows
     const float* occ_src;          // [slots][npx]
     float* occ_dst;                // [slots][npx]
     const double* poses;           // [n][n_bodies][12]
@@ -170,6 +178,20 @@ __device__ inline float occ_step(float alpha, float beta, float v, float bg_new)
 {
     const float x = fmaf(alpha, v, beta);
     return fabsf(x - bg_new) <= kSnapTau ? bg_new : x;
+}
+
+// Where a parent slot's plane and window are: this device's buffers, or a peer's (see DevParams).
+__device__ inline const float* parent_plane(const DevParams& P, int parent)
+{
+    if (P.n_dev <= 1) return P.occ_src + (size_t)parent * P.npx;
+    const int d = parent / P.shard_cap;
+    return P.occ_src_dev[d] + (size_t)(parent - d * P.shard_cap) * P.npx;
+}
+__device__ inline int4 parent_window(const DevParams& P, int parent)
+{
+    if (P.n_dev <= 1) return P.win_src[parent];
+    const int d = parent / P.shard_cap;
+    return P.win_src_dev[d][parent - d * P.shard_cap];
 }
 
 // ------------------------------------------------------------------ screen rectangle
@@ -742,9 +764,9 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     // a parent slot outside the allocation (only possible through the unchecked device-pointer
     // API) must not turn into a wild read: the particle's likelihood becomes NaN instead
     if ((unsigned)parent >= (unsigned)P.slots) return NAN;
-    const float* __restrict__ src = P.occ_src + (size_t)parent * P.npx;
+    const float* __restrict__ src = parent_plane(P, parent);
     float* __restrict__ dst = UPDATE ? P.occ_dst + (size_t)particle * P.npx : nullptr;
-    const int4 pw = P.win_src[parent];   // outside it the parent's plane is implicitly bg_old
+    const int4 pw = parent_window(P, parent);   // outside it the parent's plane is implicitly bg_old
 
     RBS_TICK_DECL;
     for (int p = threadIdx.x; p < npx; p += kBlock) m.tile[p] = kInfBits;
@@ -909,7 +931,7 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
     if (row0 >= row1) return;
     const int parent = P.parents[particle];
     if ((unsigned)parent >= (unsigned)P.slots) return;
-    const float* __restrict__ src = P.occ_src + (size_t)parent * P.npx + (size_t)row0 * P.cols;
+    const float* __restrict__ src = parent_plane(P, parent) + (size_t)row0 * P.cols;
     float* __restrict__ dst = P.occ_dst + (size_t)particle * P.npx + (size_t)row0 * P.cols;
     const float alpha = P.alpha, beta = P.beta, bg_new = P.bg_new;
 
@@ -1009,7 +1031,7 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
     if (update && P.windowed) {
         const int4 rw = r.x1 > r.x0 ? make_int4(r.x0, r.y0, r.x1, r.y1) : make_int4(P.cols, P.rows, 0, 0);
         int4 pw = make_int4(P.cols, P.rows, 0, 0);
-        if ((unsigned)parent < (unsigned)P.slots) pw = P.win_src[parent];
+        if ((unsigned)parent < (unsigned)P.slots) pw = parent_window(P, parent);
         const int4 u = make_int4(min(pw.x, rw.x), min(pw.y, rw.y), max(pw.z, rw.z), max(pw.w, rw.w));
         P.win_used[i] = u;
         P.win_dst[i] = rw;
@@ -1137,14 +1159,14 @@ __global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, 
     const int parent = P.parents[particle];
     if ((unsigned)parent >= (unsigned)P.slots) return;
     int4 pw = make_int4(0, 0, P.cols, P.rows);
-    if (WIN) pw = P.win_src[parent];
+    if (WIN) pw = parent_window(P, parent);
     // blockIdx.x = row group * nseg + column segment (segment fastest: address order)
     const int rg = (int)blockIdx.x / nseg;
     const int seg = (int)blockIdx.x - rg * nseg;
     const int r0 = rg * ROWS;
     const int c4 = seg * (int)blockDim.x + (int)threadIdx.x;
     if (c4 >= W4) return;
-    const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(P.occ_src + (size_t)parent * P.npx);
+    const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(parent_plane(P, parent));
     floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(P.occ_dst + (size_t)particle * P.npx);
     const float alpha = P.alpha, beta = P.beta, bg_new = P.bg_new;
     const int col = c4 << 2;
@@ -1224,13 +1246,13 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
     if (u.z <= u.x || u.w <= u.y) return;
     const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
     if (q.z > q.x && q.x == u.x && q.y == u.y && q.z == u.z && q.w == u.w) return;   // all raster's
-    const int4 pw = P.win_src[parent];
+    const int4 pw = parent_window(P, parent);
     const int w4 = (u.z - u.x) >> 2, ux4 = u.x >> 2, W4 = P.cols >> 2;
     const int rpc = (u.w - u.y + (int)gridDim.x - 1) / (int)gridDim.x;
     const int ry0 = u.y + (int)blockIdx.x * rpc, ry1 = min(u.w, ry0 + rpc);
     if (ry0 >= ry1) return;
     const int n4 = (ry1 - ry0) * w4;
-    const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(P.occ_src + (size_t)parent * P.npx);
+    const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(parent_plane(P, parent));
     floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(P.occ_dst + (size_t)particle * P.npx);
     const float alpha = P.alpha, beta = P.beta, bg_new = P.bg_new;
     const int lane = (int)threadIdx.x;

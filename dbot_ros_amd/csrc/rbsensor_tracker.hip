@@ -32,6 +32,14 @@ struct TrackerDev {
     const double* normals;        // host-supplied [parts][n][6] or nullptr (device RNG)
     const double* uniforms;       // host-supplied [parts][n] or nullptr
     unsigned long long seed, frame;
+    // several devices: every device holds ALL particle states and runs every kernel of this file
+    // redundantly (identical inputs, identical code: identical results); only the sensor call is
+    // sharded.  layout[g] = particle evaluated at global slot g (device g / cap); *_sorted are the
+    // sensor's inputs / outputs in slot order.
+    int* layout;                  // [n]
+    double* ll_sorted;            // [n_dev * cap]
+    double* poses_sorted;         // [cap][parts][12]   (this device's shard)
+    int* idx_sorted;              // [cap]
 };
 
 // ------------------------------------------------------------------ rotations
@@ -395,6 +403,79 @@ __global__ __launch_bounds__(1024) void filter_step_kernel(const TrackerDev T, i
     __threadfence_block();
     __syncthreads();
     for (int i = threadIdx.x; i < T.n; i += 1024) recentre_one(T, T.part_new2, i);
+}
+
+// ------------------------------------------------------------------ several devices: slot layout
+// Particles are laid out over the devices' slots by the device that holds the plane they inherit
+// (T.idx[j] / cap): a stable n_dev-way partition of the particle ids, bucket after bucket, cut
+// into the devices' fixed slot ranges [k cap, (k+1) cap).  A particle whose bucket spills over a
+// boundary is evaluated next door and reads its parent's window over xGMI; typically (a few
+// survivors with many children each) almost every particle stays with its parent.  Single block,
+// deterministic: every device computes the same layout.
+constexpr int kMaxDev = 8;
+__global__ __launch_bounds__(1024) void layout_kernel(const TrackerDev T, int n_dev, int cap)
+{
+    __shared__ int cnt[kMaxDev][1024 + 1];
+    __shared__ int bucket_start[kMaxDev + 1];
+    const int n = T.n, t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(n, t * per), hi = min(n, lo + per);
+    int c[kMaxDev];
+#pragma unroll
+    for (int b = 0; b < kMaxDev; ++b) c[b] = 0;
+    for (int j = lo; j < hi; ++j) {
+        const int b = min(max(T.idx[j] / cap, 0), n_dev - 1);
+#pragma unroll
+        for (int k = 0; k < kMaxDev; ++k) c[k] += (k == b);
+    }
+#pragma unroll
+    for (int b = 0; b < kMaxDev; ++b) cnt[b][t] = c[b];
+    __syncthreads();
+    // exclusive scan over the threads, one wave per bucket pair (n_dev <= 8, 1 024 threads: cheap)
+    if (t < kMaxDev) {
+        int run = 0;
+        for (int k = 0; k < 1024; ++k) { const int v = cnt[t][k]; cnt[t][k] = run; run += v; }
+        cnt[t][1024] = run;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int b = 0; b < kMaxDev; ++b) { bucket_start[b] = run; run += cnt[b][1024]; }
+        bucket_start[kMaxDev] = run;
+    }
+    __syncthreads();
+    int pos[kMaxDev];
+#pragma unroll
+    for (int b = 0; b < kMaxDev; ++b) pos[b] = bucket_start[b] + cnt[b][t];
+    for (int j = lo; j < hi; ++j) {
+        const int b = min(max(T.idx[j] / cap, 0), n_dev - 1);
+        int p = 0;
+#pragma unroll
+        for (int k = 0; k < kMaxDev; ++k) if (k == b) { p = pos[k]; pos[k] += 1; }
+        T.layout[p] = j;
+    }
+}
+
+// this device's shard of the sensor call: poses and parent slots of the particles at slots lo..lo+cnt
+__global__ void shard_gather_kernel(const TrackerDev T, int lo, int cnt)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= cnt) return;
+    const int j = T.layout[lo + g];
+    const int w = T.parts * 12;
+    for (int k = 0; k < w; ++k) T.poses_sorted[(size_t)g * w + k] = T.poses[(size_t)j * w + k];
+    T.idx_sorted[g] = T.idx[j];
+}
+
+// after the all-gather: log-likelihoods back to particle order; an updating call wrote particle
+// layout[g]'s plane to global slot g
+__global__ void shard_scatter_kernel(const TrackerDev T, int updated)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= T.n) return;
+    const int j = T.layout[g];
+    T.ll_new[j] = T.ll_sorted[g];
+    if (updated) T.idx[j] = g;
 }
 
 __global__ void init_kernel(const TrackerDev T)

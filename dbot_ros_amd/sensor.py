@@ -169,15 +169,14 @@ class RbSensor:
         cfg.delta_time = params.delta_time
         cfg.likelihood_precision = _capi.PRECISIONS[precision]
         cfg.state_layout = _capi.LAYOUTS[state_layout]
-        if device_ids is not None and len(device_ids) > 1:
+        if device_ids is not None and len(device_ids) >= 1:
             ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+            cfg.device_id = int(ids[0])
             cfg.n_devices = len(ids)
             cfg.device_ids = ids.ctypes.data_as(C.POINTER(C.c_int32))
         else:
             cfg.n_devices = 0
             cfg.device_ids = None
-            if device_ids is not None and len(device_ids) == 1:
-                cfg.device_id = int(device_ids[0])
         rc = self._lib.rbs_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             msg = self._lib.rbs_last_error(None).decode()

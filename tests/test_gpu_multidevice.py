@@ -1,0 +1,156 @@
+"""Several devices inside ONE handle (rbs_config.n_devices / device_ids): the
+reference's tracker node is a single process, so particle sharding lives behind the C-ABI.  On a
+one-GPU box the same ordinal is listed several times: the shards then share a device, every
+"peer" read is a local read and the log-likelihood exchange falls back from RCCL (which refuses
+duplicate devices) to device-to-device copies -- everything else (global slots, cross-shard
+ordering, the layout kernel, the replicated filter) is the code that runs on eight GPUs.  With
+two or more GPUs visible the distinct-device tests below run RCCL over xGMI."""
+import numpy as np
+import pytest
+
+import scenarios as sc
+from dbot_ros_amd import RbSensor, pose, synth
+from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
+
+pytestmark = pytest.mark.gpu
+
+
+def _devices(kind):
+    import torch
+    if kind == "same":
+        return None
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    return [0, 1]
+
+
+def _resampled_sequence(sensor, frames, n, seed=1):
+    """set_observation -> loglikes(update) -> multinomial resampling with GLOBAL parent slots."""
+    rng = np.random.default_rng(seed)
+    sensor.reset()
+    idx = np.zeros(n, dtype=np.int32)
+    out = []
+    for k, (truth, frame) in enumerate(frames):
+        sensor.set_observation(frame)
+        poses = synth.particle_poses(truth, n, rng, scale=1.0 + 0.5 * k)
+        if k % 2 == 1:      # a read-only evaluation first (non-final sampling block)
+            out.append(sensor.loglikes_poses(poses, idx.copy(), update=False))
+        ll = sensor.loglikes_poses(poses, idx, update=True)
+        out.append(ll)
+        assert (idx == np.arange(n)).all()
+        w = np.exp(ll - ll.max())
+        idx = rng.choice(n, size=n, p=w / w.sum()).astype(np.int32)      # unsorted: parents all over the shards
+    return out
+
+
+@pytest.mark.parametrize("layout", ["window", "dense"])
+@pytest.mark.parametrize("ids", [[0, 0], [0, 0, 0]])
+def test_group_sensor_matches_single_device(gpu_lib, layout, ids):
+    n = 50          # not a multiple of the shard count: the last shard is partly filled
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", state_layout=layout) as one:
+        rng = np.random.default_rng(0)
+        frames = []
+        for k in range(5):
+            t = synth.truth_pose(1, frame=k)
+            frames.append((t, synth.make_frame(one.render_depth(t), 120, 160, rng)))
+        ref = _resampled_sequence(one, frames, n)
+        ref_planes = [one.get_occlusion(s) for s in range(n)]
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", state_layout=layout, device_ids=ids) as grp:
+        got = _resampled_sequence(grp, frames, n)
+        for a, b in zip(got, ref):
+            # the same planes and kernels; a particle's tiles may be summed in another order
+            assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+        for s in range(n):
+            assert np.array_equal(grp.get_occlusion(s), ref_planes[s]), s
+        with pytest.raises(Exception):
+            grp.loglikes_poses(synth.particle_poses(frames[0][0], n, rng), np.full(n, 10 ** 6, np.int32))
+
+
+def _init_state(om, nb):
+    init = np.zeros(12 * nb)
+    for b in range(nb):
+        Rt = synth.truth_pose(nb, frame=0)[b]
+        init[12 * b + 3:12 * b + 6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+        init[12 * b:12 * b + 3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[b]
+    return init
+
+
+def _run_tracker(om, cam, P, n, nb, frames, device_ids, randomness):
+    with RbSensor(om, cam, P, max_particles=n // nb, precision="f64", device_ids=device_ids) as s:
+        trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=nb)).build()
+        tr = DeviceParticleTracker(trans, s, om, ParticleTrackerBuilder.Parameters(evaluation_count=n), np.random.default_rng(5))
+        tr.initialize([_init_state(om, nb)])
+        ests, states = [], []
+        for frame, (normals, uniforms) in zip(frames, randomness):
+            ests.append(tr.track(frame, normals, uniforms))
+            states.append(tr.get_state())
+        nres = tr.n_resamplings
+        tr.close()
+    return np.array(ests), states, nres
+
+
+@pytest.mark.parametrize("meshes,n,ids", [(("m1_l2",), 96, [0, 0]), (("m1_l2", "box12"), 120, [0, 0, 0]),
+                                           (("m1_l2",), 1500, [0, 0])])
+def test_group_device_tracker_matches_single_device(gpu_lib, meshes, n, ids):
+    """rbs_tracker_* over a handle with several shards against the same tracker over one device,
+    same host-supplied randomness: the same particles, weights, resampling decisions and estimates
+    (the slot map differs -- it names where planes live -- but names the same planes)."""
+    nb = len(meshes)
+    cols, rows = 160, 120
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    per = n // nb
+    rng = np.random.default_rng(3)
+    with RbSensor(om, cam, P, max_particles=1) as r:
+        frames = [synth.make_frame(r.render_depth(synth.truth_pose(nb, frame=k)), rows, cols, rng, occluder=False).astype(np.float32)
+                  for k in range(1, 8)]
+    randomness = [(rng.standard_normal((nb, per, 6)), rng.random((nb, per))) for _ in frames]
+    e1, s1, r1 = _run_tracker(om, cam, P, n, nb, frames, None, randomness)
+    e2, s2, r2 = _run_tracker(om, cam, P, n, nb, frames, ids, randomness)
+    assert r1 == r2 and r1 >= 1
+    assert np.abs(e1 - e2).max() <= 1e-9, np.abs(e1 - e2).max()
+    for (p1, w1, _), (p2, w2, _) in zip(s1, s2):
+        assert np.abs(p1 - p2).max() <= 1e-9
+        assert np.abs(w1 - w2).max() <= 1e-6 * max(1.0, np.abs(w1).max())
+
+
+def test_rccl_all_gather_runs_in_the_group_path(gpu_lib, monkeypatch):
+    """RBS_GROUP_SINGLE: a one-shard group on one device, so that the RCCL communicator, the
+    ncclGroupStart / ncclAllGather / ncclGroupEnd calls and the run-time binding of librccl are
+    executed on hardware even on a one-GPU box (one rank: the all-gather is an in-place copy)."""
+    monkeypatch.setenv("RBS_GROUP_SINGLE", "1")
+    n, nb = 64, 1
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    rng = np.random.default_rng(3)
+    with RbSensor(om, cam, P, max_particles=1) as r:
+        frames = [synth.make_frame(r.render_depth(synth.truth_pose(nb, frame=k)), 120, 160, rng, occluder=False).astype(np.float32)
+                  for k in range(1, 5)]
+    randomness = [(rng.standard_normal((nb, n, 6)), rng.random((nb, n))) for _ in frames]
+    e2, _, r2 = _run_tracker(om, cam, P, n, nb, frames, [0], randomness)
+    monkeypatch.delenv("RBS_GROUP_SINGLE")
+    e1, _, r1 = _run_tracker(om, cam, P, n, nb, frames, None, randomness)
+    assert r1 == r2 and np.abs(e1 - e2).max() <= 1e-9
+
+
+def test_two_gpus_sensor_and_tracker(gpu_lib):
+    """Distinct devices: peer reads of remote parents over xGMI, RCCL all-gather.  Skipped on a
+    one-GPU box."""
+    ids = _devices("distinct")
+    n = 64
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64") as one:
+        rng = np.random.default_rng(0)
+        frames = []
+        for k in range(4):
+            t = synth.truth_pose(1, frame=k)
+            frames.append((t, synth.make_frame(one.render_depth(t), 120, 160, rng)))
+        ref = _resampled_sequence(one, frames, n)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", device_ids=ids) as grp:
+        got = _resampled_sequence(grp, frames, n)
+    for a, b in zip(got, ref):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    fr = [f.astype(np.float32) for _, f in frames]
+    randomness = [(rng.standard_normal((1, n, 6)), rng.random((1, n))) for _ in fr]
+    e1, _, r1 = _run_tracker(om, cam, P, n, 1, fr, None, randomness)
+    e2, _, r2 = _run_tracker(om, cam, P, n, 1, fr, ids, randomness)
+    assert r1 == r2 and np.abs(e1 - e2).max() <= 1e-9
