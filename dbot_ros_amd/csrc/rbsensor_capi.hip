@@ -1764,6 +1764,32 @@ int32_t talloc(rbs_tracker* t, X** p, size_t count)
 extern "C" void rbs_tracker_destroy(rbs_tracker* t);
 
 namespace {
+// The filter step's weights and the tracker's mean: single-block kernels for few particles (the
+// launch chain is what counts there), grid kernels from kMultiBlockFrom particles on.
+void launch_weights(const rbt::TrackerDev& T, int updated, hipStream_t s)
+{
+    if (T.n < rbt::kMultiBlockFrom) {
+        hipLaunchKernelGGL(rbt::weights_kernel, dim3(1), dim3(1024), 0, s, T, updated);
+        return;
+    }
+    const int blocks = (T.n + rbt::kChunk - 1) / rbt::kChunk;
+    hipLaunchKernelGGL(rbt::weights_w1_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, T, updated);
+    hipLaunchKernelGGL(rbt::weights_w2_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, T);
+    hipLaunchKernelGGL(rbt::weights_w3_kernel, dim3(1), dim3(64), 0, s, T, blocks);
+    hipLaunchKernelGGL(rbt::weights_w4_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, T);
+}
+void launch_mean(const rbt::TrackerDev& T, hipStream_t s)
+{
+    if (T.n < rbt::kMultiBlockFrom) {
+        hipLaunchKernelGGL(rbt::mean_kernel, dim3(1), dim3(1024), 0, s, T);
+        return;
+    }
+    const int blocks = (T.n + rbt::kChunk - 1) / rbt::kChunk;
+    hipLaunchKernelGGL(rbt::mean_m1_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, T);
+    hipLaunchKernelGGL(rbt::mean_m2_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, T);
+    hipLaunchKernelGGL(rbt::mean_m3_kernel, dim3(1), dim3(64), 0, s, T, blocks);
+}
+
 // One device's tracker state.  cap > 0: the sensor is a shard of a group with `cap` slots per device.
 int32_t tracker_create_one(rbs_handle* sensor, const rbs_tracker_params* p, int n_dev, int cap, rbs_tracker** out)
 {
@@ -1787,7 +1813,8 @@ int32_t tracker_create_one(rbs_handle* sensor, const rbs_tracker_params* p, int 
         (rc = talloc(t, &T.ll_new, n)) || (rc = talloc(t, &T.idx, n)) || (rc = talloc(t, &T.idx2, n)) ||
         (rc = talloc(t, &T.parents, n)) || (rc = talloc(t, &T.cdf, n)) || (rc = talloc(t, &T.deflt, D)) ||
         (rc = talloc(t, &T.mean, D + (size_t)T.parts * 9)) || (rc = talloc(t, &T.poses, n * (size_t)T.parts * 12)) ||
-        (rc = talloc(t, &T.flag, 2)) || (rc = talloc(t, &t->d_normals, n * P6)) ||
+        (rc = talloc(t, &T.flag, 2)) || (rc = talloc(t, &T.red, (size_t)rbt::kRedBlocks * (3 + D))) ||
+        (rc = talloc(t, &t->d_normals, n * P6)) ||
         (rc = talloc(t, &t->d_uniforms, n * (size_t)T.parts)) ||
         (cap > 0 && ((rc = talloc(t, &T.layout, n)) || (rc = talloc(t, &T.ll_sorted, (size_t)n_dev * cap)) ||
                      (rc = talloc(t, &T.poses_sorted, (size_t)cap * T.parts * 12)) || (rc = talloc(t, &T.idx_sorted, (size_t)cap))))) {
@@ -1809,6 +1836,8 @@ int32_t rbs_tracker_create(rbs_handle* sensor, const rbs_tracker_params* p, rbs_
     const int total = sensor->shards.empty() ? sensor->max_particles : (int)sensor->shards.size() * sensor->shard_cap;
     if (!p || p->n_particles <= 0 || p->n_particles > total)
         return fail(sensor, RBS_ERR_INVALID_ARGUMENT, "tracker_create: n_particles outside 1..max_particles");
+    if (p->n_particles > rbt::kRedBlocks * rbt::kChunk)
+        return fail(sensor, RBS_ERR_INVALID_ARGUMENT, fmt("tracker_create: at most %d particles", rbt::kRedBlocks * rbt::kChunk));
     if (sensor->shards.empty()) return tracker_create_one(sensor, p, 1, 0, out);
     rbs_tracker* g = new (std::nothrow) rbs_tracker;
     if (!g) return fail(sensor, RBS_ERR_OUT_OF_MEMORY, "tracker_create: out of host memory");
@@ -1936,7 +1965,7 @@ int32_t group_tracker_track(rbs_tracker* t, const float* frame, const double* no
             RBT_HIP(t, hipSetDevice(r->s->device));
             hipStream_t s = streams[k];
             hipLaunchKernelGGL(rbt::shard_scatter_kernel, g256, b256, 0, s, T, last ? 1 : 0);
-            hipLaunchKernelGGL(rbt::weights_kernel, dim3(1), dim3(1024), 0, s, T, 0);
+            launch_weights(T, 0, s);
             hipLaunchKernelGGL(rbt::resample_kernel, g256, b256, 0, s, T, b);
             hipLaunchKernelGGL(rbt::gather_kernel, dim3((unsigned)T.n), dim3(64), 0, s, T);
             RBT_HIP(t, hipGetLastError());
@@ -1952,7 +1981,7 @@ int32_t group_tracker_track(rbs_tracker* t, const float* frame, const double* no
         rbs_tracker* r = t->reps[k];
         rbt::TrackerDev& T = r->T;
         RBT_HIP(t, hipSetDevice(r->s->device));
-        hipLaunchKernelGGL(rbt::mean_kernel, dim3(1), dim3(1024), 0, streams[k], T);
+        launch_mean(T, streams[k]);
         hipLaunchKernelGGL(rbt::recentre_kernel, g256, b256, 0, streams[k], T);
         RBT_HIP(t, hipGetLastError());
         std::swap(T.part_old, T.part_new);   // this frame's particles are the next frame's old ones
@@ -2009,7 +2038,7 @@ int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* norm
         if (fused) {
             hipLaunchKernelGGL(rbt::filter_step_kernel, dim3(1), dim3(1024), 0, s, T, b, last ? 1 : 0, last ? 1 : 0);
         } else {
-            hipLaunchKernelGGL(rbt::weights_kernel, dim3(1), dim3(1024), 0, s, T, last ? 1 : 0);
+            launch_weights(T, last ? 1 : 0, s);
             hipLaunchKernelGGL(rbt::resample_kernel, g256, b256, 0, s, T, b);
             hipLaunchKernelGGL(rbt::gather_kernel, dim3((unsigned)T.n), dim3(64), 0, s, T);
         }
@@ -2021,7 +2050,7 @@ int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* norm
         std::swap(T.idx, T.idx2);
     }
     if (!fused) {
-        hipLaunchKernelGGL(rbt::mean_kernel, dim3(1), dim3(1024), 0, s, T);
+        launch_mean(T, s);
         hipLaunchKernelGGL(rbt::recentre_kernel, g256, b256, 0, s, T);
     }
     RBT_HIP(t, hipGetLastError());

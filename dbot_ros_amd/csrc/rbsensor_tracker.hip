@@ -36,6 +36,7 @@ struct TrackerDev {
     // redundantly (identical inputs, identical code: identical results); only the sensor call is
     // sharded.  layout[g] = particle evaluated at global slot g (device g / cap); *_sorted are the
     // sensor's inputs / outputs in slot order.
+    double* red;                  // [kRedBlocks * (3 + D)] per-block partials of the multi-block filter kernels
     int* layout;                  // [n]
     double* ll_sorted;            // [n_dev * cap]
     double* poses_sorted;         // [cap][parts][12]   (this device's shard)
@@ -244,6 +245,192 @@ __global__ __launch_bounds__(1024) void weights_kernel(const TrackerDev T, int u
 {
     __shared__ double sh[1024];
     weights_body(T, updated, sh);
+}
+
+// ---- the same step for many particles: a single 1 024-thread block walks 200 000 particles in
+// 2.6 ms (measured 1.3 ms at 100 000), more than an eight-way sharded sensor call takes.  Four
+// grid launches over chunks of kChunk particles, every reduction in a fixed order (per-thread
+// chunk order, shuffle tree, block order), so every device of a sharded tracker -- and every
+// run -- computes the same bits:
+//   w1  log_w += new_ll - ll; ll = new_ll; per-block max                       -> red[blk]
+//   w2  m = max over blocks; e_i = exp(log_w_i - m) -> cdf[i]; per-block sum e, sum e (log_w - m)
+//   w3  (one block) S, KL = log n + sum(e (log_w - m))/S - log S, flag, block offsets
+//   w4  flag: cdf[i] = (offset[blk] + inclusive scan of e inside the block) / S
+constexpr int kChunk = 4096;          // particles per block (1 024 threads x 4)
+constexpr int kRedBlocks = 1024;      // at most this many chunks: 4 194 304 particles
+constexpr int kMultiBlockFrom = 8192; // below it the single-block kernels (the parity tests' path) are faster
+
+__global__ __launch_bounds__(1024) void weights_w1_kernel(const TrackerDev T, int updated)
+{
+    __shared__ double sh[16];
+    const int base = blockIdx.x * kChunk;
+    double m = -INFINITY;
+    for (int k = 0; k < 4; ++k) {
+        const int i = base + k * 1024 + (int)threadIdx.x;
+        if (i < T.n) {
+            const double nl = T.ll_new[i];
+            const double lw = T.logw[i] + (nl - T.ll[i]);
+            T.logw[i] = lw;
+            T.ll[i] = nl;
+            if (updated) T.idx[i] = i;
+            m = fmax(m, lw);
+        }
+    }
+    m = block_max(m, sh);
+    if (threadIdx.x == 0) T.red[blockIdx.x] = m;
+}
+
+__global__ __launch_bounds__(1024) void weights_w2_kernel(const TrackerDev T)
+{
+    __shared__ double sh[16];
+    double m = -INFINITY;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 1024) m = fmax(m, T.red[b]);
+    m = block_max(m, sh);
+    const int base = blockIdx.x * kChunk;
+    double se = 0.0, sl = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        const int i = base + k * 1024 + (int)threadIdx.x;
+        if (i < T.n) {
+            const double d = T.logw[i] - m;
+            const double e = exp(d);
+            T.cdf[i] = e;
+            se += e;
+            if (e > 0.0) sl += e * d;
+        }
+    }
+    se = block_sum(se, sh);
+    sl = block_sum(sl, sh);
+    if (threadIdx.x == 0) {
+        T.red[kRedBlocks + blockIdx.x] = se;
+        T.red[2 * kRedBlocks + blockIdx.x] = sl;
+    }
+}
+
+__global__ __launch_bounds__(1024) void weights_w3_kernel(const TrackerDev T, int blocks)
+{
+    if (threadIdx.x != 0) return;       // <= 1 024 partials: a serial, order-fixed sum
+    double S = 0.0, L = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+        const double se = T.red[kRedBlocks + b];
+        T.red[kRedBlocks + b] = S;       // exclusive offset of the block
+        S += se;
+        L += T.red[2 * kRedBlocks + b];
+    }
+    const double kl = log((double)T.n) + L / S - log(S);
+    const bool resample = kl > T.max_kl;
+    T.flag[0] = resample ? 1 : 0;
+    if (resample) T.flag[1] += 1;
+    T.red[0] = S;
+}
+
+__global__ __launch_bounds__(1024) void weights_w4_kernel(const TrackerDev T)
+{
+    if (!T.flag[0]) return;
+    __shared__ double sh[1024];
+    const int base = blockIdx.x * kChunk + (int)threadIdx.x * 4;   // four consecutive particles per thread
+    double e[4], run = 0.0;
+    for (int k = 0; k < 4; ++k) { e[k] = base + k < T.n ? T.cdf[base + k] : 0.0; run += e[k]; }
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const double v = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    double acc = T.red[kRedBlocks + blockIdx.x] + (threadIdx.x ? sh[threadIdx.x - 1] : 0.0);
+    const double S = T.red[0];
+    for (int k = 0; k < 4; ++k) {
+        acc += e[k];
+        if (base + k < T.n) T.cdf[base + k] = acc / S;
+    }
+}
+
+// ---- weighted mean for many particles: per-block partial sums of e_i * particle_i, then one
+// block folds them into the default pose (mean_body's tail)
+__global__ __launch_bounds__(1024) void mean_m1_kernel(const TrackerDev T)
+{
+    __shared__ double sh[16];
+    double m = -INFINITY;
+    for (int k = 0; k < 4; ++k) {
+        const int i = blockIdx.x * kChunk + k * 1024 + (int)threadIdx.x;
+        if (i < T.n) m = fmax(m, T.logw[i]);
+    }
+    m = block_max(m, sh);
+    if (threadIdx.x == 0) T.red[blockIdx.x] = m;
+}
+
+__global__ __launch_bounds__(1024) void mean_m2_kernel(const TrackerDev T)
+{
+    __shared__ double sh[16];
+    __shared__ double shb[16][kBody];
+    double m = -INFINITY;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 1024) m = fmax(m, T.red[b]);
+    m = block_max(m, sh);
+    double se = 0.0;
+    double e[4];
+    for (int k = 0; k < 4; ++k) {
+        const int i = blockIdx.x * kChunk + k * 1024 + (int)threadIdx.x;
+        e[k] = i < T.n ? exp(T.logw[i] - m) : 0.0;
+        se += e[k];
+    }
+    se = block_sum(se, sh);
+    double* out = T.red + 3 * kRedBlocks + (size_t)blockIdx.x * T.D;
+    if (threadIdx.x == 0) T.red[kRedBlocks + blockIdx.x] = se;
+    for (int b = 0; b < T.parts; ++b) {
+        double a[kBody];
+#pragma unroll
+        for (int c = 0; c < kBody; ++c) a[c] = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            const int i = blockIdx.x * kChunk + k * 1024 + (int)threadIdx.x;
+            if (i < T.n) {
+                const double* p = T.part_new + (size_t)i * T.D + b * kBody;
+#pragma unroll
+                for (int c = 0; c < kBody; ++c) a[c] += e[k] * p[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kBody; ++c)
+            for (int off = 32; off > 0; off >>= 1) a[c] += __shfl_down(a[c], off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int c = 0; c < kBody; ++c) shb[threadIdx.x >> 6][c] = a[c];
+        __syncthreads();
+        if ((int)threadIdx.x < kBody) {
+            double sum = 0.0;
+            for (int w = 0; w < 16; ++w) sum += shb[w][threadIdx.x];
+            out[b * kBody + threadIdx.x] = sum;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void mean_m3_kernel(const TrackerDev T, int blocks)
+{
+    // component c of the mean = (sum over blocks, in block order) / S
+    double S = 0.0;
+    for (int b = 0; b < blocks; ++b) S += T.red[kRedBlocks + b];
+    for (int c = threadIdx.x; c < T.D; c += 64) {
+        double sum = 0.0;
+        for (int b = 0; b < blocks; ++b) sum += T.red[3 * kRedBlocks + (size_t)b * T.D + c];
+        T.mean[c] = sum / S;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < T.parts) {
+        const int b = threadIdx.x;
+        double* z = T.deflt + b * kBody;
+        const double* mu = T.mean + b * kBody;
+        double Rm[9], Rz[9], R[9];
+        rotvec_to_matrix(mu + 3, Rm);
+        rotvec_to_matrix(z + 3, Rz);
+        matmul3(Rm, Rz, R);
+        for (int k = 0; k < 3; ++k) z[k] += mu[k];
+        matrix_to_rotvec(R, z + 3);
+        for (int k = 6; k < 12; ++k) z[k] = mu[k];
+        double* RmT = T.mean + T.D + b * 9;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) RmT[3 * r + c] = Rm[3 * c + r];
+    }
 }
 
 // parents[j] = flag ? upper_bound(cdf, u_j) : j   (multinomial resampling)
