@@ -6,7 +6,7 @@
 tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-BENCH="python bench.py --quick --steps 20 --warmup 3"
+BENCH="python bench.py --quick --steps 20 --warmup 3 $BENCH_ARGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- $BENCH > $out/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o fetch -- $BENCH > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o write -- $BENCH > $out/write.log 2>&1

@@ -93,10 +93,10 @@ if os.path.exists(sq_path):
         k = k[0]
         g = lambda c: sq.get((k, c), 0.0)
         # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves
-        summary = {"kernel": k, "workload": "bench.py default step (raster kernel of loglikes(update=true), 2000 particles)",
+        summary = {"precision": os.environ.get("RBS_PROFILE_PRECISION", "f32"), "state_layout": layout, "kernel": k, "workload": "bench.py default step (raster kernel of loglikes(update=true), 2000 particles)",
                    "per_dispatch": {c: g(c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
                                                       "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
-                                                      "SQ_BUSY_CYCLES")},
+                                                      "SQ_BUSY_CYCLES", "SQ_INSTS_SALU")},
                    "valu_instructions_per_particle": g("SQ_INSTS_VALU") / 2000.0,
                    "cycles_per_valu_instruction": 4.0 * g("SQ_ACTIVE_INST_VALU") / max(g("SQ_INSTS_VALU"), 1.0),
                    "fraction_of_wave_time_issuing_valu": g("SQ_ACTIVE_INST_VALU") / max(g("SQ_WAVE_CYCLES"), 1.0),
