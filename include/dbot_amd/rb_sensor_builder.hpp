@@ -151,6 +151,10 @@ public:
         std::string vertex_shader_file;
         std::string fragment_shader_file;
         std::string geometry_shader_file;
+        // MI355X extensions (optional rosparams particle_filter/gpu/devices and
+        // particle_filter/gpu/likelihood_precision; the reference has no such keys):
+        std::vector<int> devices;            // empty: device_id alone; several: particle sharding inside the handle
+        std::string likelihood_precision;    // "" (library default = f32) | "f32" | "f64"
     };
 
     RbSensorBuilder(const std::shared_ptr<ObjectModel>& object_model,
@@ -217,6 +221,16 @@ public:
         cfg.model_sigma = p.kinect.model_sigma;
         cfg.sigma_factor = p.kinect.sigma_factor;
         cfg.delta_time = p.delta_time;
+        cfg.likelihood_precision = p.likelihood_precision == "f64" ? RBS_PRECISION_F64
+                                 : p.likelihood_precision == "f32" ? RBS_PRECISION_F32 : RBS_PRECISION_DEFAULT;
+        std::vector<int32_t> devs(p.devices.begin(), p.devices.end());
+        if (devs.size() > 1) {               // max_particles is then the total over the devices
+            cfg.device_id = devs[0];
+            cfg.n_devices = static_cast<int32_t>(devs.size());
+            cfg.device_ids = devs.data();
+        } else if (devs.size() == 1) {
+            cfg.device_id = devs[0];
+        }
         const int32_t rc = rbs_create(&cfg, &handle_);
         if (rc != RBS_OK)
             throw std::runtime_error(std::string("RbSensor: ") + rbs_last_error(nullptr));
