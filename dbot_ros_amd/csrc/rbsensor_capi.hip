@@ -17,6 +17,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +30,10 @@
 #include <vector>
 
 using rbs::DevParams;
+
+static_assert(sizeof(rbs_config) == 208 && offsetof(rbs_config, likelihood_precision) == 184 &&
+                  offsetof(rbs_config, device_ids) == 200,
+              "rbs_config layout (ABI 2) is mirrored by dbot_ros_amd/_capi.py and tests/test_capi_cpu.py");
 
 struct rbs_handle {
     int device = 0;
