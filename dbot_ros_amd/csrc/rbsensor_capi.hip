@@ -56,6 +56,7 @@ struct rbs_handle {
     double* d_out = nullptr;
     int* d_rects[2] = {nullptr, nullptr};  // [max_particles][4], alternating per call: the previous
                                 // call's copy kernel may still be reading its rectangles
+    rbs::Groups* d_groups[2] = {nullptr, nullptr};   // [max_particles] per-group rectangles (several bodies), alternating like d_rects
     int* d_parents[2] = {nullptr, nullptr};   // [max_particles] snapshot of the caller's indices, alternating like d_rects
     int4* d_win[2] = {nullptr, nullptr};   // [max_particles] window of each plane, per buffer
     int4* d_win_used = nullptr; // [max_particles] region the copy kernel writes this call
@@ -299,7 +300,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.tile_h = std::max(4, P.tile_px / 256 / std::max(1, h->smalln_target / std::max(1, n)));
     if (const char* m = h->tile_override) { P.tile_w = std::max(16, std::atoi(m) / 16 * 16); P.tile_h = std::max(1, std::atoi(m)); }
     const size_t tiles_max = tiles_upper_bound(h->cols, h->rows, P.tile_w, std::min(P.tile_w * P.tile_h, P.tile_px));
-    const size_t need = (size_t)n * tiles_max;
+    const size_t need = (size_t)n * tiles_max * (h->d_groups[0] ? rbs::kMaxGroups : 1);
     if (need > h->partial_cap) {
         RBS_HIP(h, hipStreamSynchronize(s));
         RBS_HIP(h, hipStreamSynchronize(h->copy_stream));
@@ -314,6 +315,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     }
     int* const d_rects = h->d_rects[h->calls & 1];
     P.rects = d_rects;
+    P.groups = h->d_groups[h->calls & 1];
     P.parents = h->d_parents[h->calls & 1];
     P.item_range = h->d_item_range;
     P.item_particle = h->d_item_particle;
@@ -508,6 +510,8 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_out);
     (void)hipFree(h->d_rects[0]);
     (void)hipFree(h->d_rects[1]);
+    (void)hipFree(h->d_groups[0]);
+    (void)hipFree(h->d_groups[1]);
     (void)hipFree(h->d_parents[0]);
     (void)hipFree(h->d_parents[1]);
     (void)hipFree(h->d_win[0]);
@@ -922,6 +926,10 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMalloc(&h->d_out, sizeof(double) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_rects[0], sizeof(int) * 4 * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_rects[1], sizeof(int) * 4 * (size_t)h->max_particles));
+    if (h->n_bodies > 1 && !(std::getenv("RBS_NO_GROUPS") && std::atoi(std::getenv("RBS_NO_GROUPS")))) {
+        RBS_HIP(h, hipMalloc(&h->d_groups[0], sizeof(rbs::Groups) * (size_t)h->max_particles));
+        RBS_HIP(h, hipMalloc(&h->d_groups[1], sizeof(rbs::Groups) * (size_t)h->max_particles));
+    }
     RBS_HIP(h, hipMalloc(&h->d_parents[0], sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_parents[1], sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_win[0], sizeof(int4) * (size_t)h->max_particles));
@@ -990,10 +998,11 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
 
     {   // per-item partial sums: sized for the default tiling so no call ever allocates
-        size_t need = (size_t)h->max_particles * tiles_upper_bound(h->cols, h->rows, 256, rbs::kTilePx);
+        const size_t gmul = h->d_groups[0] ? rbs::kMaxGroups : 1;   // every group of bodies tiles its own rectangle
+        size_t need = gmul * (size_t)h->max_particles * tiles_upper_bound(h->cols, h->rows, 256, rbs::kTilePx);
         for (int nn = 1; nn < std::min(h->max_particles, h->raster_blocks); nn *= 2) {
             const int th = std::max(4, rbs::kTilePx / 256 / std::max(1, std::max(h->smalln_target, h->raster_blocks) / nn));
-            need = std::max(need, (size_t)std::min(2 * nn, h->max_particles) * tiles_upper_bound(h->cols, h->rows, 256, 256 * th));
+            need = std::max(need, gmul * (size_t)std::min(2 * nn, h->max_particles) * tiles_upper_bound(h->cols, h->rows, 256, 256 * th));
         }
         RBS_HIP(h, hipMalloc(&h->d_partial, sizeof(double) * need));
         RBS_HIP(h, hipMalloc(&h->d_item_particle, sizeof(int) * need));

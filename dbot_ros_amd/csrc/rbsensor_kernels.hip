@@ -80,6 +80,19 @@ constexpr int kMaxDevices = 8;
 constexpr double kMaxDepth = 6.0;    // KinectPixelModel max_depth
 constexpr double kHalfLifeDepth = 1.0;
 
+// Several bodies: the screen rectangles of the bodies of a particle, overlapping ones merged, at
+// most kMaxGroups of them (more: one union rectangle).  Every group is rasterized on its own --
+// its own work items, its own bodies only -- so the gaps between objects that stand apart are
+// neither scanned nor culled against; where rectangles overlap the bodies share a z-buffer as
+// before.  The copy kernel writes what lies inside the union rectangle but in no group.
+constexpr int kMaxGroups = 4;
+struct Groups {
+    int n, pad0, pad1, pad2;
+    int4 rect[kMaxGroups];
+    int first[kMaxGroups];        // first work item of the group, relative to the particle's first
+    unsigned mask[kMaxGroups];    // bodies of the group
+};
+
 struct DevParams {
     int rows, cols, npx;
     int n_bodies;
@@ -131,7 +144,8 @@ struct DevParams {
     double* out;                   // [n]
     int n;
     int bands, band_rows;          // copy blocks per particle, rows per band
-    const int* rects;              // [n][4] screen rectangles (rbs_prep_kernel)
+    const int* rects;              // [n][4] screen rectangles (rbs_prep_kernel): the union over the bodies
+    Groups* groups;                // [n] per-group rectangles, several bodies only (null for one body)
     int2* item_range;              // [n] (first work item, number of work items) of each particle
     int* item_particle;            // [items] owner of each work item
     int* ctr_this;                 // [2] this call's (items allotted, items taken) counters ...
@@ -205,12 +219,12 @@ __device__ inline int4 parent_window(const DevParams& P, int parent)
 // corners of the bounding box: 9 200 px for the 5 120-triangle ellipsoid at 0.7 m where this
 // one has 5 700 -- the pixel pass, the tile and the stored windows shrink by as much.)
 // Called by all 64 lanes of a wave; every lane returns the same rectangle.
-__device__ inline Rect particle_rect(const DevParams& P, const double* __restrict__ pose)
+__device__ inline Rect bodies_rect(const DevParams& P, const double* __restrict__ pose, int b_first, int b_last)
 {
     const int lane = threadIdx.x & 63, stride = 64;
     const float fx = (float)P.fx, fy = (float)P.fy, cx = (float)P.cx, cy = (float)P.cy;
     float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY, zmin = INFINITY, tabs = 0.f;
-    for (int b = 0; b < P.n_bodies; ++b) {
+    for (int b = b_first; b < b_last; ++b) {
         const double* Rt = pose + 12 * b;
         const float r0 = (float)Rt[0], r1 = (float)Rt[1], r2 = (float)Rt[2], r3 = (float)Rt[3], r4 = (float)Rt[4],
                     r5 = (float)Rt[5], r6 = (float)Rt[6], r7 = (float)Rt[7], r8 = (float)Rt[8];
@@ -267,6 +281,10 @@ __device__ inline Rect particle_rect(const DevParams& P, const double* __restric
     r.x1 = min(P.cols, (r.x1 + P.rect_align - 1) & ~(P.rect_align - 1));
     if (r.x1 <= r.x0 || r.y1 <= r.y0) { r.x0 = r.x1 = r.y0 = r.y1 = 0; }
     return r;
+}
+__device__ inline Rect particle_rect(const DevParams& P, const double* __restrict__ pose)
+{
+    return bodies_rect(P, pose, 0, P.n_bodies);
 }
 
 // ------------------------------------------------------------------ triangle setup
@@ -471,7 +489,7 @@ __device__ inline void raster_lane_triangle(const DevParams& P, int t, const dou
 // Caller has cleared the tile and synchronised; on return the tile is complete and synchronised.
 __device__ inline void raster_window(const DevParams& P, const double* __restrict__ pose,
                                      int wx0, int wy0, int wx1, int wy1, bool cull, unsigned* tile,
-                                     int* big, int* nbig, int* tq)
+                                     int* big, int* nbig, int* tq, unsigned body_mask)
 {
     const int tw = wx1 - wx0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -481,6 +499,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
     // cluster instead measured no better: the waves of a block finish within a few percent)
     int taken = 0;
     for (int b = 0; b < P.n_bodies; ++b) {
+        if (!((body_mask >> b) & 1u)) continue;    // a body of another group: its rectangle is elsewhere
         const double* Rt = pose + 12 * b;
         const int c0 = P.tri_begin[b] >> 6, c1 = P.tri_begin[b + 1] >> 6;
         const int t_end = P.tri_end[b];
@@ -750,7 +769,7 @@ __device__ inline Smem carve(unsigned char* smem, int kTilePx)
 // block-reduced partial log-likelihood (valid in thread 0).
 template <bool UPDATE, int PREC>
 __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect r, int tile_id,
-                                          const Smem& m)
+                                          const Smem& m, unsigned body_mask)
 {
     const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
     const int ty = tile_id / tg.nx, tx = tile_id - ty * tg.nx;
@@ -773,8 +792,8 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     __syncthreads();
     RBS_TICK(1);
     // a rectangle that is a single tile was sized from the same spheres: nothing to cull
-    raster_window(P, pose, wx0, wy0, wx1, wy1, !whole || P.n_bodies > 1, m.tile, m.big, m.nbig,
-                  m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue);   // the eval queue is idle during the raster phase
+    raster_window(P, pose, wx0, wy0, wx1, wy1, !whole || (body_mask & (body_mask - 1u)) != 0u, m.tile, m.big, m.nbig,
+                  m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue, body_mask);   // the eval queue is idle during the raster phase
     RBS_TICK(2);
 
     // Pixel pass.  Only ~1/3 of a tile's pixels are covered by the object, in runs that leave
@@ -920,6 +939,21 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     return total;
 }
 
+// Is (row, col) written by the raster kernel (inside the particle's rectangle; several bodies:
+// inside one of its groups' rectangles)?  q = the particle's union rectangle.
+__device__ inline bool raster_writes(const DevParams& P, int particle, const int4& q, int row, int col)
+{
+    if (!(row >= q.y && row < q.w && col >= q.x && col < q.z)) return false;
+    if (P.groups == nullptr) return true;
+    const Groups* G = P.groups + particle;
+    const int ng = G->n;
+    for (int g = 0; g < ng; ++g) {
+        const int4 r = G->rect[g];
+        if (row >= r.y && row < r.w && col >= r.x && col < r.z) return true;
+    }
+    return false;
+}
+
 // ------------------------------------------------------------------ copy block
 // Rows [band*band_rows, ...) of the parent's plane -> the child's slot, skipping the raster
 // block's rectangle.  VEC == 4: float4 non-temporal stream; VEC == 1: any cols.
@@ -950,7 +984,7 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
             for (int k = 0; k < kCopyUnroll; ++k) {
                 const int idx = base + k * kBlock;
                 const int col = c4 << 2;
-                ok[k] = idx < n4 && !(row >= r.y0 && row < r.y1 && col >= r.x0 && col < r.x1);
+                ok[k] = idx < n4 && !raster_writes(P, particle, make_int4(r.x0, r.y0, r.x1, r.y1), row, col);
 #if RBS_NT
                 if (ok[k]) v[k] = __builtin_nontemporal_load(&s4[idx]);
 #else
@@ -980,7 +1014,7 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
         for (int idx = threadIdx.x; idx < n1; idx += kBlock) {
             const int lr = idx / W;
             const int row = row0 + lr, col = idx - lr * W;
-            if (row >= r.y0 && row < r.y1 && col >= r.x0 && col < r.x1) continue;
+            if (raster_writes(P, particle, make_int4(r.x0, r.y0, r.x1, r.y1), row, col)) continue;
             dst[idx] = occ_step(alpha, beta, src[idx], bg_new);
         }
     }
@@ -1007,10 +1041,56 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
     const bool live = i < P.n;
     Rect r = {0, 0, 0, 0};
     int cnt = 0;
-    if (live) {
+    Groups G;
+    G.n = 0;
+    const int cap_px = min(P.tile_w * P.tile_h, P.tile_px);
+    if (live && P.groups == nullptr) {
         r = particle_rect(P, P.poses + (size_t)i * 12 * P.n_bodies);
-        const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
+        const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, cap_px);
         cnt = r.x1 > r.x0 ? tg.nx * tg.ny : 1;   // an empty rectangle still owns one (empty) item
+    } else if (live) {
+        // several bodies: one rectangle per body, overlapping ones merged (all lanes hold the same
+        // values and take the same branches)
+        Rect gr[kMaxBodies];
+        unsigned gm[kMaxBodies];
+        int ng = 0;
+        for (int b = 0; b < P.n_bodies; ++b) {
+            const Rect br = bodies_rect(P, P.poses + (size_t)i * 12 * P.n_bodies, b, b + 1);
+            if (br.x1 > br.x0) { gr[ng] = br; gm[ng] = 1u << b; ++ng; }
+        }
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (int a = 0; a < ng && !changed; ++a)
+                for (int c = a + 1; c < ng && !changed; ++c)
+                    if (gr[a].x0 < gr[c].x1 && gr[c].x0 < gr[a].x1 && gr[a].y0 < gr[c].y1 && gr[c].y0 < gr[a].y1) {
+                        gr[a].x0 = min(gr[a].x0, gr[c].x0); gr[a].y0 = min(gr[a].y0, gr[c].y0);
+                        gr[a].x1 = max(gr[a].x1, gr[c].x1); gr[a].y1 = max(gr[a].y1, gr[c].y1);
+                        gm[a] |= gm[c];
+                        gr[c] = gr[ng - 1]; gm[c] = gm[ng - 1];
+                        --ng;
+                        changed = true;
+                    }
+        }
+        if (ng > kMaxGroups) {   // more separate objects than groups: one union rectangle
+            for (int c = 1; c < ng; ++c) {
+                gr[0].x0 = min(gr[0].x0, gr[c].x0); gr[0].y0 = min(gr[0].y0, gr[c].y0);
+                gr[0].x1 = max(gr[0].x1, gr[c].x1); gr[0].y1 = max(gr[0].y1, gr[c].y1);
+                gm[0] |= gm[c];
+            }
+            ng = 1;
+        }
+        G.n = ng;
+        if (ng > 0) r = gr[0];
+        for (int g = 0; g < ng; ++g) {
+            const TileGrid tg = tile_grid(gr[g].x1 - gr[g].x0, gr[g].y1 - gr[g].y0, P.tile_w, cap_px);
+            G.rect[g] = make_int4(gr[g].x0, gr[g].y0, gr[g].x1, gr[g].y1);
+            G.mask[g] = gm[g];
+            G.first[g] = cnt;
+            cnt += tg.nx * tg.ny;
+            r.x0 = min(r.x0, gr[g].x0); r.y0 = min(r.y0, gr[g].y0);
+            r.x1 = max(r.x1, gr[g].x1); r.y1 = max(r.y1, gr[g].y1);
+        }
+        if (ng == 0) cnt = 1;
     }
     if (lane == 0) cnts[w] = cnt;
     __syncthreads();
@@ -1022,6 +1102,11 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
     __syncthreads();
     if (!live || lane != 0) return;
     reinterpret_cast<int4*>(rects)[i] = make_int4(r.x0, r.y0, r.x1, r.y1);
+    if (P.groups) {
+        Groups* out = P.groups + i;
+        out->n = G.n;
+        for (int g = 0; g < G.n; ++g) { out->rect[g] = G.rect[g]; out->first[g] = G.first[g]; out->mask[g] = G.mask[g]; }
+    }
     P.done[i] = 0;
     const int parent = P.indices[i];
     P.parents[i] = parent;
@@ -1093,7 +1178,21 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
         const int2 range = P.item_range[particle];
         const int first = range.x;
         double part = 0.0;
-        if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC>(P, particle, r, item - first, m);
+        if (P.groups == nullptr) {
+            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC>(P, particle, r, item - first, m, 0xffffffffu);
+        } else {   // several bodies: the item belongs to one group of bodies with its own rectangle
+            const Groups* G = P.groups + particle;
+            const int k = item - first, ng = __builtin_amdgcn_readfirstlane(G->n);
+            int g = 0;
+            for (int c = 1; c < ng; ++c) g += (k >= __builtin_amdgcn_readfirstlane(G->first[c])) ? 1 : 0;
+            if (ng > 0) {
+                const int4 gq = G->rect[g];
+                const Rect gr = {__builtin_amdgcn_readfirstlane(gq.x), __builtin_amdgcn_readfirstlane(gq.y),
+                                 __builtin_amdgcn_readfirstlane(gq.z), __builtin_amdgcn_readfirstlane(gq.w)};
+                part = raster_eval_tile<UPDATE, PREC>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
+                                                      (unsigned)__builtin_amdgcn_readfirstlane((int)G->mask[g]));
+            }
+        }
         if (threadIdx.x == 0) {
             // the particle's log-likelihood: its only item's sum, or -- by whichever block
             // finishes the particle's last item -- the items' sums added in item order.  The
@@ -1176,7 +1275,7 @@ __global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, 
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         const int row = r0 + k;
-        ok[k] = row < P.rows && !(in_cols && row >= q.y && row < q.w);
+        ok[k] = row < P.rows && !(in_cols && raster_writes(P, particle, q, row, col));
         const bool stored = !WIN || (col >= pw.x && col < pw.z && row >= pw.y && row < pw.w);
         v[k].x = v[k].y = v[k].z = v[k].w = P.bg_old;
         if (ok[k] && stored) v[k] = __builtin_nontemporal_load(&s4[(size_t)row * W4 + c4]);
@@ -1235,7 +1334,14 @@ __global__ __launch_bounds__(64) void rbs_wide_window_kernel(const DevParams P, 
 // written float4 that differs from the background grows the child's window (atomic min/max once
 // per wave), so a window shrinks again as soon as the values it held have decayed into the
 // background snap.
-constexpr int kWinUnroll = 4;
+// Two float4 loads in flight per lane = 32 VGPRs: exactly what three resident raster waves
+// (157 -> 160 allocated each) leave free on a SIMD, so one copy wave per SIMD runs BESIDE the
+// persistent raster blocks instead of only before and after them (with four loads, 48 VGPRs, it
+// could not: C2 3.33 -> 3.61 M/s, C3 slice 12.0 -> 12.8 M/s, C1 step 0.2055 -> 0.2015 ms).
+#ifndef RBS_WIN_UNROLL
+#define RBS_WIN_UNROLL 2
+#endif
+constexpr int kWinUnroll = RBS_WIN_UNROLL;
 __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
 {
     const int particle = (int)blockIdx.y + (int)blockIdx.z * (int)gridDim.y;
@@ -1245,7 +1351,9 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
     const int4 u = P.win_used[particle];
     if (u.z <= u.x || u.w <= u.y) return;
     const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
-    if (q.z > q.x && q.x == u.x && q.y == u.y && q.z == u.z && q.w == u.w) return;   // all raster's
+    if (q.z > q.x && q.x == u.x && q.y == u.y && q.z == u.z && q.w == u.w &&
+        (P.groups == nullptr || (P.groups[particle].n == 1)))
+        return;   // all raster's
     const int4 pw = parent_window(P, parent);
     const int w4 = (u.z - u.x) >> 2, ux4 = u.x >> 2, W4 = P.cols >> 2;
     const int rpc = (u.w - u.y + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1267,7 +1375,7 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
         for (int k = 0; k < kWinUnroll; ++k) {
             const int idx = base + k * 64 + lane;
             const int col = (ux4 + c4) << 2;
-            const bool live = idx < n4 && !(row >= q.y && row < q.w && col >= q.x && col < q.z);
+            const bool live = idx < n4 && !raster_writes(P, particle, q, row, col);
             const bool stored = live && col >= pw.x && col < pw.z && row >= pw.y && row < pw.w;
             st[k] = live ? (stored ? 2 : 1) : 0;
             at[k] = row * W4 + ux4 + c4;
@@ -1341,7 +1449,7 @@ __global__ __launch_bounds__(kBlock) void rbs_render_kernel(const DevParams P, f
             for (int p = threadIdx.x; p < npx; p += kBlock) m.tile[p] = kInfBits;
             __syncthreads();
             raster_window(P, P.poses, wx0, wy0, wx1, wy1, true, m.tile, m.big, m.nbig,
-                          m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue);
+                          m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue, 0xffffffffu);
             for (int p = threadIdx.x; p < npx; p += kBlock) {
                 const int lr = p / tw;
                 out[(wy0 + lr) * P.cols + wx0 + (p - lr * tw)] = __uint_as_float(m.tile[p]);
