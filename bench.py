@@ -29,6 +29,12 @@ in HBM before the timed region, device-pointer API.  The same JSON line carries,
 With `torch.distributed.run` (--gpus N, one rank per GPU) each rank evaluates its own 2 000-particle
 shard (weak scaling) and the per-particle log-likelihoods are all-gathered over RCCL every step
 (the weight exchange before resampling); only the headline is measured then.
+
+`python bench.py --gpus N` WITHOUT torch.distributed.run (WORLD_SIZE unset) measures the other
+multi-GPU form: ONE process, one handle over N devices (rbs_config.n_devices; --device-ids to
+list them, an ordinal may repeat on a one-GPU box): N x 2 000 particles per step through
+rbs_loglikes from host memory (frame + pose upload and log-likelihood download inside the
+clock), plus the sharded device tracker's frames/s.
 """
 import argparse
 import csv
@@ -82,6 +88,7 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true", help="no live rocprofv3 counter passes (roofline falls back to profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--device-ids", default=None, help="in-process multi-device mode: comma-separated HIP ordinals (default 0..N-1)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the process rocprofv3 wraps
     a = ap.parse_args()
     presets = {"c1": {}, "c1_readonly": {"update": 0},
@@ -400,9 +407,77 @@ def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30):
     return out
 
 
+# --------------------------------------------------------------------------------- one process, several devices
+def in_process_multi_device(a):
+    """One handle over a.gpus devices (rbs_config.n_devices): the form a single-process
+    particle_tracker node uses.  Weak scaling: a.particles per device."""
+    from dbot_ros_amd import RbSensor, pose, synth
+    from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
+    ids = [int(x) for x in a.device_ids.split(",")] if a.device_ids else list(range(a.gpus))
+    if len(ids) != a.gpus:
+        raise SystemExit("--device-ids must list --gpus ordinals")
+    om, cam, P, n_tri, nb = build_scene(a)
+    n = a.particles * a.gpus
+    dev = torch.device("cuda", ids[0])
+    torch.cuda.set_device(dev)
+    a_one = argparse.Namespace(**vars(a))
+    W = Workload(a_one, om, cam, P, nb, dev, 0)
+    rng = np.random.default_rng(5)
+    poses = np.stack([synth.particle_poses(t, n, rng).reshape(n, -1) for t in W.truths])
+    parents = synth.resample_like_indices(n, rng)
+    with RbSensor(om, cam, P, max_particles=n, precision=a.precision, state_layout=a.layout, device_ids=ids) as g:
+        g.reset()
+
+        def step(i):
+            k = W.order[i % len(W.order)]
+            g.set_observation(W.frames[k])
+            return g.loglikes_poses(poses[k], parents.copy(), update=bool(a.update))
+
+        for i in range(a.warmup):
+            step(i)
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            ll = step(i)
+        elapsed = time.perf_counter() - t0
+        if not np.isfinite(ll).all():
+            raise SystemExit("non-finite log-likelihoods in the timed run")
+        # the sharded device tracker on the same handle
+        trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=nb)).build()
+        tr = DeviceParticleTracker(trans, g, om, ParticleTrackerBuilder.Parameters(evaluation_count=n * nb), device_rng=True, seed=1)
+        init = np.zeros(12 * nb)
+        for b in range(nb):
+            Rt = W.truths[0][b]
+            init[12 * b + 3:12 * b + 6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+            init[12 * b:12 * b + 3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[b]
+        tr.initialize([init])
+        tr.track(W.frames[0])
+        nf = min(30, len(W.frames) - 1) or 1
+        t0 = time.perf_counter()
+        for k in range(1, nf + 1):
+            tr.track(W.frames[k % len(W.frames)])
+        fps = nf / (time.perf_counter() - t0)
+        tr.close()
+    print(json.dumps({
+        "metric": "particle-likelihoods/sec @640x480" if (a.cols, a.rows) == (640, 480) else f"particle-likelihoods/sec @{a.cols}x{a.rows}",
+        "value": n * a.steps / elapsed, "unit": "particle-likelihoods/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 geometry + f32 likelihood (precision F32)" if a.precision == "f32" else "f64", "data": "synthetic",
+        "config": {"workload": f"C1 x {a.gpus}: ONE process, one handle over devices {ids} (rbs_config.n_devices), {a.particles} particles per "
+                               f"device, host-pointer API (frame + poses uploaded, log-likelihoods downloaded every step), "
+                               f"{a.cols}x{a.rows}, mesh {a.mesh} ({n_tri} triangles), precision {a.precision}",
+                   "particles_per_gpu": a.particles, "resolution": [a.cols, a.rows], "triangles": int(n_tri),
+                   "sharding": f"particles/{a.gpus} inside the handle: peer reads of remote parents, RCCL all-gather in the tracker"},
+        "tracker_fps_sharded": fps, "tracker_particles": n,
+    }), flush=True)
+
+
 # --------------------------------------------------------------------------------- main
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.pmc_child:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
+        return in_process_multi_device(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -222,8 +222,10 @@ _TYPES = {_IMAGE_TYPE: Image, _INFO_TYPE: CameraInfo}
 
 
 # ------------------------------------------------------------------ bag layer
-def read_bag(path, topics=None):
-    """All messages of a v2.0 bag in file order as (topic, type, receipt Stamp, raw bytes).
+def read_bag(path, topics=None, time_order=True):
+    """All messages of a v2.0 bag as (topic, type, receipt Stamp, raw bytes), in RECEIPT-TIME order
+    (stable: file order among equal stamps), which is how rosbag::View iterates across chunks
+    (R:source/dbot_ros/util/tracking_dataset.cpp:189,204); time_order=False gives file order.
     Chunks may be uncompressed or bz2; the index records are not needed and are skipped."""
     with open(path, "rb") as fh:
         buf = fh.read()
@@ -261,6 +263,8 @@ def read_bag(path, topics=None):
                 handle(h2, d2)
         else:
             handle(header, data)
+    if time_order:
+        out.sort(key=lambda m: (m[2][0], m[2][1]))     # (secs, nsecs); list.sort is stable
     return out
 
 
@@ -368,8 +372,12 @@ class TrackingDataset:
         self.data.append(f)
 
     def load(self, first_line_only=False):
-        """first_line_only=True reproduces LoadTextFile as written (:231-283: one getline, so
-        only the first line's state is attached); the default reads every line."""
+        """Messages are replayed in receipt-time order, as rosbag::View delivers them.
+        ground_truth.txt: the reference's LoadTextFile (:231-283) does ONE getline, i.e. attaches
+        only the first line's state (to the frames within admissible_delta_time of its stamp);
+        first_line_only=True reproduces that as written.  The default reads every line -- a
+        deliberate divergence: Store() (:298-333) writes one line per frame, and a replay that
+        wants per-frame ground truth needs them all."""
         topics = {self.image_topic, self.info_topic, "/" + self.image_topic, "/" + self.info_topic}
         self._synchronize(read_bag(os.path.join(self.path, self.observations_filename), topics))
         gt = os.path.join(self.path, self.ground_truth_filename)

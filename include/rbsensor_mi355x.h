@@ -159,6 +159,23 @@ int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t*
 /* Block until everything enqueued on the handle's own stream has finished. */
 int32_t rbs_synchronize(rbs_handle* h);
 
+/* --- several devices in one handle --------------------------------------------------------
+ * rbs_config.n_devices > 1 (the reference's tracker node is ONE process,
+ * R:source/dbot_ros/tracker/particle_tracker_node.cpp:277-284): the handle shards the particles over
+ * device_ids[].  Occlusion slots are GLOBAL, 0 .. n_devices * cap - 1 with
+ * cap = ceil(max_particles / n_devices); slot g lives on device_ids[g / cap].  rbs_loglikes
+ * evaluates particle i on the device that owns slot i (an updating call writes slot i there);
+ * indices[i] may name a plane on any device -- a remote parent's window is read in place over
+ * xGMI (peer access), nothing migrates.  rbs_set_observation* upload the frame to every device.
+ * rbs_tracker_* on such a handle runs the filter replicated on every device, shards the sensor
+ * call by a parent-affine layout and exchanges the log-likelihoods with one RCCL all-gather per
+ * sampling block (librccl is bound with dlopen when such a handle is created).  The zero-copy
+ * single-device entry points rbs_set_observation_device / rbs_loglikes_device return
+ * RBS_ERR_UNSUPPORTED; slot-addressed hooks (rbs_get/set_occlusion, rbs_get_window,
+ * rbs_export/import_plane, rbs_occlusion_*device_ptr) take global slots and act on the owning
+ * device; rbs_render_depth, rbs_get_observation, the timing queries answer for device_ids[0].
+ * An ordinal may repeat in device_ids (several shards on one GPU: functional tests). */
+
 /* --- occlusion state layout -------------------------------------------------------------
  * A slot's plane is stored as a WINDOW (a pixel rectangle) plus the handle-wide background
  * level: outside its window a plane equals the value a never-covered pixel has reached
@@ -167,7 +184,7 @@ int32_t rbs_synchronize(rbs_handle* h);
  * re-tightens the child's window to the values that still differ from the background; the
  * process snaps a value within 2^-18 of the background onto it, so a window follows the object
  * instead of growing for ever.  The numbers are those of whole planes (oracle mode EAGER);
- * only the bytes moved change.  RBS_STATE=dense in the environment at rbs_create keeps whole
+ * only the bytes moved change.  rbs_config.state_layout = RBS_STATE_DENSE keeps whole
  * planes (every updating call then copies every plane in full).  Every entry point below
  * hands out / accepts whole planes in either layout. */
 /* --- inspection hooks (tests, state migration between devices) --- */

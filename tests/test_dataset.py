@@ -164,3 +164,18 @@ def test_malformed_bags_are_rejected(tmp_path):
     p.write_bytes(buf[:len(buf) - 7])
     with pytest.raises(ds.BagFormatError):
         ds.read_bag(p)
+
+
+def test_messages_are_replayed_in_receipt_time_order(tmp_path):
+    """rosbag::View iterates in time order across chunks, whatever the order the records were
+    written in; read_bag(time_order=False) exposes the file order."""
+    from dbot_ros_amd import dataset as ds
+    ims = []
+    for k in (2, 0, 1):                     # written out of order
+        im = ds.Image(np.full((4, 6), 0.5 + k, np.float32), ds.Stamp(10 + k, 0))
+        ims.append(im)
+    path = tmp_path / "o.bag"
+    ds.write_bag(str(path), [(ds.IMAGE_TOPIC, im.stamp, im) for im in ims])
+    in_file = [m[2][0] for m in ds.read_bag(str(path), time_order=False)]
+    in_time = [m[2][0] for m in ds.read_bag(str(path))]
+    assert in_file == [12, 10, 11] and in_time == [10, 11, 12]
