@@ -14,8 +14,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 BIN = os.path.join(HERE, "cpp", "shim_check")
 
 
+BIN_ASAN = os.path.join(HERE, "cpp", "shim_check_asan")
+SAN_ENV = {"ASAN_OPTIONS": "detect_leaks=0:protect_shadow_gap=0:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"}
+
+
 def _build():
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "cpp")])
+
+
+def _build_asan():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "..", "dbot_ros_amd", "csrc"), "asan"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "cpp"), "asan"])
+
+
+def _clean(stderr):
+    bad = [ln for ln in stderr.splitlines() if "AddressSanitizer" in ln or "runtime error" in ln or "SUMMARY" in ln]
+    assert not bad, "\n".join(bad[:20])
 
 
 def _scene(tmp_path):
@@ -59,6 +73,36 @@ def test_cpp_shim_builds_and_fails_loudly_without_gpu(tmp_path):
     path, *_ = _scene(tmp_path)
     out = subprocess.run([BIN, str(path)], capture_output=True, text=True, check=True).stdout
     assert out.startswith("NO_DEVICE") and "no CPU path" in out
+
+
+def test_host_code_under_sanitizers_without_gpu(tmp_path):
+    """the library's host code (argument checks, error paths, the C++ mirror's
+    exception translation) under AddressSanitizer + UndefinedBehaviorSanitizer, on the path a box
+    without a GPU takes."""
+    _build_asan()
+    from dbot_ros_amd import _capi
+    if _capi.load().rbs_device_count() > 0:
+        pytest.skip("GPU visible: covered by the gpu test")
+    path, *_ = _scene(tmp_path)
+    r = subprocess.run([BIN_ASAN, str(path)], capture_output=True, text=True, env=dict(os.environ, **SAN_ENV))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.startswith("NO_DEVICE")
+    _clean(r.stderr)
+
+
+@pytest.mark.gpu
+def test_host_code_under_sanitizers(tmp_path, gpu_lib):
+    """The same driver as test_cpp_shim_matches_oracle -- sensor construction in the node's order,
+    two loglikes calls, three frames of the device tracker -- against the ASan + UBSan build of the
+    library's host code: no report, and the very same output as the plain build."""
+    _build()
+    _build_asan()
+    path, *_ = _scene(tmp_path)
+    plain = subprocess.run([BIN, str(path)], capture_output=True, text=True, check=True)
+    r = subprocess.run([BIN_ASAN, str(path)], capture_output=True, text=True, env=dict(os.environ, **SAN_ENV))
+    assert r.returncode == 0, r.stderr[-2000:]
+    _clean(r.stderr)
+    assert r.stdout == plain.stdout
 
 
 @pytest.mark.gpu
