@@ -72,6 +72,8 @@ class RbsConfig(C.Structure):
         ("state_layout", C.c_int32),
         ("n_devices", C.c_int32),
         ("device_ids", C.POINTER(C.c_int32)),
+        ("state_slab_px", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

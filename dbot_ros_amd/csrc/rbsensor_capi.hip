@@ -31,7 +31,7 @@
 
 using rbs::DevParams;
 
-static_assert(sizeof(rbs_config) == 208 && offsetof(rbs_config, likelihood_precision) == 184 &&
+static_assert(sizeof(rbs_config) == 216 && offsetof(rbs_config, state_slab_px) == 208 && offsetof(rbs_config, likelihood_precision) == 184 &&
                   offsetof(rbs_config, device_ids) == 200,
               "rbs_config layout (ABI 2) is mirrored by dbot_ros_amd/_capi.py and tests/test_capi_cpu.py");
 
@@ -60,6 +60,14 @@ struct rbs_handle {
     int* d_parents[2] = {nullptr, nullptr};   // [max_particles] snapshot of the caller's indices, alternating like d_rects
     int4* d_win[2] = {nullptr, nullptr};   // [max_particles] window of each plane, per buffer
     int4* d_win_used = nullptr; // [max_particles] region the copy kernel writes this call
+    // window-sized slabs (rbs_config.state_slab_px): a slot holds slab_px floats and the stored region
+    // of its plane; 0 = whole planes
+    int slab_px = 0;
+    size_t plane_stride = 0;    // floats per slot: npx or slab_px
+    int4* d_reg[2] = {nullptr, nullptr};   // [max_particles] stored region of each plane, per buffer
+    int* d_err = nullptr;       // [1] sticky device flag: a region did not fit its slab
+    int* h_err = nullptr;       // pinned copy, fetched with the log-likelihoods
+    int* d_bbox = nullptr;      // [4] scratch of rbs_import_plane / rbs_set_occlusion
     bool windowed = true;       // planes valid inside their window only (RBS_STATE=dense: whole plane)
     // windowed planes whose windows have grown to a large part of the frame are served like whole
     // planes (streaming copy kernel beside two raster blocks per CU); the stored area is sampled
@@ -141,6 +149,7 @@ struct rbs_handle {
     struct Rccl* rccl = nullptr;       // group: communicators for the log-likelihood all-gather (device tracker)
     const float* snap_occ[rbs::kMaxDevices] = {};   // group: every shard's CURRENT planes / windows as of the start
     const int4* snap_win[rbs::kMaxDevices] = {};    //   of the call being fanned out (shards flip buffers one by one)
+    const int4* snap_reg[rbs::kMaxDevices] = {};
 };
 
 // RCCL, bound at run time (dlopen): a single-device handle never needs it, and a process that
@@ -242,6 +251,23 @@ int32_t flush_lazy_frame(rbs_handle* h, hipStream_t then)
     return RBS_OK;
 }
 
+// The eight instantiations of the raster kernel: updating or read-only call, likelihood precision,
+// whole planes or slabs.
+void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size_t smem, hipStream_t s, const DevParams& P)
+{
+    const int key = (update ? 4 : 0) | (h->precision == RBS_PRECISION_F32 ? 2 : 0) | (h->slab_px ? 1 : 0);
+    switch (key) {
+        case 0: hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 0, false>), grid, block, smem, s, P); break;
+        case 1: hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 0, true>), grid, block, smem, s, P); break;
+        case 2: hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 1, false>), grid, block, smem, s, P); break;
+        case 3: hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 1, true>), grid, block, smem, s, P); break;
+        case 4: hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 0, false>), grid, block, smem, s, P); break;
+        case 5: hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 0, true>), grid, block, smem, s, P); break;
+        case 6: hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 1, false>), grid, block, smem, s, P); break;
+        default: hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 1, true>), grid, block, smem, s, P); break;
+    }
+}
+
 int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indices, int n,
                          bool update, double* d_out, hipStream_t s)
 {
@@ -264,6 +290,11 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.slots = h->max_particles;
     P.n_dev = 1;
     P.shard_cap = h->max_particles;
+    P.slab_px = h->slab_px;
+    P.plane_stride = (int)h->plane_stride;
+    P.reg_src = h->d_reg[h->cur];
+    P.reg_dst = h->d_reg[1 - h->cur];
+    P.err = h->d_err;
     if (h->group) {   // the planes and windows of every shard of the group: parents are global slots
         rbs_handle* g = h->group;
         P.n_dev = (int)g->shards.size();
@@ -272,6 +303,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         for (int k = 0; k < P.n_dev; ++k) {
             P.occ_src_dev[k] = g->snap_occ[k];
             P.win_src_dev[k] = g->snap_win[k];
+            P.reg_src_dev[k] = g->snap_reg[k];
         }
     }
     P.out = d_out;
@@ -286,7 +318,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     if (h->windowed && update && h->area_pending && hipEventQuery(h->ev_area) == hipSuccess) {
         const double frac = (double)*h->h_area / ((double)h->area_n * (double)h->npx);   // sampled a few calls ago
         h->area_frac = frac;
-        if (frac > h->wide_enter) h->wide = true;
+        if (frac > h->wide_enter && !h->slab_px) h->wide = true;   // (slabs: regions that large do not fit anyway)
         else if (frac < h->wide_leave) h->wide = false;
         h->area_pending = false;
     }
@@ -374,7 +406,8 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
             const int ny = std::min(n, 32768);
             const dim3 wg((unsigned)h->win_chunks, (unsigned)ny, (unsigned)((n + ny - 1) / ny));
-            hipLaunchKernelGGL(rbs::rbs_copy_window_kernel, wg, dim3(64), 0, h->copy_stream, P);
+            if (h->slab_px) hipLaunchKernelGGL(rbs::rbs_copy_window_kernel<true>, wg, dim3(64), 0, h->copy_stream, P);
+            else hipLaunchKernelGGL(rbs::rbs_copy_window_kernel<false>, wg, dim3(64), 0, h->copy_stream, P);
             RBS_HIP(h, hipGetLastError());
             if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_stop[tslot], h->copy_stream));
             RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
@@ -391,10 +424,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     const dim3 rgrid((unsigned)(wide || mid ? std::min(h->raster_blocks, 2 * h->cu_count) : h->raster_blocks));
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
     if (update) {
-        if (h->precision == RBS_PRECISION_F32)
-            hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 1>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
-        else
-            hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 0>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
+        launch_raster(h, true, rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
@@ -436,10 +466,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
         }
     } else {
-        if (h->precision == RBS_PRECISION_F32)
-            hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 1>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
-        else
-            hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 0>), rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
+        launch_raster(h, false, rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
     }
@@ -467,14 +494,65 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
 int32_t materialize(rbs_handle* h, int slot, hipStream_t s)
 {
     if (!h->windowed) return RBS_OK;
+    if (h->slab_px) return fail(h, RBS_ERR_UNSUPPORTED, "a slab cannot be made dense in place (state_slab_px)");
     hipLaunchKernelGGL(rbs::rbs_materialize_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s,
-                       h->d_occ[h->cur] + (size_t)slot * h->npx, h->d_win[h->cur] + slot, h->rows, h->cols,
+                       h->d_occ[h->cur] + (size_t)slot * h->plane_stride, h->d_win[h->cur] + slot, h->rows, h->cols,
                        h->background);
     RBS_HIP(h, hipGetLastError());
     hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_win[h->cur] + slot, 1,
                        make_int4(0, 0, h->cols, h->rows));
     RBS_HIP(h, hipGetLastError());
     return RBS_OK;
+}
+
+// Slabs: a slot's plane as a whole plane in `d_full` (device, npx floats), on stream s.
+int32_t slab_expand(rbs_handle* h, int slot, float* d_full, hipStream_t s)
+{
+    hipLaunchKernelGGL(rbs::rbs_expand_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s,
+                       h->d_occ[h->cur] + (size_t)slot * h->plane_stride, h->d_reg[h->cur] + slot, h->d_win[h->cur] + slot,
+                       h->rows, h->cols, h->background, d_full);
+    RBS_HIP(h, hipGetLastError());
+    return RBS_OK;
+}
+
+// Slabs: store a whole plane (device, npx floats) into a slot: its stored region and window become
+// the float4-aligned bounding box of the values that differ from the background.  Synchronises
+// (the box is needed on the host to check that it fits).
+int32_t slab_store(rbs_handle* h, int slot, const float* d_full, hipStream_t s)
+{
+    const int init[4] = {h->cols, h->rows, 0, 0};
+    RBS_HIP(h, hipMemcpyAsync(h->d_bbox, init, sizeof(init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(rbs::rbs_bbox_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, d_full, h->rows,
+                       h->cols, h->background, h->d_bbox);
+    RBS_HIP(h, hipGetLastError());
+    int box[4];
+    RBS_HIP(h, hipMemcpyAsync(box, h->d_bbox, sizeof(box), hipMemcpyDeviceToHost, s));
+    RBS_HIP(h, hipStreamSynchronize(s));
+    int4 r = make_int4(box[0], box[1], std::min(box[2], h->cols), box[3]);
+    if (r.z <= r.x || r.w <= r.y) r = make_int4(h->cols, h->rows, 0, 0);   // all background
+    const long area = r.z > r.x ? (long)(r.z - r.x) * (r.w - r.y) : 0;
+    if (area > (long)h->slab_px)
+        return fail(h, RBS_ERR_OUT_OF_MEMORY,
+                    fmt("a plane whose values differ from the background over %ld px does not fit a slab of %d px (state_slab_px)", area, h->slab_px));
+    if (area > 0) {
+        hipLaunchKernelGGL(rbs::rbs_pack_kernel, dim3((unsigned)((area + 255) / 256)), dim3(256), 0, s, d_full, r, h->cols,
+                           h->d_occ[h->cur] + (size_t)slot * h->plane_stride);
+        RBS_HIP(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_win[h->cur] + slot, 1, r);
+    hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_reg[h->cur] + slot, 1, r);
+    RBS_HIP(h, hipGetLastError());
+    return RBS_OK;
+}
+
+// The sticky "a region did not fit its slab" flag, fetched by the synchronising entry points.
+int32_t check_slab_error(rbs_handle* h)
+{
+    if (!h->slab_px || !*h->h_err) return RBS_OK;
+    return fail(h, RBS_ERR_OUT_OF_MEMORY,
+                fmt("a particle's occlusion window (with its screen rectangle) exceeded the slab of %d px "
+                    "(rbs_config.state_slab_px): its log-likelihood is NaN and its plane was reset to the "
+                    "background; create the handle with a larger slab", h->slab_px));
 }
 
 // Make stream `s` (and the host, if sync) see the planes of the last updating call complete.
@@ -517,6 +595,11 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_win[0]);
     (void)hipFree(h->d_win[1]);
     (void)hipFree(h->d_win_used);
+    (void)hipFree(h->d_reg[0]);
+    (void)hipFree(h->d_reg[1]);
+    (void)hipFree(h->d_err);
+    (void)hipFree(h->d_bbox);
+    if (h->h_err) (void)hipHostFree(h->h_err);
     (void)hipFree(h->d_item_range);
     (void)hipFree(h->d_item_particle);
     (void)hipFree(h->d_ctr);
@@ -638,6 +721,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     }
     if (cfg->state_layout < RBS_STATE_DEFAULT || cfg->state_layout > RBS_STATE_DENSE)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("state_layout %d", cfg->state_layout));
+    if (cfg->state_slab_px < 0)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("state_slab_px %d", cfg->state_slab_px));
 
     DevParams& B = h->base;
     B.rows = h->rows; B.cols = h->cols; B.npx = h->npx;
@@ -919,8 +1004,23 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         RBS_HIP(h, hipMalloc(&h->d_pbg, plane));
     }
     RBS_HIP(h, hipMalloc(&h->d_render, plane));
-    RBS_HIP(h, hipMalloc(&h->d_occ[0], plane * h->max_particles));
-    RBS_HIP(h, hipMalloc(&h->d_occ[1], plane * h->max_particles));
+    // slabs apply to windowed planes only; a slab as large as a plane is a plane
+    h->slab_px = 0;
+    if (h->windowed && cfg->state_slab_px > 0 && cfg->state_slab_px < h->npx)
+        h->slab_px = std::max(1024, (cfg->state_slab_px + 3) & ~3);
+    if (h->slab_px >= h->npx) h->slab_px = 0;
+    h->plane_stride = h->slab_px ? (size_t)h->slab_px : (size_t)h->npx;
+    RBS_HIP(h, hipMalloc(&h->d_occ[0], sizeof(float) * h->plane_stride * h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_occ[1], sizeof(float) * h->plane_stride * h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_err, sizeof(int)));
+    RBS_HIP(h, hipMemset(h->d_err, 0, sizeof(int)));
+    RBS_HIP(h, hipHostMalloc(&h->h_err, sizeof(int), hipHostMallocDefault));
+    *h->h_err = 0;
+    RBS_HIP(h, hipMalloc(&h->d_bbox, sizeof(int) * 4));
+    if (h->slab_px) {
+        RBS_HIP(h, hipMalloc(&h->d_reg[0], sizeof(int4) * (size_t)h->max_particles));
+        RBS_HIP(h, hipMalloc(&h->d_reg[1], sizeof(int4) * (size_t)h->max_particles));
+    }
     RBS_HIP(h, hipMalloc(&h->d_poses, sizeof(double) * 12 * h->n_bodies * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_indices, sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_out, sizeof(double) * (size_t)h->max_particles));
@@ -986,14 +1086,15 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     }
 
     // the raster / render kernels carve the LDS depth tile from dynamic shared memory
-    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 0>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
-    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 0>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
-    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
-    RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
+    {
+        const void* kernels[] = {
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 0, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 0, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 1, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 1, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 0, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 0, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 1, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 1, true>)};
+        for (const void* k : kernels)
+            RBS_HIP(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
+    }
     RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_render_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
 
@@ -1039,6 +1140,7 @@ int32_t group_begin_call(rbs_handle* g, hipStream_t const* streams)
     for (int k = 0; k < nd; ++k) {
         g->snap_occ[k] = g->shards[k]->d_occ[g->shards[k]->cur];
         g->snap_win[k] = g->shards[k]->d_win[g->shards[k]->cur];
+        g->snap_reg[k] = g->shards[k]->d_reg[g->shards[k]->cur];
     }
     for (int a = 0; a < nd; ++a) {
         rbs_handle* A = g->shards[a];
@@ -1224,6 +1326,7 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
                                           h->d_out, h->stream))
             return gfail(g, h, rc);
         RBS_HIP(g, hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
+        if (h->slab_px) RBS_HIP(g, hipMemcpyAsync(h->h_err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         RBS_HIP(g, hipEventRecord(h->ev_out, h->stream));
     }
     for (int k = 0; k < nd; ++k) {
@@ -1236,6 +1339,8 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
     }
     if (update)
         for (int32_t i = 0; i < n; ++i) indices[i] = i;
+    for (rbs_handle* h : g->shards)
+        if (int32_t rc = check_slab_error(h)) return gfail(g, h, rc);
     return RBS_OK;
 }
 
@@ -1343,7 +1448,15 @@ int32_t rbs_reset(rbs_handle* h)
             hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(g), dim3(256), 0, h->stream, h->d_win[b],
                                h->max_particles, w0);
     }
-    const size_t n = (size_t)h->npx * h->max_particles;
+    if (h->slab_px) {
+        const unsigned g = (unsigned)((h->max_particles + 255) / 256);
+        for (int b = 0; b < 2; ++b)
+            hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(g), dim3(256), 0, h->stream, h->d_reg[b],
+                               h->max_particles, make_int4(h->cols, h->rows, 0, 0));
+    }
+    RBS_HIP(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
+    *h->h_err = 0;
+    const size_t n = h->plane_stride * h->max_particles;
     hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(2048), dim3(256), 0, h->stream, h->d_occ[0], n,
                        (float)h->init_occ);
     // the second buffer too: touches every page now instead of inside the first updating call
@@ -1483,12 +1596,13 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
                                         h->d_out, h->stream);
     if (rc != RBS_OK) return rc;
     RBS_HIP(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    if (h->slab_px) RBS_HIP(h, hipMemcpyAsync(h->h_err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     RBS_HIP(h, hipEventRecord(h->ev_out, h->stream));
     RBS_HIP(h, hipEventSynchronize(h->ev_out));
     std::memcpy(out_loglik, h->h_out, sizeof(double) * (size_t)n);
     if (update)
         for (int32_t i = 0; i < n; ++i) indices[i] = i;
-    return RBS_OK;
+    return check_slab_error(h);
 }
 
 int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t* d_indices,
@@ -1514,7 +1628,8 @@ int32_t rbs_synchronize(rbs_handle* h)
     RBS_GROUP_ALL(h, rbs_synchronize(sh_));
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;
-    return RBS_OK;
+    if (h->slab_px) RBS_HIP(h, hipMemcpy(h->h_err, h->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    return check_slab_error(h);
 }
 
 int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out)
@@ -1525,6 +1640,12 @@ int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("get_occlusion: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;
+    if (h->slab_px) {
+        if (int32_t rc = slab_expand(h, slot, h->d_render, h->stream)) return rc;
+        RBS_HIP(h, hipStreamSynchronize(h->stream));
+        RBS_HIP(h, hipMemcpy(out, h->d_render, sizeof(float) * h->npx, hipMemcpyDeviceToHost));
+        return RBS_OK;
+    }
     if (int32_t rc = materialize(h, slot, h->stream)) return rc;
     RBS_HIP(h, hipStreamSynchronize(h->stream));
     RBS_HIP(h, hipMemcpy(out, h->d_occ[h->cur] + (size_t)slot * h->npx, sizeof(float) * h->npx,
@@ -1540,6 +1661,10 @@ int32_t rbs_set_occlusion(rbs_handle* h, int32_t slot, const float* plane)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("set_occlusion: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;
+    if (h->slab_px) {
+        RBS_HIP(h, hipMemcpy(h->d_render, plane, sizeof(float) * h->npx, hipMemcpyHostToDevice));
+        return slab_store(h, slot, h->d_render, h->stream);
+    }
     RBS_HIP(h, hipMemcpy(h->d_occ[h->cur] + (size_t)slot * h->npx, plane, sizeof(float) * h->npx,
                          hipMemcpyHostToDevice));
     if (h->windowed) {   // the whole plane is explicit now; the next updating call tightens it again
@@ -1572,6 +1697,7 @@ int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out)
     if (slot < 0 || slot >= h->max_particles || !out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("occlusion_next_device_ptr: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
+    if (h->slab_px) return fail(h, RBS_ERR_UNSUPPORTED, "occlusion_next_device_ptr: slots are slabs, not planes (state_slab_px)");
     if (int32_t rc = drain(h, true)) return rc;   // planes complete before the caller touches them
     *out = h->d_occ[1 - h->cur] + (size_t)slot * h->npx;
     return RBS_OK;
@@ -1586,6 +1712,7 @@ int32_t rbs_export_plane(rbs_handle* h, int32_t slot, void* d_dst, void* stream)
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    if (h->slab_px) return slab_expand(h, slot, static_cast<float*>(d_dst), s);
     if (int32_t rc = materialize(h, slot, s)) return rc;
     RBS_HIP(h, hipMemcpyAsync(d_dst, h->d_occ[h->cur] + (size_t)slot * h->npx, sizeof(float) * h->npx,
                               hipMemcpyDeviceToDevice, s));
@@ -1601,6 +1728,7 @@ int32_t rbs_import_plane(rbs_handle* h, int32_t slot, const void* d_src, void* s
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    if (h->slab_px) return slab_store(h, slot, static_cast<const float*>(d_src), s);   // (synchronises: the box must fit)
     RBS_HIP(h, hipMemcpyAsync(h->d_occ[h->cur] + (size_t)slot * h->npx, d_src, sizeof(float) * h->npx,
                               hipMemcpyDeviceToDevice, s));
     if (h->windowed) {
@@ -2072,10 +2200,11 @@ int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* norm
     RBT_HIP(t, hipMemcpyAsync(out_state, T.deflt, sizeof(double) * T.D, hipMemcpyDeviceToHost, s));
     int flags[2] = {0, 0};
     RBT_HIP(t, hipMemcpyAsync(flags, T.flag, sizeof(flags), hipMemcpyDeviceToHost, s));
+    if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(h->h_err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
     RBT_HIP(t, hipStreamSynchronize(s));
     if (out_resamplings) *out_resamplings = flags[1];
     T.frame += 1;
-    return RBS_OK;
+    return check_slab_error(h);
 }
 
 int32_t rbs_tracker_get(rbs_tracker* t, double* particles, double* log_weights, int32_t* indices)

@@ -133,6 +133,17 @@ struct DevParams {
     int n_dev, shard_cap;
     const float* occ_src_dev[kMaxDevices];   // current planes of every device of the handle
     const int4* win_src_dev[kMaxDevices];    // ... and their windows
+    const int4* reg_src_dev[kMaxDevices];    // ... and (slabs) their stored regions
+    // Window-sized slabs (rbs_config.state_slab_px > 0; windowed planes only): a slot holds
+    // slab_px floats instead of a whole plane and stores its REGION reg = (x0, y0, x1, y1) row-major
+    // with stride x1 - x0 -- the region an updating call writes, bbox(parent window, rectangle),
+    // which contains the plane's window.  A child whose region does not fit its slab is contained
+    // like a bad parent slot (log-likelihood NaN, empty plane) and raises the sticky err flag.
+    int slab_px;                   // 0: whole planes (a slot = npx floats, stride cols)
+    int plane_stride;              // floats per slot: npx or slab_px
+    const int4* reg_src;           // [slots] stored region of each parent plane
+    int4* reg_dst;                 // [slots] stored region of each child plane (= win_used of this call)
+    int* err;                      // [1] sticky: 1 = a particle's region did not fit its slab
     const float* occ_src;          // [slots][npx]
     float* occ_dst;                // [slots][npx]
     const double* poses;           // [n][n_bodies][12]
@@ -197,9 +208,29 @@ __device__ inline float occ_step(float alpha, float beta, float v, float bg_new)
 // Where a parent slot's plane and window are: this device's buffers, or a peer's (see DevParams).
 __device__ inline const float* parent_plane(const DevParams& P, int parent)
 {
-    if (P.n_dev <= 1) return P.occ_src + (size_t)parent * P.npx;
+    if (P.n_dev <= 1) return P.occ_src + (size_t)parent * P.plane_stride;
     const int d = parent / P.shard_cap;
-    return P.occ_src_dev[d] + (size_t)(parent - d * P.shard_cap) * P.npx;
+    return P.occ_src_dev[d] + (size_t)(parent - d * P.shard_cap) * P.plane_stride;
+}
+// A plane as the kernels address it: the value of pixel (x, y) is base[(y - y0) * stride + (x - x0)].
+// Whole planes: y0 = x0 = 0, stride = cols.
+struct PlaneRef { int x0, y0, stride; };
+__device__ inline PlaneRef parent_ref(const DevParams& P, int parent)
+{
+    PlaneRef r = {0, 0, P.cols};
+    if (P.slab_px) {
+        int4 g;
+        if (P.n_dev <= 1) g = P.reg_src[parent];
+        else { const int d = parent / P.shard_cap; g = P.reg_src_dev[d][parent - d * P.shard_cap]; }
+        r.x0 = g.x; r.y0 = g.y; r.stride = max(g.z - g.x, 0);
+    }
+    return r;
+}
+__device__ inline PlaneRef child_ref(const DevParams& P, int particle)
+{
+    PlaneRef r = {0, 0, P.cols};
+    if (P.slab_px) { const int4 g = P.win_used[particle]; r.x0 = g.x; r.y0 = g.y; r.stride = max(g.z - g.x, 0); }
+    return r;
 }
 __device__ inline int4 parent_window(const DevParams& P, int parent)
 {
@@ -767,7 +798,7 @@ __device__ inline Smem carve(unsigned char* smem, int kTilePx)
 
 // One (particle, tile) work item: rasterize the tile window, evaluate its pixels, return the
 // block-reduced partial log-likelihood (valid in thread 0).
-template <bool UPDATE, int PREC>
+template <bool UPDATE, int PREC, bool SLAB>
 __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect r, int tile_id,
                                           const Smem& m, unsigned body_mask)
 {
@@ -784,7 +815,10 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     // API) must not turn into a wild read: the particle's likelihood becomes NaN instead
     if ((unsigned)parent >= (unsigned)P.slots) return NAN;
     const float* __restrict__ src = parent_plane(P, parent);
-    float* __restrict__ dst = UPDATE ? P.occ_dst + (size_t)particle * P.npx : nullptr;
+    float* __restrict__ dst = UPDATE ? P.occ_dst + (size_t)particle * P.plane_stride : nullptr;
+    // (SLAB is a template parameter: whole planes pay neither the registers nor the index arithmetic)
+    const PlaneRef sref = SLAB ? parent_ref(P, parent) : PlaneRef{0, 0, P.cols};
+    const PlaneRef dref = SLAB && UPDATE ? child_ref(P, particle) : sref;
     const int4 pw = parent_window(P, parent);   // outside it the parent's plane is implicitly bg_old
 
     RBS_TICK_DECL;
@@ -814,21 +848,24 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
             float post_;                                                                                \
             if (PREC) ll += pixel_loglik_f32(P, ed_, ep_, __int_as_float(q[3 * kEvalQueue + at_]), post_); \
             else ll += pixel_loglik(P, eg_, ed_, ep_, post_);                                           \
-            if (UPDATE) dst[eg_] = post_;                                                               \
+            /* plane 0 holds the child-plane offset in precision F32 (which needs no frame index), */   \
+            /* plane 3 in F64 */                                                                        \
+            if (UPDATE) dst[(PREC || !SLAB) ? eg_ : q[3 * kEvalQueue + at_]] = post_;                   \
         }                                                                                               \
     } while (0)
     // push this lane's pixel if `active`; evaluate 64 queued pixels as soon as there are 64
-#define RBS_PUSH_EVAL(active, gidx, depthbits, prior, obs)                                              \
+#define RBS_PUSH_EVAL(active, gidx, didx, depthbits, prior, obs)                                        \
     do {                                                                                                \
         const unsigned long long mask_ = __ballot(active);                                              \
         if (mask_) {                                                                                    \
             if (active) {                                                                               \
                 const int pos_ = (qh + qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask_ >> 32),          \
                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask_, 0))) & (kEvalQueue - 1); \
-                q[pos_] = (gidx);                                                                       \
+                q[pos_] = PREC ? (didx) : (gidx);                                                       \
                 q[kEvalQueue + pos_] = (int)(depthbits);                                                \
                 q[2 * kEvalQueue + pos_] = __float_as_int(prior);                                       \
                 if (PREC) q[3 * kEvalQueue + pos_] = __float_as_int(obs);                               \
+                else if (SLAB) q[3 * kEvalQueue + pos_] = (didx);                                       \
             }                                                                                           \
             qn += __popcll(mask_);                                                                      \
             if (qn >= 64) {                                                                             \
@@ -860,7 +897,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
         for (int q0 = wave * 64; q0 < nq; q0 += kBlock * kScanUnroll) {
             uint4 d4[kScanUnroll];
             floatx4 s4[kScanUnroll], o4[kScanUnroll];
-            int gb[kScanUnroll];
+            int gb[kScanUnroll], sb[kScanUnroll], db[kScanUnroll];   // offsets into the frame, the parent's plane, the child's
             bool vl[kScanUnroll], ac[kScanUnroll];
 #pragma unroll
             for (int u = 0; u < kScanUnroll; ++u) {
@@ -869,16 +906,18 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                 d4[u] = make_uint4(kInfBits, kInfBits, kInfBits, kInfBits);
                 s4[u] = floatx4{P.bg_old, P.bg_old, P.bg_old, P.bg_old};
                 o4[u] = floatx4{0.f, 0.f, 0.f, 0.f};
-                gb[u] = 0;
+                gb[u] = 0; sb[u] = 0; db[u] = 0;
                 ac[u] = false;
                 if (vl[u]) {
                     const int gy = wy0 + lr, gx = wx0 + (qc << 2);
                     gb[u] = gy * P.cols + gx;
+                    sb[u] = SLAB ? (gy - sref.y0) * sref.stride + (gx - sref.x0) : gb[u];
+                    db[u] = SLAB ? (gy - dref.y0) * dref.stride + (gx - dref.x0) : gb[u];
                     d4[u] = tile4[qd];
                     ac[u] = (d4[u].x & d4[u].y & d4[u].z & d4[u].w) != kInfBits;   // a finite depth lacks an exponent bit
                     const bool stored = gx >= pw.x && gx < pw.z && gy >= pw.y && gy < pw.w;
 #ifndef RBS_EXP_NO_SRCLOAD
-                    if (stored && (UPDATE || ac[u])) s4[u] = *reinterpret_cast<const floatx4*>(src + gb[u]);
+                    if (stored && (UPDATE || ac[u])) s4[u] = *reinterpret_cast<const floatx4*>(src + sb[u]);
 #endif
                     if (ac[u]) o4[u] = *reinterpret_cast<const floatx4*>(P.frame + gb[u]);
                 }
@@ -894,16 +933,16 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                 pr.z = occ_step(P.alpha, P.beta, s4[u].z, P.bg_new);
                 pr.w = occ_step(P.alpha, P.beta, s4[u].w, P.bg_new);
 #ifndef RBS_EXP_NO_DSTSTORE
-                if (UPDATE && vl[u]) *reinterpret_cast<floatx4*>(dst + gb[u]) = pr;
+                if (UPDATE && vl[u]) *reinterpret_cast<floatx4*>(dst + db[u]) = pr;
 #endif
 #ifdef RBS_EXP_NO_PUSH
                 continue;
 #endif
                 if (__ballot(ac[u]) == 0) continue;   // wave-uniform: nothing of the object in these 256 pixels
-                RBS_PUSH_EVAL(d4[u].x != kInfBits && isfinite(o4[u].x), gb[u] + 0, d4[u].x, pr.x, o4[u].x);
-                RBS_PUSH_EVAL(d4[u].y != kInfBits && isfinite(o4[u].y), gb[u] + 1, d4[u].y, pr.y, o4[u].y);
-                RBS_PUSH_EVAL(d4[u].z != kInfBits && isfinite(o4[u].z), gb[u] + 2, d4[u].z, pr.z, o4[u].z);
-                RBS_PUSH_EVAL(d4[u].w != kInfBits && isfinite(o4[u].w), gb[u] + 3, d4[u].w, pr.w, o4[u].w);
+                RBS_PUSH_EVAL(d4[u].x != kInfBits && isfinite(o4[u].x), gb[u] + 0, db[u] + 0, d4[u].x, pr.x, o4[u].x);
+                RBS_PUSH_EVAL(d4[u].y != kInfBits && isfinite(o4[u].y), gb[u] + 1, db[u] + 1, d4[u].y, pr.y, o4[u].y);
+                RBS_PUSH_EVAL(d4[u].z != kInfBits && isfinite(o4[u].z), gb[u] + 2, db[u] + 2, d4[u].z, pr.z, o4[u].z);
+                RBS_PUSH_EVAL(d4[u].w != kInfBits && isfinite(o4[u].w), gb[u] + 3, db[u] + 3, d4[u].w, pr.w, o4[u].w);
             }
         }
     } else {
@@ -926,7 +965,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
             const float prior = occ_step(P.alpha, P.beta, sv, P.bg_new);
             const bool active = dbits != kInfBits && isfinite(ov);
             if (UPDATE && valid && !active) dst[gi] = prior;
-            RBS_PUSH_EVAL(active, gi, dbits, prior, ov);
+            RBS_PUSH_EVAL(active, gi, gi, dbits, prior, ov);   // whole planes only on this path (slabs need cols % 4 == 0)
         }
     }
 #undef RBS_PUSH_EVAL
@@ -966,7 +1005,7 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
     const int parent = P.parents[particle];
     if ((unsigned)parent >= (unsigned)P.slots) return;
     const float* __restrict__ src = parent_plane(P, parent) + (size_t)row0 * P.cols;
-    float* __restrict__ dst = P.occ_dst + (size_t)particle * P.npx + (size_t)row0 * P.cols;
+    float* __restrict__ dst = P.occ_dst + (size_t)particle * P.plane_stride + (size_t)row0 * P.cols;
     const float alpha = P.alpha, beta = P.beta, bg_new = P.bg_new;
 
     if (VEC == 4) {
@@ -1117,9 +1156,24 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
         const int4 rw = r.x1 > r.x0 ? make_int4(r.x0, r.y0, r.x1, r.y1) : make_int4(P.cols, P.rows, 0, 0);
         int4 pw = make_int4(P.cols, P.rows, 0, 0);
         if ((unsigned)parent < (unsigned)P.slots) pw = parent_window(P, parent);
-        const int4 u = make_int4(min(pw.x, rw.x), min(pw.y, rw.y), max(pw.z, rw.z), max(pw.w, rw.w));
+        int4 u = make_int4(min(pw.x, rw.x), min(pw.y, rw.y), max(pw.z, rw.z), max(pw.w, rw.w));
+        int4 seed = rw;
+        if (P.slab_px) {
+            // the child's slab stores exactly the region this call writes
+            const long area = u.z > u.x && u.w > u.y ? (long)(u.z - u.x) * (long)(u.w - u.y) : 0;
+            if (area > (long)P.slab_px) {
+                // does not fit: contained like a bad parent slot (the raster and copy kernels skip the
+                // particle, its log-likelihood is NaN), its plane becomes all background, and the
+                // handle reports the error at its next synchronising call
+                P.parents[i] = -1;
+                u = make_int4(P.cols, P.rows, 0, 0);
+                seed = u;
+                atomicExch(P.err, 1);
+            }
+            P.reg_dst[i] = u;
+        }
         P.win_used[i] = u;
-        P.win_dst[i] = rw;
+        P.win_dst[i] = seed;
         if (P.area_sum && u.z > u.x && u.w > u.y)
             atomicAdd(P.area_sum, (unsigned long long)(u.z - u.x) * (unsigned long long)(u.w - u.y));
     }
@@ -1155,7 +1209,7 @@ __global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_frame_prep_kernel(cons
 // Persistent: a fixed number of raster blocks per CU keeps its LDS/VGPR share for the whole
 // launch (never starved by the many small copy blocks) and pulls (particle, tile) items from
 // an atomic queue.
-template <bool UPDATE, int PREC>
+template <bool UPDATE, int PREC, bool SLAB>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel(const DevParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1179,7 +1233,7 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
         const int first = range.x;
         double part = 0.0;
         if (P.groups == nullptr) {
-            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC>(P, particle, r, item - first, m, 0xffffffffu);
+            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC, SLAB>(P, particle, r, item - first, m, 0xffffffffu);
         } else {   // several bodies: the item belongs to one group of bodies with its own rectangle
             const Groups* G = P.groups + particle;
             const int k = item - first, ng = __builtin_amdgcn_readfirstlane(G->n);
@@ -1189,7 +1243,7 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
                 const int4 gq = G->rect[g];
                 const Rect gr = {__builtin_amdgcn_readfirstlane(gq.x), __builtin_amdgcn_readfirstlane(gq.y),
                                  __builtin_amdgcn_readfirstlane(gq.z), __builtin_amdgcn_readfirstlane(gq.w)};
-                part = raster_eval_tile<UPDATE, PREC>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
+                part = raster_eval_tile<UPDATE, PREC, SLAB>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
                                                       (unsigned)__builtin_amdgcn_readfirstlane((int)G->mask[g]));
             }
         }
@@ -1266,7 +1320,7 @@ __global__ __launch_bounds__(1024) void rbs_copy_rows_kernel(const DevParams P, 
     const int c4 = seg * (int)blockDim.x + (int)threadIdx.x;
     if (c4 >= W4) return;
     const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(parent_plane(P, parent));
-    floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(P.occ_dst + (size_t)particle * P.npx);
+    floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(P.occ_dst + (size_t)particle * P.plane_stride);
     const float alpha = P.alpha, beta = P.beta, bg_new = P.bg_new;
     const int col = c4 << 2;
     const bool in_cols = col >= q.x && col < q.z;
@@ -1342,6 +1396,7 @@ __global__ __launch_bounds__(64) void rbs_wide_window_kernel(const DevParams P, 
 #define RBS_WIN_UNROLL 2
 #endif
 constexpr int kWinUnroll = RBS_WIN_UNROLL;
+template <bool SLAB>
 __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
 {
     const int particle = (int)blockIdx.y + (int)blockIdx.z * (int)gridDim.y;
@@ -1361,7 +1416,12 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
     if (ry0 >= ry1) return;
     const int n4 = (ry1 - ry0) * w4;
     const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(parent_plane(P, parent));
-    floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(P.occ_dst + (size_t)particle * P.npx);
+    floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(P.occ_dst + (size_t)particle * P.plane_stride);
+    // float4 index of pixel (col, row) in the parent's / the child's plane (whole planes: row W4 + col/4;
+    // slabs: relative to the plane's stored region -- the child's region is u itself)
+    const PlaneRef sref = SLAB ? parent_ref(P, parent) : PlaneRef{0, 0, P.cols};
+    const int ss4 = SLAB ? sref.stride >> 2 : W4, sx4 = SLAB ? sref.x0 >> 2 : 0, sy0 = SLAB ? sref.y0 : 0;
+    const int ds4 = SLAB ? w4 : W4, dx4 = SLAB ? ux4 : 0, dy0 = SLAB ? u.y : 0;
     const float alpha = P.alpha, beta = P.beta, bg_new = P.bg_new;
     const int lane = (int)threadIdx.x;
     const int qstep = 64 / w4, rstep = 64 - qstep * w4;
@@ -1378,9 +1438,9 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
             const bool live = idx < n4 && !raster_writes(P, particle, q, row, col);
             const bool stored = live && col >= pw.x && col < pw.z && row >= pw.y && row < pw.w;
             st[k] = live ? (stored ? 2 : 1) : 0;
-            at[k] = row * W4 + ux4 + c4;
+            at[k] = ux4 + c4;
             rr[k] = row;
-            if (stored) v[k] = __builtin_nontemporal_load(&s4[at[k]]);
+            if (stored) v[k] = __builtin_nontemporal_load(&s4[(row - sy0) * ss4 + (at[k] - sx4)]);
             c4 += rstep; row += qstep;
             if (c4 >= w4) { c4 -= w4; ++row; }
         }
@@ -1396,9 +1456,9 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
             } else {
                 w.x = w.y = w.z = w.w = bg_new;
             }
-            __builtin_nontemporal_store(w, &d4[at[k]]);
+            __builtin_nontemporal_store(w, &d4[(rr[k] - dy0) * ds4 + (at[k] - dx4)]);
             if (w.x != bg_new || w.y != bg_new || w.z != bg_new || w.w != bg_new) {
-                const int col = (at[k] - rr[k] * W4) << 2;
+                const int col = at[k] << 2;
                 bx0 = min(bx0, col); bx1 = max(bx1, col + 4);
                 by0 = min(by0, rr[k]); by1 = max(by1, rr[k] + 1);
             }
@@ -1426,6 +1486,37 @@ __global__ void rbs_materialize_kernel(float* __restrict__ plane, const int4* __
     if (i >= rows * cols) return;
     const int y = i / cols, x = i - y * cols;
     if (!(x >= w.x && x < w.z && y >= w.y && y < w.w)) plane[i] = bg;
+}
+
+// Slabs: a slot's slab -> a whole plane (the background outside its window), a whole plane -> a
+// slab with stored region r, and the float4-aligned bounding box of the values of a whole plane
+// that differ from the background (out4 starts as (cols, rows, 0, 0)).
+__global__ void rbs_expand_kernel(const float* __restrict__ slab, const int4* __restrict__ reg,
+                                  const int4* __restrict__ win, int rows, int cols, float bg, float* __restrict__ out)
+{
+    const int4 r = *reg, w = *win;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int y = i / cols, x = i - y * cols;
+    const bool in = x >= w.x && x < w.z && y >= w.y && y < w.w;
+    out[i] = in ? slab[(size_t)(y - r.y) * (r.z - r.x) + (x - r.x)] : bg;
+}
+__global__ void rbs_pack_kernel(const float* __restrict__ full, int4 r, int cols, float* __restrict__ slab)
+{
+    const int w = r.z - r.x, n = w * (r.w - r.y);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ly = i / w, lx = i - ly * w;
+    slab[i] = full[(size_t)(r.y + ly) * cols + r.x + lx];
+}
+__global__ void rbs_bbox_kernel(const float* __restrict__ full, int rows, int cols, float bg, int* __restrict__ out4)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    if (full[i] == bg) return;
+    const int y = i / cols, x = i - y * cols;
+    atomicMin(out4 + 0, x & ~3); atomicMin(out4 + 1, y);
+    atomicMax(out4 + 2, (x & ~3) + 4); atomicMax(out4 + 3, y + 1);
 }
 
 __global__ void rbs_set_window_kernel(int4* __restrict__ win, int n, int4 value)

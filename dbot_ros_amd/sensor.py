@@ -134,10 +134,11 @@ class RbSensor:
     """dbot RbSensor mirror over the C-ABI handle."""
 
     def __init__(self, object_model, camera_data, params, device_id=0, max_particles=None,
-                 precision=None, state_layout=None, device_ids=None):
+                 precision=None, state_layout=None, device_ids=None, slab_px=0):
         """precision: None (library default) | "f64" | "f32" (rbs_config.likelihood_precision);
         state_layout: None | "window" | "dense"; device_ids: several HIP ordinals = particle
-        sharding inside the handle (max_particles is then the total)."""
+        sharding inside the handle (max_particles is then the total); slab_px: floats per
+        occlusion slot (rbs_config.state_slab_px; 0 = whole planes)."""
         self._lib = _capi.load()
         self._h = C.c_void_p()
         self.n_bodies = object_model.count_parts
@@ -169,6 +170,7 @@ class RbSensor:
         cfg.delta_time = params.delta_time
         cfg.likelihood_precision = _capi.PRECISIONS[precision]
         cfg.state_layout = _capi.LAYOUTS[state_layout]
+        cfg.state_slab_px = int(slab_px)
         if device_ids is not None and len(device_ids) >= 1:
             ids = np.ascontiguousarray(device_ids, dtype=np.int32)
             cfg.device_id = int(ids[0])

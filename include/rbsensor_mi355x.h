@@ -100,6 +100,17 @@ typedef struct rbs_config {
      * max_particles is the TOTAL over all devices.  See "several devices" below. */
     int32_t n_devices;
     const int32_t* device_ids;
+    /* Window-sized slabs for the occlusion state (windowed layout only).  0 = every slot is a whole
+     * plane (rows*cols floats: 2 x 1.2 MB per particle at 640x480, of which a tracked object's window
+     * touches ~3 %).  > 0 = every slot holds state_slab_px floats and stores only the region an
+     * updating call writes, bbox(parent's window, the particle's screen rectangle): e.g. rows*cols/8
+     * makes room for 8x the particles.  A particle whose region does not fit is CONTAINED -- its
+     * log-likelihood is NaN, its plane becomes all background -- and the call (rbs_loglikes), or the
+     * next synchronising call after an asynchronous one, returns RBS_ERR_OUT_OF_MEMORY; the condition
+     * is sticky until rbs_reset.  Size the slab for the object's footprint plus the distance it
+     * sweeps in ~800 frames (windows shrink back as the occlusion values decay). */
+    int32_t state_slab_px;
+    int32_t reserved0;
 } rbs_config;
 
 int32_t rbs_abi_version(void);

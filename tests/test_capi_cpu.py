@@ -34,8 +34,8 @@ def test_abi_version_and_struct_layout():
     assert lib.rbs_abi_version() == _capi.RBS_ABI_VERSION
     # rbs_config layout the ctypes mirror must match (LP64): 4 ints, 9 doubles, 2 ints, 4 ptrs, 7 doubles;
     # ABI 2: + 3 ints (precision, layout, n_devices), padding, 1 pointer (device_ids).  The library
-    # static_asserts the same 208 bytes on its side (rbsensor_capi.hip).
-    assert C.sizeof(_capi.RbsConfig) == 16 + 72 + 8 + 32 + 56 + 12 + 4 + 8
+    # static_asserts the same 216 bytes on its side (rbsensor_capi.hip).
+    assert C.sizeof(_capi.RbsConfig) == 16 + 72 + 8 + 32 + 56 + 12 + 4 + 8 + 8      # + state_slab_px, reserved0
     assert _capi.RbsConfig.device_ids.offset == 200 and _capi.RbsConfig.likelihood_precision.offset == 184
 
 
