@@ -55,7 +55,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # 1 024 SIMDs x one wave64 VALU instruction per 4 cycles x 2.4 GHz = 614.4 G/s
-WORKLOAD_FLAGS = ("particles", "cols", "rows", "mesh", "parents", "update", "sequence", "precision", "layout")
+WORKLOAD_FLAGS = ("particles", "cols", "rows", "mesh", "parents", "update", "sequence", "precision", "layout", "slab_px")
 
 
 def parse():
@@ -80,6 +80,7 @@ def parse():
                     help="with --fill-planes: only a central rectangle of this fraction of the frame")
     ap.add_argument("--precision", default="f32", choices=["f64", "f32"], help="likelihood precision of the headline run")
     ap.add_argument("--layout", default="window", choices=["window", "dense"], help="occlusion state layout of the headline run")
+    ap.add_argument("--slab-px", type=int, default=0, help="floats per occlusion slot (rbs_config.state_slab_px; 0 = whole planes)")
     ap.add_argument("--quick", action="store_true", help="headline only: no dense / f64 / host / tracker / cpu / pmc legs")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the whole-plane (state_layout=dense) comparison run")
     ap.add_argument("--no-f64-leg", action="store_true")
@@ -208,8 +209,9 @@ class ResidentRun:
 
 def make_sensor(a, om, cam, P, device, precision=None, layout=None, n=None):
     from dbot_ros_amd import RbSensor
+    lay = layout or a.layout
     return RbSensor(om, cam, P, device_id=device.index, max_particles=n or a.particles,
-                    precision=precision or a.precision, state_layout=layout or a.layout)
+                    precision=precision or a.precision, state_layout=lay, slab_px=a.slab_px if lay == "window" else 0)
 
 
 def prime(sensor, a, W):
@@ -231,7 +233,7 @@ def pmc_pass(a, counters, layout, timeout=150):
     flags = []
     for f in WORKLOAD_FLAGS:
         v = layout if f == "layout" else getattr(a, f)
-        flags += ["--" + f, str(v)]
+        flags += ["--" + f.replace("_", "-"), str(v)]
     cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--",
            sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "12", "--warmup", "3", *flags]
     env = dict(os.environ, TMPDIR="/tmp")
@@ -572,7 +574,8 @@ def main():
         "config": {"workload": f"C1: {n} particles/GPU x loglikes(update={'true' if a.update else 'false'}), {a.cols}x{a.rows} "
                                f"synthetic depth frame, mesh {a.mesh} ({n_tri} triangles), "
                                f"parents={a.parents}, " + (f"{max(1, a.sequence)}-frame moving-object sequence" if a.sequence > 0 else "one static frame")
-                               + f", likelihood precision {a.precision}, {a.layout} planes, inputs resident in HBM",
+                               + f", likelihood precision {a.precision}, {a.layout} planes"
+                               + (f" in slabs of {a.slab_px} px" if a.slab_px else "") + ", inputs resident in HBM",
                    "particles_per_gpu": n, "resolution": [a.cols, a.rows], "triangles": int(n_tri),
                    "sharding": f"particles/{world}" + (" + RCCL all-gather of log-likelihoods" if world > 1 else "")},
     }
