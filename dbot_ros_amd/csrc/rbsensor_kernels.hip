@@ -816,9 +816,6 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     if ((unsigned)parent >= (unsigned)P.slots) return NAN;
     const float* __restrict__ src = parent_plane(P, parent);
     float* __restrict__ dst = UPDATE ? P.occ_dst + (size_t)particle * P.plane_stride : nullptr;
-    // (SLAB is a template parameter: whole planes pay neither the registers nor the index arithmetic)
-    const PlaneRef sref = SLAB ? parent_ref(P, parent) : PlaneRef{0, 0, P.cols};
-    const PlaneRef dref = SLAB && UPDATE ? child_ref(P, particle) : sref;
     const int4 pw = parent_window(P, parent);   // outside it the parent's plane is implicitly bg_old
 
     RBS_TICK_DECL;
@@ -830,6 +827,10 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                   m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue, body_mask);   // the eval queue is idle during the raster phase
     RBS_TICK(2);
 
+    // (SLAB is a template parameter: whole planes pay neither the registers nor the index arithmetic;
+    // fetched here, after the raster phase, so that they are not live through it)
+    const PlaneRef sref = SLAB ? parent_ref(P, parent) : PlaneRef{0, 0, P.cols};
+    const PlaneRef dref = SLAB && UPDATE ? child_ref(P, particle) : sref;
     // Pixel pass.  Only ~1/3 of a tile's pixels are covered by the object, in runs that leave
     // most lanes of a wave idle in the expensive likelihood code, so each wave compacts its
     // covered+observed pixels into an LDS queue and evaluates them 64 at a time with full lanes.
