@@ -2138,6 +2138,12 @@ int32_t group_tracker_track(rbs_tracker* t, const float* frame, const double* no
         RBT_HIP(t, hipStreamSynchronize(streams[k]));
     }
     if (out_resamplings) *out_resamplings = flags[1];
+    for (rbs_handle* sh : g->shards) {   // slabs: a region that did not fit, on any shard
+        if (!sh->slab_px) break;
+        RBT_HIP(t, hipSetDevice(sh->device));
+        RBT_HIP(t, hipMemcpy(sh->h_err, sh->d_err, sizeof(int), hipMemcpyDeviceToHost));
+        if (int32_t rc = check_slab_error(sh)) return gfail(g, sh, rc);
+    }
     return RBS_OK;
 }
 }  // namespace
