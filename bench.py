@@ -682,7 +682,23 @@ def main():
         for i in range(hsteps):
             host_step(i, with_frame=False)
         tl = time.perf_counter() - t0
+        # the same with the frame written straight into the handle's pinned staging buffer
+        # (rbs_acquire_frame_buffer / rbs_commit_frame_buffer): what a driver callback that converts
+        # its message into that buffer pays -- no 1.2 MB host copy inside the API
+        def staged_step(i):
+            k = W.order[i % len(W.order)]
+            hs.frame_buffer()           # the producer's buffer: left as it is (its content is one of the two last frames)
+            hs.commit_frame()
+            return hs.loglikes_poses(W.poses[k], W.parents.copy(), update=bool(a.update))
+
+        for i in range(10):
+            staged_step(i)
+        t0 = time.perf_counter()
+        for i in range(hsteps):
+            staged_step(i)
+        ts = time.perf_counter() - t0
         hs.close()
+        out["host_api_staged_frame_value"] = n * hsteps / ts
         out["host_api_value"] = n * hsteps / th
         out["host_api_ms_per_step"] = th / hsteps * 1e3
         out["host_api_loglikes_only_value"] = n * hsteps / tl

@@ -28,6 +28,7 @@ EXPORTS = (
     "rbs_abi_version", "rbs_device_count", "rbs_create", "rbs_destroy", "rbs_last_error",
     "rbs_reset", "rbs_set_observation", "rbs_set_observation_f32",
     "rbs_set_observation_native_f32", "rbs_set_observation_device", "rbs_get_observation", "rbs_loglikes",
+    "rbs_acquire_frame_buffer", "rbs_commit_frame_buffer",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_export_plane", "rbs_import_plane",
     "rbs_get_window", "rbs_get_background", "rbs_raster_kernel_ms", "rbs_set_timing_every",
@@ -117,6 +118,10 @@ def load():
     lib.rbs_set_observation_f32.argtypes = [H, fp, C.c_size_t]
     lib.rbs_set_observation_native_f32.restype = C.c_int32
     lib.rbs_set_observation_native_f32.argtypes = [H, fp, C.c_int32, C.c_int32, C.c_int32]
+    lib.rbs_acquire_frame_buffer.restype = C.c_int32
+    lib.rbs_acquire_frame_buffer.argtypes = [H, C.POINTER(C.POINTER(C.c_float))]
+    lib.rbs_commit_frame_buffer.restype = C.c_int32
+    lib.rbs_commit_frame_buffer.argtypes = [H]
     lib.rbs_get_observation.restype = C.c_int32
     lib.rbs_get_observation.argtypes = [H, fp]
     lib.rbs_loglikes.restype = C.c_int32

@@ -1071,7 +1071,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         B.vtx = reinterpret_cast<const rbs::floatx4*>(h->d_vtx);
     }
     for (int k = 0; k < 2; ++k) {
-        RBS_HIP(h, hipHostMalloc(&h->h_frames[k], plane, hipHostMallocDefault));
+        RBS_HIP(h, hipHostMalloc(&h->h_frames[k], plane, hipHostMallocPortable));   // (every device of a group uploads from shard 0's)
         RBS_HIP(h, hipEventCreateWithFlags(&h->ev_frame[k], hipEventDisableTiming));
     }
     h->h_frame = h->h_frames[0];
@@ -1494,6 +1494,53 @@ int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n)
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     if (int32_t rc = next_frame_staging(h)) return rc;
     std::memcpy(h->h_frame, depth, n * sizeof(float));
+    if (int32_t rc = upload_frame(h)) return rc;
+    h->pending_frames += 1;
+    return RBS_OK;
+}
+
+int32_t rbs_acquire_frame_buffer(rbs_handle* h, float** buf)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!buf) return fail(h, RBS_ERR_INVALID_ARGUMENT, "acquire_frame_buffer: null pointer");
+    if (!h->shards.empty()) {
+        // one staging buffer (shard 0's) feeds every device: it is free once every shard's upload
+        // of the frame before last has finished
+        rbs_handle* s0 = h->shards[0];
+        s0->frame_slot ^= 1;
+        s0->h_frame = s0->h_frames[s0->frame_slot];
+        for (rbs_handle* sh : h->shards) {
+            RBS_HIP(h, hipSetDevice(sh->device));
+            sh->frame_slot = s0->frame_slot;
+            RBS_HIP(h, hipEventSynchronize(sh->ev_frame[sh->frame_slot]));
+        }
+        *buf = s0->h_frame;
+        return RBS_OK;
+    }
+    RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = next_frame_staging(h)) return rc;
+    *buf = h->h_frame;
+    return RBS_OK;
+}
+
+int32_t rbs_commit_frame_buffer(rbs_handle* h)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty()) {
+        const float* src = h->shards[0]->h_frame;
+        for (rbs_handle* sh : h->shards) {
+            RBS_HIP(h, hipSetDevice(sh->device));
+            if (int32_t rc = flush_lazy_frame(sh, sh->stream)) return gfail(h, sh, rc);
+            RBS_HIP(h, hipMemcpyAsync(sh->d_frame, src, sizeof(float) * (size_t)sh->npx, hipMemcpyHostToDevice, sh->stream));
+            RBS_HIP(h, hipEventRecord(sh->ev_frame[sh->frame_slot], sh->stream));
+            sh->lazy_frame = sh->d_frame;
+            sh->lazy_stream = sh->stream;
+            sh->pending_frames += 1;
+        }
+        return RBS_OK;
+    }
+    RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     if (int32_t rc = upload_frame(h)) return rc;
     h->pending_frames += 1;
     return RBS_OK;

@@ -236,6 +236,17 @@ class RbSensor:
             self._check(self._lib.rbs_set_observation(
                 self._h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size))
 
+    def frame_buffer(self):
+        """The handle's pinned staging buffer for the NEXT frame as a numpy float32 view
+        [rows*cols]: write the frame into it, then commit_frame() -- rbs_set_observation_f32
+        without the host copy."""
+        p = C.POINTER(C.c_float)()
+        self._check(self._lib.rbs_acquire_frame_buffer(self._h, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(self.rows * self.cols,))
+
+    def commit_frame(self):
+        self._check(self._lib.rbs_commit_frame_buffer(self._h))
+
     def set_observation_native(self, image, downsampling_factor):
         """image: the driver's full-resolution float32 frame [height, width]; sub-sampled on the
         device by the reference's rule eval(r, c) = native(r*f, c*f)."""

@@ -249,6 +249,15 @@ public:
     /// The driver's float pixels directly (no double round trip), or a frame that already lives
     /// on the sensor's GPU (`stream`: a hipStream_t, nullptr = the sensor's own).
     void set_observation_f32(const float* depth, size_t n) { check(rbs_set_observation_f32(handle_, depth, n)); }
+    /// Zero-copy hand-over: the pinned staging buffer of the NEXT frame (rows*cols floats); fill it
+    /// (the driver's conversion loop can write straight into it), then commit_frame().
+    float* frame_buffer()
+    {
+        float* p = nullptr;
+        check(rbs_acquire_frame_buffer(handle_, &p));
+        return p;
+    }
+    void commit_frame() { check(rbs_commit_frame_buffer(handle_)); }
     void set_observation_device(const float* d_depth, void* stream = nullptr)
     {
         check(rbs_set_observation_device(handle_, d_depth, stream));

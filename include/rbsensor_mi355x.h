@@ -144,6 +144,14 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
  * frame (it shares a launch with the next rbs_loglikes_device on the same stream): the caller
  * keeps `d_depth` alive and unchanged until that call's work has run. */
 int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* stream);
+/* Zero-copy hand-over of a host frame: rbs_acquire_frame_buffer gives the handle's pinned staging
+ * buffer for the NEXT frame (float[rows*cols], evaluated resolution, valid until the matching
+ * commit); the caller writes the frame straight into it -- the conversion loop of
+ * ri::to_eigen_vector (R:source/dbot_ros/util/ros_interface.h:152-168) can target it -- and
+ * rbs_commit_frame_buffer is then rbs_set_observation_f32 without the 1.2 MB host copy.  Two
+ * buffers alternate: acquiring waits for the upload that used the buffer two frames ago. */
+int32_t rbs_acquire_frame_buffer(rbs_handle* h, float** buf);
+int32_t rbs_commit_frame_buffer(rbs_handle* h);
 /* Current evaluated observation -> host float[rows*cols] (inspection). */
 int32_t rbs_get_observation(rbs_handle* h, float* out);
 

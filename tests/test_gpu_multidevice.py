@@ -154,3 +154,31 @@ def test_two_gpus_sensor_and_tracker(gpu_lib):
     e1, _, r1 = _run_tracker(om, cam, P, n, 1, fr, None, randomness)
     e2, _, r2 = _run_tracker(om, cam, P, n, 1, fr, ids, randomness)
     assert r1 == r2 and np.abs(e1 - e2).max() <= 1e-9
+
+
+@pytest.mark.parametrize("ids", [None, [0, 0]])
+def test_zero_copy_frame_staging_equals_set_observation(gpu_lib, ids):
+    """rbs_acquire_frame_buffer / rbs_commit_frame_buffer against rbs_set_observation_f32, on one
+    device and on a handle over two shards (one pinned buffer feeds every device)."""
+    n = 32
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    rng = np.random.default_rng(0)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", device_ids=ids) as a, \
+            RbSensor(om, cam, P, max_particles=n, precision="f64", device_ids=ids) as b:
+        for s in (a, b):
+            s.reset()
+        ia, ib = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for k in range(5):
+            t = synth.truth_pose(1, frame=k)
+            frame = synth.make_frame(a.render_depth(t), 120, 160, rng).astype(np.float32)
+            poses = synth.particle_poses(t, n, rng)
+            a.set_observation(frame)
+            buf = b.frame_buffer()
+            buf[:] = frame
+            b.commit_frame()
+            la = a.loglikes_poses(poses, ia, update=True)
+            lb = b.loglikes_poses(poses, ib, update=True)
+            assert np.array_equal(la, lb)
+            ia = rng.integers(0, n, n).astype(np.int32)
+            ib = ia.copy()
+        assert np.array_equal(a.get_observation(), b.get_observation(), equal_nan=True)
