@@ -318,6 +318,32 @@ __device__ inline Rect particle_rect(const DevParams& P, const double* __restric
     return bodies_rect(P, pose, 0, P.n_bodies);
 }
 
+// Binary64 division as the compiler expands it -- hardware reciprocal, two Newton steps, quotient,
+// exact remainder, one correcting FMA (Markstein) -- WITHOUT the v_div_scale / v_div_fmas /
+// v_div_fixup wrapping that rescales operands near the ends of the exponent range and patches
+// infinities, zeros and NaNs: 9 instructions instead of 13, the same bits whenever the scale
+// factors would have been 1 (operands and quotient comfortably normal: the rasterizer's depths,
+// focal lengths and plane coefficients).  At the extremes (a denominator that is zero, denormal
+// or beyond 2^1000) the result may be inf / NaN / off where IEEE gives a finite huge or tiny
+// number: every use below rejects those values on both sides (a depth must be a positive finite
+// float, a bounding box must not be empty or NaN), so outcomes stay identical to the oracle's.
+// RBS_IEEE_DIV=1 restores the plain operator (A/B builds).
+#ifndef RBS_IEEE_DIV
+#define RBS_IEEE_DIV 0
+#endif
+__device__ inline double div_f64(double a, double b)
+{
+#if RBS_IEEE_DIV
+    return a / b;
+#else
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+#endif
+}
+
 // ------------------------------------------------------------------ triangle setup
 struct Tri {
     double u0, v0, u1, v1, u2, v2;
@@ -355,7 +381,7 @@ __device__ inline bool tri_setup(const DevParams& P, int t, const double* __rest
     double u[3], v[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double iz = 1.0 / Z[k];
+        const double iz = div_f64(1.0, Z[k]);
         u[k] = P.fx * (X[k] * iz) + P.cx;
         v[k] = P.fy * (Y[k] * iz) + P.cy;
     }
@@ -381,8 +407,8 @@ __device__ inline bool tri_setup(const DevParams& P, int t, const double* __rest
     const double ny = az * bx - ax * bz;
     const double nz = ax * by - ay * bx;
     T.nv0 = (nx * X[0] + ny * Y[0]) + nz * Z[0];
-    T.pa = nx / P.fx;
-    T.pb = ny / P.fy;
+    T.pa = div_f64(nx, P.fx);
+    T.pb = div_f64(ny, P.fy);
     T.pc = (nz - T.pa * P.cx) - T.pb * P.cy;
     T.xlo = (int)xlo_d; T.xhi = (int)xhi_d; T.ylo = (int)ylo_d; T.yhi = (int)yhi_d;
     return true;
@@ -399,7 +425,7 @@ __device__ inline void tri_pixel(const Tri& T, int col, int row, unsigned* tile,
     const bool in = (E0 >= 0.0 && E1 >= 0.0 && E2 >= 0.0) || (E0 <= 0.0 && E1 <= 0.0 && E2 <= 0.0);
     if (!in) return;
     const double den = (T.pa * px + T.pb * py) + T.pc;
-    const float zf = (float)(T.nv0 / den);
+    const float zf = (float)div_f64(T.nv0, den);
     if (!(zf > 0.0f) || !(zf < INFINITY)) return;
     atomicMin(&tile[(row - wy0) * tw + (col - wx0)], __float_as_uint(zf));
 }
