@@ -263,7 +263,10 @@ __device__ inline Rect bodies_rect(const DevParams& P, const double* __restrict_
         tabs = fmaxf(tabs, fabsf(tx) + fabsf(ty) + fabsf(tz));
         // eight vertex loads in flight per lane (the vertices sit in L2; one dependent load per
         // trip would leave this kernel, which the raster kernel waits for, latency bound)
-        constexpr int kV = 8;
+#ifndef RBS_RECT_LOADS
+#define RBS_RECT_LOADS 8
+#endif
+        constexpr int kV = RBS_RECT_LOADS;
         const int v1 = P.vtx_begin[b + 1];
         for (int i0 = P.vtx_begin[b] + lane; i0 < v1; i0 += stride * kV) {
             floatx4 pv[kV];
