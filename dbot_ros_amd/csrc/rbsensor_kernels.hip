@@ -772,6 +772,10 @@ __device__ inline float fast_erfc(float x)
 // per SIMD do not hide.  No memory access at all here.
 __device__ inline double pixel_loglik_f32(const DevParams& P, float r, float prior, float o, float& posterior)
 {
+#ifdef RBS_EXP_SKIP_EVAL     // profiling builds: the queue traffic, none of the likelihood arithmetic
+    posterior = prior;
+    return (double)(r + o);
+#endif
     const float lam = (float)P.lambda, twD = (float)(P.tw / kMaxDepth), omt = (float)(1.0 - P.tw);
     const float sigma = fmaf((float)P.sf * o, o, (float)P.ms);
     const float is = fast_rcp(sigma);
