@@ -111,3 +111,29 @@ def test_product_does_not_reference_the_oracle():
     assert "oracle" not in needed
     syms = subprocess.run(["nm", "-D", _capi.LIB_PATH], capture_output=True, text=True).stdout
     assert " orc_" not in syms
+
+
+def test_register_budgets_the_kernels_overlap_depends_on():
+    """The windowed copy kernel runs BESIDE the persistent raster kernel only while three raster
+    waves (VGPRs allocated in steps of 8: <= 160 each) leave a copy wave its 32 VGPRs on a SIMD of
+    512; one register more on either side costs 5-8 %.  The compiler's
+    report, written by the Makefile next to the library, is checked here so that an innocent edit
+    cannot lose the overlap unnoticed."""
+    import re
+    path = os.path.join(os.path.dirname(_capi.LIB_PATH), "resource_usage.txt")
+    assert os.path.exists(path), "make -C dbot_ros_amd/csrc writes lib/resource_usage.txt"
+    txt = open(path).read()
+
+    def usage(mangled_part):
+        m = re.search(r"Function Name: (\S*" + re.escape(mangled_part) + r"\S*).*?VGPRs: (\d+).*?VGPRs Spill: (\d+)", txt, re.S)
+        assert m, mangled_part
+        return int(m.group(2)), int(m.group(3))
+
+    for name in ("rbs_raster_kernelILb1ELi1ELb0E", "rbs_raster_kernelILb0ELi1ELb0E", "rbs_raster_kernelILb1ELi1ELb1E"):
+        vgprs, spills = usage(name)        # precision F32: updating / read-only / slabs
+        assert vgprs <= 160 and spills == 0, (name, vgprs, spills)
+    for name in ("rbs_copy_window_kernelILb0E", "rbs_copy_window_kernelILb1E"):
+        vgprs, spills = usage(name)
+        assert vgprs <= 32 and spills == 0, (name, vgprs, spills)
+    vgprs, _ = usage("rbs_raster_kernelILb1ELi0ELb0E")   # precision F64: three waves per SIMD
+    assert vgprs <= 168
