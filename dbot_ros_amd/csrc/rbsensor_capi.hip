@@ -68,7 +68,7 @@ struct rbs_handle {
     int* d_err = nullptr;       // [1] sticky device flag: a region did not fit its slab
     int* h_err = nullptr;       // pinned copy, fetched with the log-likelihoods
     int* d_bbox = nullptr;      // [4] scratch of rbs_import_plane / rbs_set_occlusion
-    bool windowed = true;       // planes valid inside their window only (RBS_STATE=dense: whole plane)
+    bool windowed = true;       // planes valid inside their window only (state_layout dense: whole plane)
     // windowed planes whose windows have grown to a large part of the frame are served like whole
     // planes (streaming copy kernel beside two raster blocks per CU); the stored area is sampled
     // on the device every timing_every-th updating call and read back without blocking

@@ -3,22 +3,30 @@
 // One RbSensor::loglikes(deltas, indices, update) call (made once per sampling block inside
 // tracker_->track, R:source/dbot_ros/object_tracker_ros.hpp:49) is:
 //
-//   rbs_frame_prep_kernel  two independent jobs in one launch: the per-pixel model terms of a
-//                       newly handed-over frame, and per particle the conservative screen
-//                       rectangle of the bodies, its work items (one per <= 11 520-px tile,
-//                       allotted by atomicAdd) and, on windowed planes, the region the copy
-//                       kernel writes.  (rbs_prep_kernel: the rectangles alone.)
-//   rbs_raster_kernel   PERSISTENT, 3 blocks per CU, pulling work items from an atomic queue:
-//                       software depth rasterizer (wave64 = one 64-triangle cluster, culled
-//                       against the tile frustum and, for closed bodies, by its normal cone;
-//                       triangles -> LDS depth tile, ds_min_u32 z-min), then the per-pixel
-//                       Kinect likelihood + occlusion posterior over the tile, block reduce ->
-//                       the particle's log-likelihood.  VALU (FP64) bound.
+//   rbs_frame_prep_kernel  two independent jobs in one launch: ingest of a newly handed-over
+//                       frame (precision F64: + its per-pixel model terms), and per particle (one
+//                       wave each) the screen rectangle of its bodies from the projected
+//                       vertices -- one rectangle per group of overlapping bodies --, its work
+//                       items (one per <= 11 008-px tile, one atomicAdd per block of 8
+//                       particles), the snapshot of its parent index and, on windowed planes, the
+//                       region the copy kernel writes.  (rbs_prep_kernel: without a frame.)
+//   rbs_raster_kernel<UPDATE, PREC, SLAB>  PERSISTENT, 3 blocks per CU, pulling work items from
+//                       an atomic queue: software depth rasterizer (64-triangle clusters culled
+//                       against the tile frustum and, for closed bodies, by their normal cone;
+//                       triangles that clearly face away dropped by a float32 plane test and the
+//                       survivors compacted through an LDS ring, set up in binary64 with full
+//                       lanes; LDS depth tile, ds_min_u32 z-min), then the pixel pass: occlusion
+//                       process, covered pixels compacted through a second LDS ring, the Kinect
+//                       likelihood + occlusion posterior 64 pixels at a time (PREC 0: binary64
+//                       with the reference's float rounding points; PREC 1: float32 on the
+//                       exp2/log2/rcp units, every per-pixel term recomputed from the
+//                       observation), block reduce -> the particle's log-likelihood.
+//                       Bound by VALU issue (bench.py: 0.55 of the chip's issue peak).
 //   rbs_copy_window_kernel  (update only, second stream) the child's window outside its
 //                       rectangle: the parent's values advanced by the occlusion process
 //                       occ' = snap(fma(alpha, occ, beta)), the background where the parent
 //                       stores nothing; re-tightens the child's window.
-//   rbs_copy_rows_kernel  whole planes (RBS_STATE=dense, or windows grown past half the frame):
+//   rbs_copy_rows_kernel  whole planes (state_layout dense, or windows grown past half the frame):
 //                       streams the parent's plane into the child's slot outside the
 //                       rectangle.  HBM bound: 2*4*rows*cols bytes per particle-likelihood.
 //

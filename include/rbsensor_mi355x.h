@@ -208,7 +208,7 @@ int32_t rbs_synchronize(rbs_handle* h);
  * hands out / accepts whole planes in either layout. */
 /* --- inspection hooks (tests, state migration between devices) --- */
 /* Window (x0, y0, x1, y1) of a slot's current plane; (cols, rows, 0, 0) = empty (all
- * background); (0, 0, cols, rows) always with RBS_STATE=dense. */
+ * background); (0, 0, cols, rows) always with state_layout dense. */
 int32_t rbs_get_window(rbs_handle* h, int32_t slot, int32_t out[4]);
 /* Never-covered occlusion level of the current planes. */
 int32_t rbs_get_background(rbs_handle* h, float* out);

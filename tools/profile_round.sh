@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile_round.sh rNN  (RBS_STATE=dense tools/profile_round.sh rNN_dense for whole planes)
+# tools/profile_round.sh rNN  (BENCH_ARGS="--layout dense" tools/profile_round.sh rNN_dense for whole planes)
 # -- run on the GPU box (gpurun): rocprofv3 kernel stats + HBM PMC
 # passes of the default bench command; raw outputs under gpurun_out/prof_<tag>, summaries are
 # copied to profiles/ by tools/summarize_profile.py (run locally afterwards).
