@@ -1160,7 +1160,8 @@ void advance_empty(rbs_handle* h, bool update)
     h->background = std::fmaf(alpha, h->background, beta);
     h->cur = 1 - h->cur;
     h->pending_frames = 0;
-    h->calls += 1;
+    // (h->calls stays: it selects the work-item counters, and a raster kernel zeroes the counters of
+    // the call that FOLLOWS it -- a skipped call must not change which pair is next)
 }
 
 int32_t group_load_rccl(rbs_handle* g, const std::vector<int>& devs)

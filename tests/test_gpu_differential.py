@@ -1,0 +1,123 @@
+"""Differential tests across the CONFIGURATIONS of one build: whole planes on one device are the
+reference; windowed planes, slabs, handles over several shards (and their combinations) must hold
+the same planes bit for bit and return the same log-likelihoods (to 1e-12 where the tiling, hence
+the order of the additions, may differ), under randomized call patterns -- varying particle
+counts, read-only calls, skipped frames, everybody inheriting one parent, poses at and behind the
+camera plane or far off screen."""
+import numpy as np
+import pytest
+
+import scenarios as sc
+from dbot_ros_amd import RbSensor, synth
+from dbot_ros_amd.pose import pack_Rt, rotvec_to_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+CONFIGS = {
+    "window": dict(state_layout="window"),
+    "window x2 shards": dict(state_layout="window", device_ids=[0, 0]),
+    "dense x3 shards": dict(state_layout="dense", device_ids=[0, 0, 0]),
+}
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_wild_poses_and_dense_frames(gpu_lib, precision):
+    """Windows grow to the whole frame here (dense random frames, objects all over the place): the
+    windowed layouts go through their mid- and wide-window modes."""
+    n, cols, rows = 48, 160, 120
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    ref = RbSensor(om, cam, P, max_particles=n, precision=precision, state_layout="dense")
+    others = {k: RbSensor(om, cam, P, max_particles=n, precision=precision, **kw) for k, kw in CONFIGS.items()}
+    try:
+        rng = np.random.default_rng(12)
+        idx = np.zeros(n, np.int32)
+        center = np.array([0.0, 0.0, 0.7])
+        m = n
+        for k in range(60):
+            center = center + rng.normal(0, 0.03, 3)
+            center[2] = abs(center[2])
+            m = int(rng.integers(n // 2, n + 1)) if k % 4 == 1 else n
+            R = rotvec_to_matrix(rng.normal(size=(m, 1, 3)))
+            tt = center[None, None, :] + rng.normal(0, 0.05, (m, 1, 3))
+            if k % 7 == 3:
+                tt[:8, 0, 2] = rng.uniform(-0.05, 0.05, 8)
+            if k % 5 == 2:
+                tt[8:16, 0, 0] += 3.0
+            poses = pack_Rt(R, tt)
+            frame = rng.uniform(0.3, 1.5, rows * cols).astype(np.float32)
+            frame[rng.random(frame.size) < 0.05] = np.nan
+            upd = bool(rng.random() < 0.8)
+            par = idx[:m].copy()
+            ref.set_observation(frame)
+            lr = ref.loglikes_poses(poses, par.copy(), update=upd)
+            for name, s in others.items():
+                s.set_observation(frame)
+                lo = s.loglikes_poses(poses, par.copy(), update=upd)
+                assert np.array_equal(np.isnan(lo), np.isnan(lr)), (name, k)
+                ok = ~np.isnan(lr)
+                assert rel_err(lo[ok], lr[ok]).max() <= 1e-12, (name, k, rel_err(lo[ok], lr[ok]).max())
+            if upd:
+                idx = rng.integers(0, m, n).astype(np.int32)        # parents among the slots just written
+                if k % 3 == 0:
+                    idx[:] = idx[0]
+                if k % 10 == 0:
+                    for slot in (0, m // 2, m - 1):
+                        pr = ref.get_occlusion(slot)
+                        for name, s in others.items():
+                            assert np.array_equal(s.get_occlusion(slot), pr), (name, k, slot)
+    finally:
+        ref.close()
+        for s in others.values():
+            s.close()
+
+
+SLAB_CONFIGS = {
+    "slabs": dict(state_layout="window", slab_px=6400),
+    "slabs x2 shards": dict(state_layout="window", slab_px=6400, device_ids=[0, 0]),
+    "window x3 shards": dict(state_layout="window", device_ids=[0, 0, 0]),
+}
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("meshes", [("m1_l2",), ("m1_l2", "box12")])
+def test_wandering_objects_with_random_call_patterns(gpu_lib, precision, meshes):
+    """A tracked scene (windows stay a few percent of the frame, so a third of the frame per slab is
+    plenty): forty frames with changing particle counts, read-only calls, skipped frames."""
+    nmax, cols, rows = 40, 160, 120
+    nb = len(meshes)
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=nmax)
+    ref = RbSensor(om, cam, P, max_particles=nmax, precision=precision, state_layout="dense")
+    others = {k: RbSensor(om, cam, P, max_particles=nmax, precision=precision, **kw) for k, kw in SLAB_CONFIGS.items()}
+    try:
+        rng = np.random.default_rng(70)
+        parents_ok = nmax
+        for k in range(40):
+            truth = synth.truth_pose(nb, frame=int(rng.integers(0, 40)), z=float(rng.uniform(0.6, 0.9)))
+            frame = synth.make_frame(ref.render_depth(truth), rows, cols, rng)
+            for _ in range(int(rng.integers(1, 3))):          # sometimes a frame nobody evaluates
+                ref.set_observation(frame)
+                for s in others.values():
+                    s.set_observation(frame)
+            n = int(rng.integers(1, nmax + 1))
+            poses = synth.particle_poses(truth, n, rng, scale=float(rng.uniform(0.5, 3.0)))
+            par = rng.integers(0, parents_ok, n).astype(np.int32)
+            upd = bool(rng.random() < 0.7)
+            lr = ref.loglikes_poses(poses, par.copy(), update=upd)
+            for name, s in others.items():
+                lo = s.loglikes_poses(poses, par.copy(), update=upd)
+                assert rel_err(lo, lr).max() <= 1e-12, (name, k, n, upd)
+            if upd:
+                parents_ok = n
+                for slot in rng.choice(n, size=min(n, 3), replace=False):
+                    pr = ref.get_occlusion(int(slot))
+                    for name, s in others.items():
+                        assert np.array_equal(s.get_occlusion(int(slot)), pr), (name, k, slot)
+    finally:
+        ref.close()
+        for s in others.values():
+            s.close()
