@@ -121,3 +121,44 @@ def test_wandering_objects_with_random_call_patterns(gpu_lib, precision, meshes)
         ref.close()
         for s in others.values():
             s.close()
+
+
+@pytest.mark.parametrize("meshes,n", [(("m1_l2",), 240), (("m1_l2", "box12", "m1_l2"), 330)])
+def test_device_tracker_across_configurations(gpu_lib, meshes, n):
+    """rbs_tracker_* (transition, sensor, weights, KL, resampling, mean) with the same host-supplied
+    randomness on every configuration: the same estimates and the same resampling decisions.  With
+    three bodies there are two read-only sampling blocks and resamplings between them."""
+    from dbot_ros_amd import pose
+    from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
+    nb = len(meshes)
+    per = n // nb
+    cols, rows = 160, 120
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=per)
+    rng = np.random.default_rng(3)
+    with RbSensor(om, cam, P, max_particles=1) as r:
+        frames = [synth.make_frame(r.render_depth(synth.truth_pose(nb, frame=k)), rows, cols, rng, occluder=False).astype(np.float32)
+                  for k in range(1, 9)]
+    randomness = [(rng.standard_normal((nb, per, 6)), rng.random((nb, per))) for _ in frames]
+    init = np.zeros(12 * nb)
+    for b in range(nb):
+        Rt = synth.truth_pose(nb, frame=0)[b]
+        init[12 * b + 3:12 * b + 6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+        init[12 * b:12 * b + 3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[b]
+    configs = {"dense": dict(state_layout="dense"), "window": dict(state_layout="window"),
+               "slabs": dict(state_layout="window", slab_px=cols * rows // 2),
+               "window x3 shards": dict(state_layout="window", device_ids=[0, 0, 0]),
+               "slabs x2 shards": dict(state_layout="window", slab_px=cols * rows // 2, device_ids=[0, 0])}
+    results = {}
+    for name, kw in configs.items():
+        with RbSensor(om, cam, P, max_particles=per, precision="f64", **kw) as s:
+            trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=nb)).build()
+            tr = DeviceParticleTracker(trans, s, om, ParticleTrackerBuilder.Parameters(evaluation_count=n), np.random.default_rng(5))
+            tr.initialize([init])
+            ests = np.array([tr.track(f, nz, u) for f, (nz, u) in zip(frames, randomness)])
+            results[name] = (ests, tr.n_resamplings)
+            tr.close()
+    ref, nres = results["dense"]
+    assert nres >= 1
+    for name, (ests, r_) in results.items():
+        assert r_ == nres, name
+        assert np.abs(ests - ref).max() <= 1e-9, (name, np.abs(ests - ref).max())
