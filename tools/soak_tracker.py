@@ -37,10 +37,14 @@ def truth_state(k):
     return st
 
 
+CONFIGS = {"window": dict(state_layout="window"), "dense": dict(state_layout="dense"),
+           "slabs": dict(state_layout="window", slab_px=cols * rows // 8),
+           "shards": dict(state_layout="window", device_ids=[0, 0])}
+
+
 def run(layout):
-    os.environ["RBS_STATE"] = layout
     ests = []
-    with RbSensor(om, cam, P, max_particles=n) as s:
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", **CONFIGS[layout]) as s:
         tr = DeviceParticleTracker(ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters()).build(), s, om,
                                    ParticleTrackerBuilder.Parameters(evaluation_count=n), device_rng=True, seed=5)
         tr.initialize([truth_state(0)])
@@ -70,9 +74,12 @@ def run(layout):
 
 
 a = run("window")
-b = run("dense")
-d = np.abs(a - b).max(axis=1)
-print("estimates across layouts: max |difference| %.3e (bitwise identical: %s)" % (float(d.max()), bool(np.array_equal(a, b))))
-if d.max() > 1e-6:
-    print("first frame differing by more than 1e-6:", int(np.argmax(d > 1e-6)) + 1)
-    sys.exit(1)
+worst = 0.0
+for other in ("dense", "slabs", "shards"):
+    b = run(other)
+    d = np.abs(a - b).max(axis=1)
+    worst = max(worst, float(d.max()))
+    print("estimates window vs %s: max |difference| %.3e (bitwise identical: %s)" % (other, float(d.max()), bool(np.array_equal(a, b))))
+    if d.max() > 1e-6:
+        print("first frame differing by more than 1e-6:", int(np.argmax(d > 1e-6)) + 1)
+        sys.exit(1)
