@@ -405,6 +405,20 @@ def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30):
             err = float(np.linalg.norm(est[0:3] - (Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0])))
             out[n] = {"fps": n_frames / dt, "ms_per_frame": dt / n_frames * 1e3, "resamplings": tr.n_resamplings,
                       "final_position_error_m": err}
+            # the same sequence with one frame of look-ahead (rbs_tracker_submit / _result): frame k+1's
+            # host copy and upload run beside frame k's kernels -- dataset replay, or a camera
+            # ahead of its consumer
+            tr.initialize([init])
+            tr.track(frames[0])
+            t0 = time.perf_counter()
+            tr.submit(frames[1])
+            for k in range(2, n_frames + 1):
+                tr.submit(frames[k])
+                tr.result()
+            est2 = tr.result()
+            dt = time.perf_counter() - t0
+            out[n]["fps_pipelined"] = n_frames / dt
+            out[n]["pipelined_equals_synchronous"] = bool(np.array_equal(est, est2))
             tr.close()
     return out
 
@@ -709,6 +723,7 @@ def main():
         fps = tracker_fps(om, cam, dev)
         for k, v in fps.items():
             out[f"tracker_fps_{k}"] = v["fps"]
+            out[f"tracker_fps_pipelined_{k}"] = v["fps_pipelined"]
             out[f"tracker_ms_per_frame_{k}"] = v["ms_per_frame"]
         out["tracker_fps_note"] = ("device tracker (rbs_tracker_*), one object (M1), 640x480, 30-frame sequence, frame uploaded "
                                    "from host memory every frame, precision F32; resamplings " +

@@ -109,8 +109,15 @@ struct rbs_handle {
     size_t in_idx_off = 0;             // byte offset of the indices inside h_in / d_in
     hipEvent_t ev_out = nullptr;
     float* h_frames[2] = {nullptr, nullptr};   // pinned frame staging, alternating
-    hipEvent_t ev_frame[2] = {nullptr, nullptr};
+    hipEvent_t ev_frame[2] = {nullptr, nullptr};   // the upload out of h_frames[k] into d_fin[k] has finished
     int frame_slot = 0;
+    // Host frames travel on their own stream into one of two device staging buffers, and the launch
+    // stream only waits for the upload where it ingests the frame: a frame handed over while the
+    // previous frame's kernels are still running (rbs_tracker_submit) is uploaded beside them.
+    hipStream_t up_stream = nullptr;
+    float* d_fin[2] = {nullptr, nullptr};
+    hipEvent_t ev_used[2] = {nullptr, nullptr};    // the ingest kernel that read d_fin[k] has run
+    int lazy_slot = -1;                            // d_fin slot the pending (lazy) frame sits in
     float* h_frame = nullptr;   // = h_frames[frame_slot]
     float* h_native = nullptr;  // pinned staging for full-resolution frames
     float* d_native = nullptr;
@@ -244,6 +251,7 @@ int32_t flush_lazy_frame(rbs_handle* h, hipStream_t then)
                        h->base.lambda, h->lazy_frame == h->d_frame ? (float*)nullptr : h->d_frame);
     RBS_HIP(h, hipGetLastError());
     h->lazy_frame = nullptr;
+    if (h->lazy_slot >= 0) { RBS_HIP(h, hipEventRecord(h->ev_used[h->lazy_slot], h->lazy_stream)); h->lazy_slot = -1; }
     if (then != h->lazy_stream) {
         RBS_HIP(h, hipEventRecord(h->ev_fork, h->lazy_stream));
         RBS_HIP(h, hipStreamWaitEvent(then, h->ev_fork, 0));
@@ -383,6 +391,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
                            d_rects, update ? 1 : 0, h->lazy_frame, h->d_aux, h->d_pbg,
                            h->lazy_frame == h->d_frame ? (float*)nullptr : h->d_frame, aux_blocks);
         h->lazy_frame = nullptr;
+        if (h->lazy_slot >= 0) { RBS_HIP(h, hipEventRecord(h->ev_used[h->lazy_slot], s)); h->lazy_slot = -1; }
     } else {
         if (int32_t rc = flush_lazy_frame(h, s)) return rc;
         hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(64 * rbs::kPrepPerBlock), 0, s, P, d_rects, update ? 1 : 0);
@@ -614,10 +623,14 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_tri_plane);
     (void)hipFree(h->d_vtx);
     (void)hipFree(h->d_render);
+    if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
     for (int k = 0; k < 2; ++k) {
         if (h->h_frames[k]) (void)hipHostFree(h->h_frames[k]);
         if (h->ev_frame[k]) (void)hipEventDestroy(h->ev_frame[k]);
+        if (h->ev_used[k]) (void)hipEventDestroy(h->ev_used[k]);
+        (void)hipFree(h->d_fin[k]);
     }
+    if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
     if (h->h_in) (void)hipHostFree(h->h_in);
     if (h->h_out) (void)hipHostFree(h->h_out);
     (void)hipFree(h->d_in);
@@ -639,16 +652,21 @@ void release(rbs_handle* h)
     delete h;
 }
 
-// H2D of the staged frame + the per-frame model terms; stream ordered.
-int32_t upload_frame(rbs_handle* h)
+// H2D of a frame staged in pinned host memory (`src`, normally h->h_frame) on the upload stream into
+// the device staging buffer of the current slot; the launch stream waits for it, and the ingest
+// kernel (copy into d_frame + per-frame model terms) rides on the next loglikes launch
+// (flush_lazy_frame otherwise).
+int32_t upload_frame(rbs_handle* h, const float* src)
 {
+    const int k = h->frame_slot;
     const size_t n = (size_t)h->npx;
-    RBS_HIP(h, hipMemcpyAsync(h->d_frame, h->h_frame, n * sizeof(float), hipMemcpyHostToDevice,
-                              h->stream));
-    RBS_HIP(h, hipEventRecord(h->ev_frame[h->frame_slot], h->stream));
-    // the per-pixel terms kernel rides on the next loglikes launch (flush_lazy_frame otherwise)
-    h->lazy_frame = h->d_frame;
+    RBS_HIP(h, hipStreamWaitEvent(h->up_stream, h->ev_used[k], 0));   // d_fin[k]: read by the ingest kernel two frames ago
+    RBS_HIP(h, hipMemcpyAsync(h->d_fin[k], src, n * sizeof(float), hipMemcpyHostToDevice, h->up_stream));
+    RBS_HIP(h, hipEventRecord(h->ev_frame[k], h->up_stream));
+    RBS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_frame[k], 0));
+    h->lazy_frame = h->d_fin[k];
     h->lazy_stream = h->stream;
+    h->lazy_slot = k;
     return RBS_OK;
 }
 
@@ -1070,9 +1088,12 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         RBS_HIP(h, hipMemcpy(h->d_vtx, vtx.data(), sizeof(float) * vtx.size(), hipMemcpyHostToDevice));
         B.vtx = reinterpret_cast<const rbs::floatx4*>(h->d_vtx);
     }
+    RBS_HIP(h, hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k) {
         RBS_HIP(h, hipHostMalloc(&h->h_frames[k], plane, hipHostMallocPortable));   // (every device of a group uploads from shard 0's)
         RBS_HIP(h, hipEventCreateWithFlags(&h->ev_frame[k], hipEventDisableTiming));
+        RBS_HIP(h, hipEventCreateWithFlags(&h->ev_used[k], hipEventDisableTiming));
+        RBS_HIP(h, hipMalloc(&h->d_fin[k], plane));
     }
     h->h_frame = h->h_frames[0];
     {
@@ -1117,7 +1138,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipStreamSynchronize(h->copy_stream));
     // no observation yet: every pixel "no reading"
     for (int p = 0; p < h->npx; ++p) h->h_frame[p] = NAN;
-    if (int32_t rc = upload_frame(h)) return rc;
+    if (int32_t rc = upload_frame(h, h->h_frame)) return rc;
     return rbs_reset(h);
 }
 
@@ -1479,7 +1500,7 @@ int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n)
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     if (int32_t rc = next_frame_staging(h)) return rc;
     for (size_t p = 0; p < n; ++p) h->h_frame[p] = (float)depth[p];
-    if (int32_t rc = upload_frame(h)) return rc;
+    if (int32_t rc = upload_frame(h, h->h_frame)) return rc;
     h->pending_frames += 1;
     return RBS_OK;
 }
@@ -1495,7 +1516,7 @@ int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n)
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     if (int32_t rc = next_frame_staging(h)) return rc;
     std::memcpy(h->h_frame, depth, n * sizeof(float));
-    if (int32_t rc = upload_frame(h)) return rc;
+    if (int32_t rc = upload_frame(h, h->h_frame)) return rc;
     h->pending_frames += 1;
     return RBS_OK;
 }
@@ -1532,17 +1553,14 @@ int32_t rbs_commit_frame_buffer(rbs_handle* h)
         for (rbs_handle* sh : h->shards) {
             RBS_HIP(h, hipSetDevice(sh->device));
             if (int32_t rc = flush_lazy_frame(sh, sh->stream)) return gfail(h, sh, rc);
-            RBS_HIP(h, hipMemcpyAsync(sh->d_frame, src, sizeof(float) * (size_t)sh->npx, hipMemcpyHostToDevice, sh->stream));
-            RBS_HIP(h, hipEventRecord(sh->ev_frame[sh->frame_slot], sh->stream));
-            sh->lazy_frame = sh->d_frame;
-            sh->lazy_stream = sh->stream;
+            if (int32_t rc = upload_frame(sh, src)) return gfail(h, sh, rc);
             sh->pending_frames += 1;
         }
         return RBS_OK;
     }
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
-    if (int32_t rc = upload_frame(h)) return rc;
+    if (int32_t rc = upload_frame(h, h->h_frame)) return rc;
     h->pending_frames += 1;
     return RBS_OK;
 }
@@ -1927,6 +1945,18 @@ struct rbs_tracker {
     // a sensor over several devices: one replica (all particle states + the filter's kernels) per
     // shard; `s` is then the group handle and T is unused
     std::vector<rbs_tracker*> reps;
+    // pipelining (rbs_tracker_submit / rbs_tracker_result): up to two frames in flight; per slot the
+    // host-supplied randomness (pinned staging + its device image) and the frame's result (pinned)
+    double* h_normals[2] = {nullptr, nullptr};
+    double* h_uniforms[2] = {nullptr, nullptr};
+    double* d_normals2[2] = {nullptr, nullptr};
+    double* d_uniforms2[2] = {nullptr, nullptr};
+    double* h_state[2] = {nullptr, nullptr};
+    int* h_flags[2] = {nullptr, nullptr};
+    int* h_serr[2] = {nullptr, nullptr};
+    hipEvent_t ev_res[2] = {nullptr, nullptr};
+    int32_t res_rc[2] = {0, 0};       // (a handle over several devices runs submit synchronously)
+    long submitted = 0, collected = 0;
 };
 
 namespace {
@@ -2012,6 +2042,25 @@ int32_t tracker_create_one(rbs_handle* sensor, const rbs_tracker_params* p, int 
         return rc;
     }
     RBS_HIP(sensor, hipMemsetAsync(T.deflt, 0, sizeof(double) * D, sensor->stream));
+    t->d_normals2[0] = t->d_normals;
+    t->d_uniforms2[0] = t->d_uniforms;
+    if ((rc = talloc(t, &t->d_normals2[1], n * P6)) || (rc = talloc(t, &t->d_uniforms2[1], n * (size_t)T.parts))) {
+        rbs_tracker_destroy(t);
+        return rc;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (hipHostMalloc(&t->h_normals[k], sizeof(double) * n * P6, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&t->h_uniforms[k], sizeof(double) * n * T.parts, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&t->h_state[k], sizeof(double) * D, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&t->h_flags[k], sizeof(int) * 2, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&t->h_serr[k], sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&t->ev_res[k], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            rbs_tracker_destroy(t);
+            return fail(sensor, RBS_ERR_OUT_OF_MEMORY, "tracker_create: pinned host memory");
+        }
+        *t->h_serr[k] = 0;
+    }
     *out = t;
     return RBS_OK;
 }
@@ -2056,6 +2105,14 @@ void rbs_tracker_destroy(rbs_tracker* t)
     (void)hipSetDevice(t->s->device);
     (void)hipStreamSynchronize(t->s->stream);
     for (void* p : t->allocs) (void)hipFree(p);
+    for (int k = 0; k < 2; ++k) {
+        if (t->h_normals[k]) (void)hipHostFree(t->h_normals[k]);
+        if (t->h_uniforms[k]) (void)hipHostFree(t->h_uniforms[k]);
+        if (t->h_state[k]) (void)hipHostFree(t->h_state[k]);
+        if (t->h_flags[k]) (void)hipHostFree(t->h_flags[k]);
+        if (t->h_serr[k]) (void)hipHostFree(t->h_serr[k]);
+        if (t->ev_res[k]) (void)hipEventDestroy(t->ev_res[k]);
+    }
     delete t;
 }
 
@@ -2063,6 +2120,7 @@ int32_t rbs_tracker_initialize(rbs_tracker* t, const double* default_state)
 {
     if (!t) return RBS_ERR_INVALID_ARGUMENT;
     if (!default_state) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_initialize: null state");
+    t->submitted = t->collected = 0;
     if (!t->reps.empty()) {
         for (rbs_tracker* r : t->reps)
             if (int32_t rc = rbs_tracker_initialize(r, default_state)) { t->s->err = r->s->err; return rc; }
@@ -2198,13 +2256,18 @@ int32_t group_tracker_track(rbs_tracker* t, const float* frame, const double* no
 
 extern "C" {
 
-int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* normals,
-                          const double* uniforms, uint64_t seed, double* out_state,
-                          int32_t* out_resamplings)
+int32_t rbs_tracker_submit(rbs_tracker* t, const float* frame, const double* normals, const double* uniforms, uint64_t seed)
 {
     if (!t) return RBS_ERR_INVALID_ARGUMENT;
-    if (!out_state) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_track: null output");
-    if (!t->reps.empty()) return group_tracker_track(t, frame, normals, uniforms, seed, out_state, out_resamplings);
+    if (t->submitted - t->collected >= 2)
+        return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_submit: two frames are in flight already (call rbs_tracker_result)");
+    const int slot = (int)(t->submitted & 1);
+    if (!t->reps.empty()) {   // several devices: the frame runs to completion here, its result waits in the slot
+        rbs_tracker* r0 = t->reps[0];
+        t->res_rc[slot] = group_tracker_track(t, frame, normals, uniforms, seed, r0->h_state[slot], &r0->h_flags[slot][1]);
+        t->submitted += 1;
+        return t->res_rc[slot];
+    }
     rbt::TrackerDev& T = t->T;
     rbs_handle* h = t->s;
     RBT_HIP(t, hipSetDevice(h->device));
@@ -2214,13 +2277,16 @@ int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* norm
     const size_t n = (size_t)T.n;
     T.normals = nullptr;
     T.uniforms = nullptr;
+    // host-supplied randomness goes through pinned staging: the caller's buffers are free on return
     if (normals) {
-        RBT_HIP(t, hipMemcpyAsync(t->d_normals, normals, sizeof(double) * n * T.parts * 6, hipMemcpyHostToDevice, s));
-        T.normals = t->d_normals;
+        std::memcpy(t->h_normals[slot], normals, sizeof(double) * n * T.parts * 6);
+        RBT_HIP(t, hipMemcpyAsync(t->d_normals2[slot], t->h_normals[slot], sizeof(double) * n * T.parts * 6, hipMemcpyHostToDevice, s));
+        T.normals = t->d_normals2[slot];
     }
     if (uniforms) {
-        RBT_HIP(t, hipMemcpyAsync(t->d_uniforms, uniforms, sizeof(double) * n * T.parts, hipMemcpyHostToDevice, s));
-        T.uniforms = t->d_uniforms;
+        std::memcpy(t->h_uniforms[slot], uniforms, sizeof(double) * n * T.parts);
+        RBT_HIP(t, hipMemcpyAsync(t->d_uniforms2[slot], t->h_uniforms[slot], sizeof(double) * n * T.parts, hipMemcpyHostToDevice, s));
+        T.uniforms = t->d_uniforms2[slot];
     }
     T.seed = seed;
     const dim3 g256((unsigned)((T.n + 255) / 256)), b256(256);
@@ -2251,14 +2317,49 @@ int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* norm
     }
     RBT_HIP(t, hipGetLastError());
     std::swap(T.part_old, T.part_new);   // this frame's particles are the next frame's old ones
-    RBT_HIP(t, hipMemcpyAsync(out_state, T.deflt, sizeof(double) * T.D, hipMemcpyDeviceToHost, s));
-    int flags[2] = {0, 0};
-    RBT_HIP(t, hipMemcpyAsync(flags, T.flag, sizeof(flags), hipMemcpyDeviceToHost, s));
-    if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(h->h_err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
-    RBT_HIP(t, hipStreamSynchronize(s));
-    if (out_resamplings) *out_resamplings = flags[1];
+    RBT_HIP(t, hipMemcpyAsync(t->h_state[slot], T.deflt, sizeof(double) * T.D, hipMemcpyDeviceToHost, s));
+    RBT_HIP(t, hipMemcpyAsync(t->h_flags[slot], T.flag, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+    if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(t->h_serr[slot], h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    RBT_HIP(t, hipEventRecord(t->ev_res[slot], s));
     T.frame += 1;
-    return check_slab_error(h);
+    t->res_rc[slot] = RBS_OK;
+    t->submitted += 1;
+    return RBS_OK;
+}
+
+int32_t rbs_tracker_result(rbs_tracker* t, double* out_state, int32_t* out_resamplings)
+{
+    if (!t) return RBS_ERR_INVALID_ARGUMENT;
+    if (!out_state) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_result: null output");
+    if (t->collected >= t->submitted) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_result: no frame in flight");
+    const int slot = (int)(t->collected & 1);
+    t->collected += 1;
+    rbs_tracker* r = t->reps.empty() ? t : t->reps[0];
+    const int D = r->T.D;
+    if (t->reps.empty()) {
+        RBT_HIP(t, hipSetDevice(t->s->device));
+        RBT_HIP(t, hipEventSynchronize(t->ev_res[slot]));
+    }
+    std::memcpy(out_state, r->h_state[slot], sizeof(double) * D);
+    if (out_resamplings) *out_resamplings = r->h_flags[slot][1];
+    if (!t->reps.empty()) return t->res_rc[slot];
+    if (t->s->slab_px) { *t->s->h_err = *t->h_serr[slot]; return check_slab_error(t->s); }
+    return RBS_OK;
+}
+
+int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* normals,
+                          const double* uniforms, uint64_t seed, double* out_state,
+                          int32_t* out_resamplings)
+{
+    if (!t) return RBS_ERR_INVALID_ARGUMENT;
+    if (!out_state) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_track: null output");
+    if (t->submitted != t->collected)
+        return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_track: frames submitted with rbs_tracker_submit are still in flight");
+    if (int32_t rc = rbs_tracker_submit(t, frame, normals, uniforms, seed)) {
+        if (t->submitted != t->collected) t->collected = t->submitted;   // (a group's frame that failed: nothing to collect)
+        return rc;
+    }
+    return rbs_tracker_result(t, out_state, out_resamplings);
 }
 
 int32_t rbs_tracker_get(rbs_tracker* t, double* particles, double* log_weights, int32_t* indices)

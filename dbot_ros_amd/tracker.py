@@ -258,7 +258,7 @@ class DeviceParticleTracker(ParticleTracker):
         self.moving_average = None
         self.n_resamplings = 0
 
-    def track(self, image, normals=None, uniforms=None):
+    def _frame_args(self, image, normals, uniforms):
         C = self._C
         dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
         if not self.device_rng and (normals is None or uniforms is None):
@@ -271,17 +271,38 @@ class DeviceParticleTracker(ParticleTracker):
         if uniforms is not None:
             uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
             uptr = uniforms.ctypes.data_as(dp)
-        out = np.empty(self.parts * BODY)
-        nres = C.c_int32()
-        self.sensor._check(self._lib.rbs_tracker_track(self._t, img.ctypes.data_as(fp), nptr, uptr,
-                                                       C.c_uint64(self.seed), out.ctypes.data_as(dp),
-                                                       C.byref(nres)))
+        return (img, normals, uniforms), (img.ctypes.data_as(fp), nptr, uptr, C.c_uint64(self.seed))
+
+    def _estimate(self, out, nres):
         self.default = out
         self.n_resamplings = int(nres.value)
         est = self._from_model(self.default)
         rate = self.params.moving_average_update_rate
         self.moving_average = est if self.moving_average is None else rate * est + (1 - rate) * self.moving_average
         return self.moving_average.copy()
+
+    def track(self, image, normals=None, uniforms=None):
+        C = self._C
+        _keep, args = self._frame_args(image, normals, uniforms)
+        out = np.empty(self.parts * BODY)
+        nres = C.c_int32()
+        self.sensor._check(self._lib.rbs_tracker_track(self._t, *args, out.ctypes.data_as(C.POINTER(C.c_double)),
+                                                       C.byref(nres)))
+        return self._estimate(out, nres)
+
+    def submit(self, image, normals=None, uniforms=None):
+        """Enqueue one frame (rbs_tracker_submit) and return at once; at most two frames may be in
+        flight.  result() hands out the estimates in submission order."""
+        _keep, args = self._frame_args(image, normals, uniforms)
+        self.sensor._check(self._lib.rbs_tracker_submit(self._t, *args))
+
+    def result(self):
+        """The moving-average estimate of the oldest submitted frame (rbs_tracker_result)."""
+        C = self._C
+        out = np.empty(self.parts * BODY)
+        nres = C.c_int32()
+        self.sensor._check(self._lib.rbs_tracker_result(self._t, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nres)))
+        return self._estimate(out, nres)
 
     def get_state(self):
         """(particle deltas [n, parts*12], log-weights [n], occlusion slot map [n]) from the device."""

@@ -281,6 +281,16 @@ int32_t rbs_tracker_initialize(rbs_tracker* t, const double* default_state);
 int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* normals,
                           const double* uniforms, uint64_t seed, double* out_state,
                           int32_t* out_resamplings);
+/* The same frame in two halves, for callers that have the NEXT frame before they need this frame's
+ * estimate (dataset replay, a camera that outruns the consumer): rbs_tracker_submit enqueues a
+ * frame's work and returns at once -- the caller's frame / normals / uniforms buffers are free on
+ * return -- and rbs_tracker_result waits for the OLDEST submitted frame and hands out its state.
+ * Up to two frames may be in flight: the second frame's host copy and upload run beside the first
+ * frame's kernels (host frames travel on their own stream).  rbs_tracker_track == submit + result.
+ * Frames are processed strictly in order; the numbers are those of rbs_tracker_track. */
+int32_t rbs_tracker_submit(rbs_tracker* t, const float* frame, const double* normals,
+                           const double* uniforms, uint64_t seed);
+int32_t rbs_tracker_result(rbs_tracker* t, double* out_state, int32_t* out_resamplings);
 /* Inspection: particle deltas [n][n_objects*12], log-weights [n], occlusion slot map [n]
  * (any pointer may be NULL). */
 int32_t rbs_tracker_get(rbs_tracker* t, double* particles, double* log_weights, int32_t* indices);

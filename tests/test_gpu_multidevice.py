@@ -114,6 +114,68 @@ def test_group_device_tracker_matches_single_device(gpu_lib, meshes, n, ids):
         assert np.abs(w1 - w2).max() <= 1e-6 * max(1.0, np.abs(w1).max())
 
 
+@pytest.mark.parametrize("meshes,n,ids,device_rng", [(("m1_l2",), 96, None, False), (("m1_l2", "box12"), 600, None, False),
+                                                      (("m1_l2",), 4000, None, True), (("m1_l2",), 96, [0, 0], False),
+                                                      (("m1_l2",), 20000, None, True)])
+def test_pipelined_tracker_is_the_synchronous_tracker(gpu_lib, meshes, n, ids, device_rng):
+    """rbs_tracker_submit / rbs_tracker_result with two frames in flight (the caller's buffers are
+    overwritten right after submit) against rbs_tracker_track frame by frame: identical estimates,
+    resampling counts and final particles; misuse (a third frame, a result with nothing in flight,
+    track with frames in flight) is an error that leaves the pipeline usable."""
+    nb = len(meshes)
+    cols, rows = 160, 120
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    per = n // nb
+    rng = np.random.default_rng(3)
+    with RbSensor(om, cam, P, max_particles=1) as r:
+        frames = [synth.make_frame(r.render_depth(synth.truth_pose(nb, frame=k)), rows, cols, rng, occluder=False).astype(np.float32)
+                  for k in range(1, 10)]
+    randomness = [(None, None) if device_rng else (rng.standard_normal((nb, per, 6)), rng.random((nb, per))) for _ in frames]
+
+    def run(pipelined):
+        with RbSensor(om, cam, P, max_particles=per, precision="f64", device_ids=ids) as s:
+            trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=nb)).build()
+            tr = DeviceParticleTracker(trans, s, om, ParticleTrackerBuilder.Parameters(evaluation_count=n),
+                                       np.random.default_rng(5), device_rng=device_rng, seed=11)
+            tr.initialize([_init_state(om, nb)])
+            ests, counts = [], []
+            if not pipelined:
+                for f, (nm, un) in zip(frames, randomness):
+                    ests.append(tr.track(f, nm, un))
+                    counts.append(tr.n_resamplings)
+            else:
+                with pytest.raises(Exception, match="no frame in flight"):
+                    tr.result()
+                scratch_f = np.empty_like(frames[0])
+                for k, (f, (nm, un)) in enumerate(zip(frames, randomness)):
+                    scratch_f[...] = f
+                    nm_, un_ = (None, None) if nm is None else (nm.copy(), un.copy())
+                    tr.submit(scratch_f, nm_, un_)
+                    scratch_f[...] = np.nan          # the caller's buffers are its own again
+                    if nm_ is not None:
+                        nm_[...] = 1e9
+                        un_[...] = 0.5
+                    if k == 1:
+                        with pytest.raises(Exception, match="in flight"):
+                            tr.submit(f, nm, un)
+                        with pytest.raises(Exception, match="in flight"):
+                            tr.track(f, nm, un)
+                    if k >= 1:
+                        ests.append(tr.result())
+                        counts.append(tr.n_resamplings)
+                ests.append(tr.result())
+                counts.append(tr.n_resamplings)
+            state = tr.get_state()
+            tr.close()
+        return np.array(ests), counts, state
+
+    e1, c1, s1 = run(False)
+    e2, c2, s2 = run(True)
+    assert c1 == c2
+    assert np.array_equal(e1, e2)
+    assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1])
+
+
 def test_rccl_all_gather_runs_in_the_group_path(gpu_lib, monkeypatch):
     """RBS_GROUP_SINGLE: a one-shard group on one device, so that the RCCL communicator, the
     ncclGroupStart / ncclAllGather / ncclGroupEnd calls and the run-time binding of librccl are
