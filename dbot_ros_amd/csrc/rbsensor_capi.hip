@@ -364,7 +364,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.done = h->d_done;
     P.partial = h->d_partial;
 #ifdef RBS_PHASE_TIMING
-    if (!h->d_phase) { RBS_HIP(h, hipMalloc(&h->d_phase, 64)); RBS_HIP(h, hipMemset(h->d_phase, 0, 64)); }
+    if (!h->d_phase) { RBS_HIP(h, hipMalloc(&h->d_phase, 128)); RBS_HIP(h, hipMemset(h->d_phase, 0, 128)); }
     P.phase = h->d_phase;
 #endif
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_start[tslot], s));
@@ -1835,8 +1835,8 @@ int32_t rbs_debug_phase_cycles(rbs_handle* h, unsigned long long* out8)
 {
     if (!h || !h->d_phase) return RBS_ERR_INVALID_ARGUMENT;
     RBS_HIP(h, hipDeviceSynchronize());
-    RBS_HIP(h, hipMemcpy(out8, h->d_phase, 64, hipMemcpyDeviceToHost));
-    RBS_HIP(h, hipMemset(h->d_phase, 0, 64));
+    RBS_HIP(h, hipMemcpy(out8, h->d_phase, 128, hipMemcpyDeviceToHost));   // 16 counters
+    RBS_HIP(h, hipMemset(h->d_phase, 0, 128));
     return RBS_OK;
 }
 #endif

@@ -38,6 +38,7 @@
 // one rounding to float, z-min is order independent, so coverage and depth are bit-exact.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include <stdint.h>
 
@@ -77,8 +78,21 @@ constexpr int kCopyUnroll = RBS_COPY_UNROLL; // float4 loads in flight per lane 
 #ifndef RBS_SCAN_UNROLL
 #define RBS_SCAN_UNROLL 2
 #endif
+constexpr int kQPlanes_ = 4;
 constexpr int kEvalQueue = 128;             // per-wave ring of covered pixels awaiting evaluation (a power of two)
-constexpr int kQPlanes = 4;                 // ints per queued pixel: index, depth, prior, observation (F32 precision)
+constexpr int kTq = kQPlanes_ * kEvalQueue;  // the same LDS during the raster phase: a per-wave ring of triangle indices
+// Three raster waves of 160 registers leave a SIMD the 32 that one copy wave needs (F32 precision;
+// the binary64 likelihood does not fit and runs before/after the copy kernel): the budget is
+// stated to the compiler, which otherwise only aims at "three waves" = 168.
+#ifndef RBS_RASTER_VGPRS
+#define RBS_RASTER_VGPRS 80   // (the attribute counts architectural registers and the compiler doubles it on gfx90a+: 160 in all)
+#endif
+#ifndef RBS_PRETEST_CLUSTERS
+#define RBS_PRETEST_CLUSTERS 4
+#endif
+constexpr int kPre = RBS_PRETEST_CLUSTERS;  // clusters pre-tested per step
+static_assert(kPre * 64 + 63 <= kTq && (kTq & (kTq - 1)) == 0, "the triangle ring must hold a step's survivors");
+constexpr int kQPlanes = kQPlanes_;                 // ints per queued pixel: index, depth, prior, observation (F32 precision)
 constexpr int kRectAlign = 16;              // whole planes: rectangle x-alignment in pixels (64 B)
 constexpr float kSnapTau = 0x1p-18f;         // background snap of the occlusion process (oracle ORC_SNAP_TAU)
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -176,11 +190,17 @@ struct DevParams {
 #endif
 };
 #ifdef RBS_PHASE_TIMING
-#define RBS_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); atomicAdd(&P.phase[k], t_ - tick_); tick_ = t_; } } while (0)
+// (accumulated in LDS, flushed once per block: a global atomic per tick serialised the blocks)
+__shared__ unsigned long long g_phase_lds[16];
+#define RBS_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); g_phase_lds[k] += t_ - tick_; tick_ = t_; } } while (0)
 #define RBS_TICK_DECL unsigned long long tick_ = clock64()
+#define RBS_TICK_PARAM , unsigned long long& tick_
+#define RBS_TICK_ARG , tick_
 #else
 #define RBS_TICK(k) do {} while (0)
 #define RBS_TICK_DECL do {} while (0)
+#define RBS_TICK_PARAM
+#define RBS_TICK_ARG
 #endif
 
 struct Rect { int x0, y0, x1, y1; };
@@ -448,6 +468,13 @@ __device__ inline int body_of(const DevParams& P, int t)
     return b;
 }
 
+// The cluster tests below are conservative with margins of 1e-3: the hardware square root (1 ulp)
+// serves them; the correctly rounded one the build asks for elsewhere costs ~15 instructions.
+#ifndef RBS_CULL_SQRT
+#define RBS_CULL_SQRT 1
+#endif
+__device__ inline float cone_sqrt(float x) { return RBS_CULL_SQRT ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+
 // Conservative float32 test: can any triangle of the cluster (model-space bounding sphere
 // c, rho) touch the pixel window [wx0,wx1) x [wy0,wy1)?  The window's four frustum planes
 // pass through the camera centre; the sphere is culled only if it lies entirely outside one
@@ -467,10 +494,19 @@ __device__ inline bool cluster_may_touch(const DevParams& P, const double* __res
     // u >= a  <=>  fx*X + (cx-a)*Z >= 0  (Z > 0); signed distance to that plane = (.)/|n|
     const float al = cx - ((float)wx0 - 2.0f), ar = cx - ((float)wx1 + 1.0f);
     const float at = cy - ((float)wy0 - 2.0f), ab = cy - ((float)wy1 + 1.0f);
-    if (fx * X + al * Z < -rho * sqrtf(fx * fx + al * al)) return false;   // left of the window
-    if (fx * X + ar * Z > rho * sqrtf(fx * fx + ar * ar)) return false;    // right
-    if (fy * Y + at * Z < -rho * sqrtf(fy * fy + at * at)) return false;   // above
-    if (fy * Y + ab * Z > rho * sqrtf(fy * fy + ab * ab)) return false;    // below
+    // signed distance to a plane < -rho  <=>  s < 0 and s^2 > rho^2 |n|^2  (no square root)
+    const float r2 = rho * rho;
+    // (one test at a time: left to itself the scheduler interleaves the four and the kernel's
+    // register count, which the copy kernel's co-residency hangs on, goes up by 7)
+    bool out = false;
+    { const float s_ = fx * X + al * Z; out |= s_ < 0.0f && s_ * s_ > r2 * (fx * fx + al * al); }   // left of the window
+    __builtin_amdgcn_sched_barrier(0);
+    { const float s_ = fx * X + ar * Z; out |= s_ > 0.0f && s_ * s_ > r2 * (fx * fx + ar * ar); }   // right
+    __builtin_amdgcn_sched_barrier(0);
+    { const float s_ = fy * Y + at * Z; out |= s_ < 0.0f && s_ * s_ > r2 * (fy * fy + at * at); }   // above
+    __builtin_amdgcn_sched_barrier(0);
+    { const float s_ = fy * Y + ab * Z; out |= s_ > 0.0f && s_ * s_ > r2 * (fy * fy + ab * ab); }   // below
+    if (out) return false;
     return true;
 }
 
@@ -494,10 +530,10 @@ __device__ inline bool cluster_faces_away(const double* __restrict__ Rt, const f
     const float ay = r3 * cone[0] + r4 * cone[1] + r5 * cone[2];
     const float az = r6 * cone[0] + r7 * cone[1] + r8 * cone[2];
     const float rho = sph[3] * 1.001f + 1e-3f;
-    const float D = sqrtf(X * X + Y * Y + Z * Z);
+    const float D = cone_sqrt(X * X + Y * Y + Z * Z);
     const float ad = ax * X + ay * Y + az * Z;           // |c| cos psi
-    const float sp = sqrtf(fmaxf(D * D - ad * ad, 0.0f)); // |c| sin psi
-    const float lhs = ad * m - sp * sqrtf(fmaxf(1.0f - m * m, 0.0f)) - rho;
+    const float sp = cone_sqrt(fmaxf(D * D - ad * ad, 0.0f)); // |c| sin psi
+    const float lhs = ad * m - sp * cone_sqrt(fmaxf(1.0f - m * m, 0.0f)) - rho;
     return lhs > 1e-3f * (D + rho) + 1e-4f;
 }
 
@@ -522,10 +558,13 @@ __device__ inline int body_cullsign(const DevParams& P, const double* __restrict
 // One lane's triangle: setup, then its sample points (or the cooperative queue when it is big).
 __device__ inline void raster_lane_triangle(const DevParams& P, int t, const double* __restrict__ Rt, int wx0,
                                             int wy0, int wx1, int wy1, int cullsign, unsigned* tile, int tw,
-                                            int* big, int* nbig)
+                                            int* big, int* nbig RBS_TICK_PARAM)
 {
     Tri T;
-    if (!tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, cullsign, T)) return;
+    RBS_TICK(10);
+    const bool ok_ = tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, cullsign, T);
+    RBS_TICK(11);
+    if (!ok_) return;
 #ifdef RBS_EXP_SKIP_PIXELS   // profiling builds (tools/phase_timing.py): triangle setup only
     if (T.nv0 != 12345.678) return;
 #endif
@@ -538,6 +577,8 @@ __device__ inline void raster_lane_triangle(const DevParams& P, int t, const dou
         for (int col = T.xlo; col <= T.xhi; ++col)
             tri_pixel(T, col, row, tile, tw, wx0, wy0);
 }
+// (phase-timing builds: the time between a lane leaving its sample loop and the next tick is the
+// wave's sample phase -- lane 0 may leave early, so the caller ticks after reconvergence)
 
 // Rasterize every body of one particle into the LDS tile covering window
 // [wx0,wx1) x [wy0,wy1).  One wave takes one 64-triangle cluster at a time (triangles were
@@ -563,6 +604,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x == 0) *nbig = 0;
     __syncthreads();
+    RBS_TICK_DECL;
     // surviving clusters so far: dealt round-robin to the block's waves (an LDS ticket per
     // cluster instead measured no better: the waves of a block finish within a few percent)
     int taken = 0;
@@ -587,48 +629,73 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
                                                                     wx0, wy0, wx1, wy1)) &&
                              !(cullsign != 0 && cluster_faces_away(Rt, P.cluster_sphere + 4 * ci,
                                                                    P.cluster_cone + 4 * ci));
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int bit = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                if ((taken++) % (kBlock / 64) != wave) continue;
-                const int t = ((base + bit) << 6) + lane;
-                if (cullsign == 0) {   // nothing to pre-test: the cluster's lanes go straight to the setup
-                    raster_lane_triangle(P, t, Rt, wx0, wy0, wx1, wy1, 0, tile, tw, big, nbig);
-                    continue;
+            const unsigned long long mask = __ballot(hit);
+            RBS_TICK(8);
+            // this wave's share: the surviving clusters are dealt round-robin by their rank
+            const int rank = taken + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            unsigned long long mine = __ballot(hit && (rank % (kBlock / 64)) == wave);
+            taken += __popcll(mask);
+            if (cullsign == 0) {   // nothing to pre-test: the clusters' lanes go straight to the setup
+                while (mine) {
+                    const int bit = __builtin_ctzll(mine);
+                    mine &= mine - 1;
+                    raster_lane_triangle(P, ((base + bit) << 6) + lane, Rt, wx0, wy0, wx1, wy1, 0, tile, tw, big, nbig RBS_TICK_ARG);
+                    __builtin_amdgcn_wave_barrier(); RBS_TICK(12);
                 }
-                bool keep = t < t_end;
-                if (keep) {
-                    const floatx4 pl = P.tri_plane[t];
-                    const float sd = pl.x * ex + pl.y * ey + pl.z * ez + pl.w;   // eye's signed distance, winding side
-                    keep = !(fsign * sd < -eps);   // outward normal = cullsign * winding normal; NaN keeps
+                continue;
+            }
+            while (mine) {
+                // pre-test kPre clusters per step: their planes are loaded together (one exposed
+                // latency per step, not per cluster; three waves per SIMD do not hide it)
+                int tt[kPre];
+                floatx4 pl[kPre];
+#pragma unroll
+                for (int u = 0; u < kPre; ++u) {
+                    tt[u] = -1;
+                    if (mine) {   // wave-uniform
+                        const int bit = __builtin_ctzll(mine);
+                        mine &= mine - 1;
+                        tt[u] = ((base + bit) << 6) + lane;
+                    }
+                    pl[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    if (tt[u] >= 0 && tt[u] < t_end) pl[u] = P.tri_plane[tt[u]];
                 }
-                const unsigned long long km = __ballot(keep);
-                if (keep) {
-                    const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0));
-                    tq[(qh + pos) & 127] = t;
+#pragma unroll
+                for (int u = 0; u < kPre; ++u) {
+                    if (tt[u] < 0) break;   // wave-uniform
+                    const float sd = pl[u].x * ex + pl[u].y * ey + pl[u].z * ez + pl[u].w;   // eye's signed distance, winding side
+                    const bool keep = tt[u] < t_end && !(fsign * sd < -eps);   // outward normal = cullsign * winding normal; NaN keeps
+                    const unsigned long long km = __ballot(keep);
+                    if (keep) {
+                        const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0));
+                        tq[(qh + pos) & (kTq - 1)] = tt[u];
+                    }
+                    qn += __popcll(km);
                 }
-                qn += __popcll(km);
-                if (qn >= 64) {
+                while (qn >= 64) {
                     __builtin_amdgcn_wave_barrier();
-                    const int tt = tq[(qh + lane) & 127];
+                    const int t64 = tq[(qh + lane) & (kTq - 1)];
                     __builtin_amdgcn_wave_barrier();
-                    qh = (qh + 64) & 127;
+                    qh = (qh + 64) & (kTq - 1);
                     qn -= 64;
-                    raster_lane_triangle(P, tt, Rt, wx0, wy0, wx1, wy1, cullsign, tile, tw, big, nbig);
+                    raster_lane_triangle(P, t64, Rt, wx0, wy0, wx1, wy1, cullsign, tile, tw, big, nbig RBS_TICK_ARG);
+                    __builtin_amdgcn_wave_barrier(); RBS_TICK(12);
                 }
             }
         }
         if (qn > 0) {   // the body's last, partly filled batch
             __builtin_amdgcn_wave_barrier();
             if (lane < qn) {
-                const int tt = tq[(qh + lane) & 127];
-                raster_lane_triangle(P, tt, Rt, wx0, wy0, wx1, wy1, cullsign, tile, tw, big, nbig);
+                const int tt = tq[(qh + lane) & (kTq - 1)];
+                raster_lane_triangle(P, tt, Rt, wx0, wy0, wx1, wy1, cullsign, tile, tw, big, nbig RBS_TICK_ARG);
             }
             __builtin_amdgcn_wave_barrier();
+            RBS_TICK(12);
         }
     }
+    RBS_TICK(9);   // pre-test, compaction, loop bookkeeping (what 8, 10, 11, 12 do not claim)
     __syncthreads();
+    RBS_TICK(13);  // waiting for the block's other waves
     const int nb = min(*nbig, kBigCap);
     for (int e = 0; e < nb; ++e) {
         const int t = big[e];
@@ -642,6 +709,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
         }
     }
     __syncthreads();
+    RBS_TICK(14);  // big triangles
 }
 
 // ------------------------------------------------------------------ pixel model
@@ -1252,7 +1320,7 @@ __global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_frame_prep_kernel(cons
 // launch (never starved by the many small copy blocks) and pulls (particle, tile) items from
 // an atomic queue.
 template <bool UPDATE, int PREC, bool SLAB>
-__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel(const DevParams P)
+__device__ __forceinline__ void raster_kernel_body(const DevParams& P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Smem m = carve(smem, P.tile_px);
@@ -1260,6 +1328,7 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
     if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr_next[0] = 0; P.ctr_next[1] = 0; }
 #ifdef RBS_PHASE_TIMING
     const unsigned long long c0_ = clock64(), w0_ = wall_clock64();
+    if (threadIdx.x < 16) g_phase_lds[threadIdx.x] = 0;
 #endif
     for (;;) {
         if (threadIdx.x == 0) *m.item = atomicAdd(&P.ctr_this[1], 1);
@@ -1314,10 +1383,26 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel
     }
 #ifdef RBS_PHASE_TIMING
     if (threadIdx.x == 0) {   // block lifetime in shader cycles (clock64) and in 100 MHz wall ticks
+        for (int k = 0; k < 16; ++k)
+            if (k != 5 && k != 6) atomicAdd(&P.phase[k], g_phase_lds[k]);
         atomicAdd(&P.phase[5], clock64() - c0_);
         atomicAdd(&P.phase[6], wall_clock64() - w0_);
     }
 #endif
+}
+
+// The two precisions are two overloads of one kernel template: the register budget is an attribute
+// and cannot depend on a template parameter.
+template <bool UPDATE, int PREC, bool SLAB, typename std::enable_if<PREC != 0, int>::type = 0>
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) __attribute__((amdgpu_num_vgpr(RBS_RASTER_VGPRS)))
+void rbs_raster_kernel(const DevParams P)
+{
+    raster_kernel_body<UPDATE, PREC, SLAB>(P);
+}
+template <bool UPDATE, int PREC, bool SLAB, typename std::enable_if<PREC == 0, int>::type = 0>
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel(const DevParams P)
+{
+    raster_kernel_body<UPDATE, PREC, SLAB>(P);
 }
 
 template <int VEC>

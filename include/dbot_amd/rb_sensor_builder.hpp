@@ -359,18 +359,25 @@ public:
     /// R:source/dbot_ros/object_tracker_ros.hpp:49  current_state_ = tracker_->track(image)
     State track(const Obsrv& image)
     {
-        frame_.resize(image.size());
-        for (size_t i = 0; i < image.size(); ++i) frame_[i] = static_cast<float>(image[i]);
+        to_frame(image);
         State model(parts_);
         int32_t nres = 0;
         check(rbs_tracker_track(t_, frame_.data(), nullptr, nullptr, seed_, model.data().data(), &nres));
-        resamplings_ = nres;
-        State est = from_model(model);
-        if (!have_average_) { average_ = est; have_average_ = true; }
-        else
-            for (size_t k = 0; k < est.data().size(); ++k)
-                average_.data()[k] = rate_ * est.data()[k] + (1.0 - rate_) * average_.data()[k];
-        return average_;
+        return averaged(model, nres);
+    }
+    /// The same frame in two halves (rbs_tracker_submit / rbs_tracker_result): a caller that has
+    /// the next image before it needs this estimate keeps up to two frames in flight.
+    void submit(const Obsrv& image)
+    {
+        to_frame(image);
+        check(rbs_tracker_submit(t_, frame_.data(), nullptr, nullptr, seed_));
+    }
+    State result()
+    {
+        State model(parts_);
+        int32_t nres = 0;
+        check(rbs_tracker_result(t_, model.data().data(), &nres));
+        return averaged(model, nres);
     }
     int resamplings() const { return resamplings_; }
 
@@ -378,6 +385,21 @@ private:
     void check(int32_t rc) const
     {
         if (rc != RBS_OK) throw std::runtime_error(std::string("ParticleTracker: ") + rbs_last_error(sensor_->handle()));
+    }
+    void to_frame(const Obsrv& image)
+    {
+        frame_.resize(image.size());
+        for (size_t i = 0; i < image.size(); ++i) frame_[i] = static_cast<float>(image[i]);
+    }
+    State averaged(const State& model, int32_t nres)
+    {
+        resamplings_ = nres;
+        State est = from_model(model);
+        if (!have_average_) { average_ = est; have_average_ = true; }
+        else
+            for (size_t k = 0; k < est.data().size(); ++k)
+                average_.data()[k] = rate_ * est.data()[k] + (1.0 - rate_) * average_.data()[k];
+        return average_;
     }
     // camera-frame pose of the ORIGINAL mesh frame <-> pose of the centred mesh frame
     State to_model(const State& s) const { return shift(s, +1.0); }

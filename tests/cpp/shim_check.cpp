@@ -125,6 +125,17 @@ int main(int argc, char** argv)
             for (double v : est.data()) std::printf(" %.17g", v);
             std::printf("\n");
         }
+        // the same three frames with two in flight: the same estimates
+        tracker->initialize(initial_poses);
+        tracker->submit(frame);
+        tracker->submit(frame);
+        for (int k = 0; k < 3; ++k) {
+            State est = tracker->result();
+            if (k == 0) tracker->submit(frame);
+            std::printf("PIP%d", k);
+            for (double v : est.data()) std::printf(" %.17g", v);
+            std::printf("\n");
+        }
     }
     // error path: wrong observation size must surface as std::runtime_error
     try {

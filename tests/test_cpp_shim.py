@@ -146,4 +146,6 @@ def test_cpp_shim_matches_oracle(tmp_path, gpu_lib, monkeypatch, precision):
             est = tr.track(frame)
             got = np.array(lines[f"TRK{k}"], dtype=np.float64)
             assert np.abs(got - est).max() <= 1e-12, (k, np.abs(got - est).max())
+            # ParticleTracker::submit / result with two frames in flight: the same estimates
+            assert lines[f"PIP{k}"] == lines[f"TRK{k}"], k
         tr.close()

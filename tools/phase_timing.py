@@ -19,7 +19,7 @@ with RbSensor(om, cam, P, max_particles=n) as s:
     s.set_observation(synth.make_frame(s.render_depth(truth), 480, 640, rng))
     poses = synth.particle_poses(truth, n, rng)
     idx = rng.permutation(n).astype(np.int32)
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 16)()
     for rep in range(3):
         s.loglikes_poses(poses, idx.copy(), update=bool(upd))
         lib.rbs_debug_phase_cycles(s._h, out)
@@ -28,4 +28,7 @@ with RbSensor(om, cam, P, max_particles=n) as s:
         tot = c[1:5].sum()
         print("rep", rep, "ms", "%.3f" % s.last_kernel_ms(), {names[k]: "%.1f%%" % (100 * c[k] / tot) for k in range(1, 5)},
               "wave0 cycles per item: %.0f" % (tot / n),
-              "| block lifetime: %.0f cycles, %.1f us wall -> %.2f GHz shader clock" % (c[5] / 768, c[6] / 768 / 100.0, c[5] / max(c[6], 1) * 0.1))
+              "\n   raster phase of wave 0:", {nm: "%.1f%%" % (100 * c[k] / max(c[2], 1)) for k, nm in
+                                           ((8, "cluster cull"), (9, "pre-test+queue"), (10, "before setup"), (11, "setup"), (12, "sample loops"),
+                                            (13, "barrier wait"), (14, "big triangles"))},
+              "\n   | block lifetime: %.0f cycles, %.1f us wall -> %.2f GHz shader clock" % (c[5] / 768, c[6] / 768 / 100.0, c[5] / max(c[6], 1) * 0.1))
