@@ -622,6 +622,10 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
         const float eps = 1e-5f * (1.0f + sqrtf(ex * ex + ey * ey + ez * ez));
         const float fsign = (float)cullsign;
         int qh = 0, qn = 0;   // ring queue of surviving triangle indices: head, count (wave-uniform)
+#ifdef RBS_PHASE_TIMING
+        if (threadIdx.x == 0 && eps + fsign == -12345.f) P.out[0] = 0.0;   // (waits for the pose)
+        RBS_TICK(0);    // the body's pose and what is derived from it
+#endif
         for (int base = c0; base < c1; base += 64) {
             // 64 clusters culled at once, one per lane (every wave computes the same mask)
             const int ci = base + lane;
@@ -1330,11 +1334,18 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
     const unsigned long long c0_ = clock64(), w0_ = wall_clock64();
     if (threadIdx.x < 16) g_phase_lds[threadIdx.x] = 0;
 #endif
+    RBS_TICK_DECL;
+    // The first round is dealt statically (block b takes item b): 768 blocks drawing their first
+    // ticket at the same instant serialise on the counter, up to 10 us.  Everything after goes
+    // through the ticket counter -- dealing further whole rounds statically as well (every block
+    // runs that many items under any schedule) gains nothing at 2 000 particles and costs 8-25 %
+    // where items differ (several tiles per particle, several bodies: C2, C4, 20 000 particles).
+    const int grid = (int)gridDim.x;
+    const int static_end = grid;
+    int item = (int)blockIdx.x;
     for (;;) {
-        if (threadIdx.x == 0) *m.item = atomicAdd(&P.ctr_this[1], 1);
-        __syncthreads();
-        const int item = __builtin_amdgcn_readfirstlane(*m.item);
         if (item >= total) break;
+        RBS_TICK(7);
         // wave-uniform: tell the compiler, so the pose / rectangle / parent index become scalar
         // loads held in SGPRs instead of per-lane vector loads in every loop
         const int particle = __builtin_amdgcn_readfirstlane(P.item_particle[item]);
@@ -1343,6 +1354,10 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
         const int2 range = P.item_range[particle];
         const int first = range.x;
         double part = 0.0;
+#ifdef RBS_PHASE_TIMING
+        if (threadIdx.x == 0 && q.x + range.y == -12345) P.out[0] = 0.0;   // (waits for the descriptor's loads)
+        RBS_TICK(15);   // the item's descriptor
+#endif
         if (P.groups == nullptr) {
             if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC, SLAB>(P, particle, r, item - first, m, 0xffffffffu);
         } else {   // several bodies: the item belongs to one group of bodies with its own rectangle
@@ -1379,7 +1394,17 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
                 }
             }
         }
-        __syncthreads();
+        if (item + grid >= static_end) {
+            if (threadIdx.x == 0) *m.item = static_end + atomicAdd(&P.ctr_this[1], 1);
+            __syncthreads();
+            item = __builtin_amdgcn_readfirstlane(*m.item);   // (written again at the end of the next item, many barriers away)
+        } else {
+            item += grid;
+            __syncthreads();
+        }
+#ifdef RBS_PHASE_TIMING
+        tick_ = clock64();   // (the item's own phases were clocked inside)
+#endif
     }
 #ifdef RBS_PHASE_TIMING
     if (threadIdx.x == 0) {   // block lifetime in shader cycles (clock64) and in 100 MHz wall ticks

@@ -31,4 +31,5 @@ with RbSensor(om, cam, P, max_particles=n) as s:
               "\n   raster phase of wave 0:", {nm: "%.1f%%" % (100 * c[k] / max(c[2], 1)) for k, nm in
                                            ((8, "cluster cull"), (9, "pre-test+queue"), (10, "before setup"), (11, "setup"), (12, "sample loops"),
                                             (13, "barrier wait"), (14, "big triangles"))},
+              "\n   per item, cycles: ticket %.0f, descriptor %.0f, pose + eye %.0f, cluster cull %.0f" % (c[7] / n, c[15] / n, c[0] / n, c[8] / n),
               "\n   | block lifetime: %.0f cycles, %.1f us wall -> %.2f GHz shader clock" % (c[5] / 768, c[6] / 768 / 100.0, c[5] / max(c[6], 1) * 0.1))
