@@ -118,6 +118,13 @@ struct rbs_handle {
     float* d_fin[2] = {nullptr, nullptr};
     hipEvent_t ev_used[2] = {nullptr, nullptr};    // the ingest kernel that read d_fin[k] has run
     int lazy_slot = -1;                            // d_fin slot the pending (lazy) frame sits in
+    // Precision F32 keeps no per-pixel terms, so a host frame needs no ingest at all: the staging
+    // image d_fin[k] IS the observation until the next frame replaces it, and only the raster
+    // kernel (not the rectangles kernel before it) waits for the upload.
+    const float* cur_frame = nullptr;              // what the kernels read: d_frame, or d_fin[cur_slot]
+    int cur_slot = -1;
+    int frame_wait = -1;                           // ev_frame[] the raster launches wait for
+    hipEvent_t ev_reader = nullptr;                // orders the handle's stream after a reader on a caller's stream
     float* h_frame = nullptr;   // = h_frames[frame_slot]
     float* h_native = nullptr;  // pinned staging for full-resolution frames
     float* d_native = nullptr;
@@ -288,7 +295,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.win_src = h->d_win[h->cur];
     P.win_dst = h->d_win[1 - h->cur];
     P.win_used = h->d_win_used;
-    P.frame = h->d_frame;
+    P.frame = h->cur_frame;
     P.aux = h->d_aux;
     P.pbg = h->d_pbg;
     P.occ_src = h->d_occ[h->cur];
@@ -431,6 +438,8 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     // wide windows: two raster blocks per CU leave the streaming copy its registers
     const bool mid = h->windowed && update && !wide && h->area_frac > h->mid_enter;
     const dim3 rgrid((unsigned)(wide || mid ? std::min(h->raster_blocks, 2 * h->cu_count) : h->raster_blocks));
+    // a host frame that is read where it was uploaded: only now does the stream wait for the upload
+    if (h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
     if (update) {
         launch_raster(h, true, rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
@@ -480,6 +489,11 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
     }
     if (timed) { RBS_HIP(h, hipEventRecord(h->ev_stop[tslot], s)); h->timed_calls += 1; }
+    if (h->cur_slot >= 0 && s != h->stream) {
+        // the staging image is released on the handle's stream: keep that stream behind its readers
+        RBS_HIP(h, hipEventRecord(h->ev_reader, s));
+        RBS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_reader, 0));
+    }
     if (update) h->join_pending = slot;   // joined lazily: by the next call, or by drain()
     if (h->group) {
         // other shards read this shard's planes: one event that covers both streams of this call
@@ -628,6 +642,7 @@ void release(rbs_handle* h)
         if (h->h_frames[k]) (void)hipHostFree(h->h_frames[k]);
         if (h->ev_frame[k]) (void)hipEventDestroy(h->ev_frame[k]);
         if (h->ev_used[k]) (void)hipEventDestroy(h->ev_used[k]);
+        if (k == 0 && h->ev_reader) (void)hipEventDestroy(h->ev_reader);
         (void)hipFree(h->d_fin[k]);
     }
     if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
@@ -652,6 +667,19 @@ void release(rbs_handle* h)
     delete h;
 }
 
+// The staging image that served as the observation stops doing so (a new frame is coming): it may
+// be overwritten once everything launched so far has run.
+int32_t release_frame_slot(rbs_handle* h)
+{
+    if (h->cur_slot >= 0) {
+        RBS_HIP(h, hipEventRecord(h->ev_used[h->cur_slot], h->stream));
+        h->cur_slot = -1;
+    }
+    h->cur_frame = h->d_frame;
+    h->frame_wait = -1;
+    return RBS_OK;
+}
+
 // H2D of a frame staged in pinned host memory (`src`, normally h->h_frame) on the upload stream into
 // the device staging buffer of the current slot; the launch stream waits for it, and the ingest
 // kernel (copy into d_frame + per-frame model terms) rides on the next loglikes launch
@@ -663,6 +691,14 @@ int32_t upload_frame(rbs_handle* h, const float* src)
     RBS_HIP(h, hipStreamWaitEvent(h->up_stream, h->ev_used[k], 0));   // d_fin[k]: read by the ingest kernel two frames ago
     RBS_HIP(h, hipMemcpyAsync(h->d_fin[k], src, n * sizeof(float), hipMemcpyHostToDevice, h->up_stream));
     RBS_HIP(h, hipEventRecord(h->ev_frame[k], h->up_stream));
+    if (int32_t rc = release_frame_slot(h)) return rc;
+    static const bool ingest = [] { const char* e = std::getenv("RBS_FRAME_INGEST"); return e && std::atoi(e) != 0; }();
+    if (!h->d_aux && !ingest) {   // (callers have flushed any pending frame)
+        h->cur_frame = h->d_fin[k];
+        h->cur_slot = k;
+        h->frame_wait = k;
+        return RBS_OK;
+    }
     RBS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_frame[k], 0));
     h->lazy_frame = h->d_fin[k];
     h->lazy_stream = h->stream;
@@ -1017,6 +1053,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMemcpy(h->d_soup, soup.data(), soup.size() * sizeof(double), hipMemcpyHostToDevice));
     B.soup = h->d_soup;
     RBS_HIP(h, hipMalloc(&h->d_frame, plane));
+    h->cur_frame = h->d_frame;
     if (h->precision == RBS_PRECISION_F64) {   // F32 derives the per-pixel terms from the observation on the fly
         RBS_HIP(h, hipMalloc(&h->d_aux, sizeof(double) * rbs::AUX_PLANES * (size_t)h->npx));
         RBS_HIP(h, hipMalloc(&h->d_pbg, plane));
@@ -1093,6 +1130,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         RBS_HIP(h, hipHostMalloc(&h->h_frames[k], plane, hipHostMallocPortable));   // (every device of a group uploads from shard 0's)
         RBS_HIP(h, hipEventCreateWithFlags(&h->ev_frame[k], hipEventDisableTiming));
         RBS_HIP(h, hipEventCreateWithFlags(&h->ev_used[k], hipEventDisableTiming));
+        if (k == 0) RBS_HIP(h, hipEventCreateWithFlags(&h->ev_reader, hipEventDisableTiming));
         RBS_HIP(h, hipMalloc(&h->d_fin[k], plane));
     }
     h->h_frame = h->h_frames[0];
@@ -1577,6 +1615,7 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     RBS_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer reuse
+    if (int32_t rc = release_frame_slot(h)) return rc;
     const size_t n = (size_t)width * height;
     if (n > h->native_cap) {
         if (h->h_native) (void)hipHostFree(h->h_native);
@@ -1609,6 +1648,7 @@ int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* st
     // here: it shares a launch with the next rbs_loglikes* call's rectangles kernel when that
     // call comes on the same stream, and is launched on `s` by whatever needs the frame otherwise
     if (int32_t rc = flush_lazy_frame(h, s)) return rc;   // an earlier frame nobody evaluated
+    if (int32_t rc = release_frame_slot(h)) return rc;
     h->lazy_frame = d_depth;
     h->lazy_stream = s;
     h->pending_frames += 1;
@@ -1623,7 +1663,8 @@ int32_t rbs_get_observation(rbs_handle* h, float* out)
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     RBS_HIP(h, hipStreamSynchronize(h->stream));
-    RBS_HIP(h, hipMemcpy(out, h->d_frame, sizeof(float) * h->npx, hipMemcpyDeviceToHost));
+    if (h->frame_wait >= 0) RBS_HIP(h, hipEventSynchronize(h->ev_frame[h->frame_wait]));
+    RBS_HIP(h, hipMemcpy(out, h->cur_frame, sizeof(float) * h->npx, hipMemcpyDeviceToHost));
     return RBS_OK;
 }
 
