@@ -87,6 +87,9 @@ constexpr int kTq = kQPlanes_ * kEvalQueue;  // the same LDS during the raster p
 #ifndef RBS_RASTER_VGPRS
 #define RBS_RASTER_VGPRS 80   // (the attribute counts architectural registers and the compiler doubles it on gfx90a+: 160 in all)
 #endif
+#ifndef RBS_PF_POSE
+#define RBS_PF_POSE 1
+#endif
 #ifndef RBS_PRETEST_CLUSTERS
 #define RBS_PRETEST_CLUSTERS 4
 #endif
@@ -481,11 +484,11 @@ __device__ inline float cone_sqrt(float x) { return RBS_CULL_SQRT ? __builtin_am
 // of them, with the window widened by 2 px and the radius by 1 mm + 0.1 % so float rounding
 // can never cull a cluster the binary64 rasterizer would have touched.  Wave-uniform.
 __device__ inline bool cluster_may_touch(const DevParams& P, const double* __restrict__ Rt,
-                                         const float* __restrict__ sph, int wx0, int wy0, int wx1,
+                                         const floatx4 sph, int wx0, int wy0, int wx1,
                                          int wy1)
 {
-    const float sx = sph[0], sy = sph[1], sz = sph[2];
-    const float rho = sph[3] * 1.001f + 1e-3f;
+    const float sx = sph.x, sy = sph.y, sz = sph.z;
+    const float rho = sph.w * 1.001f + 1e-3f;
     const float X = (float)Rt[0] * sx + (float)Rt[1] * sy + (float)Rt[2] * sz + (float)Rt[9];
     const float Y = (float)Rt[3] * sx + (float)Rt[4] * sy + (float)Rt[5] * sz + (float)Rt[10];
     const float Z = (float)Rt[6] * sx + (float)Rt[7] * sy + (float)Rt[8] * sz + (float)Rt[11];
@@ -496,15 +499,10 @@ __device__ inline bool cluster_may_touch(const DevParams& P, const double* __res
     const float at = cy - ((float)wy0 - 2.0f), ab = cy - ((float)wy1 + 1.0f);
     // signed distance to a plane < -rho  <=>  s < 0 and s^2 > rho^2 |n|^2  (no square root)
     const float r2 = rho * rho;
-    // (one test at a time: left to itself the scheduler interleaves the four and the kernel's
-    // register count, which the copy kernel's co-residency hangs on, goes up by 7)
     bool out = false;
     { const float s_ = fx * X + al * Z; out |= s_ < 0.0f && s_ * s_ > r2 * (fx * fx + al * al); }   // left of the window
-    __builtin_amdgcn_sched_barrier(0);
     { const float s_ = fx * X + ar * Z; out |= s_ > 0.0f && s_ * s_ > r2 * (fx * fx + ar * ar); }   // right
-    __builtin_amdgcn_sched_barrier(0);
     { const float s_ = fy * Y + at * Z; out |= s_ < 0.0f && s_ * s_ > r2 * (fy * fy + at * at); }   // above
-    __builtin_amdgcn_sched_barrier(0);
     { const float s_ = fy * Y + ab * Z; out |= s_ > 0.0f && s_ * s_ > r2 * (fy * fy + ab * ab); }   // below
     if (out) return false;
     return true;
@@ -516,20 +514,20 @@ __device__ inline bool cluster_may_touch(const DevParams& P, const double* __res
 //   n.(p - eye) >= n.(c - eye) - rho >= |c| cos(psi + phi) - rho,   psi = angle(axis, c - eye),
 // so the cluster is back-facing when |c| (cos psi cos phi - sin psi sin phi) - rho > 0; a
 // margin of 1e-3 (|c| + rho) + 1e-4 absorbs the float rounding.  One cluster per lane.
-__device__ inline bool cluster_faces_away(const double* __restrict__ Rt, const float* __restrict__ sph,
-                                          const float* __restrict__ cone)
+__device__ inline bool cluster_faces_away(const double* __restrict__ Rt, const floatx4 sph, const floatx4 cone4)
 {
+    const float cone[4] = {cone4.x, cone4.y, cone4.z, cone4.w};
     const float m = cone[3];
     if (!(m > 0.0f)) return false;
     const float r0 = (float)Rt[0], r1 = (float)Rt[1], r2 = (float)Rt[2], r3 = (float)Rt[3], r4 = (float)Rt[4],
                 r5 = (float)Rt[5], r6 = (float)Rt[6], r7 = (float)Rt[7], r8 = (float)Rt[8];
-    const float X = r0 * sph[0] + r1 * sph[1] + r2 * sph[2] + (float)Rt[9];
-    const float Y = r3 * sph[0] + r4 * sph[1] + r5 * sph[2] + (float)Rt[10];
-    const float Z = r6 * sph[0] + r7 * sph[1] + r8 * sph[2] + (float)Rt[11];
+    const float X = r0 * sph.x + r1 * sph.y + r2 * sph.z + (float)Rt[9];
+    const float Y = r3 * sph.x + r4 * sph.y + r5 * sph.z + (float)Rt[10];
+    const float Z = r6 * sph.x + r7 * sph.y + r8 * sph.z + (float)Rt[11];
     const float ax = r0 * cone[0] + r1 * cone[1] + r2 * cone[2];
     const float ay = r3 * cone[0] + r4 * cone[1] + r5 * cone[2];
     const float az = r6 * cone[0] + r7 * cone[1] + r8 * cone[2];
-    const float rho = sph[3] * 1.001f + 1e-3f;
+    const float rho = sph.w * 1.001f + 1e-3f;
     const float D = cone_sqrt(X * X + Y * Y + Z * Z);
     const float ad = ax * X + ay * Y + az * Z;           // |c| cos psi
     const float sp = cone_sqrt(fmaxf(D * D - ad * ad, 0.0f)); // |c| sin psi
@@ -595,15 +593,26 @@ __device__ inline void raster_lane_triangle(const DevParams& P, int t, const dou
 // depths are unchanged bit for bit.
 // Small triangles are rasterized by their lane; triangles whose clipped bbox exceeds kBigThresh
 // pixels are queued in LDS and rasterized by the whole block, pixel-parallel.
-// Caller has cleared the tile and synchronised; on return the tile is complete and synchronised.
+// Clears the tile first; on return the tile is complete and synchronised.
 __device__ inline void raster_window(const DevParams& P, const double* __restrict__ pose,
                                      int wx0, int wy0, int wx1, int wy1, bool cull, unsigned* tile,
                                      int* big, int* nbig, int* tq, unsigned body_mask)
 {
     const int tw = wx1 - wx0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // The first body's pose is the item's first dependent load (4 000 of an item's 150 000 cycles
+    // when waited for): its two cache lines are touched before the tile is cleared, so that the
+    // loads that follow the clear hit the scalar cache.  (Holding the twelve values themselves
+    // across the clear costs the registers the setup needs: 32 spills.)
+    int b0 = 0;
+    while (b0 < P.n_bodies && !((body_mask >> b0) & 1u)) ++b0;
+    double touch0 = 0.0, touch1 = 0.0;
+    if (RBS_PF_POSE && b0 < P.n_bodies) { touch0 = pose[12 * b0]; touch1 = pose[12 * b0 + 11]; }
+    const int npx = tw * (wy1 - wy0);
+    for (int p = threadIdx.x; p < npx; p += kBlock) tile[p] = kInfBits;
     if (threadIdx.x == 0) *nbig = 0;
     __syncthreads();
+    if (RBS_PF_POSE) asm volatile("" ::"s"(touch0), "s"(touch1));   // (the touches are not dead code)
     RBS_TICK_DECL;
     // surviving clusters so far: dealt round-robin to the block's waves (an LDS ticket per
     // cluster instead measured no better: the waves of a block finish within a few percent)
@@ -629,10 +638,13 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
         for (int base = c0; base < c1; base += 64) {
             // 64 clusters culled at once, one per lane (every wave computes the same mask)
             const int ci = base + lane;
-            const bool hit = ci < c1 && (!cull || cluster_may_touch(P, Rt, P.cluster_sphere + 4 * ci,
-                                                                    wx0, wy0, wx1, wy1)) &&
-                             !(cullsign != 0 && cluster_faces_away(Rt, P.cluster_sphere + 4 * ci,
-                                                                   P.cluster_cone + 4 * ci));
+            floatx4 sph = floatx4{0.f, 0.f, 0.f, 0.f}, cone = sph;
+            if (ci < c1) {
+                sph = reinterpret_cast<const floatx4*>(P.cluster_sphere)[ci];
+                cone = reinterpret_cast<const floatx4*>(P.cluster_cone)[ci];
+            }
+            const bool hit = ci < c1 && (!cull || cluster_may_touch(P, Rt, sph, wx0, wy0, wx1, wy1)) &&
+                             !(cullsign != 0 && cluster_faces_away(Rt, sph, cone));
             const unsigned long long mask = __ballot(hit);
             RBS_TICK(8);
             // this wave's share: the surviving clusters are dealt round-robin by their rank
@@ -932,9 +944,6 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     const int4 pw = parent_window(P, parent);   // outside it the parent's plane is implicitly bg_old
 
     RBS_TICK_DECL;
-    for (int p = threadIdx.x; p < npx; p += kBlock) m.tile[p] = kInfBits;
-    __syncthreads();
-    RBS_TICK(1);
     // a rectangle that is a single tile was sized from the same spheres: nothing to cull
     raster_window(P, pose, wx0, wy0, wx1, wy1, !whole || (body_mask & (body_mask - 1u)) != 0u, m.tile, m.big, m.nbig,
                   m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue, body_mask);   // the eval queue is idle during the raster phase
@@ -1689,8 +1698,6 @@ __global__ __launch_bounds__(kBlock) void rbs_render_kernel(const DevParams P, f
         for (int wx0 = r.x0; wx0 < r.x1; wx0 += tg.tw) {
             const int wx1 = min(r.x1, wx0 + tg.tw), wy1 = min(r.y1, wy0 + tg.th);
             const int tw = wx1 - wx0, npx = tw * (wy1 - wy0);
-            for (int p = threadIdx.x; p < npx; p += kBlock) m.tile[p] = kInfBits;
-            __syncthreads();
             raster_window(P, P.poses, wx0, wy0, wx1, wy1, true, m.tile, m.big, m.nbig,
                           m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue, 0xffffffffu);
             for (int p = threadIdx.x; p < npx; p += kBlock) {
