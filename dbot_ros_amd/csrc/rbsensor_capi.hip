@@ -106,6 +106,8 @@ struct rbs_handle {
     unsigned char* h_in = nullptr;
     double* h_out = nullptr;
     unsigned char* d_in = nullptr;     // device image of h_in
+    unsigned char* h_in_dev = nullptr; // h_in / h_out as the device addresses them (kernels read / write them in place)
+    double* h_out_dev = nullptr;
     size_t in_idx_off = 0;             // byte offset of the indices inside h_in / d_in
     hipEvent_t ev_out = nullptr;
     float* h_frames[2] = {nullptr, nullptr};   // pinned frame staging, alternating
@@ -284,7 +286,7 @@ void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size
 }
 
 int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indices, int n,
-                         bool update, double* d_out, hipStream_t s)
+                         bool update, double* d_out, hipStream_t s, const double* host_poses = nullptr)
 {
     DevParams P = h->base;
     occlusion_coeffs(h, h->pending_frames, &P.alpha, &P.beta);
@@ -301,6 +303,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.occ_src = h->d_occ[h->cur];
     P.occ_dst = h->d_occ[1 - h->cur];
     P.poses = d_poses;
+    P.poses_src = host_poses;   // pinned host memory the rectangles kernel pulls the poses from (into d_poses)
     P.indices = d_indices;
     P.slots = h->max_particles;
     P.n_dev = 1;
@@ -1140,6 +1143,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         const size_t in_bytes = pose_bytes + sizeof(int) * (size_t)h->max_particles;
         RBS_HIP(h, hipHostMalloc(&h->h_in, in_bytes, hipHostMallocDefault));
         RBS_HIP(h, hipHostMalloc(&h->h_out, sizeof(double) * (size_t)h->max_particles, hipHostMallocDefault));
+        RBS_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_in_dev), h->h_in, 0));
+        RBS_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_out_dev), h->h_out, 0));
         RBS_HIP(h, hipMalloc(&h->d_in, in_bytes));
         RBS_HIP(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
     }
@@ -1355,6 +1360,42 @@ void release_group(rbs_handle* g)
     delete g;
 }
 
+// The host-pointer call on one device: poses and parent slots are staged in pinned memory, and
+// -- no copy engine involved -- the rectangles kernel pulls them from there over PCIe (writing the
+// device copy of the poses the raster kernel reads) and the raster kernel stores the
+// log-likelihoods straight into the pinned result buffer.  A separate H2D copy of 200 KB queued
+// behind the frame's upload on the same engine, and each copy <-> kernel hand-over costs ~10 us:
+// together 30 us of a 300 us step.  RBS_HOST_STAGED_COPIES=1 restores the copies.
+int32_t host_call(rbs_handle* h, const double* poses, const int32_t* indices, int n, bool update)
+{
+    static const bool copies = [] { const char* e = std::getenv("RBS_HOST_STAGED_COPIES"); return e && std::atoi(e) != 0; }();
+    const size_t pose_bytes = sizeof(double) * 12 * h->n_bodies * (size_t)n;
+    std::memcpy(h->h_in, poses, pose_bytes);
+    std::memcpy(h->h_in + h->in_idx_off, indices, sizeof(int) * (size_t)n);
+    if (copies) {
+        if (pose_bytes == h->in_idx_off) {
+            RBS_HIP(h, hipMemcpyAsync(h->d_in, h->h_in, pose_bytes + sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+        } else {
+            RBS_HIP(h, hipMemcpyAsync(h->d_in, h->h_in, pose_bytes, hipMemcpyHostToDevice, h->stream));
+            RBS_HIP(h, hipMemcpyAsync(h->d_in + h->in_idx_off, h->h_in + h->in_idx_off, sizeof(int) * (size_t)n,
+                                      hipMemcpyHostToDevice, h->stream));
+        }
+        if (int32_t rc = enqueue_loglikes(h, reinterpret_cast<const double*>(h->d_in),
+                                          reinterpret_cast<const int*>(h->d_in + h->in_idx_off), n, update, h->d_out, h->stream))
+            return rc;
+        RBS_HIP(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        if (int32_t rc = enqueue_loglikes(h, reinterpret_cast<const double*>(h->d_in),
+                                          reinterpret_cast<const int*>(h->h_in_dev + h->in_idx_off), n, update,
+                                          reinterpret_cast<double*>(h->h_out_dev), h->stream,
+                                          reinterpret_cast<const double*>(h->h_in_dev)))
+            return rc;
+    }
+    if (h->slab_px) RBS_HIP(h, hipMemcpyAsync(h->h_err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    RBS_HIP(h, hipEventRecord(h->ev_out, h->stream));
+    return RBS_OK;
+}
+
 // rbs_loglikes on a group: particle i is evaluated by shard i / shard_cap and (update) written
 // to global slot i; `indices` are global parent slots.
 int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int32_t n, int32_t update, double* out)
@@ -1375,19 +1416,7 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
             RBS_HIP(g, hipEventRecord(h->ev_done, h->stream));
             continue;
         }
-        const size_t pose_bytes = sizeof(double) * stride * (size_t)cnt;
-        std::memcpy(h->h_in, poses + stride * (size_t)lo, pose_bytes);
-        std::memcpy(h->h_in + h->in_idx_off, indices + lo, sizeof(int) * (size_t)cnt);
-        RBS_HIP(g, hipMemcpyAsync(h->d_in, h->h_in, pose_bytes, hipMemcpyHostToDevice, h->stream));
-        RBS_HIP(g, hipMemcpyAsync(h->d_in + h->in_idx_off, h->h_in + h->in_idx_off, sizeof(int) * (size_t)cnt,
-                                  hipMemcpyHostToDevice, h->stream));
-        if (int32_t rc = enqueue_loglikes(h, reinterpret_cast<const double*>(h->d_in),
-                                          reinterpret_cast<const int*>(h->d_in + h->in_idx_off), cnt, update != 0,
-                                          h->d_out, h->stream))
-            return gfail(g, h, rc);
-        RBS_HIP(g, hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
-        if (h->slab_px) RBS_HIP(g, hipMemcpyAsync(h->h_err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        RBS_HIP(g, hipEventRecord(h->ev_out, h->stream));
+        if (int32_t rc = host_call(h, poses + stride * (size_t)lo, indices + lo, cnt, update != 0)) return gfail(g, h, rc);
     }
     for (int k = 0; k < nd; ++k) {
         rbs_handle* h = g->shards[k];
@@ -1685,26 +1714,9 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
                         fmt("loglikes: indices[%d] = %d outside 0..%d", i, indices[i],
                             h->max_particles - 1));
     RBS_HIP(h, hipSetDevice(h->device));
-    // pinned staging (a copy from pageable memory is staged by the runtime anyway, synchronously):
-    // poses and indices travel in ONE H2D copy; the call waits for the log-likelihoods' D2H copy
-    // only -- the occlusion planes are finished by the second stream and joined by the next call
-    const size_t pose_bytes = sizeof(double) * 12 * h->n_bodies * (size_t)n;
-    std::memcpy(h->h_in, poses, pose_bytes);
-    std::memcpy(h->h_in + h->in_idx_off, indices, sizeof(int) * (size_t)n);
-    if (pose_bytes == h->in_idx_off) {
-        RBS_HIP(h, hipMemcpyAsync(h->d_in, h->h_in, pose_bytes + sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
-    } else {
-        RBS_HIP(h, hipMemcpyAsync(h->d_in, h->h_in, pose_bytes, hipMemcpyHostToDevice, h->stream));
-        RBS_HIP(h, hipMemcpyAsync(h->d_in + h->in_idx_off, h->h_in + h->in_idx_off, sizeof(int) * (size_t)n,
-                                  hipMemcpyHostToDevice, h->stream));
-    }
-    const int32_t rc = enqueue_loglikes(h, reinterpret_cast<const double*>(h->d_in),
-                                        reinterpret_cast<const int*>(h->d_in + h->in_idx_off), n, update != 0,
-                                        h->d_out, h->stream);
-    if (rc != RBS_OK) return rc;
-    RBS_HIP(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
-    if (h->slab_px) RBS_HIP(h, hipMemcpyAsync(h->h_err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    RBS_HIP(h, hipEventRecord(h->ev_out, h->stream));
+    // the call waits for the log-likelihoods only -- the occlusion planes are finished by the second
+    // stream and joined by the next call
+    if (int32_t rc = host_call(h, poses, indices, n, update != 0)) return rc;
     RBS_HIP(h, hipEventSynchronize(h->ev_out));
     std::memcpy(out_loglik, h->h_out, sizeof(double) * (size_t)n);
     if (update)

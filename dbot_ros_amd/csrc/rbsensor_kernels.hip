@@ -172,6 +172,7 @@ struct DevParams {
     const float* occ_src;          // [slots][npx]
     float* occ_dst;                // [slots][npx]
     const double* poses;           // [n][n_bodies][12]
+    const double* poses_src;       // host-pointer calls: pinned host memory the rectangles kernel copies the poses from (into `poses`)
     const int* indices;            // [n] parent slot as the caller passed it: read by the rectangles kernel ONLY,
                                    //   in the caller's stream order (the caller may rewrite it right after the call)
     int* parents;                  // [n] the rectangles kernel's snapshot of `indices`, double-buffered across calls
@@ -1206,6 +1207,16 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
     Groups G;
     G.n = 0;
     const int cap_px = min(P.tile_w * P.tile_h, P.tile_px);
+    if (P.poses_src && live) {
+        // a host-pointer call: the particle's pose is pulled from pinned host memory (one PCIe read of
+        // 96 B per body instead of a copy-engine transfer ahead of this kernel) into the device
+        // array everything else reads -- this wave included, once its own stores have landed
+        const int m = 12 * P.n_bodies;
+        double* dstp = const_cast<double*>(P.poses) + (size_t)i * m;
+        const double* srcp = P.poses_src + (size_t)i * m;
+        for (int k = lane; k < m; k += 64) dstp[k] = srcp[k];
+        __threadfence_block();
+    }
     if (live && P.groups == nullptr) {
         r = particle_rect(P, P.poses + (size_t)i * 12 * P.n_bodies);
         const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, cap_px);
@@ -1326,6 +1337,9 @@ __global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_frame_prep_kernel(cons
 }
 
 // Three 4-wave blocks per CU = 3 waves/SIMD = 168 VGPRs (a few spilled dwords).
+#ifndef RBS_RASTER_MINWAVES_F64
+#define RBS_RASTER_MINWAVES_F64 3
+#endif
 #ifndef RBS_RASTER_MINWAVES
 #define RBS_RASTER_MINWAVES 3
 #endif
@@ -1434,7 +1448,7 @@ void rbs_raster_kernel(const DevParams P)
     raster_kernel_body<UPDATE, PREC, SLAB>(P);
 }
 template <bool UPDATE, int PREC, bool SLAB, typename std::enable_if<PREC == 0, int>::type = 0>
-__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) void rbs_raster_kernel(const DevParams P)
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) void rbs_raster_kernel(const DevParams P)
 {
     raster_kernel_body<UPDATE, PREC, SLAB>(P);
 }
