@@ -2008,6 +2008,8 @@ struct rbs_tracker {
     int* h_flags[2] = {nullptr, nullptr};
     int* h_serr[2] = {nullptr, nullptr};
     hipEvent_t ev_res[2] = {nullptr, nullptr};
+    double* h_state_dev[2] = {nullptr, nullptr};   // h_state / h_flags as the device addresses them
+    int* h_flags_dev[2] = {nullptr, nullptr};
     int32_t res_rc[2] = {0, 0};       // (a handle over several devices runs submit synchronously)
     long submitted = 0, collected = 0;
 };
@@ -2113,6 +2115,8 @@ int32_t tracker_create_one(rbs_handle* sensor, const rbs_tracker_params* p, int 
             return fail(sensor, RBS_ERR_OUT_OF_MEMORY, "tracker_create: pinned host memory");
         }
         *t->h_serr[k] = 0;
+        RBS_HIP(sensor, hipHostGetDevicePointer(reinterpret_cast<void**>(&t->h_state_dev[k]), t->h_state[k], 0));
+        RBS_HIP(sensor, hipHostGetDevicePointer(reinterpret_cast<void**>(&t->h_flags_dev[k]), t->h_flags[k], 0));
     }
     *out = t;
     return RBS_OK;
@@ -2342,11 +2346,15 @@ int32_t rbs_tracker_submit(rbs_tracker* t, const float* frame, const double* nor
         T.uniforms = t->d_uniforms2[slot];
     }
     T.seed = seed;
+    T.host_state = t->h_state_dev[slot];
+    T.host_flags = t->h_flags_dev[slot];
     const dim3 g256((unsigned)((T.n + 255) / 256)), b256(256);
     const char* nf = std::getenv("RBS_TRACKER_FUSED");
     const bool fused = T.n <= rbt::kFusedFilterMax && !(nf && std::atoi(nf) == 0);
     for (int b = 0; b < T.parts; ++b) {
         const bool last = b == T.parts - 1;
+        // (the transition fused into the sensor's rectangles kernel -- one launch less -- measured no
+        // gain: 3 987 against 3 976 frames/s at 2 000 particles)
         hipLaunchKernelGGL(rbt::propagate_kernel, g256, b256, 0, s, T, b);
         RBT_HIP(t, hipGetLastError());
         if (int32_t rc = enqueue_loglikes(h, T.poses, T.idx, T.n, last, T.ll_new, s)) return rc;
@@ -2354,8 +2362,7 @@ int32_t rbs_tracker_submit(rbs_tracker* t, const float* frame, const double* nor
             hipLaunchKernelGGL(rbt::filter_step_kernel, dim3(1), dim3(1024), 0, s, T, b, last ? 1 : 0, last ? 1 : 0);
         } else {
             launch_weights(T, last ? 1 : 0, s);
-            hipLaunchKernelGGL(rbt::resample_kernel, g256, b256, 0, s, T, b);
-            hipLaunchKernelGGL(rbt::gather_kernel, dim3((unsigned)T.n), dim3(64), 0, s, T);
+            hipLaunchKernelGGL(rbt::resample_gather_kernel, dim3((unsigned)T.n), dim3(64), 0, s, T, b);
         }
         RBT_HIP(t, hipGetLastError());
         std::swap(T.part_old, T.part_old2);
@@ -2365,13 +2372,15 @@ int32_t rbs_tracker_submit(rbs_tracker* t, const float* frame, const double* nor
         std::swap(T.idx, T.idx2);
     }
     if (!fused) {
+        // (re-centring inside the single mean block was tried: its two rounds of rotations per thread
+        // on one CU take longer than the separate launch, 25 us against 16.5 + 5)
         launch_mean(T, s);
         hipLaunchKernelGGL(rbt::recentre_kernel, g256, b256, 0, s, T);
     }
     RBT_HIP(t, hipGetLastError());
     std::swap(T.part_old, T.part_new);   // this frame's particles are the next frame's old ones
-    RBT_HIP(t, hipMemcpyAsync(t->h_state[slot], T.deflt, sizeof(double) * T.D, hipMemcpyDeviceToHost, s));
-    RBT_HIP(t, hipMemcpyAsync(t->h_flags[slot], T.flag, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+    // (the estimate and the flags were stored into h_state[slot] / h_flags[slot] by the kernel that
+    // finished them: no copies behind the last kernel)
     if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(t->h_serr[slot], h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
     RBT_HIP(t, hipEventRecord(t->ev_res[slot], s));
     T.frame += 1;

@@ -41,6 +41,10 @@ struct TrackerDev {
     double* ll_sorted;            // [n_dev * cap]
     double* poses_sorted;         // [cap][parts][12]   (this device's shard)
     int* idx_sorted;              // [cap]
+    // pinned host memory the kernel that finishes the frame writes the estimate ([D]) and the flags
+    // ([2]) into, or nullptr: no device-to-host copies after the last kernel
+    double* host_state;
+    int* host_flags;
 };
 
 // ------------------------------------------------------------------ rotations
@@ -115,54 +119,57 @@ __device__ inline double u01(unsigned hi, unsigned lo)   // 53-bit uniform in [0
 // transition of bodies 0..b with their accumulated noise (vel' = vf vel + sigma o n,
 // pose' = pose + vel'), write the new particle and its absolute poses
 // R = R(delta) R(default), t = t(delta) + t(default)   (SURVEY A.1).
+__device__ inline void propagate_body(const TrackerDev& T, int b, int i, int bb)
+{
+    double s[kBody];
+#pragma unroll
+    for (int k = 0; k < kBody; ++k) s[k] = T.part_old[(size_t)i * T.D + bb * kBody + k];
+    if (bb <= b) {
+        double nz[6];
+        if (bb == b) {
+            if (T.normals) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nz[k] = T.normals[((size_t)b * T.n + i) * 6 + k];
+            } else {  // Box-Muller on Philox uniforms: 3 pairs
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr) {
+                    const uint4 r = philox(T.seed, (T.frame << 8) | (unsigned)b, ((unsigned long long)i << 2) | pr);
+                    const double u1 = 1.0 - u01(r.x, r.y), u2 = u01(r.z, r.w);
+                    const double rad = sqrt(-2.0 * log(u1));
+                    nz[2 * pr] = rad * cos(6.283185307179586 * u2);
+                    nz[2 * pr + 1] = rad * sin(6.283185307179586 * u2);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) T.noise[((size_t)i * T.parts + bb) * 6 + k] = nz[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) nz[k] = T.noise[((size_t)i * T.parts + bb) * 6 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            s[6 + k] = T.vf * s[6 + k] + T.sigma[k] * nz[k];
+            s[k] = s[k] + s[6 + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kBody; ++k) T.part_new[(size_t)i * T.D + bb * kBody + k] = s[k];
+    double Rd[9], R0[9], R[9];
+    rotvec_to_matrix(s + 3, Rd);
+    rotvec_to_matrix(T.deflt + bb * kBody + 3, R0);
+    matmul3(Rd, R0, R);
+    double* out = T.poses + ((size_t)i * T.parts + bb) * 12;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[9 + k] = s[k] + T.deflt[bb * kBody + k];
+}
+
 __global__ void propagate_kernel(const TrackerDev T, int b)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T.n) return;
-    for (int bb = 0; bb < T.parts; ++bb) {
-        double s[kBody];
-#pragma unroll
-        for (int k = 0; k < kBody; ++k) s[k] = T.part_old[(size_t)i * T.D + bb * kBody + k];
-        if (bb <= b) {
-            double nz[6];
-            if (bb == b) {
-                if (T.normals) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) nz[k] = T.normals[((size_t)b * T.n + i) * 6 + k];
-                } else {  // Box-Muller on Philox uniforms: 3 pairs
-#pragma unroll
-                    for (int pr = 0; pr < 3; ++pr) {
-                        const uint4 r = philox(T.seed, (T.frame << 8) | (unsigned)b, ((unsigned long long)i << 2) | pr);
-                        const double u1 = 1.0 - u01(r.x, r.y), u2 = u01(r.z, r.w);
-                        const double rad = sqrt(-2.0 * log(u1));
-                        nz[2 * pr] = rad * cos(6.283185307179586 * u2);
-                        nz[2 * pr + 1] = rad * sin(6.283185307179586 * u2);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) T.noise[((size_t)i * T.parts + bb) * 6 + k] = nz[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) nz[k] = T.noise[((size_t)i * T.parts + bb) * 6 + k];
-            }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                s[6 + k] = T.vf * s[6 + k] + T.sigma[k] * nz[k];
-                s[k] = s[k] + s[6 + k];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kBody; ++k) T.part_new[(size_t)i * T.D + bb * kBody + k] = s[k];
-        double Rd[9], R0[9], R[9];
-        rotvec_to_matrix(s + 3, Rd);
-        rotvec_to_matrix(T.deflt + bb * kBody + 3, R0);
-        matmul3(Rd, R0, R);
-        double* out = T.poses + ((size_t)i * T.parts + bb) * 12;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) out[k] = R[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) out[9 + k] = s[k] + T.deflt[bb * kBody + k];
-    }
+    for (int bb = 0; bb < T.parts; ++bb) propagate_body(T, b, i, bb);
 }
 
 // ------------------------------------------------------------------ f1: weights, KL, resampling
@@ -346,6 +353,16 @@ __global__ __launch_bounds__(1024) void weights_w4_kernel(const TrackerDev T)
     }
 }
 
+// The frame's result for the host (called by a whole block after T.deflt is complete).
+__device__ inline void publish_result(const TrackerDev& T)
+{
+    if (!T.host_state) return;
+    __threadfence_block();
+    __syncthreads();
+    for (int k = threadIdx.x; k < T.D; k += blockDim.x) T.host_state[k] = T.deflt[k];
+    if (threadIdx.x < 2) T.host_flags[threadIdx.x] = T.flag[threadIdx.x];
+}
+
 // ---- weighted mean for many particles: per-block partial sums of e_i * particle_i, then one
 // block folds them into the default pose (mean_body's tail)
 __global__ __launch_bounds__(1024) void mean_m1_kernel(const TrackerDev T)
@@ -431,6 +448,7 @@ __global__ __launch_bounds__(64) void mean_m3_kernel(const TrackerDev T, int blo
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) RmT[3 * r + c] = Rm[3 * c + r];
     }
+    publish_result(T);
 }
 
 // parents[j] = flag ? upper_bound(cdf, u_j) : j   (multinomial resampling)
@@ -480,6 +498,15 @@ __device__ inline void gather_one(const TrackerDev& T, int j, int k0, int kstep)
 __global__ void gather_kernel(const TrackerDev T)
 {
     gather_one(T, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x);
+}
+
+// Resampling and gather in one launch: the block that copies child j draws its parent first.
+__global__ __launch_bounds__(64) void resample_gather_kernel(const TrackerDev T, int b)
+{
+    if (threadIdx.x == 0) resample_one(T, b, (int)blockIdx.x);
+    __threadfence_block();
+    __syncthreads();
+    gather_one(T, (int)blockIdx.x, (int)threadIdx.x, 64);
 }
 
 // ------------------------------------------------------------------ tracker: mean + re-centring
@@ -537,6 +564,7 @@ __device__ inline void mean_body(const TrackerDev& T, const double* __restrict__
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) RmT[3 * r + c] = Rm[3 * c + r];
     }
+    publish_result(T);
 }
 
 __global__ __launch_bounds__(1024) void mean_kernel(const TrackerDev T)
