@@ -274,14 +274,14 @@ void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size
 {
     const int key = (update ? 4 : 0) | (h->precision == RBS_PRECISION_F32 ? 2 : 0) | (h->slab_px ? 1 : 0);
     switch (key) {
-        case 0: hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 0, false>), grid, block, smem, s, P); break;
-        case 1: hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 0, true>), grid, block, smem, s, P); break;
-        case 2: hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 1, false>), grid, block, smem, s, P); break;
-        case 3: hipLaunchKernelGGL((rbs::rbs_raster_kernel<false, 1, true>), grid, block, smem, s, P); break;
-        case 4: hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 0, false>), grid, block, smem, s, P); break;
-        case 5: hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 0, true>), grid, block, smem, s, P); break;
-        case 6: hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 1, false>), grid, block, smem, s, P); break;
-        default: hipLaunchKernelGGL((rbs::rbs_raster_kernel<true, 1, true>), grid, block, smem, s, P); break;
+        case 0: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f64<false, false>), grid, block, smem, s, P); break;
+        case 1: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f64<false, true>), grid, block, smem, s, P); break;
+        case 2: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f32<false, false>), grid, block, smem, s, P); break;
+        case 3: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f32<false, true>), grid, block, smem, s, P); break;
+        case 4: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f64<true, false>), grid, block, smem, s, P); break;
+        case 5: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f64<true, true>), grid, block, smem, s, P); break;
+        case 6: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f32<true, false>), grid, block, smem, s, P); break;
+        default: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f32<true, true>), grid, block, smem, s, P); break;
     }
 }
 
@@ -1152,10 +1152,10 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     // the raster / render kernels carve the LDS depth tile from dynamic shared memory
     {
         const void* kernels[] = {
-            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 0, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 0, true>),
-            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 1, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<false, 1, true>),
-            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 0, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 0, true>),
-            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 1, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel<true, 1, true>)};
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<false, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<false, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<true, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<true, true>)};
         for (const void* k : kernels)
             RBS_HIP(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
     }

@@ -38,7 +38,6 @@
 // one rounding to float, z-min is order independent, so coverage and depth are bit-exact.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <type_traits>
 #include <math.h>
 #include <stdint.h>
 
@@ -1439,18 +1438,18 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
 #endif
 }
 
-// The two precisions are two overloads of one kernel template: the register budget is an attribute
-// and cannot depend on a template parameter.
-template <bool UPDATE, int PREC, bool SLAB, typename std::enable_if<PREC != 0, int>::type = 0>
+// The two precisions are two kernels: the register budget is an attribute and cannot depend on a
+// template parameter.
+template <bool UPDATE, bool SLAB>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) __attribute__((amdgpu_num_vgpr(RBS_RASTER_VGPRS)))
-void rbs_raster_kernel(const DevParams P)
+void rbs_raster_kernel_f32(const DevParams P)
 {
-    raster_kernel_body<UPDATE, PREC, SLAB>(P);
+    raster_kernel_body<UPDATE, 1, SLAB>(P);
 }
-template <bool UPDATE, int PREC, bool SLAB, typename std::enable_if<PREC == 0, int>::type = 0>
-__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) void rbs_raster_kernel(const DevParams P)
+template <bool UPDATE, bool SLAB>
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) void rbs_raster_kernel_f64(const DevParams P)
 {
-    raster_kernel_body<UPDATE, PREC, SLAB>(P);
+    raster_kernel_body<UPDATE, 0, SLAB>(P);
 }
 
 template <int VEC>

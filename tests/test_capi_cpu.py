@@ -129,12 +129,11 @@ def test_register_budgets_the_kernels_overlap_depends_on():
         assert m, mangled_part
         return int(m.group(2)), int(m.group(3))
 
-    # (the kernel's template arguments are followed by the enable_if that selects the overload)
-    for name in ("rbs_raster_kernelILb1ELi1ELb0ET", "rbs_raster_kernelILb0ELi1ELb0ET", "rbs_raster_kernelILb1ELi1ELb1ET"):
+    for name in ("rbs_raster_kernel_f32ILb1ELb0EE", "rbs_raster_kernel_f32ILb0ELb0EE", "rbs_raster_kernel_f32ILb1ELb1EE"):
         vgprs, spills = usage(name)        # precision F32: updating / read-only / slabs
         assert vgprs <= 160 and spills == 0, (name, vgprs, spills)   # the budget is stated: amdgpu_num_vgpr
     for name in ("rbs_copy_window_kernelILb0E", "rbs_copy_window_kernelILb1E"):
         vgprs, spills = usage(name)
         assert vgprs <= 32 and spills == 0, (name, vgprs, spills)
-    vgprs, _ = usage("rbs_raster_kernelILb1ELi0ELb0ET")   # precision F64: three waves per SIMD
+    vgprs, _ = usage("rbs_raster_kernel_f64ILb1ELb0EE")   # precision F64: three waves per SIMD
     assert vgprs <= 168
