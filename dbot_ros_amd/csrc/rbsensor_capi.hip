@@ -127,6 +127,9 @@ struct rbs_handle {
     int cur_slot = -1;
     int frame_wait = -1;                           // ev_frame[] the raster launches wait for
     hipEvent_t ev_reader = nullptr;                // orders the handle's stream after a reader on a caller's stream
+    // the older routes, kept behind environment switches read at rbs_create (A/B runs, differential tests):
+    bool frame_ingest = false;                     // RBS_FRAME_INGEST=1: host frames are copied into d_frame by the ingest kernel
+    bool host_copies = false;                      // RBS_HOST_STAGED_COPIES=1: poses / results travel as H2D / D2H copies
     float* h_frame = nullptr;   // = h_frames[frame_slot]
     float* h_native = nullptr;  // pinned staging for full-resolution frames
     float* d_native = nullptr;
@@ -695,8 +698,7 @@ int32_t upload_frame(rbs_handle* h, const float* src)
     RBS_HIP(h, hipMemcpyAsync(h->d_fin[k], src, n * sizeof(float), hipMemcpyHostToDevice, h->up_stream));
     RBS_HIP(h, hipEventRecord(h->ev_frame[k], h->up_stream));
     if (int32_t rc = release_frame_slot(h)) return rc;
-    static const bool ingest = [] { const char* e = std::getenv("RBS_FRAME_INGEST"); return e && std::atoi(e) != 0; }();
-    if (!h->d_aux && !ingest) {   // (callers have flushed any pending frame)
+    if (!h->d_aux && !h->frame_ingest) {   // (callers have flushed any pending frame)
         h->cur_frame = h->d_fin[k];
         h->cur_slot = k;
         h->frame_wait = k;
@@ -1128,6 +1130,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         RBS_HIP(h, hipMemcpy(h->d_vtx, vtx.data(), sizeof(float) * vtx.size(), hipMemcpyHostToDevice));
         B.vtx = reinterpret_cast<const rbs::floatx4*>(h->d_vtx);
     }
+    if (const char* e = std::getenv("RBS_FRAME_INGEST")) h->frame_ingest = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RBS_HOST_STAGED_COPIES")) h->host_copies = std::atoi(e) != 0;
     RBS_HIP(h, hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k) {
         RBS_HIP(h, hipHostMalloc(&h->h_frames[k], plane, hipHostMallocPortable));   // (every device of a group uploads from shard 0's)
@@ -1368,7 +1372,7 @@ void release_group(rbs_handle* g)
 // together 30 us of a 300 us step.  RBS_HOST_STAGED_COPIES=1 restores the copies.
 int32_t host_call(rbs_handle* h, const double* poses, const int32_t* indices, int n, bool update)
 {
-    static const bool copies = [] { const char* e = std::getenv("RBS_HOST_STAGED_COPIES"); return e && std::atoi(e) != 0; }();
+    const bool copies = h->host_copies;
     const size_t pose_bytes = sizeof(double) * 12 * h->n_bodies * (size_t)n;
     std::memcpy(h->h_in, poses, pose_bytes);
     std::memcpy(h->h_in + h->in_idx_off, indices, sizeof(int) * (size_t)n);

@@ -162,3 +162,52 @@ def test_device_tracker_across_configurations(gpu_lib, meshes, n):
     for name, (ests, r_) in results.items():
         assert r_ == nres, name
         assert np.abs(ests - ref).max() <= 1e-9, (name, np.abs(ests - ref).max())
+
+
+@pytest.mark.parametrize("precision,layout,ids", [("f32", "window", None), ("f32", "dense", None), ("f64", "window", None),
+                                                  ("f32", "window", [0, 0])])
+def test_host_call_routes_agree_bit_for_bit(gpu_lib, monkeypatch, precision, layout, ids):
+    """The host-pointer call's fast route -- frame read where it was uploaded (F32), poses and
+    parent slots pulled from pinned memory by the rectangles kernel, log-likelihoods stored into
+    pinned memory by the raster kernel -- against the older route (ingest copy, H2D / D2H copies;
+    RBS_FRAME_INGEST=1, RBS_HOST_STAGED_COPIES=1, read at rbs_create): the same numbers and planes
+    bit for bit over a resampled sequence with repeated, skipped and frame-buffer frames."""
+    n, cols, rows = 64, 160, 120
+    om, cam, P = sc.make_scene(("m1_l2", "box12"), cols, rows, max_particles=n)
+
+    def make(old):
+        monkeypatch.setenv("RBS_FRAME_INGEST", "1" if old else "0")
+        monkeypatch.setenv("RBS_HOST_STAGED_COPIES", "1" if old else "0")
+        return RbSensor(om, cam, P, max_particles=n, precision=precision, state_layout=layout, device_ids=ids)
+
+    new, old = make(False), make(True)
+    try:
+        rng = np.random.default_rng(21)
+        with RbSensor(om, cam, P, max_particles=1) as r:
+            frames = [synth.make_frame(r.render_depth(synth.truth_pose(2, frame=k)), rows, cols, rng).astype(np.float32) for k in range(12)]
+        idx = {id(new): np.arange(n, dtype=np.int32), id(old): np.arange(n, dtype=np.int32)}
+        for k in range(40):
+            f = frames[k % len(frames)]
+            m = n if k % 5 else n // 2
+            poses = synth.particle_poses(synth.truth_pose(2, frame=k % len(frames)), m, rng)
+            parents = rng.integers(0, n, m).astype(np.int32)
+            upd = k % 4 != 3
+            outs = []
+            for s in (new, old):
+                if k % 6 == 2:                      # two frames, the first never evaluated
+                    s.set_observation(frames[(k + 1) % len(frames)])
+                if k % 3 == 1:                      # through the handle's pinned buffer
+                    np.copyto(s.frame_buffer(), f)
+                    s.commit_frame()
+                elif k % 7 != 6:                    # (k % 7 == 6: the previous frame again, no new observation)
+                    s.set_observation(f)
+                outs.append(s.loglikes_poses(poses, parents.copy(), update=upd))
+            assert np.array_equal(outs[0], outs[1], equal_nan=True), k
+            if k % 10 == 9:
+                assert np.array_equal(new.get_observation(), old.get_observation(), equal_nan=True), k
+        for slot in range(0, n, 7):
+            assert np.array_equal(new.get_window(slot), old.get_window(slot)), slot
+            assert np.array_equal(new.get_occlusion(slot), old.get_occlusion(slot)), slot
+    finally:
+        new.close()
+        old.close()
