@@ -371,6 +371,56 @@ def cpu_baseline(om, cam, P, truth, frame, seconds):
     return out
 
 
+# --------------------------------------------------------------------------------- host API from C++
+def write_host_workload(f, om, cam, P, frames, poses, parents, update):
+    """The binary workload tests/cpp/host_bench.cpp reads (layout in its header comment)."""
+    import struct
+    frames = np.ascontiguousarray(frames, dtype=np.float32)
+    poses = np.ascontiguousarray(poses, dtype=np.float64)
+    n, F = poses.shape[1], frames.shape[0]
+    f.write(struct.pack("6i", cam.rows, cam.cols, om.count_parts, n, F, int(update)))
+    f.write(np.ascontiguousarray(cam.camera_matrix, dtype=np.float64).tobytes())
+    f.write(struct.pack("7d", P.occlusion.p_occluded_visible, P.occlusion.p_occluded_occluded,
+                        P.occlusion.initial_occlusion_prob, P.kinect.tail_weight, P.kinect.model_sigma,
+                        P.kinect.sigma_factor, P.delta_time))
+    for v, t in zip(om.vertices, om.triangles):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        t = np.ascontiguousarray(t, dtype=np.int32)
+        f.write(struct.pack("2i", len(v), len(t)))
+        f.write(v.tobytes())
+        f.write(t.tobytes())
+    f.write(frames.tobytes())
+    f.write(poses.tobytes())
+    f.write(np.ascontiguousarray(parents, dtype=np.int32).tobytes())
+
+
+def native_host_leg(a, om, cam, P, W, steps):
+    """Write the workload where tests/cpp/host_bench can read it and run that binary (built by
+    __graft_entry__.build()).  Returns {} when the binary is missing."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "cpp", "host_bench")
+    if not os.path.exists(exe):
+        return {}
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        path = f.name
+        write_host_workload(f, om, cam, P, W.frames, W.poses, W.parents, bool(a.update))
+    try:
+        env = dict(os.environ, RBS_PRECISION=a.precision, RBS_STATE=a.layout)
+        r = subprocess.run([exe, path, str(steps), "10"], capture_output=True, text=True, timeout=300, env=env)
+        line = next((l for l in r.stdout.splitlines() if l.startswith("host_bench ")), None)
+        if not line:
+            return {"host_api_native_note": "host_bench did not run: " + (r.stdout + r.stderr)[-200:]}
+        tok = line.split()
+        return {"host_api_native_value": float(tok[2]), "host_api_native_ms_per_step": float(tok[4]),
+                "host_api_native_note": "the host-pointer step (rbs_set_observation_f32 + rbs_loglikes, synchronous) called from C++ "
+                                        "(tests/cpp/host_bench.cpp), frames cycling forwards through the sequence"}
+    except Exception as e:   # noqa: BLE001 -- a benchmark leg must not take the headline down
+        return {"host_api_native_note": "host_bench failed: %r" % (e,)}
+    finally:
+        os.unlink(path)
+
+
 # --------------------------------------------------------------------------------- tracker FPS
 def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30):
     """Frames/s of the device tracker (rbs_tracker_*: transition, weights, KL, resampling and mean
@@ -718,6 +768,11 @@ def main():
         out["host_api_loglikes_only_value"] = n * hsteps / tl
         out["host_api_note"] = ("rbs_set_observation_f32 (1.2 MB frame from host memory) + rbs_loglikes (poses + parent indices "
                                 "from host memory, log-likelihoods back to host memory, synchronous), called through ctypes")
+        # the same step driven from C++ through the C-ABI (tests/cpp/host_bench.cpp): what the
+        # reference's own filter, which is C++, would pay -- no interpreter between the calls
+        nat = native_host_leg(a, om, cam, P, W, hsteps)
+        if nat:
+            out.update(nat)
     # ---- tracker FPS, the second half of the metric
     if single and not a.no_tracker_fps:
         fps = tracker_fps(om, cam, dev)

@@ -1,0 +1,79 @@
+// host_bench.cpp -- the host-pointer step (rbs_set_observation_f32 + rbs_loglikes) driven from
+// C++ through the C-ABI, the way the reference's own (C++) filter would call it; bench.py's
+// host_api_* leg goes through Python/ctypes and pays the interpreter per call.
+//   host_bench <workload.bin> <steps> [warmup]
+// workload.bin (written by bench.py, native endianness):
+//   int32 rows, cols, n_objects, n, F, update; double K[9]; double params[7]
+//   (p_occluded_visible, p_occluded_occluded, initial_occlusion_prob, tail_weight, model_sigma,
+//   sigma_factor, delta_time); per object: int32 nv, nt; double v[3 nv]; int32 t[3 nt];
+//   float frames[F][rows*cols]; double poses[F][n][n_objects][12]; int32 parents[n]
+// Prints one line: "host_bench particle-likelihoods/s <v> ms/step <t> checksum <sum of finite log-likelihoods of the last step>".
+#include <rbsensor_mi355x.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+template <typename T>
+static bool rd(std::FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n, f) == n; }
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) { std::fprintf(stderr, "usage: host_bench workload.bin steps [warmup]\n"); return 2; }
+    std::FILE* f = std::fopen(argv[1], "rb");
+    if (!f) { std::perror(argv[1]); return 2; }
+    const int steps = std::atoi(argv[2]), warmup = argc > 3 ? std::atoi(argv[3]) : 10;
+    int32_t hd[6];
+    double K[9], prm[7];
+    if (!rd(f, hd, 6) || !rd(f, K, 9) || !rd(f, prm, 7)) return 2;
+    const int rows = hd[0], cols = hd[1], nobj = hd[2], n = hd[3], F = hd[4], update = hd[5];
+    std::vector<double> verts;
+    std::vector<int32_t> tris, vcnt(nobj), tcnt(nobj);
+    for (int b = 0; b < nobj; ++b) {
+        int32_t c[2];
+        if (!rd(f, c, 2)) return 2;
+        vcnt[b] = c[0]; tcnt[b] = c[1];
+        const size_t v0 = verts.size(), t0 = tris.size();
+        verts.resize(v0 + 3 * (size_t)c[0]); tris.resize(t0 + 3 * (size_t)c[1]);
+        if (!rd(f, verts.data() + v0, 3 * (size_t)c[0]) || !rd(f, tris.data() + t0, 3 * (size_t)c[1])) return 2;
+    }
+    const size_t npx = (size_t)rows * cols, stride = (size_t)12 * nobj * n;
+    std::vector<float> frames(npx * F);
+    std::vector<double> poses(stride * F), out(n);
+    std::vector<int32_t> parents(n), idx(n);
+    if (!rd(f, frames.data(), frames.size()) || !rd(f, poses.data(), poses.size()) || !rd(f, parents.data(), (size_t)n)) return 2;
+    std::fclose(f);
+
+    rbs_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = RBS_ABI_VERSION;
+    cfg.rows = rows; cfg.cols = cols;
+    std::memcpy(cfg.K, K, sizeof K);
+    cfg.max_particles = n; cfg.n_objects = nobj;
+    cfg.vertices = verts.data(); cfg.vertex_counts = vcnt.data();
+    cfg.triangles = tris.data(); cfg.triangle_counts = tcnt.data();
+    cfg.p_occluded_visible = prm[0]; cfg.p_occluded_occluded = prm[1]; cfg.initial_occlusion_prob = prm[2];
+    cfg.tail_weight = prm[3]; cfg.model_sigma = prm[4]; cfg.sigma_factor = prm[5]; cfg.delta_time = prm[6];
+    rbs_handle* h = nullptr;
+    if (rbs_create(&cfg, &h) != RBS_OK) { std::printf("NO_DEVICE %s\n", h ? rbs_last_error(h) : "rbs_create failed"); return 0; }
+    auto step = [&](int i) -> int32_t {
+        const int k = i % F;
+        if (int32_t rc = rbs_set_observation_f32(h, frames.data() + npx * k, npx)) return rc;
+        idx = parents;
+        return rbs_loglikes(h, poses.data() + stride * k, idx.data(), n, update, out.data());
+    };
+    for (int i = 0; i < warmup; ++i)
+        if (step(i)) { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < steps; ++i)
+        if (step(i)) { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    double sum = 0.0;
+    for (double v : out) if (std::isfinite(v)) sum += v;
+    std::printf("host_bench particle-likelihoods/s %.1f ms/step %.5f checksum %.10g\n", (double)n * steps / dt, dt / steps * 1e3, sum);
+    rbs_destroy(h);
+    return 0;
+}

@@ -149,3 +149,37 @@ def test_cpp_shim_matches_oracle(tmp_path, gpu_lib, monkeypatch, precision):
             # ParticleTracker::submit / result with two frames in flight: the same estimates
             assert lines[f"PIP{k}"] == lines[f"TRK{k}"], k
         tr.close()
+
+
+@pytest.mark.gpu
+def test_native_host_bench_computes_what_python_computes(tmp_path, gpu_lib, monkeypatch):
+    """tests/cpp/host_bench.cpp (bench.py's host_api_native_* leg: the host-pointer step driven from
+    C++) on a small workload: the checksum of its last step's log-likelihoods equals the one the
+    same calls give through ctypes."""
+    import bench
+    _build()
+    exe = os.path.join(os.path.dirname(BIN), "host_bench")
+    assert os.path.exists(exe)
+    monkeypatch.setenv("RBS_PRECISION", "f32")
+    from dbot_ros_amd import RbSensor
+    n, rows, cols, F, steps, warm = 48, 120, 160, 5, 4, 3
+    om = ObjectModel([synth.mesh_m1(level=2)[0]], [synth.mesh_m1(level=2)[1]], center=True)
+    cam = CameraData(synth.camera_matrix(cols, rows), rows, cols)
+    P = RbSensorBuilder.Parameters(sample_count=n)
+    rng = np.random.default_rng(4)
+    truths = [synth.truth_pose(1, frame=k) for k in range(F)]
+    with RbSensor(om, cam, P, max_particles=n) as s:
+        frames = np.stack([synth.make_frame(s.render_depth(t), rows, cols, rng) for t in truths]).astype(np.float32)
+        poses = np.stack([synth.particle_poses(t, n, rng).reshape(n, -1) for t in truths])
+        parents = rng.permutation(n).astype(np.int32)
+        for i in list(range(warm)) + list(range(steps)):
+            s.set_observation(frames[i % F])
+            ll = s.loglikes_poses(poses[i % F], parents.copy(), update=True)
+    path = tmp_path / "w.bin"
+    with open(path, "wb") as f:
+        bench.write_host_workload(f, om, cam, P, frames, poses, parents, True)
+    out = subprocess.run([exe, str(path), str(steps), str(warm)], capture_output=True, text=True, check=True).stdout
+    tok = out.split()
+    assert tok[0] == "host_bench", out
+    want = float(ll[np.isfinite(ll)].sum())
+    assert abs(float(tok[6]) - want) <= 1e-8 * max(1.0, abs(want)), (tok[6], want)
