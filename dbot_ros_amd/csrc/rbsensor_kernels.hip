@@ -86,9 +86,6 @@ constexpr int kTq = kQPlanes_ * kEvalQueue;  // the same LDS during the raster p
 #ifndef RBS_RASTER_VGPRS
 #define RBS_RASTER_VGPRS 80   // (the attribute counts architectural registers and the compiler doubles it on gfx90a+: 160 in all)
 #endif
-#ifndef RBS_PF_POSE
-#define RBS_PF_POSE 1
-#endif
 #ifndef RBS_PRETEST_CLUSTERS
 #define RBS_PRETEST_CLUSTERS 4
 #endif
@@ -473,10 +470,7 @@ __device__ inline int body_of(const DevParams& P, int t)
 
 // The cluster tests below are conservative with margins of 1e-3: the hardware square root (1 ulp)
 // serves them; the correctly rounded one the build asks for elsewhere costs ~15 instructions.
-#ifndef RBS_CULL_SQRT
-#define RBS_CULL_SQRT 1
-#endif
-__device__ inline float cone_sqrt(float x) { return RBS_CULL_SQRT ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+__device__ inline float cone_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // Conservative float32 test: can any triangle of the cluster (model-space bounding sphere
 // c, rho) touch the pixel window [wx0,wx1) x [wy0,wy1)?  The window's four frustum planes
@@ -607,12 +601,12 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
     int b0 = 0;
     while (b0 < P.n_bodies && !((body_mask >> b0) & 1u)) ++b0;
     double touch0 = 0.0, touch1 = 0.0;
-    if (RBS_PF_POSE && b0 < P.n_bodies) { touch0 = pose[12 * b0]; touch1 = pose[12 * b0 + 11]; }
+    if (b0 < P.n_bodies) { touch0 = pose[12 * b0]; touch1 = pose[12 * b0 + 11]; }
     const int npx = tw * (wy1 - wy0);
     for (int p = threadIdx.x; p < npx; p += kBlock) tile[p] = kInfBits;
     if (threadIdx.x == 0) *nbig = 0;
     __syncthreads();
-    if (RBS_PF_POSE) asm volatile("" ::"s"(touch0), "s"(touch1));   // (the touches are not dead code)
+    asm volatile("" ::"s"(touch0), "s"(touch1));   // (the touches are not dead code)
     RBS_TICK_DECL;
     // surviving clusters so far: dealt round-robin to the block's waves (an LDS ticket per
     // cluster instead measured no better: the waves of a block finish within a few percent)
