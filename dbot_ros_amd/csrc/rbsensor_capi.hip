@@ -81,6 +81,15 @@ struct rbs_handle {
     bool wide = false;
     double area_frac = 0.0;     // last sampled stored-window area / frame area
     double mid_enter = 0.15;    // above it: two raster blocks per CU, so the windowed copy runs beside them
+    // Raster / copy balance: the windowed copy kernel runs beside the persistent raster blocks and
+    // a call ends when the later of the two does.  When the copy kernel outlasts the raster kernel
+    // (several bodies far apart: one window spans them and the copy fills the gaps) the next calls
+    // run a few raster blocks fewer, and take them back when the raster kernel is the later one
+    // again.  Decided from the kernel timers of the last timed call; the results do not depend on
+    // the number of blocks.  RBS_BALANCE=0 pins the grid.
+    bool balance = true;
+    int balance_blocks = 0;     // current grid of the raster kernel (0: raster_blocks)
+    long balance_seen = 0;      // timed_calls the rule has looked at
     double wide_enter = 0.50, wide_leave = 0.35;   // measured: the streaming copy wins from about half the frame
     int cu_count = 256;
     int smalln_target = 768;    // few particles: aim at about this many work items per call
@@ -443,7 +452,25 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     }
     // wide windows: two raster blocks per CU leave the streaming copy its registers
     const bool mid = h->windowed && update && !wide && h->area_frac > h->mid_enter;
-    const dim3 rgrid((unsigned)(wide || mid ? std::min(h->raster_blocks, 2 * h->cu_count) : h->raster_blocks));
+    if (h->balance && h->windowed && update && !wide && !mid && h->timed_calls > h->balance_seen && h->raster_blocks == 3 * h->cu_count) {
+        const int last = (int)((h->timed_calls - 1) % rbs_handle::kRing);
+        if (h->ring_update[last] && hipEventQuery(h->ev_raster_stop[last]) == hipSuccess && hipEventQuery(h->ev_copy_stop[last]) == hipSuccess) {
+            float r_ms = 0.f, c_ms = 0.f;
+            if (hipEventElapsedTime(&r_ms, h->ev_raster_start[last], h->ev_raster_stop[last]) == hipSuccess &&
+                hipEventElapsedTime(&c_ms, h->ev_copy_start[last], h->ev_copy_stop[last]) == hipSuccess && r_ms > 0.f) {
+                const int step = std::max(1, h->cu_count / 8), lo = 5 * h->cu_count / 2;
+                int cur = h->balance_blocks ? h->balance_blocks : h->raster_blocks;
+                if (c_ms > 1.04f * r_ms) cur = std::max(lo, cur - step);
+                else if (c_ms < 0.92f * r_ms) cur = std::min(h->raster_blocks, cur + step);
+                h->balance_blocks = cur;
+            } else {
+                (void)hipGetLastError();
+            }
+            h->balance_seen = h->timed_calls;
+        }
+    }
+    const int full_grid = h->balance && h->balance_blocks && h->windowed && update ? h->balance_blocks : h->raster_blocks;
+    const dim3 rgrid((unsigned)(wide || mid ? std::min(h->raster_blocks, 2 * h->cu_count) : full_grid));
     // a host frame that is read where it was uploaded: only now does the stream wait for the upload
     if (h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
@@ -1044,6 +1071,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         h->smalln_target = 2 * std::max(1, prop.multiProcessorCount);   // measured best at 64..500 particles
         if (const char* m = std::getenv("RBS_SMALLN_TARGET")) h->smalln_target = std::max(1, std::atoi(m));
         if (const char* m = std::getenv("RBS_MID_ENTER")) h->mid_enter = std::atof(m);
+        if (const char* m = std::getenv("RBS_BALANCE")) h->balance = std::atoi(m) != 0;
         if (const char* m = std::getenv("RBS_WIDE_ENTER")) { h->wide_enter = std::atof(m); h->wide_leave = h->wide_enter * 0.67; }
         if (const char* m = std::getenv("RBS_RECT_ALIGN")) h->rect_align = std::atoi(m) >= 16 ? 16 : (std::atoi(m) >= 8 ? 8 : 4);
         if (const char* m = std::getenv("RBS_TIMING_EVERY")) h->timing_every = std::max(1, std::atoi(m));
