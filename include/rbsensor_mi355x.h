@@ -159,7 +159,10 @@ int32_t rbs_get_observation(rbs_handle* h, float* out);
  *          of each body (delta composed with the default pose by the caller).
  * indices: [n] in: occlusion slot each particle inherits from; out (update != 0): identity.
  * update:  non-zero -> write the posterior occlusion of particle i into slot i.
- * out_loglik: [n] doubles.  Host pointers; synchronous. */
+ * out_loglik: [n] doubles.  Host pointers; synchronous: the call returns when the log-likelihoods
+ * are in out_loglik (the caller's buffers are staged through pinned memory that the kernels read
+ * and write in place -- no copy-engine transfer besides the frame's); the occlusion planes of an
+ * updating call are finished in the background and joined by the next call on the handle. */
 int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32_t n,
                      int32_t update, double* out_loglik);
 
