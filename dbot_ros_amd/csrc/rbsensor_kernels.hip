@@ -707,6 +707,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
     __syncthreads();
     RBS_TICK(13);  // waiting for the block's other waves
     const int nb = min(*nbig, kBigCap);
+    if (nb == 0) return;   // block-uniform; the usual case (a barrier costs an item about 1 %)
     for (int e = 0; e < nb; ++e) {
         const int t = big[e];
         const double* Rt = pose + 12 * body_of(P, t);
@@ -919,7 +920,7 @@ __device__ inline Smem carve(unsigned char* smem, int kTilePx)
 // block-reduced partial log-likelihood (valid in thread 0).
 template <bool UPDATE, int PREC, bool SLAB>
 __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect r, int tile_id,
-                                          const Smem& m, unsigned body_mask)
+                                          const Smem& m, unsigned body_mask, bool draw, int& ticket)
 {
     const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
     const int ty = tile_id / tg.nx, tx = tile_id - ty * tg.nx;
@@ -1090,6 +1091,9 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     RBS_EVAL_BATCH(qn);
 #undef RBS_EVAL_BATCH
     RBS_TICK(3);
+    // the next item's ticket is drawn here: its round trip (~2 us) passes while the block's waves
+    // gather at the reduction's barrier, instead of after it with everybody waiting
+    if (draw && threadIdx.x == 0) ticket = atomicAdd(&P.ctr_this[1], 1);
     const double total = block_reduce_sum(ll, m.red);
     RBS_TICK(4);
     return total;
@@ -1370,12 +1374,14 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
         const int2 range = P.item_range[particle];
         const int first = range.x;
         double part = 0.0;
+        const bool draw = item + grid >= static_end;   // the next item comes from the ticket counter
+        int ticket = -1;
 #ifdef RBS_PHASE_TIMING
         if (threadIdx.x == 0 && q.x + range.y == -12345) P.out[0] = 0.0;   // (waits for the descriptor's loads)
         RBS_TICK(15);   // the item's descriptor
 #endif
         if (P.groups == nullptr) {
-            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC, SLAB>(P, particle, r, item - first, m, 0xffffffffu);
+            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC, SLAB>(P, particle, r, item - first, m, 0xffffffffu, draw, ticket);
         } else {   // several bodies: the item belongs to one group of bodies with its own rectangle
             const Groups* G = P.groups + particle;
             const int k = item - first, ng = __builtin_amdgcn_readfirstlane(G->n);
@@ -1386,7 +1392,7 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
                 const Rect gr = {__builtin_amdgcn_readfirstlane(gq.x), __builtin_amdgcn_readfirstlane(gq.y),
                                  __builtin_amdgcn_readfirstlane(gq.z), __builtin_amdgcn_readfirstlane(gq.w)};
                 part = raster_eval_tile<UPDATE, PREC, SLAB>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
-                                                      (unsigned)__builtin_amdgcn_readfirstlane((int)G->mask[g]));
+                                                      (unsigned)__builtin_amdgcn_readfirstlane((int)G->mask[g]), draw, ticket);
             }
         }
         if (threadIdx.x == 0) {
@@ -1410,8 +1416,11 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
                 }
             }
         }
-        if (item + grid >= static_end) {
-            if (threadIdx.x == 0) *m.item = static_end + atomicAdd(&P.ctr_this[1], 1);
+        if (draw) {
+            if (threadIdx.x == 0) {
+                if (ticket < 0) ticket = atomicAdd(&P.ctr_this[1], 1);   // (an item that ended before its reduction)
+                *m.item = static_end + ticket;
+            }
             __syncthreads();
             item = __builtin_amdgcn_readfirstlane(*m.item);   // (written again at the end of the next item, many barriers away)
         } else {
