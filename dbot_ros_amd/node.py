@@ -61,12 +61,16 @@ def to_eigen_vector(native_image, downsampling_factor):
     return np.ascontiguousarray(img[: rows * f: f, : cols * f: f]).ravel()
 
 
-def replay_dataset(params, dataset, mesh_package_path, initial_states, device_id=0, seed=0, max_frames=None):
+def replay_dataset(params, dataset, mesh_package_path, initial_states, device_id=0, seed=0, max_frames=None,
+                   look_ahead=False):
     """Run the tracker over a recorded TrackingDataset (dbot_ros_amd.dataset) the way
     the node runs over live topics: K from the bag's camera_info (frame 0, as GetCameraMatrix does,
     R:source/dbot_ros/util/tracking_dataset.cpp:157-164), every depth image sub-sampled by
     `downsampling_factor` (R:source/dbot_ros/util/ros_interface.h:152-168) and handed to
     tracker.track (R:source/dbot_ros/object_tracker_ros.hpp:44-49).
+    look_ahead: a recorded sequence has the next frame at hand, so frame k+1 is submitted before
+    frame k's estimate is collected (tracker.submit / tracker.result: two frames in flight, the
+    same numbers); False drives tracker.track frame by frame as a live camera would.
     Returns (estimates [frames, parts*12], wall seconds of the tracking loop)."""
     import time
     tracker, object_model, camera_data, _ = build_particle_tracker(params, dataset.get_camera_matrix(0),
@@ -78,8 +82,15 @@ def replay_dataset(params, dataset, mesh_package_path, initial_states, device_id
         frames = [dataset.frame_vector(i, f) for i in range(n)]      # host decode outside the timed loop
         ests = []
         t0 = time.perf_counter()
-        for fr in frames:
-            ests.append(tracker.track(fr))
+        if look_ahead and hasattr(tracker, "submit") and frames:
+            tracker.submit(frames[0])
+            for fr in frames[1:]:
+                tracker.submit(fr)
+                ests.append(tracker.result())
+            ests.append(tracker.result())
+        else:
+            for fr in frames:
+                ests.append(tracker.track(fr))
         wall = time.perf_counter() - t0
     finally:
         tracker.close()
