@@ -143,3 +143,6 @@ def test_replay_of_a_recorded_dataset(tmp_path, gpu_lib):
     assert ests.shape == (12, 12) and wall > 0
     err = [np.linalg.norm(ests[i, 0:3] - data.get_ground_truth(i)[0:3]) for i in range(12)]
     assert max(err[-4:]) < 0.025, err
+    # a recording has the next frame at hand: one frame of look-ahead gives the very same estimates
+    ests2, _ = node.replay_dataset(tree, data, str(tmp_path), [truth_state(0)], seed=3, look_ahead=True)
+    assert np.array_equal(ests, ests2)
