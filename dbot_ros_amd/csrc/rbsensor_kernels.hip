@@ -452,12 +452,15 @@ __device__ inline void tri_pixel(const Tri& T, int col, int row, unsigned* tile,
     const double px = (double)col, py = (double)row;
     const double E0 = T.e01u * (py - T.v0) - T.e01v * (px - T.u0);
     const double E1 = T.e12u * (py - T.v1) - T.e12v * (px - T.u1);
+    double mn = fmin(E0, E1), mx = fmax(E0, E1);   // (folded as they come: two values live, not three)
     const double E2 = T.e20u * (py - T.v2) - T.e20v * (px - T.u2);
+    mn = fmin(mn, E2);
+    mx = fmax(mx, E2);
     // all three >= 0 or all three <= 0, as min / max (E is finite: the setup rejected anything else):
     // four instructions and one branch instead of two compare chains with a branch between them.
     // With three waves per SIMD a branch in this loop costs the wave more than the instructions it
     // guards: 3 % of the kernel.
-    const bool in = ((int)(fmin(fmin(E0, E1), E2) >= 0.0) | (int)(fmax(fmax(E0, E1), E2) <= 0.0)) != 0;
+    const bool in = ((int)(mn >= 0.0) | (int)(mx <= 0.0)) != 0;
     if (!in) return;
     const double den = (T.pa * px + T.pb * py) + T.pc;
     const float zf = (float)div_f64(T.nv0, den);
