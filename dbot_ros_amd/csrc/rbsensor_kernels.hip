@@ -445,11 +445,10 @@ __device__ inline bool tri_setup(const DevParams& P, int t, const double* __rest
     return true;
 }
 
-// Coverage test + depth for one integer pixel; z-min into the LDS tile.
-__device__ inline void tri_pixel(const Tri& T, int col, int row, unsigned* tile, int tw, int wx0,
-                                 int wy0)
+// Coverage test + depth for one integer pixel (px, py: its coordinates as doubles); z-min into the
+// LDS tile at `at`.
+__device__ inline void tri_sample(const Tri& T, double px, double py, unsigned* at)
 {
-    const double px = (double)col, py = (double)row;
     const double E0 = T.e01u * (py - T.v0) - T.e01v * (px - T.u0);
     const double E1 = T.e12u * (py - T.v1) - T.e12v * (px - T.u1);
     double mn = fmin(E0, E1), mx = fmax(E0, E1);   // (folded as they come: two values live, not three)
@@ -464,7 +463,12 @@ __device__ inline void tri_pixel(const Tri& T, int col, int row, unsigned* tile,
     if (!in) return;
     const double den = (T.pa * px + T.pb * py) + T.pc;
     const float zf = (float)div_f64(T.nv0, den);
-    if (((int)in & (int)(zf > 0.0f) & (int)(zf < INFINITY)) != 0) atomicMin(&tile[(row - wy0) * tw + (col - wx0)], __float_as_uint(zf));
+    // a depth must be a positive finite float (zf > 0 && zf < inf): one class test, +denormal | +normal
+    if (__builtin_amdgcn_classf(zf, 0x180)) atomicMin(at, __float_as_uint(zf));
+}
+__device__ inline void tri_pixel(const Tri& T, int col, int row, unsigned* tile, int tw, int wx0, int wy0)
+{
+    tri_sample(T, (double)col, (double)row, &tile[(row - wy0) * tw + (col - wx0)]);
 }
 
 __device__ inline int body_of(const DevParams& P, int t)
