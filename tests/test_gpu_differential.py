@@ -211,3 +211,42 @@ def test_host_call_routes_agree_bit_for_bit(gpu_lib, monkeypatch, precision, lay
     finally:
         new.close()
         old.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_results_do_not_depend_on_the_raster_grid(gpu_lib, monkeypatch, precision):
+    """The raster kernel's grid varies at run time (the raster / copy balance rule gives blocks to
+    the copy kernel and takes them back; small calls split tiles by the number of blocks): the
+    first round of items is static, the rest is drawn from a ticket counter, multi-tile particles
+    are summed in item order.  Whatever the grid, the same log-likelihoods and planes bit for bit."""
+    n, cols, rows = 96, 320, 240
+    om, cam, P = sc.make_scene(("m1_l2", "box12"), cols, rows, max_particles=n)
+    sensors = []
+    for blocks in ("768", "640", "97", "8"):
+        monkeypatch.setenv("RBS_RASTER_BLOCKS", blocks)
+        sensors.append(RbSensor(om, cam, P, max_particles=n, precision=precision))
+    monkeypatch.delenv("RBS_RASTER_BLOCKS")
+    try:
+        rng = np.random.default_rng(33)
+        with RbSensor(om, cam, P, max_particles=1) as r:
+            frames = [synth.make_frame(r.render_depth(synth.truth_pose(2, frame=k)), rows, cols, rng).astype(np.float32) for k in range(6)]
+        for k in range(18):
+            m = n if k % 4 else 17
+            poses = synth.particle_poses(synth.truth_pose(2, frame=k % 6), m, rng)
+            if k % 5 == 2:
+                poses = poses.copy().reshape(m, 2, 12)
+                poses[: m // 3, :, 11] *= 0.45          # close to the camera: rectangles of several tiles
+                poses = poses.reshape(m, -1)
+            parents = rng.integers(0, n, m).astype(np.int32)
+            outs = []
+            for s in sensors:
+                s.set_observation(frames[k % 6])
+                outs.append(s.loglikes_poses(poses, parents.copy(), update=k % 3 != 2))
+            for o in outs[1:]:
+                assert np.array_equal(outs[0], o, equal_nan=True), k
+        for slot in range(0, n, 11):
+            for s in sensors[1:]:
+                assert np.array_equal(sensors[0].get_occlusion(slot), s.get_occlusion(slot)), slot
+    finally:
+        for s in sensors:
+            s.close()
