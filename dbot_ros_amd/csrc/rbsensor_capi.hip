@@ -431,9 +431,9 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipEventRecord(h->ev_fork, s));
         RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
         if (h->windowed && !wide) {
-            // the windowed copy is small and the raster blocks leave it no registers once they
-            // are resident (3 x 168 VGPRs per SIMD): it goes first, under the scan kernel and the
-            // raster kernel's ramp-up
+            // the windowed copy goes first: its one-wave blocks (32 VGPRs) then run beside the
+            // persistent raster blocks (3 x 160 VGPRs per SIMD: precision F32; the binary64
+            // likelihood's 3 x 168 leave it the ramp-up and the tail only)
             if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
             const int ny = std::min(n, 32768);
             const dim3 wg((unsigned)h->win_chunks, (unsigned)ny, (unsigned)((n + ny - 1) / ny));

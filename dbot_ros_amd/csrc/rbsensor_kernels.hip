@@ -1577,7 +1577,7 @@ __global__ __launch_bounds__(64) void rbs_wide_window_kernel(const DevParams P, 
 // per wave), so a window shrinks again as soon as the values it held have decayed into the
 // background snap.
 // Two float4 loads in flight per lane = 32 VGPRs: exactly what three resident raster waves
-// (157 -> 160 allocated each) leave free on a SIMD, so one copy wave per SIMD runs BESIDE the
+// (160 each, by a stated budget) leave free on a SIMD, so one copy wave per SIMD runs BESIDE the
 // persistent raster blocks instead of only before and after them (with four loads, 48 VGPRs, it
 // could not: C2 3.33 -> 3.61 M/s, C3 slice 12.0 -> 12.8 M/s, C1 step 0.2055 -> 0.2015 ms).
 #ifndef RBS_WIN_UNROLL
