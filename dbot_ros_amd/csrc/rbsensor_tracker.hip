@@ -515,12 +515,18 @@ __device__ inline void mean_body(const TrackerDev& T, const double* __restrict__
                                  double (*shb)[kBody])
 {
     const int n = T.n;
-    double m = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += 1024) m = fmax(m, T.logw[i]);
-    m = block_max(m, sh);
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) s += exp(T.logw[i] - m);
-    const double S = block_sum(s, sh);
+    // After a resampling every log-weight is 0 (gather_one): max 0, exp(0) = 1, their sum n -- the
+    // same bits as the general route below, without its two block reductions and 2 n exponentials.
+    const bool uniform = T.flag[0] != 0;   // block-uniform
+    double m = 0.0, S = (double)n;
+    if (!uniform) {
+        m = -INFINITY;
+        for (int i = threadIdx.x; i < n; i += 1024) m = fmax(m, T.logw[i]);
+        m = block_max(m, sh);
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += 1024) s += exp(T.logw[i] - m);
+        S = block_sum(s, sh);
+    }
     // the twelve components of a body are reduced together: each one's additions are exactly
     // those of block_sum (same per-thread order, same shuffle tree, same order over the waves),
     // with two barriers per body instead of twenty-four
@@ -529,7 +535,7 @@ __device__ inline void mean_body(const TrackerDev& T, const double* __restrict__
 #pragma unroll
         for (int k = 0; k < kBody; ++k) a[k] = 0.0;
         for (int i = threadIdx.x; i < n; i += 1024) {
-            const double w = exp(T.logw[i] - m) / S;
+            const double w = (uniform ? 1.0 : exp(T.logw[i] - m)) / S;
             const double* p = part_new + (size_t)i * T.D + b * kBody;
 #pragma unroll
             for (int k = 0; k < kBody; ++k) a[k] += w * p[k];
