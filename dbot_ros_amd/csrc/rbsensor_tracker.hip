@@ -230,18 +230,26 @@ __device__ inline void weights_body(const TrackerDev& T, int updated, double* sh
         if (resample) T.flag[1] += 1;
     }
     if (!resample) return;   // block-uniform
-    // inclusive scan of the per-thread sums -> exclusive offsets, then the running cdf
-    __syncthreads();
-    sh[threadIdx.x] = local;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const double v = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
-        __syncthreads();
-        sh[threadIdx.x] += v;
-        __syncthreads();
+    // scan of the per-thread sums -> exclusive offsets, then the running cdf: inside a wave by
+    // shuffles, across the sixteen waves through LDS (two barriers; a Hillis-Steele scan over the
+    // 1 024 threads took twenty)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double v = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
     }
-    double run = threadIdx.x ? sh[threadIdx.x - 1] : 0.0;
-    const double total = sh[1023];
+    const double below = __shfl_up(v, 1, 64);   // the wave's sum up to the previous lane
+    __syncthreads();
+    if (lane == 63) sh[wv] = v;
+    __syncthreads();
+    double prefix = 0.0, total = 0.0;
+    for (int k = 0; k < 16; ++k) {
+        if (k < wv) prefix += sh[k];
+        total += sh[k];
+    }
+    double run = prefix + (lane ? below : 0.0);
     for (int i = lo; i < hi; ++i) {
         run += exp(T.logw[i] - m);
         T.cdf[i] = run / total;
