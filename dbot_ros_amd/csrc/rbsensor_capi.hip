@@ -2044,6 +2044,7 @@ struct rbs_tracker {
     int* h_flags_dev[2] = {nullptr, nullptr};
     int32_t res_rc[2] = {0, 0};       // (a handle over several devices runs submit synchronously)
     long submitted = 0, collected = 0;
+    bool recentre_pending = false;    // T.part_old still holds the particles before the last frame's re-centring
 };
 
 namespace {
@@ -2210,6 +2211,7 @@ int32_t rbs_tracker_initialize(rbs_tracker* t, const double* default_state)
     if (!t) return RBS_ERR_INVALID_ARGUMENT;
     if (!default_state) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_initialize: null state");
     t->submitted = t->collected = 0;
+    t->recentre_pending = false;
     if (!t->reps.empty()) {
         for (rbs_tracker* r : t->reps)
             if (int32_t rc = rbs_tracker_initialize(r, default_state)) { t->s->err = r->s->err; return rc; }
@@ -2274,7 +2276,7 @@ int32_t group_tracker_track(rbs_tracker* t, const float* frame, const double* no
         for (int k = 0; k < nd; ++k) {
             rbs_tracker* r = t->reps[k];
             RBT_HIP(t, hipSetDevice(r->s->device));
-            hipLaunchKernelGGL(rbt::propagate_kernel, g256, b256, 0, streams[k], r->T, b);
+            hipLaunchKernelGGL(rbt::propagate_kernel, g256, b256, 0, streams[k], r->T, b, 0);
             hipLaunchKernelGGL(rbt::layout_kernel, dim3(1), dim3(1024), 0, streams[k], r->T, nd, cap);
             const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
             if (cnt > 0)
@@ -2319,7 +2321,7 @@ int32_t group_tracker_track(rbs_tracker* t, const float* frame, const double* no
         rbt::TrackerDev& T = r->T;
         RBT_HIP(t, hipSetDevice(r->s->device));
         launch_mean(T, streams[k]);
-        hipLaunchKernelGGL(rbt::recentre_kernel, g256, b256, 0, streams[k], T);
+        hipLaunchKernelGGL(rbt::recentre_kernel, g256, b256, 0, streams[k], T, T.part_new);
         RBT_HIP(t, hipGetLastError());
         std::swap(T.part_old, T.part_new);   // this frame's particles are the next frame's old ones
         if (k == 0) {
@@ -2387,7 +2389,8 @@ int32_t rbs_tracker_submit(rbs_tracker* t, const float* frame, const double* nor
         const bool last = b == T.parts - 1;
         // (the transition fused into the sensor's rectangles kernel -- one launch less -- measured no
         // gain: 3 987 against 3 976 frames/s at 2 000 particles)
-        hipLaunchKernelGGL(rbt::propagate_kernel, g256, b256, 0, s, T, b);
+        hipLaunchKernelGGL(rbt::propagate_kernel, g256, b256, 0, s, T, b, b == 0 && t->recentre_pending ? 1 : 0);
+        if (b == 0) t->recentre_pending = false;
         RBT_HIP(t, hipGetLastError());
         if (int32_t rc = enqueue_loglikes(h, T.poses, T.idx, T.n, last, T.ll_new, s)) return rc;
         if (fused) {
@@ -2407,7 +2410,11 @@ int32_t rbs_tracker_submit(rbs_tracker* t, const float* frame, const double* nor
         // (re-centring inside the single mean block was tried: its two rounds of rotations per thread
         // on one CU take longer than the separate launch, 25 us against 16.5 + 5)
         launch_mean(T, s);
-        hipLaunchKernelGGL(rbt::recentre_kernel, g256, b256, 0, s, T);
+        // the re-centring itself rides in the next frame's first transition launch (the thread that
+        // moves particle i re-centres it first); rbs_tracker_get applies it on demand
+        static const bool now = [] { const char* e = std::getenv("RBS_TRACKER_RECENTRE_NOW"); return e && std::atoi(e) != 0; }();
+        if (now) hipLaunchKernelGGL(rbt::recentre_kernel, g256, b256, 0, s, T, T.part_new);
+        else t->recentre_pending = true;
     }
     RBT_HIP(t, hipGetLastError());
     std::swap(T.part_old, T.part_new);   // this frame's particles are the next frame's old ones
@@ -2465,6 +2472,11 @@ int32_t rbs_tracker_get(rbs_tracker* t, double* particles, double* log_weights, 
     }
     rbt::TrackerDev& T = t->T;
     RBT_HIP(t, hipSetDevice(t->s->device));
+    if (t->recentre_pending) {   // (deferred into the next frame's transition launch: apply it now)
+        hipLaunchKernelGGL(rbt::recentre_kernel, dim3((unsigned)((T.n + 255) / 256)), dim3(256), 0, t->s->stream, T, T.part_old);
+        RBT_HIP(t, hipGetLastError());
+        t->recentre_pending = false;
+    }
     RBT_HIP(t, hipStreamSynchronize(t->s->stream));
     if (particles) RBT_HIP(t, hipMemcpy(particles, T.part_old, sizeof(double) * (size_t)T.n * T.D, hipMemcpyDeviceToHost));
     if (log_weights) RBT_HIP(t, hipMemcpy(log_weights, T.logw, sizeof(double) * (size_t)T.n, hipMemcpyDeviceToHost));

@@ -119,9 +119,12 @@ __device__ inline double u01(unsigned hi, unsigned lo)   // 53-bit uniform in [0
 // transition of bodies 0..b with their accumulated noise (vel' = vf vel + sigma o n,
 // pose' = pose + vel'), write the new particle and its absolute poses
 // R = R(delta) R(default), t = t(delta) + t(default)   (SURVEY A.1).
-__device__ inline void propagate_body(const TrackerDev& T, int b, int i, int bb)
+__device__ inline void recentre_body(const TrackerDev& T, double* __restrict__ p, int bb);
+
+__device__ inline void propagate_body(const TrackerDev& T, int b, int i, int bb, bool recentre)
 {
     double s[kBody];
+    if (recentre) recentre_body(T, T.part_old + (size_t)i * T.D + bb * kBody, bb);   // last frame's re-centring, deferred into this launch
 #pragma unroll
     for (int k = 0; k < kBody; ++k) s[k] = T.part_old[(size_t)i * T.D + bb * kBody + k];
     if (bb <= b) {
@@ -165,11 +168,14 @@ __device__ inline void propagate_body(const TrackerDev& T, int b, int i, int bb)
     for (int k = 0; k < 3; ++k) out[9 + k] = s[k] + T.deflt[bb * kBody + k];
 }
 
-__global__ void propagate_kernel(const TrackerDev T, int b)
+// recentre: the re-centring of the previous frame's particles (recentre_kernel's work) has been
+// deferred into this launch -- one launch and one kernel boundary less per frame; the thread owns
+// particle i, so it re-centres the old particle in place first (same operations, same bits).
+__global__ void propagate_kernel(const TrackerDev T, int b, int recentre)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T.n) return;
-    for (int bb = 0; bb < T.parts; ++bb) propagate_body(T, b, i, bb);
+    for (int bb = 0; bb < T.parts; ++bb) propagate_body(T, b, i, bb, recentre != 0);
 }
 
 // ------------------------------------------------------------------ f1: weights, KL, resampling
@@ -589,22 +595,23 @@ __global__ __launch_bounds__(1024) void mean_kernel(const TrackerDev T)
 }
 
 // delta_i <- delta_i (-) mean:  t -= t_mean,  R(delta_i) <- R(delta_i) R(mean)^T
+__device__ inline void recentre_body(const TrackerDev& T, double* __restrict__ p, int b)
+{
+    for (int k = 0; k < 3; ++k) p[k] -= T.mean[b * kBody + k];
+    double Rd[9], R[9];
+    rotvec_to_matrix(p + 3, Rd);
+    matmul3(Rd, T.mean + T.D + b * 9, R);
+    matrix_to_rotvec(R, p + 3);
+}
 __device__ inline void recentre_one(const TrackerDev& T, double* __restrict__ part_new, int i)
 {
-    for (int b = 0; b < T.parts; ++b) {
-        double* p = part_new + (size_t)i * T.D + b * kBody;
-        for (int k = 0; k < 3; ++k) p[k] -= T.mean[b * kBody + k];
-        double Rd[9], R[9];
-        rotvec_to_matrix(p + 3, Rd);
-        matmul3(Rd, T.mean + T.D + b * 9, R);
-        matrix_to_rotvec(R, p + 3);
-    }
+    for (int b = 0; b < T.parts; ++b) recentre_body(T, part_new + (size_t)i * T.D + b * kBody, b);
 }
 
-__global__ void recentre_kernel(const TrackerDev T)
+__global__ void recentre_kernel(const TrackerDev T, double* __restrict__ particles)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < T.n) recentre_one(T, T.part_new, i);
+    if (i < T.n) recentre_one(T, particles, i);
 }
 
 // Few particles: the whole filter step after the sensor call -- weights and KL test, resampling,
