@@ -165,6 +165,12 @@ struct rbs_handle {
     long calls = 0;
     int join_pending = -1;      // ring slot whose copy kernel later work on the planes must wait for
     std::string err;
+    bool frame_acquired = false;       // rbs_acquire_frame_buffer without its rbs_commit_frame_buffer yet
+    // A call that failed half-way through a fan-out (some shards enqueued, others not) or between a
+    // tracker's buffer swaps leaves the handle's double buffers out of step: every later call is
+    // refused with this message until rbs_reset (rbs_tracker_initialize) re-establishes a known state.
+    bool poisoned = false;
+    std::string poison_msg;
     // ---- several devices in one handle (rbs_config.n_devices > 1) ----
     // A GROUP handle owns one single-device handle ("shard") per device; global slot g lives on
     // shard g / shard_cap.  Every call is fanned out to the shards by the calling thread; a
@@ -721,6 +727,10 @@ int32_t upload_frame(rbs_handle* h, const float* src)
 {
     const int k = h->frame_slot;
     const size_t n = (size_t)h->npx;
+    // (the two staging images alternate, so k is never the image that serves as the observation --
+    // should it be, its readers are recorded first: the wait below must not be on a stale event)
+    if (k == h->cur_slot)
+        if (int32_t rc = release_frame_slot(h)) return rc;
     RBS_HIP(h, hipStreamWaitEvent(h->up_stream, h->ev_used[k], 0));   // d_fin[k]: read by the ingest kernel two frames ago
     RBS_HIP(h, hipMemcpyAsync(h->d_fin[k], src, n * sizeof(float), hipMemcpyHostToDevice, h->up_stream));
     RBS_HIP(h, hipEventRecord(h->ev_frame[k], h->up_stream));
@@ -794,8 +804,9 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     h->delta_time = cfg->delta_time;
     switch (cfg->likelihood_precision) {
         case RBS_PRECISION_DEFAULT:
-            // the caller leaves it open: the library's default, unless the environment names one
-            // (the exactness test-suites of an unchanged caller pin F64 this way)
+            // the caller leaves it open: the library's default (F64, the reference CPU model's arithmetic),
+            // unless the environment names one (tooling: A/B runs of an unchanged caller); a precision
+            // the caller names is never overridden
             h->precision = RBS_PRECISION_LIBRARY_DEFAULT;
             if (const char* m = std::getenv("RBS_PRECISION")) {
                 if (!std::strcmp(m, "f64")) h->precision = RBS_PRECISION_F64;
@@ -1226,6 +1237,32 @@ int32_t gfail(rbs_handle* g, rbs_handle* shard, int32_t rc)
     return rc;
 }
 
+// A failure after part of a call was enqueued: wait for everything that was enqueued (nothing may
+// still be writing when the caller reacts), and refuse further calls until rbs_reset.
+int32_t poison(rbs_handle* h, int32_t rc)
+{
+    const std::string why = h->err;
+    std::vector<rbs_handle*> all(h->shards.begin(), h->shards.end());
+    if (all.empty()) all.push_back(h);
+    for (rbs_handle* sh : all) {
+        (void)hipSetDevice(sh->device);
+        if (sh->stream) (void)hipStreamSynchronize(sh->stream);
+        if (sh->copy_stream) (void)hipStreamSynchronize(sh->copy_stream);
+        if (sh->up_stream) (void)hipStreamSynchronize(sh->up_stream);
+    }
+    (void)hipGetLastError();
+    h->poisoned = true;
+    h->poison_msg = why;
+    h->err = why;
+    return rc;
+}
+#define RBS_REFUSE_POISONED(h)                                                                \
+    do {                                                                                      \
+        if ((h)->poisoned)                                                                    \
+            return fail(h, RBS_ERR_HIP, "the handle is in an undefined state after a failed call (" + (h)->poison_msg + \
+                                            "): call rbs_reset / rbs_tracker_initialize");    \
+    } while (0)
+
 // Every shard orders its next call after EVERY shard's previous one: a call reads parents from
 // the other shards' current planes (complete only when their previous updating call is) and
 // overwrites the buffer the other shards' previous call was still reading.  All waits are
@@ -1437,25 +1474,26 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
     for (int32_t i = 0; i < n; ++i)
         if (indices[i] < 0 || indices[i] >= nd * cap)
             return fail(g, RBS_ERR_INVALID_ARGUMENT, fmt("loglikes: indices[%d] = %d outside 0..%d", i, indices[i], nd * cap - 1));
-    if (int32_t rc = group_begin_call(g, nullptr)) return rc;
+    // from here on a failure leaves some shards advanced and others not: the group is poisoned
+    if (int32_t rc = group_begin_call(g, nullptr)) return poison(g, rc);
     const size_t stride = (size_t)12 * g->n_bodies;
     for (int k = 0; k < nd; ++k) {
         rbs_handle* h = g->shards[k];
         const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
-        RBS_HIP(g, hipSetDevice(h->device));
+        if (hipSetDevice(h->device) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, fmt("hipSetDevice(%d) failed", h->device)));
         if (cnt <= 0) {
             advance_empty(h, update != 0);
-            RBS_HIP(g, hipEventRecord(h->ev_done, h->stream));
+            if (hipEventRecord(h->ev_done, h->stream) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, "hipEventRecord failed"));
             continue;
         }
-        if (int32_t rc = host_call(h, poses + stride * (size_t)lo, indices + lo, cnt, update != 0)) return gfail(g, h, rc);
+        if (int32_t rc = host_call(h, poses + stride * (size_t)lo, indices + lo, cnt, update != 0)) return poison(g, gfail(g, h, rc));
     }
     for (int k = 0; k < nd; ++k) {
         rbs_handle* h = g->shards[k];
         const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
         if (cnt <= 0) continue;
-        RBS_HIP(g, hipSetDevice(h->device));
-        RBS_HIP(g, hipEventSynchronize(h->ev_out));
+        if (hipSetDevice(h->device) != hipSuccess || hipEventSynchronize(h->ev_out) != hipSuccess)
+            return poison(g, fail(g, RBS_ERR_HIP, fmt("device %d: waiting for the log-likelihoods failed", h->device)));
         std::memcpy(out + lo, h->h_out, sizeof(double) * (size_t)cnt);
     }
     if (update)
@@ -1489,6 +1527,19 @@ rbs_handle* shard_of(rbs_handle* g, int32_t slot, int32_t* local)
             for (rbs_handle* sh_ : (h)->shards) {                                             \
                 const int32_t rc_ = call;                                                     \
                 if (rc_) return gfail(h, sh_, rc_);                                           \
+            }                                                                                 \
+            return RBS_OK;                                                                    \
+        }                                                                                     \
+    } while (0)
+// A call that changes every shard's state: a failure on the first shard (argument errors land
+// there) changed nothing; one on a later shard leaves the shards out of step -> poisoned.
+#define RBS_GROUP_ALL_MUT(h, call)                                                            \
+    do {                                                                                      \
+        if (!(h)->shards.empty()) {                                                           \
+            for (size_t k_ = 0; k_ < (h)->shards.size(); ++k_) {                              \
+                rbs_handle* sh_ = (h)->shards[k_];                                            \
+                const int32_t rc_ = call;                                                     \
+                if (rc_) return k_ == 0 ? gfail(h, sh_, rc_) : poison(h, gfail(h, sh_, rc_)); \
             }                                                                                 \
             return RBS_OK;                                                                    \
         }                                                                                     \
@@ -1556,9 +1607,24 @@ void rbs_destroy(rbs_handle* h)
 int32_t rbs_reset(rbs_handle* h)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
-    RBS_GROUP_ALL(h, rbs_reset(sh_));
+    if (!h->shards.empty()) {
+        for (rbs_handle* sh_ : h->shards)
+            if (int32_t rc_ = rbs_reset(sh_)) return gfail(h, sh_, rc_);
+        for (rbs_handle* sh_ : h->shards) {   // idle streams: a clean slate for the group's call ordering
+            RBS_HIP(h, hipSetDevice(sh_->device));
+            RBS_HIP(h, hipEventRecord(sh_->ev_done, sh_->stream));
+        }
+        h->poisoned = false;
+        h->frame_acquired = false;
+        return RBS_OK;
+    }
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;   // no copy kernel may still be writing planes
+    // (a call that failed between its kernels may have left the work-item counters of either parity
+    // in use: both pairs start from zero again)
+    RBS_HIP(h, hipMemsetAsync(h->d_ctr, 0, 4 * sizeof(int), h->stream));
+    h->poisoned = false;
+    h->frame_acquired = false;
     h->cur = 0;
     h->pending_frames = 0;
     h->background = (float)h->init_occ;
@@ -1591,7 +1657,9 @@ int32_t rbs_reset(rbs_handle* h)
 int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
-    RBS_GROUP_ALL(h, rbs_set_observation(sh_, depth, n));
+    RBS_REFUSE_POISONED(h);
+    h->frame_acquired = false;   // (an acquired buffer that was never committed is abandoned)
+    RBS_GROUP_ALL_MUT(h, rbs_set_observation(sh_, depth, n));
     if (!depth || n != (size_t)h->npx)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("set_observation: expected %d pixels, got %zu", h->npx, n));
@@ -1607,7 +1675,9 @@ int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n)
 int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
-    RBS_GROUP_ALL(h, rbs_set_observation_f32(sh_, depth, n));
+    RBS_REFUSE_POISONED(h);
+    h->frame_acquired = false;   // (an acquired buffer that was never committed is abandoned)
+    RBS_GROUP_ALL_MUT(h, rbs_set_observation_f32(sh_, depth, n));
     if (!depth || n != (size_t)h->npx)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("set_observation_f32: expected %d pixels, got %zu", h->npx, n));
@@ -1624,6 +1694,9 @@ int32_t rbs_acquire_frame_buffer(rbs_handle* h, float** buf)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
     if (!buf) return fail(h, RBS_ERR_INVALID_ARGUMENT, "acquire_frame_buffer: null pointer");
+    RBS_REFUSE_POISONED(h);
+    if (h->frame_acquired)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "acquire_frame_buffer: the buffer handed out last has not been committed (rbs_commit_frame_buffer)");
     if (!h->shards.empty()) {
         // one staging buffer (shard 0's) feeds every device: it is free once every shard's upload
         // of the frame before last has finished
@@ -1636,23 +1709,32 @@ int32_t rbs_acquire_frame_buffer(rbs_handle* h, float** buf)
             RBS_HIP(h, hipEventSynchronize(sh->ev_frame[sh->frame_slot]));
         }
         *buf = s0->h_frame;
+        h->frame_acquired = true;
         return RBS_OK;
     }
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = next_frame_staging(h)) return rc;
     *buf = h->h_frame;
+    h->frame_acquired = true;
     return RBS_OK;
 }
 
 int32_t rbs_commit_frame_buffer(rbs_handle* h)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_REFUSE_POISONED(h);
+    // a commit uploads the buffer the matching acquire handed out: without one (or after another
+    // rbs_set_observation* call took the acquire's place) there is nothing defined to upload, and the
+    // upload would land in the image the kernels in flight are reading
+    if (!h->frame_acquired)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "commit_frame_buffer: no buffer acquired (rbs_acquire_frame_buffer comes first, once per frame)");
+    h->frame_acquired = false;
     if (!h->shards.empty()) {
         const float* src = h->shards[0]->h_frame;
         for (rbs_handle* sh : h->shards) {
-            RBS_HIP(h, hipSetDevice(sh->device));
-            if (int32_t rc = flush_lazy_frame(sh, sh->stream)) return gfail(h, sh, rc);
-            if (int32_t rc = upload_frame(sh, src)) return gfail(h, sh, rc);
+            if (hipSetDevice(sh->device) != hipSuccess) return poison(h, fail(h, RBS_ERR_HIP, fmt("hipSetDevice(%d) failed", sh->device)));
+            if (int32_t rc = flush_lazy_frame(sh, sh->stream)) return poison(h, gfail(h, sh, rc));
+            if (int32_t rc = upload_frame(sh, src)) return poison(h, gfail(h, sh, rc));
             sh->pending_frames += 1;
         }
         return RBS_OK;
@@ -1668,7 +1750,9 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
                                        int32_t height, int32_t f)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
-    RBS_GROUP_ALL(h, rbs_set_observation_native_f32(sh_, native, width, height, f));
+    RBS_REFUSE_POISONED(h);
+    h->frame_acquired = false;
+    RBS_GROUP_ALL_MUT(h, rbs_set_observation_native_f32(sh_, native, width, height, f));
     if (!native || f <= 0 || width <= 0 || height <= 0 || height / f != h->rows || width / f != h->cols)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("set_observation_native: %dx%d / %d does not give the evaluated %dx%d", width,
@@ -1700,6 +1784,8 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
 int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* stream)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_REFUSE_POISONED(h);
+    h->frame_acquired = false;
     if (!h->shards.empty())
         return fail(h, RBS_ERR_UNSUPPORTED, "set_observation_device: a handle over several devices takes host frames (or drive it through rbs_tracker_*)");
     if (!d_depth) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_observation_device: null pointer");
@@ -1733,6 +1819,7 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
                      int32_t update, double* out_loglik)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_REFUSE_POISONED(h);
     if (n < 0 || n > h->max_particles)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("loglikes: n = %d outside 0..max_particles = %d", n, h->max_particles));
@@ -1760,6 +1847,7 @@ int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t*
                             int32_t n, int32_t update, double* d_out_loglik, void* stream)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_REFUSE_POISONED(h);
     if (!h->shards.empty())
         return fail(h, RBS_ERR_UNSUPPORTED, "loglikes_device: a handle over several devices is driven through rbs_loglikes or rbs_tracker_*");
     if (n < 0 || n > h->max_particles)
@@ -2045,6 +2133,7 @@ struct rbs_tracker {
     int32_t res_rc[2] = {0, 0};       // (a handle over several devices runs submit synchronously)
     long submitted = 0, collected = 0;
     bool recentre_pending = false;    // T.part_old still holds the particles before the last frame's re-centring
+    bool poisoned = false;            // a frame failed half-way (buffers partly swapped): rbs_tracker_initialize first
 };
 
 namespace {
@@ -2129,7 +2218,11 @@ int32_t tracker_create_one(rbs_handle* sensor, const rbs_tracker_params* p, int 
         rbs_tracker_destroy(t);
         return rc;
     }
-    RBS_HIP(sensor, hipMemsetAsync(T.deflt, 0, sizeof(double) * D, sensor->stream));
+    if (hipMemsetAsync(T.deflt, 0, sizeof(double) * D, sensor->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        rbs_tracker_destroy(t);
+        return fail(sensor, RBS_ERR_HIP, "tracker_create: hipMemsetAsync failed");
+    }
     t->d_normals2[0] = t->d_normals;
     t->d_uniforms2[0] = t->d_uniforms;
     if ((rc = talloc(t, &t->d_normals2[1], n * P6)) || (rc = talloc(t, &t->d_uniforms2[1], n * (size_t)T.parts))) {
@@ -2148,8 +2241,12 @@ int32_t tracker_create_one(rbs_handle* sensor, const rbs_tracker_params* p, int 
             return fail(sensor, RBS_ERR_OUT_OF_MEMORY, "tracker_create: pinned host memory");
         }
         *t->h_serr[k] = 0;
-        RBS_HIP(sensor, hipHostGetDevicePointer(reinterpret_cast<void**>(&t->h_state_dev[k]), t->h_state[k], 0));
-        RBS_HIP(sensor, hipHostGetDevicePointer(reinterpret_cast<void**>(&t->h_flags_dev[k]), t->h_flags[k], 0));
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&t->h_state_dev[k]), t->h_state[k], 0) != hipSuccess ||
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&t->h_flags_dev[k]), t->h_flags[k], 0) != hipSuccess) {
+            (void)hipGetLastError();
+            rbs_tracker_destroy(t);
+            return fail(sensor, RBS_ERR_HIP, "tracker_create: hipHostGetDevicePointer failed");
+        }
     }
     *out = t;
     return RBS_OK;
@@ -2212,6 +2309,7 @@ int32_t rbs_tracker_initialize(rbs_tracker* t, const double* default_state)
     if (!default_state) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_initialize: null state");
     t->submitted = t->collected = 0;
     t->recentre_pending = false;
+    t->poisoned = false;
     if (!t->reps.empty()) {
         for (rbs_tracker* r : t->reps)
             if (int32_t rc = rbs_tracker_initialize(r, default_state)) { t->s->err = r->s->err; return rc; }
@@ -2219,6 +2317,8 @@ int32_t rbs_tracker_initialize(rbs_tracker* t, const double* default_state)
             RBT_HIP(t, hipSetDevice(sh->device));
             RBT_HIP(t, hipEventRecord(sh->ev_done, sh->stream));
         }
+        t->s->poisoned = false;
+        t->s->frame_acquired = false;
         return RBS_OK;
     }
     rbt::TrackerDev& T = t->T;
@@ -2347,9 +2447,33 @@ int32_t group_tracker_track(rbs_tracker* t, const float* frame, const double* no
 
 extern "C" {
 
+// The body of rbs_tracker_submit; a failure in here happens after some of the frame's work was
+// enqueued and some of the tracker's buffers were swapped.
+static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const double* normals, const double* uniforms, uint64_t seed);
+
 int32_t rbs_tracker_submit(rbs_tracker* t, const float* frame, const double* normals, const double* uniforms, uint64_t seed)
 {
     if (!t) return RBS_ERR_INVALID_ARGUMENT;
+    if (t->poisoned || t->s->poisoned)
+        return tfail(t, RBS_ERR_HIP, "tracker_submit: an earlier frame failed half-way (" + (t->s->poisoned ? t->s->poison_msg : t->err) +
+                                         "): call rbs_tracker_initialize");
+    const long before = t->submitted;
+    const int32_t rc = tracker_submit_impl(t, frame, normals, uniforms, seed);
+    if (rc != RBS_OK && !(rc == RBS_ERR_INVALID_ARGUMENT && t->submitted == before)) {
+        // drain what was enqueued and refuse further frames: the particle buffers are out of step
+        const std::string why = t->err.empty() ? t->s->err : t->err;
+        if (t->reps.empty()) { (void)hipSetDevice(t->s->device); (void)hipStreamSynchronize(t->s->stream); (void)hipStreamSynchronize(t->s->copy_stream); }
+        else for (rbs_tracker* r : t->reps) { (void)hipSetDevice(r->s->device); (void)hipStreamSynchronize(r->s->stream); (void)hipStreamSynchronize(r->s->copy_stream); }
+        (void)hipGetLastError();
+        t->poisoned = true;
+        t->err = why;
+        t->s->err = why;
+    }
+    return rc;
+}
+
+static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const double* normals, const double* uniforms, uint64_t seed)
+{
     if (t->submitted - t->collected >= 2)
         return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_submit: two frames are in flight already (call rbs_tracker_result)");
     const int slot = (int)(t->submitted & 1);

@@ -21,7 +21,7 @@
 //                       with the reference's float rounding points; PREC 1: float32 on the
 //                       exp2/log2/rcp units, every per-pixel term recomputed from the
 //                       observation), block reduce -> the particle's log-likelihood.
-//                       Bound by VALU issue (bench.py: 0.55 of the chip's issue peak).
+//                       Bound by VALU issue (bench.py measures the fraction of the chip's issue peak live).
 //   rbs_copy_window_kernel  (update only, second stream) the child's window outside its
 //                       rectangle: the parent's values advanced by the occlusion process
 //                       occ' = snap(fma(alpha, occ, beta)), the background where the parent
@@ -829,8 +829,8 @@ __device__ inline double pixel_loglik(const DevParams& P, int gi, float r, float
 // exp / erf / log and the mixture algebra change.  Written for RELATIVE accuracy: 1 + erf(x) as
 // erfc(-x) (no cancellation in the lower tail) through t exp(-z^2 + poly(t)), t = 1/(1 + z/2)
 // (Numerical Recipes' erfcc, fractional error 1.2e-7 everywhere); E1/(E1-1) as
-// 1/(1 - exp(-lam r)); log(sum / p_bg) as log(sum) - log(p_bg) with log(p_bg) computed once per
-// frame pixel in binary64.  About 50 VALU instructions per 64 pixels instead of 125 (ocml's
+// 1/(1 - exp(-lam r)); log(sum / p_bg) as log(sum) - log(p_bg), log(p_bg) recomputed per evaluated
+// pixel in float32 like every other term that depends on the observation only.  About 50 VALU instructions per 64 pixels instead of 125 (ocml's
 // expf / erfcf / logf and correctly rounded divisions) or 250 (binary64).  Per-pixel error of
 // the log term: 1.3e-7 mean, 1.7e-6 max, bias -3e-8 (numpy float32 emulation over 4e5 random
 // pixels); the particle's sum is accumulated in binary64.  tests/: <= 1e-5 relative against the

@@ -154,7 +154,7 @@ public:
         // MI355X extensions (optional rosparams particle_filter/gpu/devices and
         // particle_filter/gpu/likelihood_precision; the reference has no such keys):
         std::vector<int> devices;            // empty: device_id alone; several: particle sharding inside the handle
-        std::string likelihood_precision;    // "" (library default = f32) | "f32" | "f64"
+        std::string likelihood_precision;    // "" (library default = f64, the reference CPU model's arithmetic) | "f64" | "f32" (opt-in, see rbsensor_mi355x.h)
     };
 
     RbSensorBuilder(const std::shared_ptr<ObjectModel>& object_model,

@@ -49,20 +49,24 @@ enum {
 };
 
 /* rbs_config.likelihood_precision: the arithmetic of the per-pixel Kinect likelihood (exp / erf /
- * log and the mixture algebra).  Coverage, depth and the occlusion process do not depend on it:
- * geometry is binary64, depth and occlusion state are float, the per-particle sum is binary64.
- *   F64  binary64 with the reference CPU path's float rounding points: agrees with
- *        the device-rule oracle to ~1e-15 and with the reference-semantics oracle to ~5e-9.
- *   F32  float32 likelihood on the exp2 / log2 / rcp units, per-pixel terms derived from the
- *        observation on the fly (no per-frame planes): raster kernel 1.5x faster; agrees with the
- *        reference-semantics oracle to <= 1e-5 relative (BASELINE.json north_star's tolerance;
- *        measured <= 7e-7) for every particle whose sum is well conditioned, and to <= 1e-6 of
- *        the sum of the magnitudes of the per-pixel terms for all (measured 7e-8): float32-level
- *        agreement, ~5e-4 absolute on log-likelihoods of magnitude 1e4.
- * DEFAULT = the library's default, RBS_PRECISION_LIBRARY_DEFAULT (RBS_PRECISION=f64|f32 in the
- * environment overrides DEFAULT only). */
+ * log and the mixture algebra).  Coverage and depth do not depend on it (binary64 geometry, float
+ * depth), nor does the occlusion process' time step; the per-particle sum is binary64 in both.
+ *   F64  (the library default) binary64 with the reference CPU path's float rounding points
+ *        (SURVEY A.4): agrees with the device-rule oracle to ~1e-15 and with the
+ *        reference-semantics oracle to ~5e-9 -- inside BASELINE.json north_star's 1e-5 for every
+ *        particle -- and reproduces the oracle's resampling (parent) indices.
+ *   F32  OPT-IN.  float32 likelihood on the exp2 / log2 / rcp units, per-pixel terms derived from
+ *        the observation on the fly.  It does NOT meet north_star's bar for every particle and does
+ *        NOT reproduce parent indices at large particle counts: against the reference-semantics
+ *        oracle it is within 1e-5 relative only for particles whose sum is well conditioned
+ *        (|ll| >= 0.1 of the sum of the magnitudes of the per-pixel terms); for all particles the
+ *        bound is 1e-6 of that sum of magnitudes, i.e. float32-level agreement, ~5e-4 absolute on
+ *        log-likelihoods of magnitude 1e4.  The occlusion POSTERIOR (carried state) is computed in
+ *        float32 as well: stored planes differ from the oracle's by up to 2e-6.
+ * DEFAULT = RBS_PRECISION_LIBRARY_DEFAULT.  (Tooling only: RBS_PRECISION=f64|f32 in the environment
+ * replaces DEFAULT; it never overrides a precision the caller named.) */
 enum { RBS_PRECISION_DEFAULT = 0, RBS_PRECISION_F64 = 1, RBS_PRECISION_F32 = 2 };
-#define RBS_PRECISION_LIBRARY_DEFAULT RBS_PRECISION_F32
+#define RBS_PRECISION_LIBRARY_DEFAULT RBS_PRECISION_F64
 /* rbs_config.state_layout: how occlusion planes are stored ("occlusion state layout" below).
  * DEFAULT = windowed (RBS_STATE=dense in the environment overrides DEFAULT only: tooling). */
 enum { RBS_STATE_DEFAULT = 0, RBS_STATE_WINDOWED = 1, RBS_STATE_DENSE = 2 };

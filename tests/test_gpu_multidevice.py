@@ -244,3 +244,44 @@ def test_zero_copy_frame_staging_equals_set_observation(gpu_lib, ids):
             ia = rng.integers(0, n, n).astype(np.int32)
             ib = ia.copy()
         assert np.array_equal(a.get_observation(), b.get_observation(), equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ids", [None, [0, 0]])
+def test_frame_buffer_calls_must_pair(gpu_lib, ids):
+    """a commit without its acquire, or a second acquire, would upload into the image the
+    kernels in flight read and count the frame twice -- both are refused, the handle stays usable,
+    and an acquire that another rbs_set_observation* call replaced is abandoned."""
+    from dbot_ros_amd.sensor import RbSensorError
+    n = 8
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    rng = np.random.default_rng(1)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", device_ids=ids) as s, \
+            RbSensor(om, cam, P, max_particles=n, precision="f64", device_ids=ids) as ref:
+        s.reset(); ref.reset()
+        t = synth.truth_pose(1, frame=0)
+        frame = synth.make_frame(ref.render_depth(t), 120, 160, rng).astype(np.float32)
+        poses = synth.particle_poses(t, n, rng)
+        with pytest.raises(RbSensorError, match="no buffer acquired"):
+            s.commit_frame()
+        buf = s.frame_buffer()
+        with pytest.raises(RbSensorError, match="not been committed"):
+            s.frame_buffer()
+        buf[:] = frame
+        s.commit_frame()
+        with pytest.raises(RbSensorError, match="no buffer acquired"):
+            s.commit_frame()                       # one commit per acquire: the frame is not counted twice
+        ref.set_observation(frame)
+        idx = np.zeros(n, np.int32)
+        a = s.loglikes_poses(poses, idx.copy(), update=True)
+        b = ref.loglikes_poses(poses, idx.copy(), update=True)
+        assert np.array_equal(a, b)
+        # an acquire replaced by a plain set_observation: abandoned, its commit refused
+        s.frame_buffer()
+        s.set_observation(frame); ref.set_observation(frame)
+        with pytest.raises(RbSensorError, match="no buffer acquired"):
+            s.commit_frame()
+        idx = np.arange(n, dtype=np.int32)
+        a = s.loglikes_poses(poses, idx.copy(), update=True)
+        b = ref.loglikes_poses(poses, idx.copy(), update=True)
+        assert np.array_equal(a, b)

@@ -26,8 +26,8 @@ def state_layout(request, monkeypatch):
     """Every parity test runs on both layouts of the occlusion state: windowed planes (default)
     and whole planes (RBS_STATE=dense).  The numbers must not depend on the layout."""
     monkeypatch.setenv("RBS_STATE", request.param)
-    # the bars of this module are those of likelihood precision F64 (the library's default is F32:
-    # tests/test_gpu_f32.py)
+    # the bars of this module are those of likelihood precision F64, the library's default (pinned
+    # here all the same; the opt-in F32: tests/test_gpu_f32.py)
     monkeypatch.setenv("RBS_PRECISION", "f64")
     return request.param
 
