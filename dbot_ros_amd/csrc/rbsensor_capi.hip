@@ -363,7 +363,9 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     // whatever the number of blocks of a call: the split decides the order in which a
     // particle's partial sums are added, and the switch between the modes depends on when an
     // asynchronous read-back lands -- results must not.
-    P.tile_px = !h->windowed && h->raster_blocks <= 2 * h->cu_count ? rbs::kTilePxBig : rbs::kTilePx;
+    const bool f64 = h->precision == RBS_PRECISION_F64;   // (its math tables take a little of the LDS tile)
+    P.tile_px = !h->windowed && h->raster_blocks <= 2 * h->cu_count ? (f64 ? rbs::kTilePxBigF64 : rbs::kTilePxBig)
+                                                                     : (f64 ? rbs::kTilePxF64 : rbs::kTilePx);
     P.tile_w = 256;
     P.tile_h = std::max(4, P.tile_px / 256 / std::max(1, h->smalln_target / std::max(1, n)));
     if (const char* m = h->tile_override) { P.tile_w = std::max(16, std::atoi(m) / 16 * 16); P.tile_h = std::max(1, std::atoi(m)); }
@@ -481,7 +483,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     if (h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
     if (update) {
-        launch_raster(h, true, rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
+        launch_raster(h, true, rgrid, block, rbs::smem_bytes(P.tile_px, f64), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
@@ -523,7 +525,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
         }
     } else {
-        launch_raster(h, false, rgrid, block, rbs::smem_bytes(P.tile_px), s, P);
+        launch_raster(h, false, rgrid, block, rbs::smem_bytes(P.tile_px, f64), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
     }
@@ -827,6 +829,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     B.fx = K[0]; B.fy = K[4]; B.cx = K[2]; B.cy = K[5];
     B.tw = cfg->tail_weight; B.ms = cfg->model_sigma; B.sf = cfg->sigma_factor;
     B.lambda = -std::log(0.5) / rbs::kHalfLifeDepth;
+    B.cv0 = (1.0 - cfg->tail_weight) / std::sqrt(M_PI);
     B.bands = copy_bands_for(h->rows, h->cols);
     B.band_rows = (h->rows + B.bands - 1) / B.bands;
 
@@ -1200,10 +1203,10 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<true, true>),
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<true, true>)};
         for (const void* k : kernels)
-            RBS_HIP(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
+            RBS_HIP(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig, false)));
     }
     RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_render_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig)));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig, false)));
 
     {   // per-item partial sums: sized for the default tiling so no call ever allocates
         const size_t gmul = h->d_groups[0] ? rbs::kMaxGroups : 1;   // every group of bodies tiles its own rectangle
@@ -1994,7 +1997,7 @@ int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out)
     P.tile_w = 256;
     P.tile_px = rbs::kTilePxBig;
     P.tile_h = P.tile_px / 256;
-    hipLaunchKernelGGL(rbs::rbs_render_kernel, dim3(1), dim3(rbs::kBlock), rbs::smem_bytes(P.tile_px),
+    hipLaunchKernelGGL(rbs::rbs_render_kernel, dim3(1), dim3(rbs::kBlock), rbs::smem_bytes(P.tile_px, false),
                        h->stream, P, h->d_render);
     RBS_HIP(h, hipGetLastError());
     RBS_HIP(h, hipMemcpyAsync(out, h->d_render, sizeof(float) * h->npx, hipMemcpyDeviceToHost,

@@ -41,6 +41,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "rbs_math.h"
+
 namespace rbs {
 
 // tuning knobs (overridable with -D for A/B experiments; defaults are the measured best)
@@ -68,6 +70,14 @@ namespace rbs {
 constexpr int kBlock = RBS_BLOCK;          // threads per raster block (a multiple of 64)
 constexpr int kTilePx = RBS_TILE_PX;       // LDS depth tile (u32 per pixel) of a launch with 3 blocks per CU
 constexpr int kTilePxBig = 16384;          // ... of a launch with 2 blocks per CU (whole planes / wide windows)
+// Precision F64 keeps the erfc and log tables of rbs_math.h in LDS (per-lane table reads: 5.9 KB
+// per block), taken from the depth tile so that the same number of blocks stays resident.
+#ifndef RBS_MATH_LDS
+#define RBS_MATH_LDS 1
+#endif
+constexpr int kMathTabDoubles = RBS_MATH_LDS ? rbsm::kErfcIntervals * rbsm::kErfcCoefs + rbsm::kLogIntervals * 2 : 0;
+constexpr int kMathTabPx = (kMathTabDoubles * 8 + 63) / 64 * 16;   // the tables' size in tile pixels, a multiple of 16
+constexpr int kTilePxF64 = kTilePx - kMathTabPx, kTilePxBigF64 = kTilePxBig - kMathTabPx;
 #ifndef RBS_BIG_CAP
 #define RBS_BIG_CAP 256
 #endif
@@ -139,6 +149,7 @@ struct DevParams {
     const double* aux;             // per-frame-pixel terms, [npx][4] binary64 (frame_aux_kernel)
     const float* pbg;              // per-frame-pixel background density, rounded to float
     double tw, ms, sf, lambda;     // tail_weight, model_sigma, sigma_factor, ln2/half_life
+    double cv0;                    // (1 - tail_weight) / sqrt(pi): c_v = cv0 / (sqrt2 sigma)
     float alpha, beta;             // occlusion process over the elapsed frames
     float bg_old, bg_new;          // never-covered level before / after this call's step
     int windowed;                  // planes are valid inside their window only (else implicit bg)
@@ -747,7 +758,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
 //   p_bg(o)    = tw/D + (1-tw) lam exp(lam/2 (lam sigma^2 - 2o))        (rounded to float)
 // Algebraically identical to SURVEY A.3 / oracle orc_prob_*; binary64 results differ from the
 // oracle's expression order by a few ulp, far below the float rounding of a, b that follows.
-enum { AUX_INV_S2S = 0, AUX_K = 1, AUX_CV = 2, AUX_EO = 3, AUX_PLANES = 4 };
+enum { AUX_INV_S2S = 0, AUX_K = 1, AUX_OBS = 2, AUX_EO = 3, AUX_PLANES = 4 };
 
 // keep != nullptr: `frame` is the caller's buffer and is also copied into the handle's own.
 __device__ inline void frame_aux_pixel(int i, const float* __restrict__ frame, double* __restrict__ aux,
@@ -757,16 +768,12 @@ __device__ inline void frame_aux_pixel(int i, const float* __restrict__ frame, d
     const float of = frame[i];
     if (keep) keep[i] = of;
     if (!aux) return;   // likelihood precision F32 derives these terms from the observation on the fly
-    const double o = (double)of;
-    const double sigma = ms + sf * o * o;
-    const double eo = exp(0.5 * lam * (-2.0 * o + lam * sigma * sigma));
     // the four terms of a pixel side by side (32 B): one cache line per evaluated pixel, not four
+    double t4[4];
+    rbsm::frame_terms((double)of, tw, ms, sf, lam, t4);
     double* a4 = aux + (size_t)AUX_PLANES * i;
-    a4[AUX_INV_S2S] = 1.0 / (sqrt(2.0) * sigma);
-    a4[AUX_K] = lam * sigma / sqrt(2.0);
-    a4[AUX_CV] = (1.0 - tw) / (sqrt(2.0 * M_PI) * sigma);
-    a4[AUX_EO] = 0.5 * (1.0 - tw) * lam * eo;
-    pbg[i] = (float)(tw / kMaxDepth + (1.0 - tw) * lam * eo);
+    a4[0] = t4[0]; a4[1] = t4[1]; a4[2] = t4[2]; a4[3] = t4[3];
+    (void)pbg;   // (p_bg = tw/D + 2 e_o is formed from the entry where it is needed: no plane of its own)
 }
 
 __global__ void frame_aux_kernel(const float* __restrict__ frame, double* __restrict__ aux,
@@ -778,49 +785,32 @@ __global__ void frame_aux_kernel(const float* __restrict__ frame, double* __rest
 }
 
 // log-likelihood ratio of one covered, observed pixel + posterior occlusion.
-// Rounding points as in the oracle: a, b, p_bg -> float; a+b and the ratios in float; log in
-// double.
-__device__ inline double pixel_loglik(const DevParams& P, int gi, float r, float prior, float& posterior)
+// Rounding points as in the oracle: a, b, p_bg -> float; a+b and the ratios in float (correctly
+// rounded divisions); log in double.  The transcendentals are rbs_math.h's fixed-length binary64
+// sequences (exp to 4e-16 relative, erfc to 1e-16 absolute, log to 1e-16 absolute + its own
+// rounding) instead of ocml's general-purpose exp / erf / log: about 125 VALU instructions per 64
+// pixels instead of 250, no divergent ranges, no scratch.  The float roundings of a and b then
+// agree with the oracle's (libm) except where a term lies within ~1e-15 relative of a rounding
+// boundary -- about one pixel in 1e7 -- which tests/ bound (planes: <= 1e-4 of pixels at 1 ulp;
+// log-likelihoods: 1e-9).
+struct MathTabs { const double* erfc; const double* logt; };
+
+__device__ inline double pixel_loglik(const DevParams& P, const MathTabs& M, int gi, float r, float prior, float& posterior)
 {
-    const float o = P.frame[gi];   // finite: the pixel was queued because it is
-    // the five per-frame terms of this pixel: one memory round trip
+    // the per-frame terms of this pixel, observation included: one 32-byte entry, one memory round trip
     typedef double doublex2 __attribute__((ext_vector_type(2)));
     const doublex2* a4 = reinterpret_cast<const doublex2*>(P.aux + (size_t)AUX_PLANES * gi);
     const doublex2 a01 = a4[0], a23 = a4[1];
-    const double inv_s2s = a01.x, kk = a01.y, cv = a23.x, eo = a23.y;
-    // p_bg = tw/D + (1-tw) lam e, and the stored e_o is exactly half of the second term (a
-    // power-of-two scaling commutes with every rounding): the same double, hence the same float,
-    // as frame_aux_pixel's pbg -- without a fifth load
-    const float pbg = (float)(P.tw / kMaxDepth + 2.0 * eo);
+    // what depends on the rendered depth alone runs while that entry travels
+    const rbsm::PixelConsts C = {P.lambda, P.tw / kMaxDepth, P.cv0};
+    const double rd = (double)r;
+    const double g = rbsm::depth_term(C, rd);
     __builtin_amdgcn_sched_barrier(0);
 #ifdef RBS_EXP_SKIP_EVAL     // profiling builds: the loads, none of the transcendental work
     posterior = prior;
-    return inv_s2s + kk + cv + eo + (double)pbg + (double)r + (double)o;
+    return a01.x + a01.y + a23.x + a23.y + g;
 #endif
-    const double w = ((double)r - (double)o) * inv_s2s;
-    const double twD = P.tw / kMaxDepth;
-#if defined(RBS_EXP_NOERF)      // profiling builds: what each transcendental costs (finite stand-ins)
-#define RBS_ERF_(x) (fabs(x) * 1e-3)
-#else
-#define RBS_ERF_(x) erf(x)
-#endif
-#if defined(RBS_EXP_NOEXP)
-#define RBS_EXP_(x) (2.0 + fabs(x))
-#else
-#define RBS_EXP_(x) exp(x)
-#endif
-    const double pv = twD + cv * RBS_EXP_(-(w * w));
-    const double E1 = RBS_EXP_((double)r * P.lambda);
-    const double po = twD + eo * (E1 / (E1 - 1.0)) * (1.0 + RBS_ERF_(w + kk));
-    const float a = (float)(pv * (1.0 - (double)prior));
-    const float b = (float)(po * (double)prior);
-    const float sum = a + b;
-    posterior = b / sum;
-#if defined(RBS_EXP_NOLOG)
-    return (double)(sum / pbg);
-#else
-    return log((double)(sum / pbg));
-#endif
+    return rbsm::pixel_loglik_f64(C, g, a01.x, a01.y, a23.x, a23.y, rd, prior, M.erfc, M.logt, posterior);
 }
 
 // Likelihood precision F32 (rbs_config.likelihood_precision = RBS_PRECISION_F32): the same model
@@ -914,6 +904,7 @@ __device__ inline double block_reduce_sum(double v, double* red)
 // ------------------------------------------------------------------ raster work item
 struct Smem {
     unsigned* tile; int* big; double* red; int* nbig; int* item; int* evalq;
+    double* mtab;   // precision F64: the erfc and log tables of rbs_math.h (kMathTabDoubles doubles)
 };
 __device__ inline Smem carve(unsigned char* smem, int kTilePx)
 {
@@ -924,6 +915,7 @@ __device__ inline Smem carve(unsigned char* smem, int kTilePx)
     m.nbig = reinterpret_cast<int*>(m.red + kBlock / 64);
     m.item = m.nbig + 1;
     m.evalq = m.nbig + 4;   // per wave: kQPlanes planes of kEvalQueue ints
+    m.mtab = reinterpret_cast<double*>(m.evalq + kQPlanes * (kBlock / 64) * kEvalQueue);   // (16-byte aligned: everything before it is)
     return m;
 }
 
@@ -966,6 +958,8 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     double ll = 0.0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int* q = m.evalq + wave * kQPlanes * kEvalQueue;   // planes: pixel index, depth bits, prior, observation
+    const MathTabs mt = RBS_MATH_LDS ? MathTabs{m.mtab, m.mtab + rbsm::kErfcIntervals * rbsm::kErfcCoefs}
+                                     : MathTabs{rbsm::kErfcTab, rbsm::kLogTab};
     int qh = 0, qn = 0;                                // ring: head, count (wave-uniform)
     // evaluate the 64 (or, at the end, `cnt_`) oldest queued pixels
 #define RBS_EVAL_BATCH(cnt_)                                                                            \
@@ -976,7 +970,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
             const float ed_ = __int_as_float(q[kEvalQueue + at_]), ep_ = __int_as_float(q[2 * kEvalQueue + at_]); \
             float post_;                                                                                \
             if (PREC) ll += pixel_loglik_f32(P, ed_, ep_, __int_as_float(q[3 * kEvalQueue + at_]), post_); \
-            else ll += pixel_loglik(P, eg_, ed_, ep_, post_);                                           \
+            else ll += pixel_loglik(P, mt, eg_, ed_, ep_, post_);                                       \
             /* plane 0 holds the child-plane offset in precision F32 (which needs no frame index), */   \
             /* plane 3 in F64 */                                                                        \
             if (UPDATE) dst[(PREC || !SLAB) ? eg_ : q[3 * kEvalQueue + at_]] = post_;                   \
@@ -1361,6 +1355,11 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
     const Smem m = carve(smem, P.tile_px);
     const int total = P.ctr_this[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr_next[0] = 0; P.ctr_next[1] = 0; }
+    if (PREC == 0 && RBS_MATH_LDS) {   // once per persistent block (the first item's tile clear ends in a barrier)
+        constexpr int ne = rbsm::kErfcIntervals * rbsm::kErfcCoefs, nl = rbsm::kLogIntervals * 2;
+        for (int i = threadIdx.x; i < ne; i += kBlock) m.mtab[i] = rbsm::kErfcTab[i];
+        for (int i = threadIdx.x; i < nl; i += kBlock) m.mtab[ne + i] = rbsm::kLogTab[i];
+    }
 #ifdef RBS_PHASE_TIMING
     const unsigned long long c0_ = clock64(), w0_ = wall_clock64();
     if (threadIdx.x < 16) g_phase_lds[threadIdx.x] = 0;
@@ -1751,9 +1750,11 @@ __global__ void rbs_fill_kernel(float* __restrict__ p, size_t n, float v)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
-constexpr size_t smem_bytes(int tile_px)
+constexpr size_t smem_bytes(int tile_px, bool math_tables)
 {
     return sizeof(unsigned) * (size_t)tile_px + sizeof(int) * kBigCap + sizeof(double) * (kBlock / 64) + 16 +
-           sizeof(int) * kQPlanes * (kBlock / 64) * kEvalQueue;
+           sizeof(int) * kQPlanes * (kBlock / 64) * kEvalQueue + (math_tables ? sizeof(double) * kMathTabDoubles : 0);
 }
+static_assert(smem_bytes(kTilePxF64, true) <= smem_bytes(kTilePx, false) && smem_bytes(kTilePxBigF64, true) <= smem_bytes(kTilePxBig, false),
+              "the F64 kernel's LDS block must not be larger than the F32 kernel's: the same number of blocks per CU");
 }  // namespace rbs

@@ -312,6 +312,27 @@ void orc_set_observation(orc_sensor* s, const double* depth)
 
 /* ---------------------------------------------------------------- the hot function */
 
+/* One covered, observed pixel: the term log((a + b) / p_bg) it adds to the particle's
+ * log-likelihood and its posterior occlusion b / (a + b).  Rounding points: a = p_vis (1 - occ),
+ * b = p_occ occ and p_bg -> float ("float temporaries upstream"); a + b and both ratios in float;
+ * log in double. */
+double orc_pixel_term(const orc_sensor* s, float o, float r, float occ, float* posterior)
+{
+    const float a = (float)(orc_prob_visible(s, (double)o, (double)r) * (1.0 - (double)occ));
+    const float b = (float)(orc_prob_occluded(s, (double)o, (double)r) * (double)occ);
+    const float pbg = (float)orc_prob_occluded(s, (double)o, INFINITY);
+    const float sum = a + b;
+    *posterior = b / sum;
+    return log((double)(sum / pbg));
+}
+
+/* The same for n pixels (tests: the device's own exp / erfc / log against libm's, pixel by pixel). */
+void orc_pixel_terms(const orc_sensor* s, const float* o, const float* r, const float* occ, int64_t n,
+                     double* term, float* posterior)
+{
+    for (int64_t i = 0; i < n; ++i) term[i] = orc_pixel_term(s, o[i], r[i], occ[i], &posterior[i]);
+}
+
 /* One particle of orc_loglikes; depth/covered are per-thread scratch (depth all +inf on entry
  * and on exit). */
 static double loglik_one(orc_sensor* s, const double* pose, int32_t parent, int32_t child,
@@ -352,15 +373,12 @@ static double loglik_one(orc_sensor* s, const double* pose, int32_t parent, int3
         } else {
             occ = orc_eager_prior(alpha, beta, pocc[p], bg_now);
         }
-        const float a = (float)(orc_prob_visible(s, (double)o, (double)r) * (1.0 - (double)occ));
-        const float b = (float)(orc_prob_occluded(s, (double)o, (double)r) * (double)occ);
-        const float pbg = (float)orc_prob_occluded(s, (double)o, INFINITY);
-        const float sum = a + b;
-        const double term = log((double)(sum / pbg));
+        float post;
+        const double term = orc_pixel_term(s, o, r, occ, &post);
         ll += term;
         abs_ll += fabs(term);
         if (update) {
-            cocc[p] = b / sum;
+            cocc[p] = post;
             if (lazy) cstamp[p] = s->clock;
         }
     }

@@ -101,6 +101,10 @@ double orc_prob_occluded(const orc_sensor* s, double obs, double rendered); /* r
 double orc_propagate(const orc_sensor* s, double occ, double dt);
 void orc_eager_coeffs(const orc_sensor* s, int32_t n_frames, float* alpha, float* beta);
 float orc_eager_prior(float alpha, float beta, float occ, float bg_now);
+/* One covered, observed pixel: its log-likelihood term and posterior occlusion. */
+double orc_pixel_term(const orc_sensor* s, float obs, float rendered, float occ, float* posterior);
+void orc_pixel_terms(const orc_sensor* s, const float* obs, const float* rendered, const float* occ, int64_t n,
+                     double* term, float* posterior);
 float orc_background(const orc_sensor* s);  /* EAGER: never-covered level at the last updating call */
 /* Per particle of the last orc_loglikes* call: the sum of the MAGNITUDES of the per-pixel log
  * terms its log-likelihood adds up -- the conditioning of that sum, against which a float32

@@ -62,6 +62,7 @@ def load():
         for f in (lib.orc_prob_visible, lib.orc_prob_occluded, lib.orc_propagate):
             f.restype = C.c_double
             f.argtypes = [H, C.c_double, C.c_double]
+        lib.orc_pixel_terms.argtypes = [H, fp, fp, fp, C.c_int64, dp, fp]
         lib.orc_eager_coeffs.argtypes = [H, C.c_int32, fp, fp]
         lib.orc_background.restype = C.c_float
         lib.orc_background.argtypes = [H]
@@ -170,6 +171,17 @@ class Oracle:
 
     def prob_occluded(self, o, r):
         return self._lib.orc_prob_occluded(self._h, float(o), float(r))
+
+    def pixel_terms(self, obs, rendered, occ):
+        """Per pixel: the term log((a+b)/p_bg) and the posterior occlusion (orc_pixel_term)."""
+        fp = C.POINTER(C.c_float)
+        o = np.ascontiguousarray(obs, dtype=np.float32)
+        r = np.ascontiguousarray(rendered, dtype=np.float32)
+        c = np.ascontiguousarray(occ, dtype=np.float32)
+        term, post = np.empty(o.size), np.empty(o.size, dtype=np.float32)
+        self._lib.orc_pixel_terms(self._h, o.ctypes.data_as(fp), r.ctypes.data_as(fp), c.ctypes.data_as(fp), o.size,
+                                  term.ctypes.data_as(C.POINTER(C.c_double)), post.ctypes.data_as(fp))
+        return term, post
 
     def propagate(self, occ, dt):
         return self._lib.orc_propagate(self._h, float(occ), float(dt))
