@@ -90,9 +90,8 @@ constexpr int kCopyUnroll = RBS_COPY_UNROLL; // float4 loads in flight per lane 
 constexpr int kQPlanes_ = 4;
 constexpr int kEvalQueue = 128;             // per-wave ring of covered pixels awaiting evaluation (a power of two)
 constexpr int kTq = kQPlanes_ * kEvalQueue;  // the same LDS during the raster phase: a per-wave ring of triangle indices
-// Three raster waves of 160 registers leave a SIMD the 32 that one copy wave needs (F32 precision;
-// the binary64 likelihood does not fit and runs before/after the copy kernel): the budget is
-// stated to the compiler, which otherwise only aims at "three waves" = 168.
+// Three raster waves of 160 registers leave a SIMD the 32 that one copy wave needs (both
+// precisions): the budget is stated to the compiler, which otherwise only aims at "three waves" = 168.
 #ifndef RBS_RASTER_VGPRS
 #define RBS_RASTER_VGPRS 80   // (the attribute counts architectural registers and the compiler doubles it on gfx90a+: 160 in all)
 #endif
@@ -1459,8 +1458,19 @@ void rbs_raster_kernel_f32(const DevParams P)
 {
     raster_kernel_body<UPDATE, 1, SLAB>(P);
 }
+// The same budget for the binary64 likelihood: on rbs_math.h's functions it fits 160 registers
+// without scratch, so the windowed copy kernel runs beside it as well (C1 9.27 -> 9.72 M/s, C2 3.24
+// -> 3.45; ocml's exp / erf / log needed 168 + 72 spilled).  RBS_RASTER_VGPRS_F64=0: no budget.
+#ifndef RBS_RASTER_VGPRS_F64
+#define RBS_RASTER_VGPRS_F64 80
+#endif
+#if RBS_RASTER_VGPRS_F64
+#define RBS_F64_BUDGET __attribute__((amdgpu_num_vgpr(RBS_RASTER_VGPRS_F64)))
+#else
+#define RBS_F64_BUDGET
+#endif
 template <bool UPDATE, bool SLAB>
-__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) void rbs_raster_kernel_f64(const DevParams P)
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_kernel_f64(const DevParams P)
 {
     raster_kernel_body<UPDATE, 0, SLAB>(P);
 }

@@ -137,5 +137,7 @@ def test_register_budgets_the_kernels_overlap_depends_on():
     for name in ("rbs_copy_window_kernelILb0E", "rbs_copy_window_kernelILb1E"):
         vgprs, spills = usage(name)
         assert vgprs <= 32 and spills == 0, (name, vgprs, spills)
-    vgprs, _ = usage("rbs_raster_kernel_f64ILb1ELb0EE")   # precision F64: three waves per SIMD
-    assert vgprs <= 168
+    for name in ("rbs_raster_kernel_f64ILb1ELb0EE", "rbs_raster_kernel_f64ILb0ELb0EE", "rbs_raster_kernel_f64ILb1ELb1EE",
+                 "rbs_raster_kernel_f64ILb0ELb1EE"):
+        vgprs, spills = usage(name)        # precision F64 (the default): the same budget, and NO scratch at all
+        assert vgprs <= 160 and spills == 0, (name, vgprs, spills)
