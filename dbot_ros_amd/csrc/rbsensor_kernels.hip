@@ -63,6 +63,15 @@ namespace rbs {
 #ifndef RBS_BIG_THRESH
 #define RBS_BIG_THRESH 96
 #endif
+// float32 filter of the coverage test in the per-lane sample loops (tri_filter): bit-exact by
+// construction and green on every depth test, but MEASURED SLOWER on C1 (raster kernel F32 0.146 ->
+// 0.154 ms, F64 0.184 -> 0.187): the loop's instruction count barely moves (36 -> 29 per sample, +25
+// per triangle for the filter's coefficients), and its binary64 edge functions were filling the
+// bubbles of the division's dependent chain for free.  Two samples per trip (two divisions in
+// flight) measured no better either (0.146 -> 0.149).  Off by default; kept as the documented experiment.
+#ifndef RBS_EDGE_FILTER
+#define RBS_EDGE_FILTER 0
+#endif
 
 #ifndef RBS_BLOCK
 #define RBS_BLOCK 256
@@ -391,7 +400,40 @@ struct Tri {
     double e01u, e01v, e12u, e12v, e20u, e20v;
     double pa, pb, pc, nv0;
     int xlo, xhi, ylo, yhi;
+    // float32 FILTER of the three edge functions over the bounding box (tri_filter): sample (i, j)
+    // of the box has E_k ~ fB[k] i + fA[k] j + fC[k] with |error| < thr
+    float fA[3], fB[3], fC[3], thr;
 };
+
+// The coverage rule is a sign test on three binary64 edge functions, 21 binary64 instructions per
+// sample -- and a binary64 instruction holds the VALU 1.65x as long as a float32 one on this chip
+// (profiles/r03_valu_issue_microbench.txt).  An exact floating-point FILTER decides almost every
+// sample in float32 instead: the edge functions are evaluated in box-local coordinates (vertex
+// minus the box's corner, rounded to float: magnitudes of a few pixels, not hundreds) with a
+// rigorous bound `thr` on their distance from the oracle's binary64 values; all three clearly
+// positive or all clearly negative -> covered, one clearly positive and one clearly negative ->
+// not covered, anything else (a sample within `thr` of an edge: about one in 1e4, or a non-finite
+// intermediate) -> the oracle's own binary64 expression decides (tri_inside_exact).  Coverage is
+// therefore bit-exact by construction.
+// Bound: with L = max(box width, box height) + 1 every local coordinate, edge component and sample
+// offset is <= 2L in magnitude; the local vertices carry a relative rounding u = 2^-24, the edges
+// 2 more, each product and sum one more: |E_float - E_exact| <= 32 u L^2 (generous), and the
+// oracle's binary64 value is within 1e-13 L^2 of E_exact.  thr = 64 u L^2.
+__device__ inline void tri_filter(Tri& T, double xlo_d, double ylo_d)
+{
+    const float lu0 = (float)(T.u0 - xlo_d), lv0 = (float)(T.v0 - ylo_d);
+    const float lu1 = (float)(T.u1 - xlo_d), lv1 = (float)(T.v1 - ylo_d);
+    const float lu2 = (float)(T.u2 - xlo_d), lv2 = (float)(T.v2 - ylo_d);
+    // E_k(i, j) = eu_k (j - lv_k) - ev_k (i - lu_k)
+    const float eu0 = lu1 - lu0, ev0 = lv1 - lv0;
+    const float eu1 = lu2 - lu1, ev1 = lv2 - lv1;
+    const float eu2 = lu0 - lu2, ev2 = lv0 - lv2;
+    T.fA[0] = eu0; T.fB[0] = -ev0; T.fC[0] = fmaf(ev0, lu0, -(eu0 * lv0));
+    T.fA[1] = eu1; T.fB[1] = -ev1; T.fC[1] = fmaf(ev1, lu1, -(eu1 * lv1));
+    T.fA[2] = eu2; T.fB[2] = -ev2; T.fC[2] = fmaf(ev2, lu2, -(eu2 * lv2));
+    const float L = (float)(max(T.xhi - T.xlo, T.yhi - T.ylo) + 2);
+    T.thr = (64.0f * 0x1p-24f) * L * L;
+}
 
 // Same operations, same order as oracle/rbsensor_oracle.c raster_triangle().  The clip window
 // [wx0,wx1) x [wy0,wy1) is a sub-rectangle of the image, so clipping to it instead of to the
@@ -452,12 +494,15 @@ __device__ inline bool tri_setup(const DevParams& P, int t, const double* __rest
     T.pb = div_f64(ny, P.fy);
     T.pc = (nz - T.pa * P.cx) - T.pb * P.cy;
     T.xlo = (int)xlo_d; T.xhi = (int)xhi_d; T.ylo = (int)ylo_d; T.yhi = (int)yhi_d;
+#if RBS_EDGE_FILTER
+    tri_filter(T, xlo_d, ylo_d);
+#endif
     return true;
 }
 
-// Coverage test + depth for one integer pixel (px, py: its coordinates as doubles); z-min into the
-// LDS tile at `at`.
-__device__ inline void tri_sample(const Tri& T, double px, double py, unsigned* at)
+// The oracle's coverage rule on one integer sample point (px, py as doubles): all three edge
+// functions >= 0 or all three <= 0.
+__device__ inline bool tri_inside_exact(const Tri& T, double px, double py)
 {
     const double E0 = T.e01u * (py - T.v0) - T.e01v * (px - T.u0);
     const double E1 = T.e12u * (py - T.v1) - T.e12v * (px - T.u1);
@@ -467,10 +512,23 @@ __device__ inline void tri_sample(const Tri& T, double px, double py, unsigned* 
     mx = fmax(mx, E2);
     // all three >= 0 or all three <= 0, as min / max (E is finite: the setup rejected anything else):
     // four instructions and one branch instead of two compare chains with a branch between them.
+    return ((int)(mn >= 0.0) | (int)(mx <= 0.0)) != 0;
+}
+// Depth of a covered sample; z-min into the LDS tile at `at`.
+__device__ inline void tri_depth(const Tri& T, double px, double py, unsigned* at)
+{
+    const double den = (T.pa * px + T.pb * py) + T.pc;
+    const float zf = (float)div_f64(T.nv0, den);
+    // a depth must be a positive finite float (zf > 0 && zf < inf): one class test, +denormal | +normal
+    if (__builtin_amdgcn_classf(zf, 0x180)) atomicMin(at, __float_as_uint(zf));
+}
+// Coverage test + depth for one integer pixel (px, py: its coordinates as doubles); z-min into the
+// LDS tile at `at`.
+__device__ inline void tri_sample(const Tri& T, double px, double py, unsigned* at)
+{
     // With three waves per SIMD a branch in this loop costs the wave more than the instructions it
     // guards: 3 % of the kernel.
-    const bool in = ((int)(mn >= 0.0) | (int)(mx <= 0.0)) != 0;
-    if (!in) return;
+    if (!tri_inside_exact(T, px, py)) return;
     const double den = (T.pa * px + T.pb * py) + T.pc;
     const float zf = (float)div_f64(T.nv0, den);
     // a depth must be a positive finite float (zf > 0 && zf < inf): one class test, +denormal | +normal
@@ -586,9 +644,35 @@ __device__ inline void raster_lane_triangle(const DevParams& P, int t, const dou
         if (slot < kBigCap) { big[slot] = t; return; }
     }
     // (one flat loop over the box's samples instead of rows x columns: fewer trips, 3 % slower)
+#if RBS_EDGE_FILTER
+    const float thr = T.thr, nthr = -T.thr;
+    float fj = 0.0f;
+    for (int row = T.ylo; row <= T.yhi; ++row, fj += 1.0f) {
+        const float r0 = fmaf(T.fA[0], fj, T.fC[0]), r1 = fmaf(T.fA[1], fj, T.fC[1]), r2 = fmaf(T.fA[2], fj, T.fC[2]);
+        unsigned* trow = tile + (row - wy0) * tw - wx0;
+        float fi = 0.0f;
+        for (int col = T.xlo; col <= T.xhi; ++col, fi += 1.0f) {
+            const float e0 = fmaf(T.fB[0], fi, r0), e1 = fmaf(T.fB[1], fi, r1), e2 = fmaf(T.fB[2], fi, r2);
+            const float mn = __builtin_fminf(__builtin_fminf(e0, e1), e2), mx = __builtin_fmaxf(__builtin_fmaxf(e0, e1), e2);
+            bool in = mn > thr || mx < nthr;                          // clearly inside (either winding)
+            const bool out = mn < nthr && mx > thr;                   // clearly outside
+            if (__builtin_expect(__ballot(!in && !out) != 0, 0)) {    // within thr of an edge (or not finite): the oracle's expression
+                if (!in && !out) {
+                    // (opaque to the optimiser: the row-invariant half of the binary64 expression must not be
+                    // hoisted into the row loop -- it is needed about once in 1e4 samples)
+                    double px = (double)col, py = (double)row;
+                    asm volatile("" : "+v"(px), "+v"(py));
+                    in = tri_inside_exact(T, px, py);
+                }
+            }
+            if (in) tri_depth(T, (double)col, (double)row, trow + col);
+        }
+    }
+#else
     for (int row = T.ylo; row <= T.yhi; ++row)
         for (int col = T.xlo; col <= T.xhi; ++col)
             tri_pixel(T, col, row, tile, tw, wx0, wy0);
+#endif
 }
 // (phase-timing builds: the time between a lane leaving its sample loop and the next tick is the
 // wave's sample phase -- lane 0 may leave early, so the caller ticks after reconvergence)
