@@ -15,7 +15,8 @@ in HBM before the timed region, device-pointer API.  The same JSON line carries,
                   (SURVEY 8d's definition of the metric)
   tracker_fps_*   frames/s of the full per-frame step (frame upload + transition + loglikes +
                   weights + KL + resampling + mean) at 200 / 2 000 / 20 000 particles
-  f64_*           the same resident steps with likelihood precision F64
+  f32_*           the same resident steps with the opt-in float32 likelihood (the headline is F64,
+                  the library default and the reference CPU model's arithmetic)
   roofline        dominant kernel of the headline run (windowed planes: the raster kernel, bound by
                   VALU issue): achieved = VALU wave-instructions/s from a LIVE rocprofv3 PMC pass
                   of this very command (child process) / live HIP-event kernel time; frac <= 1;
@@ -54,7 +55,15 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # 1 024 SIMDs x one wave64 VALU instruction per 4 cycles x 2.4 GHz = 614.4 G/s
+# VALU issue ceilings of this chip, MEASURED (tools/valu_bench.hip, profiles/r03_valu_issue_microbench.txt:
+# chip-wide G wave64-instructions/s with 3 waves per SIMD, the raster kernel's occupancy): a binary64
+# add / mul / fma issues at 0.62x the rate of a float32 / integer instruction, a binary64 transcendental
+# (v_rcp_f64: every division) at 0.19x.  Round 2 priced every instruction at 614.4 G/s (4 cycles at
+# 2.4 GHz): too high for the binary64 half of this kernel, too low for the rest.
+VALU_PEAK_F32_GINST = 735.0
+VALU_PEAK_F64_GINST = 454.0
+VALU_PEAK_TRANS_F64_GINST = 142.0
+REPEATS = 5                   # the headline is the median of this many timed regions of --steps steps each
 WORKLOAD_FLAGS = ("particles", "cols", "rows", "mesh", "parents", "update", "sequence", "precision", "layout", "slab_px")
 
 
@@ -78,18 +87,22 @@ def parse():
                          "the windowed layout's worst case")
     ap.add_argument("--fill-fraction", type=float, default=1.0,
                     help="with --fill-planes: only a central rectangle of this fraction of the frame")
-    ap.add_argument("--precision", default="f32", choices=["f64", "f32"], help="likelihood precision of the headline run")
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"],
+                    help="likelihood precision of the headline run (f64 = the library default, the reference CPU model's arithmetic)")
     ap.add_argument("--layout", default="window", choices=["window", "dense"], help="occlusion state layout of the headline run")
     ap.add_argument("--slab-px", type=int, default=0, help="floats per occlusion slot (rbs_config.state_slab_px; 0 = whole planes)")
     ap.add_argument("--quick", action="store_true", help="headline only: no dense / f64 / host / tracker / cpu / pmc legs")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the whole-plane (state_layout=dense) comparison run")
-    ap.add_argument("--no-f64-leg", action="store_true")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the opt-in float32-likelihood comparison run")
     ap.add_argument("--no-host-leg", action="store_true")
     ap.add_argument("--no-tracker-fps", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="no live rocprofv3 counter passes (roofline falls back to profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--device-ids", default=None, help="in-process multi-device mode: comma-separated HIP ordinals (default 0..N-1)")
+    ap.add_argument("--in-process", action="store_true",
+                    help="ONE process, one handle over --gpus devices through the host-pointer API (the default for --gpus > 1 "
+                         "without torch.distributed.run; with --gpus 1 the same steps on a plain handle, for comparison)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the process rocprofv3 wraps
     a = ap.parse_args()
     presets = {"c1": {}, "c1_readonly": {"update": 0},
@@ -100,7 +113,7 @@ def parse():
     for k, v in presets.get(a.config, {}).items():
         setattr(a, k, v)
     if a.quick or a.config not in (None, "c1"):
-        a.no_dense_leg = a.no_f64_leg = a.no_host_leg = a.no_tracker_fps = a.no_cpu_baseline = True
+        a.no_dense_leg = a.no_f32_leg = a.no_host_leg = a.no_tracker_fps = a.no_cpu_baseline = True
         a.no_pmc = a.no_pmc or a.quick
     return a
 
@@ -274,6 +287,66 @@ def hbm_bytes(fetch, write, kernel):
     return fetch[kernel].get("FETCH_SIZE", 0.0) * 1024.0 * 2.0 + write[kernel].get("WRITE_SIZE", 0.0) * 1024.0
 
 
+def roofline_for(a, n, raster_ms, copy_ms, alg_bytes, copy_dominant, live):
+    """The `roofline` object of the dominant kernel of one device's launch of n particles: live
+    rocprofv3 counter passes of this same command (child processes), the committed summary as a
+    fall-back.  Windowed planes: the raster kernel, bound by VALU issue -- priced against the
+    MEASURED issue ceiling of its own instruction mix (binary64 / binary64 transcendental / other:
+    VALU_PEAK_* above), with the busy fraction of the SIMDs and the instruction count per unit of
+    work beside it, so that neither padding nor a cheaper mix can pass for progress.  Whole planes:
+    the copy kernel, bound by HBM."""
+    sq = mix = fetch = write = None
+    if live:
+        sq = pmc_pass(a, ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "SQ_WAVES"], a.layout)
+        mix = pmc_pass(a, ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64"], a.layout)
+        fetch = pmc_pass(a, ["FETCH_SIZE"], a.layout)
+        write = pmc_pass(a, ["WRITE_SIZE"], a.layout)
+    pmc_live = sq is not None and "rbs_raster_kernel" in sq
+    if not pmc_live:               # a box without counters: the committed summary of this command
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", "r03_raster_sq.json")))
+            if j.get("precision") == a.precision and j.get("state_layout") == a.layout:
+                sq = {"rbs_raster_kernel": j["per_dispatch"]}
+                mix = sq
+        except Exception:           # noqa: BLE001
+            sq = None
+    rsq = (sq or {}).get("rbs_raster_kernel", {})
+    rmix = (mix or {}).get("rbs_raster_kernel", {})
+    valu = rsq.get("SQ_INSTS_VALU")
+    raster_traffic = hbm_bytes(fetch, write, "rbs_raster_kernel")
+    copy_kernel = "rbs_copy_window_kernel" if a.layout == "window" else "rbs_copy_rows_kernel"
+    copy_traffic = hbm_bytes(fetch, write, copy_kernel)
+    if copy_dominant:
+        achieved = alg_bytes / (copy_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": copy_traffic, "kernel": copy_kernel, "kernel_ms": copy_ms}
+    else:
+        ginst = (valu / (raster_ms * 1e-3) / 1e9) if valu else None
+        peak = frac = f64_share = None
+        if valu and "SQ_INSTS_VALU_FMA_F64" in rmix:
+            n64 = rmix["SQ_INSTS_VALU_FMA_F64"] + rmix.get("SQ_INSTS_VALU_MUL_F64", 0.0) + rmix.get("SQ_INSTS_VALU_ADD_F64", 0.0)
+            ntr = rmix.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+            rest = max(0.0, valu - n64 - ntr)
+            t_min = (n64 / VALU_PEAK_F64_GINST + ntr / VALU_PEAK_TRANS_F64_GINST + rest / VALU_PEAK_F32_GINST) / 1e9   # s: nothing but issue
+            peak = valu / t_min / 1e9
+            frac = ginst / peak
+            f64_share = (n64 + ntr) / valu
+        roof = {"bound": "valu_issue", "achieved": ginst, "peak": peak, "unit": "G wave-instructions/s", "frac": frac,
+                "peak_note": "issue ceiling of THIS kernel's instruction mix from measured per-class rates (binary64 454, binary64 "
+                             "transcendental 142, other 735 G wave-instructions/s: profiles/r03_valu_issue_microbench.txt)",
+                "traffic": raster_traffic, "kernel": "rbs_raster_kernel", "kernel_ms": raster_ms,
+                "f64_share_of_valu_instructions": f64_share,
+                "valu_wave_instructions_per_launch": valu,
+                "valu_instr_per_particle_likelihood": (valu / n) if valu else None,
+                "valu_busy_frac": (rsq["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (raster_ms * 1e-3 * 2.4e9)) if rsq.get("SQ_ACTIVE_INST_VALU") else None,
+                "valu_busy_note": "SQ_ACTIVE_INST_VALU quad-cycles x 4 / (1 024 SIMDs x kernel time x 2.4 GHz): share of SIMD time with a VALU instruction in flight",
+                "wave_time_waiting_frac": (rsq["SQ_WAIT_ANY"] / rsq["SQ_WAVE_CYCLES"]) if rsq.get("SQ_WAVE_CYCLES") else None,
+                "hbm_actual_GBps": (raster_traffic / (raster_ms * 1e-3) / 1e9) if raster_traffic else None,
+                "hbm_actual_frac": (raster_traffic / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if raster_traffic else None,
+                "algorithmic_equiv_GBps": alg_bytes / (raster_ms * 1e-3) / 1e9}
+    return roof, pmc_live, copy_traffic
+
+
 # --------------------------------------------------------------------------------- CPU baseline
 def usable_cores():
     """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota
@@ -422,7 +495,7 @@ def native_host_leg(a, om, cam, P, W, steps):
 
 
 # --------------------------------------------------------------------------------- tracker FPS
-def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30):
+def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30, precision=None):
     """Frames/s of the device tracker (rbs_tracker_*: transition, weights, KL, resampling and mean
     on the GPU, device RNG, one host sync per frame; the frame is uploaded from host memory every
     frame) on the 30-frame sequence.  Second half of BASELINE.json's metric."""
@@ -433,7 +506,7 @@ def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30):
     frames = None
     for n in counts:
         P = RbSensorBuilder.Parameters(sample_count=n)
-        with RbSensor(om, cam, P, device_id=device.index, max_particles=max(1, n // nb)) as s:
+        with RbSensor(om, cam, P, device_id=device.index, max_particles=max(1, n // nb), precision=precision) as s:
             if frames is None:
                 rng = np.random.default_rng(0)
                 frames = [synth.make_frame(s.render_depth(synth.truth_pose(nb, frame=k)), cam.rows, cam.cols, rng,
@@ -491,7 +564,8 @@ def in_process_multi_device(a):
     rng = np.random.default_rng(5)
     poses = np.stack([synth.particle_poses(t, n, rng).reshape(n, -1) for t in W.truths])
     parents = synth.resample_like_indices(n, rng)
-    with RbSensor(om, cam, P, max_particles=n, precision=a.precision, state_layout=a.layout, device_ids=ids) as g:
+    with RbSensor(om, cam, P, max_particles=n, precision=a.precision, state_layout=a.layout,
+                  device_ids=ids if a.gpus > 1 else None, device_id=ids[0]) as g:
         g.reset()
 
         def step(i):
@@ -501,12 +575,23 @@ def in_process_multi_device(a):
 
         for i in range(a.warmup):
             step(i)
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            ll = step(i)
-        elapsed = time.perf_counter() - t0
+        regions = []
+        for rep in range(REPEATS):
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                ll = step(i)
+            regions.append(time.perf_counter() - t0)
+        elapsed = float(np.median(regions))
         if not np.isfinite(ll).all():
             raise SystemExit("non-finite log-likelihoods in the timed run")
+        # the dominant kernel on the handle's first device (every device runs the same launch on its shard)
+        g.set_timing_every(2)
+        for i in range(64):
+            step(i)
+        g.synchronize()
+        call_ms, copy_ms, n_used = g.timing_summary(64)
+        raster_ms = g.raster_kernel_ms(64)
+        g.set_timing_every(8)
         # the sharded device tracker on the same handle
         trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=nb)).build()
         tr = DeviceParticleTracker(trans, g, om, ParticleTrackerBuilder.Parameters(evaluation_count=n * nb), device_rng=True, seed=1)
@@ -523,24 +608,34 @@ def in_process_multi_device(a):
             tr.track(W.frames[k % len(W.frames)])
         fps = nf / (time.perf_counter() - t0)
         tr.close()
-    print(json.dumps({
+    alg_bytes = (2.0 if a.update else 1.0) * 4.0 * a.rows * a.cols * a.particles     # per device launch, SURVEY 8d
+    copy_dominant = bool(a.update) and copy_ms > raster_ms
+    roof, pmc_live, copy_traffic = roofline_for(a, a.particles, raster_ms, copy_ms, alg_bytes, copy_dominant, not a.no_pmc and not a.quick)
+    roof.update({"counters_live": bool(pmc_live), "counters_note": "instruction counts from a single-device pass of the same per-device launch",
+                 "kernel_launches_averaged": n_used, "raster_kernel_ms": raster_ms, "copy_kernel_ms": copy_ms,
+                 "call_ms_launch_stream": call_ms, "per_device": True, "algorithmic_bytes_per_launch": alg_bytes})
+    line = {
         "metric": "particle-likelihoods/sec @640x480" if (a.cols, a.rows) == (640, 480) else f"particle-likelihoods/sec @{a.cols}x{a.rows}",
         "value": n * a.steps / elapsed, "unit": "particle-likelihoods/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 geometry + f32 likelihood (precision F32)" if a.precision == "f32" else "f64", "data": "synthetic",
+        "ms_per_step": elapsed / a.steps * 1e3, "timed_regions": REPEATS, "timed_regions_ms_per_step": [e / a.steps * 1e3 for e in regions],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 geometry + f32 likelihood (precision F32, opt-in)" if a.precision == "f32" else "f64", "data": "synthetic",
         "config": {"workload": f"C1 x {a.gpus}: ONE process, one handle over devices {ids} (rbs_config.n_devices), {a.particles} particles per "
                                f"device, host-pointer API (frame + poses uploaded, log-likelihoods downloaded every step), "
                                f"{a.cols}x{a.rows}, mesh {a.mesh} ({n_tri} triangles), precision {a.precision}",
                    "particles_per_gpu": a.particles, "resolution": [a.cols, a.rows], "triangles": int(n_tri),
                    "sharding": f"particles/{a.gpus} inside the handle: peer reads of remote parents, RCCL all-gather in the tracker"},
-        "tracker_fps_sharded": fps, "tracker_particles": n,
-    }), flush=True)
+        "tracker_fps_sharded": fps, "tracker_particles": n, "roofline": roof,
+    }
+    if a.gpus == 1 and not a.no_cpu_baseline and not a.quick:
+        line["cpu_baseline"] = cpu_baseline(om, cam, P, W.truths[0], W.frames[0], a.cpu_seconds)
+    print(json.dumps(line), flush=True)
 
 
 # --------------------------------------------------------------------------------- main
 def main():
     a = parse()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.pmc_child:
+    if (a.gpus > 1 or a.in_process) and "WORLD_SIZE" not in os.environ and not a.pmc_child:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
         return in_process_multi_device(a)
@@ -599,12 +694,20 @@ def main():
             dist.all_gather(host, d_out.cpu())
             d_all.copy_(torch.cat(host))
 
-    elapsed = run.timed(a.steps, a.warmup, after=exchange if world > 1 else None,
-                        barrier=dist.barrier if world > 1 else None)
+    # REPEATS timed regions of exactly --steps steps each (every one bracketed by barrier +
+    # synchronize on both sides, the MAX over ranks taken per region); the headline is the MEDIAN
+    # region -- a 20-step region is 4 ms, and one region alone moved by 7 % between runs
+    regions = []
+    for rep in range(REPEATS):
+        el = run.timed(a.steps, a.warmup if rep == 0 else 0, after=exchange if world > 1 else None,
+                       barrier=dist.barrier if world > 1 else None)
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        regions.append(el)
+    elapsed = float(np.median(regions))
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         # every rank must hold every rank's log-likelihoods after the exchange
         ref = d_all.view(world, n)[rank].cpu().numpy()
         if not np.array_equal(ref, d_out.cpu().numpy()):
@@ -632,8 +735,9 @@ def main():
         "unit": "particle-likelihoods/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3,
+        "timed_regions": REPEATS, "timed_regions_ms_per_step": [e / a.steps * 1e3 for e in regions],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 geometry + f32 likelihood (precision F32)" if a.precision == "f32" else "f64",
+        "dtype": "f64 geometry + f32 likelihood (precision F32, opt-in)" if a.precision == "f32" else "f64",
         "data": "synthetic",
         "config": {"workload": f"C1: {n} particles/GPU x loglikes(update={'true' if a.update else 'false'}), {a.cols}x{a.rows} "
                                f"synthetic depth frame, mesh {a.mesh} ({n_tri} triangles), "
@@ -644,43 +748,10 @@ def main():
                    "sharding": f"particles/{world}" + (" + RCCL all-gather of log-likelihoods" if world > 1 else "")},
     }
     single = world == 1
-    # ---- live counter passes of this same command (child processes under rocprofv3)
-    sq = fetch = write = None
-    if single and not a.no_pmc:
-        sq = pmc_pass(a, ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "SQ_WAVES"], a.layout)
-        fetch = pmc_pass(a, ["FETCH_SIZE"], a.layout)
-        write = pmc_pass(a, ["WRITE_SIZE"], a.layout)
-    pmc_live = sq is not None and "rbs_raster_kernel" in sq
-    if not pmc_live:               # a box without counters: the committed summary of this command
-        try:
-            j = json.load(open(os.path.join(ROOT, "profiles", "r02_raster_sq.json")))
-            if j.get("precision") == a.precision and j.get("state_layout") == a.layout:
-                sq = {"rbs_raster_kernel": j["per_dispatch"]}
-        except Exception:           # noqa: BLE001
-            sq = None
-    rsq = (sq or {}).get("rbs_raster_kernel", {})
-    valu = rsq.get("SQ_INSTS_VALU")
-    raster_traffic = hbm_bytes(fetch, write, "rbs_raster_kernel")
-    copy_kernel = "rbs_copy_window_kernel" if a.layout == "window" else "rbs_copy_rows_kernel"
-    copy_traffic = hbm_bytes(fetch, write, copy_kernel)
-    if copy_dominant:
-        achieved = alg_bytes / (copy_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": copy_traffic, "kernel": copy_kernel, "kernel_ms": copy_ms}
-    else:
-        # windowed planes: the raster kernel is dominant and bound by VALU issue (every wave64 VALU
-        # instruction, float32 or binary64, holds a SIMD's issue port ~4 cycles: measured 4.1-4.2)
-        ginst = (valu / (raster_ms * 1e-3) / 1e9) if valu else None
-        roof = {"bound": "valu_issue", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                "frac": (ginst / VALU_PEAK_GINST) if ginst else None,
-                "traffic": raster_traffic, "kernel": "rbs_raster_kernel", "kernel_ms": raster_ms,
-                "valu_wave_instructions_per_launch": valu,
-                "valu_wave_instructions_per_particle": (valu / n) if valu else None,
-                "valu_busy_frac_of_simd_time": (rsq["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (raster_ms * 1e-3 * 2.4e9)) if rsq.get("SQ_ACTIVE_INST_VALU") else None,
-                "wave_time_waiting_frac": (rsq["SQ_WAIT_ANY"] / rsq["SQ_WAVE_CYCLES"]) if rsq.get("SQ_WAVE_CYCLES") else None,
-                "hbm_actual_GBps": (raster_traffic / (raster_ms * 1e-3) / 1e9) if raster_traffic else None,
-                "hbm_actual_frac": (raster_traffic / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if raster_traffic else None,
-                "algorithmic_equiv_GBps": alg_bytes / (raster_ms * 1e-3) / 1e9}
+    # (several ranks: rank 0's device; live counter passes only on request -- the other ranks would
+    # wait minutes at the next collective -- otherwise the committed counters of the same launch)
+    roof, pmc_live, copy_traffic = roofline_for(a, n, raster_ms, copy_ms, alg_bytes, copy_dominant,
+                                                not a.no_pmc and (single or os.environ.get("RBS_BENCH_PMC_MULTI") == "1"))
     roof.update({"counters_live": bool(pmc_live), "kernel_launches_averaged": n_used,
                  "raster_kernel_ms": raster_ms, "copy_kernel_ms": copy_ms, "call_ms_launch_stream": call_ms,
                  "copy_kernel_hbm_bytes_per_launch": copy_traffic,
@@ -711,18 +782,22 @@ def main():
                                 "dense_traffic": dtraffic,
                                 "dense_traffic_over_algorithmic": (dtraffic / alg_bytes) if dtraffic else None,
                                 "dense_kernel_launches_averaged": d_used, "dense_raster_kernel_ms": d_raster_ms})
-    # ---- likelihood precision F64, same steps
-    if single and a.precision == "f32" and not a.no_f64_leg:
-        s64 = make_sensor(a, om, cam, P, dev, precision="f64")
-        prime(s64, a, W)
-        r64 = ResidentRun(a, W, s64, stream, d_out)
+    # ---- the other likelihood precision, same steps (F32 is opt-in: float32-level agreement only)
+    other = "f32" if a.precision == "f64" else "f64"
+    if single and not a.no_f32_leg:
+        so = make_sensor(a, om, cam, P, dev, precision=other)
+        prime(so, a, W)
+        ro = ResidentRun(a, W, so, stream, d_out)
         s_ = 300
-        t64 = r64.timed(s_, a.warmup)
-        k64 = r64.kernel_times(400)
-        s64.close()
-        out["f64_value"] = n * s_ / t64
-        out["f64_ms_per_step"] = t64 / s_ * 1e3
-        out["f64_raster_kernel_ms"] = k64[0]
+        to = ro.timed(s_, a.warmup)
+        ko = ro.kernel_times(400)
+        so.close()
+        out[f"{other}_value"] = n * s_ / to
+        out[f"{other}_ms_per_step"] = to / s_ * 1e3
+        out[f"{other}_raster_kernel_ms"] = ko[0]
+        if other == "f32":
+            out["f32_note"] = ("opt-in rbs_config.likelihood_precision = F32: float32 likelihood over binary64 geometry; within 1e-5 of the "
+                               "reference semantics only for well-conditioned sums, parent indices not reproduced at large particle counts")
     # ---- host-pointer API: frame upload + pose upload + log-likelihood download inside the clock
     if single and not a.no_host_leg:
         hs = make_sensor(a, om, cam, P, dev)
@@ -775,13 +850,23 @@ def main():
             out.update(nat)
     # ---- tracker FPS, the second half of the metric
     if single and not a.no_tracker_fps:
-        fps = tracker_fps(om, cam, dev)
+        fps = tracker_fps(om, cam, dev, precision=a.precision)
+        # BASELINE config C2 as a tracker: 20 000 evaluations per frame = 6 666 particles x 3 sampling
+        # blocks (meshes M1, M2, M3), two read-only blocks and one updating block per frame
+        from dbot_ros_amd import ObjectModel, synth
+        meshes = [synth.mesh_m1(), synth.mesh_m2(), synth.mesh_m3()]
+        om_c2 = ObjectModel([v for v, _ in meshes], [t for _, t in meshes], center=True)
+        c2 = tracker_fps(om_c2, cam, dev, counts=(20000,), precision=a.precision)[20000]
+        out["tracker_fps_c2"] = c2["fps"]
+        out["tracker_fps_pipelined_c2"] = c2["fps_pipelined"]
+        out["tracker_c2_note"] = ("C2: 6 666 particles x 3 bodies (M1, M2, M3) = 20 000 particle-likelihoods per frame, 640x480; "
+                                  f"{c2['resamplings']} resamplings, final position error {c2['final_position_error_m']:.4f} m")
         for k, v in fps.items():
             out[f"tracker_fps_{k}"] = v["fps"]
             out[f"tracker_fps_pipelined_{k}"] = v["fps_pipelined"]
             out[f"tracker_ms_per_frame_{k}"] = v["ms_per_frame"]
         out["tracker_fps_note"] = ("device tracker (rbs_tracker_*), one object (M1), 640x480, 30-frame sequence, frame uploaded "
-                                   "from host memory every frame, precision F32; resamplings " +
+                                   "from host memory every frame, precision " + a.precision.upper() + "; resamplings " +
                                    "/".join(str(v["resamplings"]) for v in fps.values()))
     if single and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(om, cam, P, W.truths[0], W.frames[0], a.cpu_seconds)

@@ -93,7 +93,7 @@ if os.path.exists(sq_path):
         k = k[0]
         g = lambda c: sq.get((k, c), 0.0)
         # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves
-        summary = {"precision": os.environ.get("RBS_PROFILE_PRECISION", "f32"), "state_layout": layout, "kernel": k, "workload": "bench.py default step (raster kernel of loglikes(update=true), 2000 particles)",
+        summary = {"precision": os.environ.get("RBS_PROFILE_PRECISION", "f64"), "state_layout": layout, "kernel": k, "workload": "bench.py default step (raster kernel of loglikes(update=true), 2000 particles)",
                    "per_dispatch": {c: g(c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
                                                       "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
                                                       "SQ_BUSY_CYCLES", "SQ_INSTS_SALU")},
@@ -102,6 +102,16 @@ if os.path.exists(sq_path):
                    "fraction_of_wave_time_issuing_valu": g("SQ_ACTIVE_INST_VALU") / max(g("SQ_WAVE_CYCLES"), 1.0),
                    "fraction_waiting": g("SQ_WAIT_ANY") / max(g("SQ_WAVE_CYCLES"), 1.0),
                    "fraction_issue_stalled": g("SQ_WAIT_INST_ANY") / max(g("SQ_WAVE_CYCLES"), 1.0)}
+        # the instruction mix (its own --pmc pass): what bench.py prices the kernel's issue ceiling with
+        mix_path = os.path.join(src, "mix", "mix_counter_collection.csv")
+        if os.path.exists(mix_path):
+            mx, _ = per_dispatch(mix_path)
+            km = [kk for (kk, c) in mx if "rbs_raster_kernel" in kk]
+            if km:
+                for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64"):
+                    summary["per_dispatch"][c] = mx.get((km[0], c), 0.0)
+                n64 = sum(summary["per_dispatch"][c] for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64"))
+                summary["f64_share_of_valu_instructions"] = n64 / max(g("SQ_INSTS_VALU"), 1.0)
         json.dump(summary, open(os.path.join(dst, f"{tag}_raster_sq.json"), "w"), indent=1)
         print(json.dumps(summary, indent=1))
 print(json.dumps(out, indent=1)[:1500])
