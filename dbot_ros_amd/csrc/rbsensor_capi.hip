@@ -44,7 +44,9 @@ struct rbs_handle {
     double p_ov = 0, p_oo = 0, init_occ = 0, delta_time = 0;
     double* d_soup = nullptr;
     float* d_frame = nullptr;
-    double* d_aux = nullptr;    // per-frame-pixel model terms, [4][npx]
+    double* d_aux = nullptr;    // per-frame-pixel model terms, [npx][4] (precision F64), of a frame ingested from device memory
+    double* d_aux_slot[2] = {nullptr, nullptr};   // ... of the host frame uploaded into d_fin[k] (computed on the upload stream)
+    const double* cur_aux = nullptr;              // what the kernels read: d_aux, or d_aux_slot[cur_slot]
     float* d_pbg = nullptr;
     float* d_occ[2] = {nullptr, nullptr};
     int cur = 0;
@@ -129,7 +131,8 @@ struct rbs_handle {
     float* d_fin[2] = {nullptr, nullptr};
     hipEvent_t ev_used[2] = {nullptr, nullptr};    // the ingest kernel that read d_fin[k] has run
     int lazy_slot = -1;                            // d_fin slot the pending (lazy) frame sits in
-    // Precision F32 keeps no per-pixel terms, so a host frame needs no ingest at all: the staging
+    // A host frame needs no ingest on the launch stream (precision F64: its per-pixel terms are
+    // computed behind the copy on the upload stream, into d_aux_slot[k]): the staging
     // image d_fin[k] IS the observation until the next frame replaces it, and only the raster
     // kernel (not the rectangles kernel before it) waits for the upload.
     const float* cur_frame = nullptr;              // what the kernels read: d_frame, or d_fin[cur_slot]
@@ -316,7 +319,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.win_dst = h->d_win[1 - h->cur];
     P.win_used = h->d_win_used;
     P.frame = h->cur_frame;
-    P.aux = h->d_aux;
+    P.aux = h->cur_aux;
     P.pbg = h->d_pbg;
     P.occ_src = h->d_occ[h->cur];
     P.occ_dst = h->d_occ[1 - h->cur];
@@ -644,6 +647,8 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_soup);
     (void)hipFree(h->d_frame);
     (void)hipFree(h->d_aux);
+    (void)hipFree(h->d_aux_slot[0]);
+    (void)hipFree(h->d_aux_slot[1]);
     (void)hipFree(h->d_pbg);
     (void)hipFree(h->d_occ[0]);
     (void)hipFree(h->d_occ[1]);
@@ -717,6 +722,7 @@ int32_t release_frame_slot(rbs_handle* h)
         h->cur_slot = -1;
     }
     h->cur_frame = h->d_frame;
+    h->cur_aux = h->d_aux;
     h->frame_wait = -1;
     return RBS_OK;
 }
@@ -735,10 +741,23 @@ int32_t upload_frame(rbs_handle* h, const float* src)
         if (int32_t rc = release_frame_slot(h)) return rc;
     RBS_HIP(h, hipStreamWaitEvent(h->up_stream, h->ev_used[k], 0));   // d_fin[k]: read by the ingest kernel two frames ago
     RBS_HIP(h, hipMemcpyAsync(h->d_fin[k], src, n * sizeof(float), hipMemcpyHostToDevice, h->up_stream));
+    if (h->d_aux && !h->frame_ingest) {
+        // precision F64: the frame's per-pixel model terms are computed right behind the copy, on the
+        // upload stream, into the slot's own table -- the launch stream does not wait for the frame
+        // until the raster kernel needs it, so a caller's transition and the rectangles kernel run
+        // while the frame is still travelling (a tracker frame: 35 us of 400)
+        hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->up_stream,
+                           h->d_fin[k], h->d_aux_slot[k], h->d_pbg, h->npx, h->base.tw, h->base.ms, h->base.sf,
+                           h->base.lambda, (float*)nullptr);
+        RBS_HIP(h, hipGetLastError());
+    }
     RBS_HIP(h, hipEventRecord(h->ev_frame[k], h->up_stream));
     if (int32_t rc = release_frame_slot(h)) return rc;
-    if (!h->d_aux && !h->frame_ingest) {   // (callers have flushed any pending frame)
+    if (!h->frame_ingest) {   // (callers have flushed any pending frame)
+        // the staging image IS the observation (and, F64, its slot's table the model terms) until the
+        // next frame replaces it
         h->cur_frame = h->d_fin[k];
+        h->cur_aux = h->d_aux ? h->d_aux_slot[k] : nullptr;
         h->cur_slot = k;
         h->frame_wait = k;
         return RBS_OK;
@@ -1103,6 +1122,9 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     h->cur_frame = h->d_frame;
     if (h->precision == RBS_PRECISION_F64) {   // F32 derives the per-pixel terms from the observation on the fly
         RBS_HIP(h, hipMalloc(&h->d_aux, sizeof(double) * rbs::AUX_PLANES * (size_t)h->npx));
+        RBS_HIP(h, hipMalloc(&h->d_aux_slot[0], sizeof(double) * rbs::AUX_PLANES * (size_t)h->npx));
+        RBS_HIP(h, hipMalloc(&h->d_aux_slot[1], sizeof(double) * rbs::AUX_PLANES * (size_t)h->npx));
+        h->cur_aux = h->d_aux;
         RBS_HIP(h, hipMalloc(&h->d_pbg, plane));
     }
     RBS_HIP(h, hipMalloc(&h->d_render, plane));
@@ -2489,8 +2511,7 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
     rbt::TrackerDev& T = t->T;
     rbs_handle* h = t->s;
     RBT_HIP(t, hipSetDevice(h->device));
-    if (frame)
-        if (int32_t rc = rbs_set_observation_f32(h, frame, (size_t)h->npx)) return rc;
+    if (frame && h->npx <= 0) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_submit: bad sensor");
     hipStream_t s = h->stream;
     const size_t n = (size_t)T.n;
     T.normals = nullptr;
@@ -2512,6 +2533,8 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
     const dim3 g256((unsigned)((T.n + 255) / 256)), b256(256);
     const char* nf = std::getenv("RBS_TRACKER_FUSED");
     const bool fused = T.n <= rbt::kFusedFilterMax && !(nf && std::atoi(nf) == 0);
+    static const bool tail_on = [] { const char* e = std::getenv("RBS_TRACKER_TAIL"); return !(e && std::atoi(e) == 0); }();
+    const bool tail = !fused && tail_on && T.n < rbt::kMultiBlockFrom;   // (RBS_TRACKER_TAIL=0: the three separate launches, A/B)
     for (int b = 0; b < T.parts; ++b) {
         const bool last = b == T.parts - 1;
         // (the transition fused into the sensor's rectangles kernel -- one launch less -- measured no
@@ -2519,9 +2542,21 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
         hipLaunchKernelGGL(rbt::propagate_kernel, g256, b256, 0, s, T, b, b == 0 && t->recentre_pending ? 1 : 0);
         if (b == 0) t->recentre_pending = false;
         RBT_HIP(t, hipGetLastError());
+        // the frame is handed over AFTER the first transition launch: the transition (and the
+        // sensor's rectangles kernel behind it) do not depend on it, and run while the host copies
+        // the frame into pinned memory and the copy engine uploads it
+        if (b == 0 && frame)
+            if (int32_t rc = rbs_set_observation_f32(h, frame, (size_t)h->npx)) return rc;
         if (int32_t rc = enqueue_loglikes(h, T.poses, T.idx, T.n, last, T.ll_new, s)) return rc;
         if (fused) {
             hipLaunchKernelGGL(rbt::filter_step_kernel, dim3(1), dim3(1024), 0, s, T, b, last ? 1 : 0, last ? 1 : 0);
+        } else if (tail && last) {
+            // the estimate first (one launch, the result event right behind it), the gather after
+            hipLaunchKernelGGL(rbt::filter_tail_kernel, dim3(1), dim3(1024), 0, s, T, b, 1);
+            RBT_HIP(t, hipGetLastError());
+            if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(t->h_serr[slot], h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+            RBT_HIP(t, hipEventRecord(t->ev_res[slot], s));
+            hipLaunchKernelGGL(rbt::gather_kernel, dim3((unsigned)T.n), dim3(64), 0, s, T);
         } else {
             launch_weights(T, last ? 1 : 0, s);
             hipLaunchKernelGGL(rbt::resample_gather_kernel, dim3((unsigned)T.n), dim3(64), 0, s, T, b);
@@ -2536,7 +2571,7 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
     if (!fused) {
         // (re-centring inside the single mean block was tried: its two rounds of rotations per thread
         // on one CU take longer than the separate launch, 25 us against 16.5 + 5)
-        launch_mean(T, s);
+        if (!tail) launch_mean(T, s);
         // the re-centring itself rides in the next frame's first transition launch (the thread that
         // moves particle i re-centres it first); rbs_tracker_get applies it on demand
         static const bool now = [] { const char* e = std::getenv("RBS_TRACKER_RECENTRE_NOW"); return e && std::atoi(e) != 0; }();
@@ -2547,8 +2582,10 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
     std::swap(T.part_old, T.part_new);   // this frame's particles are the next frame's old ones
     // (the estimate and the flags were stored into h_state[slot] / h_flags[slot] by the kernel that
     // finished them: no copies behind the last kernel)
-    if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(t->h_serr[slot], h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
-    RBT_HIP(t, hipEventRecord(t->ev_res[slot], s));
+    if (!tail) {
+        if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(t->h_serr[slot], h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+        RBT_HIP(t, hipEventRecord(t->ev_res[slot], s));
+    }
     T.frame += 1;
     t->res_rc[slot] = RBS_OK;
     t->submitted += 1;

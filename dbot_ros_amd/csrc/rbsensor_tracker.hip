@@ -525,8 +525,10 @@ __global__ __launch_bounds__(64) void resample_gather_kernel(const TrackerDev T,
 
 // ------------------------------------------------------------------ tracker: mean + re-centring
 // Single block: mean = sum_i softmax(log_w)_i * particle_i; fold it into the default pose.
+// via != nullptr: particle i is part_new[via[i]] -- the mean of the RESAMPLED particles straight from
+// the parents' rows, before (instead of after) the gather: the same values in the same order.
 __device__ inline void mean_body(const TrackerDev& T, const double* __restrict__ part_new, double* sh,
-                                 double (*shb)[kBody])
+                                 double (*shb)[kBody], const int* __restrict__ via = nullptr)
 {
     const int n = T.n;
     // After a resampling every log-weight is 0 (gather_one): max 0, exp(0) = 1, their sum n -- the
@@ -550,7 +552,7 @@ __device__ inline void mean_body(const TrackerDev& T, const double* __restrict__
         for (int k = 0; k < kBody; ++k) a[k] = 0.0;
         for (int i = threadIdx.x; i < n; i += 1024) {
             const double w = (uniform ? 1.0 : exp(T.logw[i] - m)) / S;
-            const double* p = part_new + (size_t)i * T.D + b * kBody;
+            const double* p = part_new + (size_t)(via ? via[i] : i) * T.D + b * kBody;
 #pragma unroll
             for (int k = 0; k < kBody; ++k) a[k] += w * p[k];
         }
@@ -612,6 +614,26 @@ __global__ void recentre_kernel(const TrackerDev T, double* __restrict__ particl
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < T.n) recentre_one(T, particles, i);
+}
+
+// The LAST sampling block's filter step up to the frame's estimate in ONE single-block launch:
+// weights + KL test, resampling (parents only), the weighted mean of the resampled particles read
+// through their parents' rows, the new default pose, and the result stored into the caller's
+// pinned slot.  The gather -- which the estimate does not need -- follows as its own launch, behind
+// the event the host waits for: the host wakes up and stages the next frame while it runs.  Same
+// operations in the same order as weights_kernel / resample_gather_kernel / mean_kernel (three
+// launches, 32 us at 2 000 particles; this one 20).
+__global__ __launch_bounds__(1024) void filter_tail_kernel(const TrackerDev T, int b, int updated)
+{
+    __shared__ double sh[1024];
+    __shared__ double shb[16][kBody];
+    weights_body(T, updated, sh);
+    __threadfence_block();
+    __syncthreads();
+    for (int j = threadIdx.x; j < T.n; j += 1024) resample_one(T, b, j);
+    __threadfence_block();
+    __syncthreads();
+    mean_body(T, T.part_new, sh, shb, T.parents);
 }
 
 // Few particles: the whole filter step after the sensor call -- weights and KL test, resampling,
