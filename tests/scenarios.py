@@ -8,6 +8,23 @@ MESHES = {"m1": synth.mesh_m1, "m2": synth.mesh_m2, "m3": synth.mesh_m3, "m4": s
           "box12": synth.mesh_box12, "m1_l2": lambda: synth.mesh_m1(level=2)}
 
 
+def usable_threads():
+    """CPUs this process may use: the affinity mask capped by the cgroup quota (the GPU boxes report
+    256 hardware threads and grant 16 CPUs: a team sized by os.cpu_count() is throttled)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def make_scene(mesh_names=("m1",), cols=640, rows=480, max_particles=16, z=0.7):
     vs, fs = zip(*[MESHES[m]() for m in mesh_names])
     om = ObjectModel(list(vs), list(fs), center=True)

@@ -1,10 +1,12 @@
 """BASELINE.json configurations at their FULL sizes, and adversarial geometry, on the GPU.
 
-The oracle cannot follow at these sizes, so each full-size case checks (i) the first particles
-against the oracle (same poses, same frame), (ii) determinism (two runs bitwise equal) and
-(iii) permutation equivariance (permuting the particles permutes the log-likelihoods) over ALL
-particles -- size-independent properties that hold only if no particle depends on its position
-in the call.  Precision F64 is held to the module bars of test_gpu_parity.py, F32 to those of
+Each full-size case checks (i) particles against the threaded oracle (same poses, same frame) --
+EVERY particle of C1 and C2, a RANDOM subset where the population is larger (C3, C4: the oracle
+does ~24 k particle-likelihoods/s on a GPU box's 16 CPUs) --, (ii) determinism (two runs bitwise
+equal) and (iii) permutation equivariance (permuting the particles permutes the
+log-likelihoods) over ALL particles -- size-independent properties that hold only if no particle
+depends on its position in the call.  C3 and C4 also run at their REAL sizes (200 000 / 50 000
+particles) on one GPU, as one handle over eight shards with window-sized slabs.  Precision F64 is held to the module bars of test_gpu_parity.py, F32 to those of
 test_gpu_f32.py.
 """
 import numpy as np
@@ -31,15 +33,43 @@ def _check_against_oracle(ll, ref, S, precision):
         assert (d <= 1e-6 * np.maximum(1.0, S)).all(), (d / np.maximum(1.0, S)).max()
 
 
-def _full_size_case(meshes, cols, rows, n, k_oracle, precision, blocks_readonly=0):
+def _oracle_for_subset(om, cam, P, frame, poses, sel, blocks_readonly, chunk, threads):
+    """The device's two-frame run restricted to the particles `sel`, on the CPU oracle: frame 1
+    (every particle inherits slot 0: blocks_readonly read-only calls, then the updating one), frame
+    2 (particle i inherits its own slot i).  Slots are private to a particle in this run, so any
+    subset is a population of its own: chunks of <= `chunk` slots, OpenMP over the particles."""
+    refs, sums = None, None
+    for lo in range(0, len(sel), chunk):
+        part = sel[lo:lo + chunk]
+        k = len(part)
+        orc = ob.Oracle(om, cam, P, max_particles=k, mode=ob.EAGER)
+        orc.reset(threads=threads)
+        orc.set_observation(frame)
+        io = np.zeros(k, np.int32)
+        r = [orc.loglikes_poses(poses[part], io.copy(), update=False, threads=threads) for _ in range(blocks_readonly)]
+        r.append(orc.loglikes_poses(poses[part], io, update=True, threads=threads))
+        S = [orc.last_abs_sums(k)]
+        orc.set_observation(frame)
+        r.append(orc.loglikes_poses(poses[part], np.arange(k, dtype=np.int32), update=True, threads=threads))
+        S.append(orc.last_abs_sums(k))
+        orc.close()
+        refs = r if refs is None else [np.concatenate([a, b]) for a, b in zip(refs, r)]
+        sums = S if sums is None else [np.concatenate([a, b]) for a, b in zip(sums, S)]
+    return refs, sums
+
+
+def _full_size_case(meshes, cols, rows, n, k_oracle, precision, blocks_readonly=0, chunk=1000, **sensor_kw):
+    """k_oracle particles -- ALL of them when k_oracle >= n, a RANDOM subset otherwise -- against the
+    oracle; determinism and permutation equivariance over all n."""
     nb = len(meshes)
     om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
-    eager = ob.Oracle(om, cam, P, max_particles=k_oracle, mode=ob.EAGER)
+    render = ob.Oracle(om, cam, P, max_particles=1, mode=ob.EAGER)
     rng = np.random.default_rng(21)
     truth = synth.truth_pose(nb)
-    frame = synth.make_frame(eager.render_depth(truth), rows, cols, rng)
+    frame = synth.make_frame(render.render_depth(truth), rows, cols, rng)
+    render.close()
     poses = synth.particle_poses(truth, n, rng, scale=2.0)
-    with RbSensor(om, cam, P, max_particles=n, precision=precision) as g:
+    with RbSensor(om, cam, P, max_particles=n, precision=precision, **sensor_kw) as g:
         def run(p):
             g.reset()
             g.set_observation(frame)
@@ -57,36 +87,53 @@ def _full_size_case(meshes, cols, rows, n, k_oracle, precision, blocks_readonly=
         c = run(poses[perm])
         for x, y in zip(a, c):
             assert np.array_equal(x[perm], y)                             # permutation equivariance
-        # the first k particles against the oracle, both frames
-        eager.reset()
-        eager.set_observation(frame)
-        io = np.zeros(k_oracle, np.int32)
-        refs = [eager.loglikes_poses(poses[:k_oracle], io.copy(), update=False) for _ in range(blocks_readonly)]
-        refs.append(eager.loglikes_poses(poses[:k_oracle], io, update=True))
-        S = [eager.last_abs_sums(k_oracle)]
-        eager.set_observation(frame)
-        refs.append(eager.loglikes_poses(poses[:k_oracle], np.arange(k_oracle, dtype=np.int32), update=True))
-        S.append(eager.last_abs_sums(k_oracle))
-        for j, (x, r) in enumerate(zip(a, refs)):
-            _check_against_oracle(x[:k_oracle], r, S[min(max(j - blocks_readonly, 0), 1)], precision)
+    sel = np.arange(n) if k_oracle >= n else np.sort(rng.choice(n, size=k_oracle, replace=False))
+    refs, S = _oracle_for_subset(om, cam, P, frame, poses, sel, blocks_readonly, chunk, sc.usable_threads())
+    for j, (x, r) in enumerate(zip(a, refs)):
+        _check_against_oracle(x[sel], r, S[min(max(j - blocks_readonly, 0), 1)], precision)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_c1_full_size_every_particle(gpu_lib, precision):
+    """BASELINE C1: 2 000 particles, M1, 640x480 -- EVERY particle against the oracle."""
+    _full_size_case(("m1",), 640, 480, 2000, 2000, precision)
 
 
 @pytest.mark.parametrize("precision", ["f64", "f32"])
 def test_c2_full_size(gpu_lib, precision):
     """BASELINE C2: 20 000 evaluations = 6 666 particles x meshes [M1, M2, M3], 640x480; two
-    read-only blocks and the updating block per frame."""
-    _full_size_case(("m1", "m2", "m3"), 640, 480, 6666, 48, precision, blocks_readonly=2)
+    read-only blocks and the updating block per frame -- EVERY particle against the oracle."""
+    _full_size_case(("m1", "m2", "m3"), 640, 480, 6666, 6666, precision, blocks_readonly=2, chunk=834)
 
 
 @pytest.mark.parametrize("precision", ["f64", "f32"])
 def test_c3_slice_full_size(gpu_lib, precision):
-    """BASELINE C3's per-GPU slice: 25 000 particles (of 200 000 over 8 GPUs), M1, 640x480."""
-    _full_size_case(("m1",), 640, 480, 25000, 64, precision)
+    """BASELINE C3's per-GPU slice: 25 000 particles (of 200 000 over 8 GPUs), M1, 640x480; a random
+    1 000 against the oracle."""
+    _full_size_case(("m1",), 640, 480, 25000, 1000, precision)
 
 
-def test_c4_slice_full_size(gpu_lib):
-    """BASELINE C4's per-GPU slice: 6 250 particles (of 50 000), M4 = 50 880 triangles, 1280x960."""
-    _full_size_case(("m4",), 1280, 960, 6250, 6, "f32")
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_c4_slice_full_size(gpu_lib, precision):
+    """BASELINE C4's per-GPU slice: 6 250 particles (of 50 000), M4 = 50 880 triangles, 1280x960; a
+    random 256 against the oracle."""
+    _full_size_case(("m4",), 1280, 960, 6250, 256, precision, chunk=128)
+
+
+def test_c3_all_200000_particles_on_one_gpu_in_eight_shards(gpu_lib):
+    """BASELINE C3 at its REAL size on one GPU: 200 000 particles, M1, 640x480, one handle over eight
+    shards of 25 000 slots (device_ids = [0] * 8: the whole multi-device code path -- global
+    parents, peer reads, the fan-out) with window-sized slabs of rows*cols/8 floats (61 GB of
+    occlusion state; whole planes would be 492 GB).  A random 1 000 particles against the oracle,
+    determinism and permutation equivariance over all 200 000."""
+    _full_size_case(("m1",), 640, 480, 200000, 1000, "f64", device_ids=[0] * 8, slab_px=640 * 480 // 8)
+
+
+def test_c4_all_50000_particles_on_one_gpu_in_eight_shards(gpu_lib):
+    """BASELINE C4 at its REAL size on one GPU: 50 000 particles, M4 (50 880 triangles), 1280x960,
+    eight shards of 6 250 slots, slabs of rows*cols/8 floats (61 GB).  A random 256 particles
+    against the oracle, determinism and permutation equivariance over all 50 000."""
+    _full_size_case(("m4",), 1280, 960, 50000, 256, "f64", chunk=128, device_ids=[0] * 8, slab_px=1280 * 960 // 8)
 
 
 @pytest.mark.parametrize("precision,tol", [("f64", 1e-9), ("f32", 1e-4)])
