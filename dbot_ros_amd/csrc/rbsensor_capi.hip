@@ -1528,6 +1528,69 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
     return RBS_OK;
 }
 
+// rbs_set_observation_device on a group: `d_depth` lives on the handle's FIRST device; every shard
+// ingests it from there (its ingest kernel reads the 1.2 MB over xGMI, peer access) once the work
+// enqueued on the caller's stream so far -- whatever produced the frame -- has run.
+int32_t group_set_observation_device(rbs_handle* g, const float* d_depth, hipStream_t stream)
+{
+    rbs_handle* s0 = g->shards[0];
+    RBS_HIP(g, hipSetDevice(s0->device));
+    hipStream_t cs = stream ? stream : s0->stream;
+    RBS_HIP(g, hipEventRecord(s0->ev_reader, cs));
+    for (size_t k = 0; k < g->shards.size(); ++k) {
+        rbs_handle* h = g->shards[k];
+        if (hipSetDevice(h->device) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, fmt("hipSetDevice(%d) failed", h->device)));
+        if (int32_t rc = flush_lazy_frame(h, h->stream)) return k == 0 ? gfail(g, h, rc) : poison(g, gfail(g, h, rc));
+        if (int32_t rc = release_frame_slot(h)) return k == 0 ? gfail(g, h, rc) : poison(g, gfail(g, h, rc));
+        if (hipStreamWaitEvent(h->stream, s0->ev_reader, 0) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, "hipStreamWaitEvent failed"));
+        h->lazy_frame = d_depth;
+        h->lazy_stream = h->stream;
+        h->pending_frames += 1;
+    }
+    return RBS_OK;
+}
+
+// rbs_loglikes_device on a group: poses / parent slots / results are arrays on the handle's FIRST
+// device in global particle order; shard k evaluates particles [k cap, (k+1) cap) on its own stream
+// -- its rectangles kernel pulls its slice of the poses and parent slots over xGMI (the route the
+// host-pointer call uses for pinned memory), its raster kernel stores its log-likelihoods into the
+// caller's array in place -- after the work enqueued on the caller's stream so far, and the caller's
+// stream is ordered after every shard: d_out is complete in `stream` order, nothing synchronises
+// with the host.
+int32_t group_loglikes_device(rbs_handle* g, const double* d_poses, const int32_t* d_indices, int32_t n, int32_t update,
+                              double* d_out, hipStream_t stream)
+{
+    const int nd = (int)g->shards.size(), cap = g->shard_cap;
+    rbs_handle* s0 = g->shards[0];
+    RBS_HIP(g, hipSetDevice(s0->device));
+    hipStream_t cs = stream ? stream : s0->stream;
+    RBS_HIP(g, hipEventRecord(s0->ev_reader, cs));           // the producers of poses / indices on the caller's stream
+    for (int k = 0; k < nd; ++k) {
+        RBS_HIP(g, hipSetDevice(g->shards[k]->device));
+        RBS_HIP(g, hipStreamWaitEvent(g->shards[k]->stream, s0->ev_reader, 0));
+    }
+    // from here on a failure leaves some shards advanced and others not: the group is poisoned
+    if (int32_t rc = group_begin_call(g, nullptr)) return poison(g, rc);
+    const size_t stride = (size_t)12 * g->n_bodies;
+    for (int k = 0; k < nd; ++k) {
+        rbs_handle* h = g->shards[k];
+        const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
+        if (hipSetDevice(h->device) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, fmt("hipSetDevice(%d) failed", h->device)));
+        if (cnt <= 0) {
+            advance_empty(h, update != 0);
+            if (hipEventRecord(h->ev_done, h->stream) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, "hipEventRecord failed"));
+            continue;
+        }
+        if (int32_t rc = enqueue_loglikes(h, reinterpret_cast<const double*>(h->d_in), d_indices + lo, cnt, update != 0, d_out + lo,
+                                          h->stream, d_poses + stride * (size_t)lo))
+            return poison(g, gfail(g, h, rc));
+    }
+    if (hipSetDevice(s0->device) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, "hipSetDevice failed"));
+    for (int k = 0; k < nd; ++k)
+        if (hipStreamWaitEvent(cs, g->shards[k]->ev_done, 0) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, "hipStreamWaitEvent failed"));
+    return RBS_OK;
+}
+
 // Route a global slot to its shard.
 rbs_handle* shard_of(rbs_handle* g, int32_t slot, int32_t* local)
 {
@@ -1811,9 +1874,8 @@ int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* st
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
     RBS_REFUSE_POISONED(h);
     h->frame_acquired = false;
-    if (!h->shards.empty())
-        return fail(h, RBS_ERR_UNSUPPORTED, "set_observation_device: a handle over several devices takes host frames (or drive it through rbs_tracker_*)");
     if (!d_depth) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_observation_device: null pointer");
+    if (!h->shards.empty()) return group_set_observation_device(h, d_depth, static_cast<hipStream_t>(stream));
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     // the ingest kernel (copy into the handle's buffer + per-pixel model terms) is not launched
@@ -1873,14 +1935,13 @@ int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t*
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
     RBS_REFUSE_POISONED(h);
-    if (!h->shards.empty())
-        return fail(h, RBS_ERR_UNSUPPORTED, "loglikes_device: a handle over several devices is driven through rbs_loglikes or rbs_tracker_*");
     if (n < 0 || n > h->max_particles)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("loglikes_device: n = %d outside 0..max_particles = %d", n, h->max_particles));
     if (n == 0) return RBS_OK;
     if (!d_poses || !d_indices || !d_out_loglik)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, "loglikes_device: null pointer");
+    if (!h->shards.empty()) return group_loglikes_device(h, d_poses, d_indices, n, update, d_out_loglik, static_cast<hipStream_t>(stream));
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     return enqueue_loglikes(h, d_poses, d_indices, n, update != 0, d_out_loglik, s);

@@ -196,8 +196,13 @@ int32_t rbs_synchronize(rbs_handle* h);
  * rbs_tracker_* on such a handle runs the filter replicated on every device, shards the sensor
  * call by a parent-affine layout and exchanges the log-likelihoods with one RCCL all-gather per
  * sampling block (librccl is bound with dlopen when such a handle is created).  The zero-copy
- * single-device entry points rbs_set_observation_device / rbs_loglikes_device return
- * RBS_ERR_UNSUPPORTED; slot-addressed hooks (rbs_get/set_occlusion, rbs_get_window,
+ * entry points work on such a handle too: rbs_set_observation_device takes a frame in the memory of
+ * the FIRST device (device_ids[0]) and every device ingests it from there over xGMI;
+ * rbs_loglikes_device takes poses / parent slots / results as arrays on the first device in global
+ * particle order -- device k pulls its slice [k cap, (k+1) cap) and stores its log-likelihoods in
+ * place (peer access) -- with `stream` a stream of the first device (NULL = the library's): the
+ * devices start after the work enqueued on it so far, and it is ordered after all of them, so
+ * d_out_loglik is complete in `stream` order without a host synchronisation; slot-addressed hooks (rbs_get/set_occlusion, rbs_get_window,
  * rbs_export/import_plane, rbs_occlusion_*device_ptr) take global slots and act on the owning
  * device; rbs_render_depth, rbs_get_observation, the timing queries answer for device_ids[0].
  * An ordinal may repeat in device_ids (several shards on one GPU: functional tests). */
