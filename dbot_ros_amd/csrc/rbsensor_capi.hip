@@ -67,8 +67,9 @@ struct rbs_handle {
     int slab_px = 0;
     size_t plane_stride = 0;    // floats per slot: npx or slab_px
     int4* d_reg[2] = {nullptr, nullptr};   // [max_particles] stored region of each plane, per buffer
-    int* d_err = nullptr;       // [1] sticky device flag: a region did not fit its slab
+    int* d_err = nullptr;       // [2] device: [0] a region did not fit its slab, [1] the largest region asked for so far (px)
     int* h_err = nullptr;       // pinned copy, fetched with the log-likelihoods
+    bool slab_auto = false;     // the slab size is the library's choice (rbs_config.state_slab_px == 0 with many particles)
     int* d_bbox = nullptr;      // [4] scratch of rbs_import_plane / rbs_set_occlusion
     bool windowed = true;       // planes valid inside their window only (state_layout dense: whole plane)
     // windowed planes whose windows have grown to a large part of the frame are served like whole
@@ -612,14 +613,71 @@ int32_t slab_store(rbs_handle* h, int slot, const float* d_full, hipStream_t s)
     return RBS_OK;
 }
 
-// The sticky "a region did not fit its slab" flag, fetched by the synchronising entry points.
+int32_t drain(rbs_handle* h, bool host_sync);
+
+// "A region did not fit its slab" (h_err[0], fetched by the synchronising entry points): the message
+// of the calls that cannot repair it themselves (asynchronous calls, the device tracker).
 int32_t check_slab_error(rbs_handle* h)
 {
-    if (!h->slab_px || !*h->h_err) return RBS_OK;
+    if (!h->slab_px || !h->h_err[0]) return RBS_OK;
     return fail(h, RBS_ERR_OUT_OF_MEMORY,
                 fmt("a particle's occlusion window (with its screen rectangle) exceeded the slab of %d px "
-                    "(rbs_config.state_slab_px): its log-likelihood is NaN and its plane was reset to the "
-                    "background; create the handle with a larger slab", h->slab_px));
+                    "(rbs_config.state_slab_px) in a call that had already returned: its log-likelihood is NaN and its "
+                    "plane was reset to the background; the slabs have been enlarged for the calls that follow", h->slab_px));
+}
+
+// Every slot gets `new_slab` floats (> the current size).  A slot stores its region row-major from
+// its first float, so the planes move with one strided copy; the regions' tables stay as they are.
+// Only the CURRENT buffer holds state (the other one is written from scratch by the next updating
+// call).  The caller has drained the handle.
+int32_t grow_slabs(rbs_handle* h, int new_slab)
+{
+    new_slab = std::min(h->npx, (new_slab + 1023) & ~1023);
+    if (new_slab <= h->slab_px) return RBS_OK;
+    float* nb[2] = {nullptr, nullptr};
+    const size_t bytes = sizeof(float) * (size_t)new_slab * h->max_particles;
+    for (int k = 0; k < 2; ++k)
+        if (hipMalloc(&nb[k], bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(nb[0]);
+            return fail(h, RBS_ERR_OUT_OF_MEMORY, fmt("enlarging the occlusion slabs from %d to %d px per slot needs 2 x %zu bytes more", h->slab_px, new_slab, bytes));
+        }
+    RBS_HIP(h, hipMemcpy2DAsync(nb[h->cur], sizeof(float) * (size_t)new_slab, h->d_occ[h->cur], sizeof(float) * (size_t)h->slab_px,
+                                sizeof(float) * (size_t)h->slab_px, (size_t)h->max_particles, hipMemcpyDeviceToDevice, h->stream));
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(h->d_occ[0]);
+    (void)hipFree(h->d_occ[1]);
+    h->d_occ[0] = nb[0];
+    h->d_occ[1] = nb[1];
+    h->slab_px = new_slab;
+    h->plane_stride = (size_t)new_slab;
+    return RBS_OK;
+}
+
+// What a call must put back to be run again: an updating call only flips the buffers and moves the
+// background level on -- the planes it read are intact.
+struct CallState { int cur; int pending_frames; float background; };
+CallState save_call_state(const rbs_handle* h) { return {h->cur, h->pending_frames, h->background}; }
+void restore_call_state(rbs_handle* h, const CallState& c) { h->cur = c.cur; h->pending_frames = c.pending_frames; h->background = c.background; }
+
+// Slab size that holds a region of `need` px with room to move.
+int slab_for(const rbs_handle* h, int need) { return (int)std::min<long>(h->npx, (long)need + need / 4 + 1024); }
+
+// After a synchronising call on an idle handle: enlarge the slabs BEFORE a region fills one (the
+// regions move a few pixels per frame; three quarters full is the trigger).  Clears the flag.
+int32_t slab_housekeeping(rbs_handle* h)
+{
+    if (!h->slab_px) return RBS_OK;
+    const bool overflowed = h->h_err[0] != 0;
+    if (overflowed || (long)h->h_err[1] * 4 > (long)h->slab_px * 3) {
+        if (int32_t rc = drain(h, true)) return rc;
+        if (int32_t rc = grow_slabs(h, slab_for(h, h->h_err[1]))) return rc;
+    }
+    if (overflowed) {
+        RBS_HIP(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));   // (the flag; the maximum stays)
+        h->h_err[0] = 0;
+    }
+    return RBS_OK;
 }
 
 // Make stream `s` (and the host, if sync) see the planes of the last updating call complete.
@@ -839,7 +897,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     }
     if (cfg->state_layout < RBS_STATE_DEFAULT || cfg->state_layout > RBS_STATE_DENSE)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("state_layout %d", cfg->state_layout));
-    if (cfg->state_slab_px < 0)
+    if (cfg->state_slab_px < RBS_SLAB_WHOLE_PLANES)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("state_slab_px %d", cfg->state_slab_px));
 
     DevParams& B = h->base;
@@ -1132,14 +1190,20 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     h->slab_px = 0;
     if (h->windowed && cfg->state_slab_px > 0 && cfg->state_slab_px < h->npx)
         h->slab_px = std::max(1024, (cfg->state_slab_px + 3) & ~3);
+    else if (h->windowed && cfg->state_slab_px == 0 && h->max_particles > 8192 && (h->cols & 3) == 0 && h->npx / 8 >= 4096) {
+        // many particles, nothing asked for: an eighth of a plane per slot (8x the particles in the same
+        // memory, the same numbers); the slabs grow when a region comes close to filling one
+        h->slab_px = (h->npx / 8 + 3) & ~3;
+        h->slab_auto = true;
+    }
     if (h->slab_px >= h->npx) h->slab_px = 0;
     h->plane_stride = h->slab_px ? (size_t)h->slab_px : (size_t)h->npx;
     RBS_HIP(h, hipMalloc(&h->d_occ[0], sizeof(float) * h->plane_stride * h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_occ[1], sizeof(float) * h->plane_stride * h->max_particles));
-    RBS_HIP(h, hipMalloc(&h->d_err, sizeof(int)));
-    RBS_HIP(h, hipMemset(h->d_err, 0, sizeof(int)));
-    RBS_HIP(h, hipHostMalloc(&h->h_err, sizeof(int), hipHostMallocDefault));
-    *h->h_err = 0;
+    RBS_HIP(h, hipMalloc(&h->d_err, 2 * sizeof(int)));
+    RBS_HIP(h, hipMemset(h->d_err, 0, 2 * sizeof(int)));
+    RBS_HIP(h, hipHostMalloc(&h->h_err, 2 * sizeof(int), hipHostMallocDefault));
+    h->h_err[0] = h->h_err[1] = 0;
     RBS_HIP(h, hipMalloc(&h->d_bbox, sizeof(int) * 4));
     if (h->slab_px) {
         RBS_HIP(h, hipMalloc(&h->d_reg[0], sizeof(int4) * (size_t)h->max_particles));
@@ -1485,8 +1549,40 @@ int32_t host_call(rbs_handle* h, const double* poses, const int32_t* indices, in
                                           reinterpret_cast<const double*>(h->h_in_dev)))
             return rc;
     }
-    if (h->slab_px) RBS_HIP(h, hipMemcpyAsync(h->h_err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (h->slab_px) RBS_HIP(h, hipMemcpyAsync(h->h_err, h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     RBS_HIP(h, hipEventRecord(h->ev_out, h->stream));
+    return RBS_OK;
+}
+
+// Slabs of a group: every shard keeps the SAME slab size (a shard addresses its neighbours' planes
+// with its own stride).  before != nullptr: a call overflowed -- take it back on every shard first.
+// Otherwise housekeeping: enlarge when the largest region asked for on any shard has filled three
+// quarters of a slab.  Drains every shard when it acts.
+int32_t group_grow_slabs(rbs_handle* g, const std::vector<CallState>* before)
+{
+    rbs_handle* s0 = g->shards[0];
+    if (!s0->slab_px) return RBS_OK;
+    int need = 0;
+    bool overflowed = false;
+    for (rbs_handle* h : g->shards) { need = std::max(need, h->h_err[1]); overflowed = overflowed || h->h_err[0] != 0; }
+    if (!before && !overflowed && (long)need * 4 <= (long)s0->slab_px * 3) return RBS_OK;
+    for (size_t k = 0; k < g->shards.size(); ++k) {
+        rbs_handle* h = g->shards[k];
+        RBS_HIP(g, hipSetDevice(h->device));
+        if (int32_t rc = drain(h, true)) return gfail(g, h, rc);
+        if (before) restore_call_state(h, (*before)[k]);
+    }
+    const int target = slab_for(s0, need);
+    for (rbs_handle* h : g->shards) {
+        RBS_HIP(g, hipSetDevice(h->device));
+        if (int32_t rc = grow_slabs(h, target)) return gfail(g, h, rc);
+        if (h->h_err[0]) {
+            RBS_HIP(g, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
+            h->h_err[0] = 0;
+        }
+        RBS_HIP(g, hipStreamSynchronize(h->stream));
+        RBS_HIP(g, hipEventRecord(h->ev_done, h->stream));
+    }
     return RBS_OK;
 }
 
@@ -1499,33 +1595,43 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
     for (int32_t i = 0; i < n; ++i)
         if (indices[i] < 0 || indices[i] >= nd * cap)
             return fail(g, RBS_ERR_INVALID_ARGUMENT, fmt("loglikes: indices[%d] = %d outside 0..%d", i, indices[i], nd * cap - 1));
-    // from here on a failure leaves some shards advanced and others not: the group is poisoned
-    if (int32_t rc = group_begin_call(g, nullptr)) return poison(g, rc);
+    std::vector<CallState> before;
+    for (rbs_handle* h : g->shards) before.push_back(save_call_state(h));
     const size_t stride = (size_t)12 * g->n_bodies;
-    for (int k = 0; k < nd; ++k) {
-        rbs_handle* h = g->shards[k];
-        const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
-        if (hipSetDevice(h->device) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, fmt("hipSetDevice(%d) failed", h->device)));
-        if (cnt <= 0) {
-            advance_empty(h, update != 0);
-            if (hipEventRecord(h->ev_done, h->stream) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, "hipEventRecord failed"));
-            continue;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // from here on a failure leaves some shards advanced and others not: the group is poisoned
+        if (int32_t rc = group_begin_call(g, nullptr)) return poison(g, rc);
+        for (int k = 0; k < nd; ++k) {
+            rbs_handle* h = g->shards[k];
+            const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
+            if (hipSetDevice(h->device) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, fmt("hipSetDevice(%d) failed", h->device)));
+            if (cnt <= 0) {
+                advance_empty(h, update != 0);
+                if (hipEventRecord(h->ev_done, h->stream) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, "hipEventRecord failed"));
+                continue;
+            }
+            if (int32_t rc = host_call(h, poses + stride * (size_t)lo, indices + lo, cnt, update != 0)) return poison(g, gfail(g, h, rc));
         }
-        if (int32_t rc = host_call(h, poses + stride * (size_t)lo, indices + lo, cnt, update != 0)) return poison(g, gfail(g, h, rc));
-    }
-    for (int k = 0; k < nd; ++k) {
-        rbs_handle* h = g->shards[k];
-        const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
-        if (cnt <= 0) continue;
-        if (hipSetDevice(h->device) != hipSuccess || hipEventSynchronize(h->ev_out) != hipSuccess)
-            return poison(g, fail(g, RBS_ERR_HIP, fmt("device %d: waiting for the log-likelihoods failed", h->device)));
-        std::memcpy(out + lo, h->h_out, sizeof(double) * (size_t)cnt);
+        bool overflow = false;
+        for (int k = 0; k < nd; ++k) {
+            rbs_handle* h = g->shards[k];
+            const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
+            if (cnt <= 0) continue;
+            if (hipSetDevice(h->device) != hipSuccess || hipEventSynchronize(h->ev_out) != hipSuccess)
+                return poison(g, fail(g, RBS_ERR_HIP, fmt("device %d: waiting for the log-likelihoods failed", h->device)));
+            std::memcpy(out + lo, h->h_out, sizeof(double) * (size_t)cnt);
+            overflow = overflow || (h->slab_px && h->h_err[0]);
+        }
+        if (!overflow) break;
+        if (attempt == 1) return gfail(g, g->shards[0], check_slab_error(g->shards[0]));
+        // a region did not fit its slab on some shard: the whole call is taken back on every shard
+        // (the planes it read are intact), every shard's slabs are enlarged alike -- a shard reads
+        // its neighbours' planes with its own stride -- and the call runs again
+        if (int32_t rc = group_grow_slabs(g, &before)) return poison(g, rc);
     }
     if (update)
         for (int32_t i = 0; i < n; ++i) indices[i] = i;
-    for (rbs_handle* h : g->shards)
-        if (int32_t rc = check_slab_error(h)) return gfail(g, h, rc);
-    return RBS_OK;
+    return group_grow_slabs(g, nullptr);   // (housekeeping: enlarge before a region fills a slab)
 }
 
 // rbs_set_observation_device on a group: `d_depth` lives on the handle's FIRST device; every shard
@@ -1729,8 +1835,8 @@ int32_t rbs_reset(rbs_handle* h)
             hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(g), dim3(256), 0, h->stream, h->d_reg[b],
                                h->max_particles, make_int4(h->cols, h->rows, 0, 0));
     }
-    RBS_HIP(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
-    *h->h_err = 0;
+    RBS_HIP(h, hipMemsetAsync(h->d_err, 0, 2 * sizeof(int), h->stream));
+    h->h_err[0] = h->h_err[1] = 0;
     const size_t n = h->plane_stride * h->max_particles;
     hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(2048), dim3(256), 0, h->stream, h->d_occ[0], n,
                        (float)h->init_occ);
@@ -1922,12 +2028,24 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
     RBS_HIP(h, hipSetDevice(h->device));
     // the call waits for the log-likelihoods only -- the occlusion planes are finished by the second
     // stream and joined by the next call
+    const CallState before = save_call_state(h);
     if (int32_t rc = host_call(h, poses, indices, n, update != 0)) return rc;
     RBS_HIP(h, hipEventSynchronize(h->ev_out));
+    if (h->slab_px && h->h_err[0]) {
+        // a region did not fit its slab: the planes this call read are intact (double buffer), so the
+        // call is taken back, the slabs are enlarged to hold the largest region asked for, and the
+        // call runs again -- the caller sees the numbers of whole planes, later
+        if (int32_t rc = drain(h, true)) return rc;
+        restore_call_state(h, before);
+        if (int32_t rc = slab_housekeeping(h)) return rc;
+        if (int32_t rc = host_call(h, poses, indices, n, update != 0)) return rc;
+        RBS_HIP(h, hipEventSynchronize(h->ev_out));
+        if (h->h_err[0]) return check_slab_error(h);   // (cannot happen: a region is never larger than the frame)
+    }
     std::memcpy(out_loglik, h->h_out, sizeof(double) * (size_t)n);
     if (update)
         for (int32_t i = 0; i < n; ++i) indices[i] = i;
-    return check_slab_error(h);
+    return slab_housekeeping(h);
 }
 
 int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t* d_indices,
@@ -1950,11 +2068,27 @@ int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t*
 int32_t rbs_synchronize(rbs_handle* h)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
-    RBS_GROUP_ALL(h, rbs_synchronize(sh_));
+    if (!h->shards.empty()) {
+        int32_t first = RBS_OK;
+        for (rbs_handle* sh_ : h->shards) {
+            RBS_HIP(h, hipSetDevice(sh_->device));
+            if (int32_t rc = drain(sh_, true)) return gfail(h, sh_, rc);
+            if (sh_->slab_px) RBS_HIP(h, hipMemcpy(sh_->h_err, sh_->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost));
+            if (first == RBS_OK && check_slab_error(sh_) != RBS_OK) first = gfail(h, sh_, RBS_ERR_OUT_OF_MEMORY);
+        }
+        if (int32_t rc = group_grow_slabs(h, nullptr)) return rc;
+        return first;
+    }
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;
-    if (h->slab_px) RBS_HIP(h, hipMemcpy(h->h_err, h->d_err, sizeof(int), hipMemcpyDeviceToHost));
-    return check_slab_error(h);
+    if (h->slab_px) RBS_HIP(h, hipMemcpy(h->h_err, h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    // an asynchronous call whose region did not fit is reported here, ONCE; the slabs are enlarged
+    // either way so that the calls that follow fit
+    const int32_t rc = check_slab_error(h);
+    const std::string msg = h->err;
+    if (int32_t rc2 = slab_housekeeping(h)) return rc2;
+    if (rc) h->err = msg;
+    return rc;
 }
 
 int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out)
@@ -2320,13 +2454,13 @@ int32_t tracker_create_one(rbs_handle* sensor, const rbs_tracker_params* p, int 
             hipHostMalloc(&t->h_uniforms[k], sizeof(double) * n * T.parts, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc(&t->h_state[k], sizeof(double) * D, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc(&t->h_flags[k], sizeof(int) * 2, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(&t->h_serr[k], sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&t->h_serr[k], 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&t->ev_res[k], hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             rbs_tracker_destroy(t);
             return fail(sensor, RBS_ERR_OUT_OF_MEMORY, "tracker_create: pinned host memory");
         }
-        *t->h_serr[k] = 0;
+        t->h_serr[k][0] = t->h_serr[k][1] = 0;
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&t->h_state_dev[k]), t->h_state[k], 0) != hipSuccess ||
             hipHostGetDevicePointer(reinterpret_cast<void**>(&t->h_flags_dev[k]), t->h_flags[k], 0) != hipSuccess) {
             (void)hipGetLastError();
@@ -2521,13 +2655,17 @@ int32_t group_tracker_track(rbs_tracker* t, const float* frame, const double* no
         RBT_HIP(t, hipStreamSynchronize(streams[k]));
     }
     if (out_resamplings) *out_resamplings = flags[1];
+    int32_t slab_rc = RBS_OK;
     for (rbs_handle* sh : g->shards) {   // slabs: a region that did not fit, on any shard
         if (!sh->slab_px) break;
         RBT_HIP(t, hipSetDevice(sh->device));
-        RBT_HIP(t, hipMemcpy(sh->h_err, sh->d_err, sizeof(int), hipMemcpyDeviceToHost));
-        if (int32_t rc = check_slab_error(sh)) return gfail(g, sh, rc);
+        RBT_HIP(t, hipMemcpy(sh->h_err, sh->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost));
+        if (slab_rc == RBS_OK && check_slab_error(sh) != RBS_OK) slab_rc = gfail(g, sh, RBS_ERR_OUT_OF_MEMORY);
     }
-    return RBS_OK;
+    const std::string msg = g->err;
+    if (int32_t rc = group_grow_slabs(g, nullptr)) return rc;   // (every stream is idle here: enlarge before a region fills a slab)
+    if (slab_rc) g->err = msg;
+    return slab_rc;
 }
 }  // namespace
 
@@ -2615,7 +2753,7 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
             // the estimate first (one launch, the result event right behind it), the gather after
             hipLaunchKernelGGL(rbt::filter_tail_kernel, dim3(1), dim3(1024), 0, s, T, b, 1);
             RBT_HIP(t, hipGetLastError());
-            if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(t->h_serr[slot], h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+            if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(t->h_serr[slot], h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
             RBT_HIP(t, hipEventRecord(t->ev_res[slot], s));
             hipLaunchKernelGGL(rbt::gather_kernel, dim3((unsigned)T.n), dim3(64), 0, s, T);
         } else {
@@ -2644,7 +2782,7 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
     // (the estimate and the flags were stored into h_state[slot] / h_flags[slot] by the kernel that
     // finished them: no copies behind the last kernel)
     if (!tail) {
-        if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(t->h_serr[slot], h->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+        if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(t->h_serr[slot], h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         RBT_HIP(t, hipEventRecord(t->ev_res[slot], s));
     }
     T.frame += 1;
@@ -2669,7 +2807,21 @@ int32_t rbs_tracker_result(rbs_tracker* t, double* out_state, int32_t* out_resam
     std::memcpy(out_state, r->h_state[slot], sizeof(double) * D);
     if (out_resamplings) *out_resamplings = r->h_flags[slot][1];
     if (!t->reps.empty()) return t->res_rc[slot];
-    if (t->s->slab_px) { *t->s->h_err = *t->h_serr[slot]; return check_slab_error(t->s); }
+    if (t->s->slab_px) {
+        // the frame has run: a region that did not fit cannot be repaired here (the filter has resampled
+        // on the contained particle's NaN) and is an error -- but the slabs are enlarged BEFORE that,
+        // whenever the largest region asked for has filled three quarters of one, at a frame boundary
+        // with nothing in flight (regions move a few pixels per frame)
+        rbs_handle* h = t->s;
+        h->h_err[0] = t->h_serr[slot][0];
+        h->h_err[1] = t->h_serr[slot][1];
+        const int32_t rc = check_slab_error(h);
+        const std::string msg = h->err;
+        if (t->submitted == t->collected)
+            if (int32_t rc2 = slab_housekeeping(h)) return rc2;
+        if (rc) { h->err = msg; t->err = msg; t->poisoned = true; }
+        return rc;
+    }
     return RBS_OK;
 }
 

@@ -183,7 +183,7 @@ struct DevParams {
     int plane_stride;              // floats per slot: npx or slab_px
     const int4* reg_src;           // [slots] stored region of each parent plane
     int4* reg_dst;                 // [slots] stored region of each child plane (= win_used of this call)
-    int* err;                      // [1] sticky: 1 = a particle's region did not fit its slab
+    int* err;                      // [2] sticky: [0] 1 = a particle's region did not fit its slab, [1] the largest region asked for (px)
     const float* occ_src;          // [slots][npx]
     float* occ_dst;                // [slots][npx]
     const double* poses;           // [n][n_bodies][12]
@@ -1380,6 +1380,9 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
         if (P.slab_px) {
             // the child's slab stores exactly the region this call writes
             const long area = u.z > u.x && u.w > u.y ? (long)(u.z - u.x) * (long)(u.w - u.y) : 0;
+            // the largest region any particle has asked for (err[1]): the host grows the slabs before one
+            // overflows.  A plain read first: once the maximum has settled nobody touches the atomic.
+            if (area > (long)P.err[1]) atomicMax(P.err + 1, (int)min(area, 0x7fffffffL));
             if (area > (long)P.slab_px) {
                 // does not fit: contained like a bad parent slot (the raster and copy kernels skip the
                 // particle, its log-likelihood is NaN), its plane becomes all background, and the

@@ -138,7 +138,8 @@ class RbSensor:
         """precision: None (library default) | "f64" | "f32" (rbs_config.likelihood_precision);
         state_layout: None | "window" | "dense"; device_ids: several HIP ordinals = particle
         sharding inside the handle (max_particles is then the total); slab_px: floats per
-        occlusion slot (rbs_config.state_slab_px; 0 = whole planes)."""
+        occlusion slot (rbs_config.state_slab_px; 0 = the library's choice: whole planes up to 8 192 particles per
+        device, growing slabs of rows*cols/8 above; -1 = whole planes always)."""
         self._lib = _capi.load()
         self._h = C.c_void_p()
         self.n_bodies = object_model.count_parts

@@ -70,6 +70,8 @@ enum { RBS_PRECISION_DEFAULT = 0, RBS_PRECISION_F64 = 1, RBS_PRECISION_F32 = 2 }
 /* rbs_config.state_layout: how occlusion planes are stored ("occlusion state layout" below).
  * DEFAULT = windowed (RBS_STATE=dense in the environment overrides DEFAULT only: tooling). */
 enum { RBS_STATE_DEFAULT = 0, RBS_STATE_WINDOWED = 1, RBS_STATE_DENSE = 2 };
+/* rbs_config.state_slab_px: see the field. */
+#define RBS_SLAB_WHOLE_PLANES (-1)
 
 typedef struct rbs_handle rbs_handle;
 
@@ -104,15 +106,24 @@ typedef struct rbs_config {
      * max_particles is the TOTAL over all devices.  See "several devices" below. */
     int32_t n_devices;
     const int32_t* device_ids;
-    /* Window-sized slabs for the occlusion state (windowed layout only).  0 = every slot is a whole
-     * plane (rows*cols floats: 2 x 1.2 MB per particle at 640x480, of which a tracked object's window
-     * touches ~3 %).  > 0 = every slot holds state_slab_px floats and stores only the region an
-     * updating call writes, bbox(parent's window, the particle's screen rectangle): e.g. rows*cols/8
-     * makes room for 8x the particles.  A particle whose region does not fit is CONTAINED -- its
-     * log-likelihood is NaN, its plane becomes all background -- and the call (rbs_loglikes), or the
-     * next synchronising call after an asynchronous one, returns RBS_ERR_OUT_OF_MEMORY; the condition
-     * is sticky until rbs_reset.  Size the slab for the object's footprint plus the distance it
-     * sweeps in ~800 frames (windows shrink back as the occlusion values decay). */
+    /* Window-sized slabs for the occlusion state (windowed layout only).  A slot then holds
+     * state_slab_px floats instead of a whole plane (rows*cols floats: 2 x 1.2 MB per particle at
+     * 640x480, of which a tracked object's window touches ~3 %) and stores only the region an updating
+     * call writes, bbox(parent's window, the particle's screen rectangle).  The numbers are those of
+     * whole planes.
+     *   0   the library's choice: whole planes up to 8 192 particles (per device), slabs of
+     *       rows*cols/8 floats above (8x the particles in the same memory);
+     *   >0  slabs of that many floats;   RBS_SLAB_WHOLE_PLANES (-1)  whole planes whatever the count.
+     * Slabs GROW: at every synchronising call the library enlarges them once the largest region any
+     * particle has asked for fills three quarters of a slab, and a synchronous rbs_loglikes whose
+     * region does not fit all the same is taken back, the slabs enlarged, and run again -- the caller
+     * sees the numbers of whole planes (state memory grows towards that of whole planes in the
+     * worst case; enlarging needs the new buffers beside the old ones for a moment and fails with
+     * RBS_ERR_OUT_OF_MEMORY if they do not fit).  Only a call that has already RETURNED cannot be
+     * repaired -- rbs_loglikes_device, a frame of rbs_tracker_*: a region that outgrows its slab by
+     * more than a quarter within one such call is contained (log-likelihood NaN, plane reset to the
+     * background) and reported once, by the next synchronising call / that frame's result; the slabs
+     * have been enlarged when that call returns. */
     int32_t state_slab_px;
     int32_t reserved0;
 } rbs_config;

@@ -43,7 +43,10 @@ def test_slabs_hold_the_same_planes_as_whole_planes(gpu_lib, precision, meshes, 
             assert (np.abs(x - y) / np.maximum(1.0, np.abs(y))).max() <= 1e-9
 
 
-def test_a_region_that_does_not_fit_is_contained_and_reported(gpu_lib):
+def test_a_region_that_does_not_fit_grows_the_slabs(gpu_lib):
+    """a region that outgrows its slab in a synchronous call is not an error any
+    more -- the call is taken back, the slabs are enlarged, the call runs again: the numbers of whole
+    planes, for the particle that did not fit and for everybody else, and the handle goes on."""
     n = 8
     om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
     rng = np.random.default_rng(0)
@@ -57,25 +60,130 @@ def test_a_region_that_does_not_fit_is_contained_and_reported(gpu_lib):
         for s in (g, whole):
             s.reset()
             s.set_observation(frame)
-        ref = whole.loglikes_poses(near, np.zeros(n, np.int32), update=True)
-        idx = np.zeros(n, np.int32)
-        out = np.empty(n)
-        import ctypes as C
-        rc = g._lib.rbs_loglikes(g._h, near.reshape(n, -1).ctypes.data_as(C.POINTER(C.c_double)),
-                                 idx.ctypes.data_as(C.POINTER(C.c_int32)), n, 1, out.ctypes.data_as(C.POINTER(C.c_double)))
-        assert rc == _capi.RBS_ERR_OUT_OF_MEMORY
-        assert b"state_slab_px" in g._lib.rbs_last_error(g._h)
-        assert np.isnan(out[3]) and np.array_equal(np.delete(out, 3), np.delete(ref, 3))     # the others are untouched
-        assert g.get_window(3) == (640, 480, 0, 0)                                      # its plane: all background
-        assert np.array_equal(g.get_occlusion(2), whole.get_occlusion(2))
-        with pytest.raises(RbSensorError):                                               # sticky until reset
-            g.loglikes_poses(poses, np.arange(n, dtype=np.int32), update=False)
-        g.reset()
-        g.set_observation(frame)
-        whole.reset()
-        whole.set_observation(frame)
+        a = whole.loglikes_poses(poses, np.zeros(n, np.int32), update=True)
+        b = g.loglikes_poses(poses, np.zeros(n, np.int32), update=True)
+        assert np.array_equal(a, b)
+        for s in (g, whole):
+            s.set_observation(frame)
+        idx = rng.permutation(n).astype(np.int32)
+        ref = whole.loglikes_poses(near, idx.copy(), update=True)
+        got = g.loglikes_poses(near, idx.copy(), update=True)           # overflows, is repaired, returns
+        assert np.isfinite(got).all() and np.array_equal(got, ref)
+        for s_ in range(n):
+            assert np.array_equal(g.get_occlusion(s_), whole.get_occlusion(s_))
+        assert g.get_window(3) != (640, 480, 0, 0)                       # its plane is there, not contained
+        # ... and the handle carries on, a read-only call and further updating ones
+        for k in range(3):
+            for s in (g, whole):
+                s.set_observation(frame)
+            idx = rng.integers(0, n, n).astype(np.int32)
+            upd = k != 0
+            assert np.array_equal(g.loglikes_poses(near, idx.copy(), update=upd), whole.loglikes_poses(near, idx.copy(), update=upd))
+
+
+def test_a_region_that_does_not_fit_grows_the_slabs_of_every_shard(gpu_lib):
+    """The same on a handle over three shards: the whole fan-out is taken back, every shard's slabs
+    grow alike (a shard reads its neighbours' planes with its own stride), the call runs again."""
+    n = 9
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
+    rng = np.random.default_rng(2)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=16384, device_ids=[0, 0, 0]) as g, \
+            RbSensor(om, cam, P, max_particles=n, precision="f64") as whole:
+        truth = synth.truth_pose(1)
+        frame = synth.make_frame(whole.render_depth(truth), 480, 640, rng)
+        poses = synth.particle_poses(truth, n, rng)
+        near = poses.copy()
+        near[7, 0, 9:12] = (0.0, 0.0, 0.25)          # a particle of the LAST shard
+        for s in (g, whole):
+            s.reset()
+            s.set_observation(frame)
         assert np.array_equal(g.loglikes_poses(poses, np.zeros(n, np.int32), update=True),
                               whole.loglikes_poses(poses, np.zeros(n, np.int32), update=True))
+        for k in range(3):
+            for s in (g, whole):
+                s.set_observation(frame)
+            idx = rng.permutation(n).astype(np.int32)      # parents on other shards
+            ref = whole.loglikes_poses(near, idx.copy(), update=True)
+            got = g.loglikes_poses(near, idx.copy(), update=True)
+            assert np.isfinite(got).all() and np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+        for s_ in range(n):
+            assert np.array_equal(g.get_occlusion(s_), whole.get_occlusion(s_))
+
+
+def test_slabs_grow_ahead_of_an_approaching_object(gpu_lib):
+    """An object that comes closer frame by frame: the regions grow a little per frame, and the slabs
+    are enlarged at a synchronising call BEFORE one overflows (three quarters full) -- no call is
+    ever repeated, asynchronous callers included, and the numbers stay those of whole planes."""
+    import torch
+    n = 16
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
+    rng = np.random.default_rng(1)
+    dev = torch.device("cuda", 0)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=8192) as g, \
+            RbSensor(om, cam, P, max_particles=n, precision="f64") as whole:
+        for s in (g, whole):
+            s.reset()
+        idx = np.zeros(n, np.int32)
+        d_out = torch.empty(n, dtype=torch.float64, device=dev)
+        for k in range(40):
+            truth = synth.truth_pose(1, frame=k)
+            truth[0, 11] = 0.7 - 0.011 * k                # 0.7 m -> 0.27 m: the footprint grows ~7x
+            frame = synth.make_frame(whole.render_depth(truth), 480, 640, rng, occluder=False).astype(np.float32)
+            poses = synth.particle_poses(truth, n, rng)
+            whole.set_observation(frame)
+            ref = whole.loglikes_poses(poses, idx.copy(), update=True)
+            # the asynchronous route: device pointers, then one synchronising call per frame
+            d_frame = torch.from_numpy(frame).to(dev)
+            d_poses = torch.from_numpy(np.ascontiguousarray(poses.reshape(n, -1))).to(dev)
+            d_idx = torch.from_numpy(idx).to(dev)
+            torch.cuda.synchronize()
+            g.set_observation_device(d_frame.data_ptr(), None)
+            g.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, True, d_out.data_ptr(), None)
+            g.synchronize()                                # never reports an overflow: the slabs grew in time
+            assert np.array_equal(d_out.cpu().numpy(), ref), k
+            idx = np.sort(rng.integers(0, n, n)).astype(np.int32)
+        for s_ in (0, n - 1):
+            assert np.array_equal(g.get_occlusion(s_), whole.get_occlusion(s_))
+
+
+def test_an_overflow_in_an_asynchronous_call_is_reported_once(gpu_lib):
+    """A call that has already returned cannot be repeated: a region that outgrows its slab at once
+    (here: a particle three times closer out of the blue) is contained -- NaN, plane reset -- and the
+    next synchronising call says so, once; the slabs have grown, the calls that follow fit."""
+    import torch
+    n = 8
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
+    rng = np.random.default_rng(0)
+    dev = torch.device("cuda", 0)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=16384) as g, \
+            RbSensor(om, cam, P, max_particles=n, precision="f64") as whole:
+        truth = synth.truth_pose(1)
+        frame = synth.make_frame(g.render_depth(truth), 480, 640, rng).astype(np.float32)
+        near = synth.particle_poses(truth, n, rng)
+        near[3, 0, 9:12] = (0.0, 0.0, 0.25)
+        for s in (g, whole):
+            s.reset()
+            s.set_observation(frame)
+        ref = whole.loglikes_poses(near, np.zeros(n, np.int32), update=True)
+        d_poses = torch.from_numpy(np.ascontiguousarray(near.reshape(n, -1))).to(dev)
+        d_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_out = torch.empty(n, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        g.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, True, d_out.data_ptr(), None)
+        with pytest.raises(RbSensorError) as e:
+            g.synchronize()
+        assert e.value.code == _capi.RBS_ERR_OUT_OF_MEMORY and "state_slab_px" in str(e.value)
+        out = d_out.cpu().numpy()
+        assert np.isnan(out[3]) and np.array_equal(np.delete(out, 3), np.delete(ref, 3))     # the others are untouched
+        assert g.get_window(3) == (640, 480, 0, 0)                                      # its plane: all background
+        g.synchronize()                                                                  # reported once
+        # the same poses again now fit (particle 3 starts from the background: compare the others' planes
+        # and everybody's second-call likelihood against a whole-plane handle given the same history)
+        whole.set_occlusion(3, np.full(640 * 480, whole.get_background(), np.float32))
+        for s in (g, whole):
+            s.set_observation(frame)
+        idx = np.arange(n, dtype=np.int32)
+        assert np.array_equal(g.loglikes_poses(near, idx.copy(), update=True), whole.loglikes_poses(near, idx.copy(), update=True))
 
 
 def test_plane_hooks_on_slabs(gpu_lib):
@@ -135,7 +243,7 @@ def test_c3_slice_on_an_eighth_of_the_memory(gpu_lib):
     om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
     rng = np.random.default_rng(21)
     out = []
-    for slab in (0, 640 * 480 // 8):
+    for slab in (-1, 640 * 480 // 8):      # whole planes (above 8 192 particles 0 = the library's choice = slabs) / slabs
         with RbSensor(om, cam, P, max_particles=n, slab_px=slab) as g:
             if not out:
                 truth = synth.truth_pose(1)
