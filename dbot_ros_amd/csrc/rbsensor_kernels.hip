@@ -885,6 +885,8 @@ __device__ inline double pixel_loglik(const DevParams& P, const MathTabs& M, int
 {
     // the per-frame terms of this pixel, observation included: one 32-byte entry, one memory round trip
     typedef double doublex2 __attribute__((ext_vector_type(2)));
+    // (with every lane reading one fixed entry instead -- no gather latency at all -- the kernel is 2.5 %
+    // faster: prefetching the next batch's entries across the scan loop is not worth its registers)
     const doublex2* a4 = reinterpret_cast<const doublex2*>(P.aux + (size_t)AUX_PLANES * gi);
     const doublex2 a01 = a4[0], a23 = a4[1];
     // what depends on the rendered depth alone runs while that entry travels
