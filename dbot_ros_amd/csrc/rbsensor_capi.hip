@@ -108,6 +108,9 @@ struct rbs_handle {
     size_t partial_cap = 0;
     float* d_cluster_sphere = nullptr;
     float* d_cluster_cone = nullptr;
+    double* d_cluster_vtx = nullptr;   // [clusters][3][64] unique vertices of each cluster (vertex sharing)
+    int* d_cluster_nv = nullptr;       // [clusters]
+    unsigned* d_tri_local = nullptr;   // [n_tri] positions of a triangle's vertices in its cluster's list
     float* d_vtx = nullptr;         // [sum of vertex counts][4] float32 vertices (screen rectangles)
     float* d_tri_plane = nullptr;   // [n_tri][4] model-space plane of each triangle (float32 pre-cull)
     int precision = RBS_PRECISION_F64;
@@ -738,6 +741,9 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_cluster_sphere);
     (void)hipFree(h->d_cluster_cone);
+    (void)hipFree(h->d_cluster_vtx);
+    (void)hipFree(h->d_cluster_nv);
+    (void)hipFree(h->d_tri_local);
     (void)hipFree(h->d_tri_plane);
     (void)hipFree(h->d_vtx);
     (void)hipFree(h->d_render);
@@ -930,6 +936,9 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     std::vector<float> cluster_sphere(4 * (n_alloc / 64), 0.f);
     std::vector<float> cluster_cone(4 * (n_alloc / 64), -2.f);   // min cos -2: never culled
     std::vector<float> tri_plane(4 * n_alloc, std::nanf(""));    // NaN: never pre-culled
+    std::vector<double> cluster_vtx((size_t)192 * (n_alloc / 64), 0.0);
+    std::vector<int> cluster_nv(n_alloc / 64, 0);
+    std::vector<unsigned> tri_local(n_alloc, 0xffffffffu);
     const bool allow_cull = !(std::getenv("RBS_NO_CULL") && std::atoi(std::getenv("RBS_NO_CULL")));
     size_t voff = 0, toff = 0;
     for (int b = 0; b < h->n_bodies; ++b) {
@@ -1063,6 +1072,30 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
                     soup[(size_t)(3 * k + c3) * n_alloc + base + j] = V[3 * T[3 * t + k] + c3];
         }
         B.tri_end[b] = (int)base + nt;
+        // vertex sharing: the unique vertices (by index) of every cluster of 64 and, per triangle, where
+        // its three sit in that list; a cluster with more than 64 of them is set up per triangle
+        for (size_t c = base / 64; c < (size_t)B.tri_begin[b + 1] / 64; ++c) {
+            const size_t j0 = c * 64 - base, j1 = std::min<size_t>(j0 + 64, (size_t)nt);
+            std::map<int, int> local;
+            bool fits = true;
+            for (size_t j = j0; j < j1 && fits; ++j)
+                for (int k = 0; k < 3; ++k) {
+                    const int vi = T[3 * order[j].second + k];
+                    if (local.find(vi) == local.end()) {
+                        if (local.size() == 64) { fits = false; break; }
+                        const int pos = (int)local.size();
+                        local[vi] = pos;
+                        for (int c3 = 0; c3 < 3; ++c3) cluster_vtx[c * 192 + 64 * c3 + pos] = V[3 * vi + c3];
+                    }
+                }
+            if (!fits || local.empty()) continue;
+            cluster_nv[c] = (int)local.size();
+            for (size_t j = j0; j < j1; ++j) {
+                unsigned pk = 0;
+                for (int k = 0; k < 3; ++k) pk |= (unsigned)local[T[3 * order[j].second + k]] << (8 * k);
+                tri_local[base + j] = pk;
+            }
+        }
         // model-space plane of each triangle, unit normal of its winding (float32 pre-cull only)
         for (int j = 0; j < nt; ++j) {
             double p[3][3];
@@ -1238,6 +1271,15 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMemcpy(h->d_cluster_cone, cluster_cone.data(), sizeof(float) * cluster_cone.size(),
                          hipMemcpyHostToDevice));
     B.cluster_cone = h->d_cluster_cone;
+    RBS_HIP(h, hipMalloc(&h->d_cluster_vtx, sizeof(double) * cluster_vtx.size()));
+    RBS_HIP(h, hipMemcpy(h->d_cluster_vtx, cluster_vtx.data(), sizeof(double) * cluster_vtx.size(), hipMemcpyHostToDevice));
+    B.cluster_vtx = h->d_cluster_vtx;
+    RBS_HIP(h, hipMalloc(&h->d_cluster_nv, sizeof(int) * cluster_nv.size()));
+    RBS_HIP(h, hipMemcpy(h->d_cluster_nv, cluster_nv.data(), sizeof(int) * cluster_nv.size(), hipMemcpyHostToDevice));
+    B.cluster_nv = h->d_cluster_nv;
+    RBS_HIP(h, hipMalloc(&h->d_tri_local, sizeof(unsigned) * tri_local.size()));
+    RBS_HIP(h, hipMemcpy(h->d_tri_local, tri_local.data(), sizeof(unsigned) * tri_local.size(), hipMemcpyHostToDevice));
+    B.tri_local = h->d_tri_local;
     RBS_HIP(h, hipMalloc(&h->d_tri_plane, sizeof(float) * tri_plane.size()));
     RBS_HIP(h, hipMemcpy(h->d_tri_plane, tri_plane.data(), sizeof(float) * tri_plane.size(), hipMemcpyHostToDevice));
     B.tri_plane = reinterpret_cast<const rbs::floatx4*>(h->d_tri_plane);

@@ -72,6 +72,9 @@ namespace rbs {
 #ifndef RBS_EDGE_FILTER
 #define RBS_EDGE_FILTER 0
 #endif
+#ifndef RBS_SHARE_VERTICES
+#define RBS_SHARE_VERTICES 1   // raster_shared_cluster (0: every triangle transforms its own three vertices)
+#endif
 
 #ifndef RBS_BLOCK
 #define RBS_BLOCK 256
@@ -148,6 +151,11 @@ struct DevParams {
     const float* cluster_sphere;   // [n_tri/64][4] model-space bounding sphere of each cluster
     const float* cluster_cone;     // [n_tri/64][4] outward-normal cone of each cluster: unit axis, min cos
                                    //   (min cos <= -1: never cull this cluster)
+    // Vertex sharing inside a cluster (raster_shared_cluster): the cluster's UNIQUE vertices and,
+    // per triangle, the three positions of its vertices in that list.
+    const double* cluster_vtx;     // [n_tri/64][3][64] x / y / z of the cluster's unique vertices (the soup's own values)
+    const int* cluster_nv;         // [n_tri/64] number of unique vertices, 0: more than 64 (the cluster is set up per triangle)
+    const unsigned* tri_local;     // [n_tri] i0 | i1 << 8 | i2 << 16, 0xffffffff for padding
     int body_cull[kMaxBodies];     // 0: keep every triangle; +1/-1: the body is a closed, consistently
                                    //   oriented surface (sign of its signed volume): back faces may go
     int tile_px;                   // pixels of this launch's LDS depth tile (its dynamic shared memory is sized for it)
@@ -445,32 +453,11 @@ __device__ inline void tri_filter(Tri& T, double xlo_d, double ylo_d)
 // orientation; a triangle whose projected area has that sign faces away from the camera and is
 // dropped -- every sample it covers is covered, no farther away, by a front face (see
 // raster_window).
-__device__ inline bool tri_setup(const DevParams& P, int t, const double* __restrict__ Rt,
-                                 int wx0, int wy0, int wx1, int wy1, int cullsign, Tri& T)
+// The second half of the setup, from the camera-space vertices X, Y, Z and their projections u, v.
+__device__ inline bool tri_finish(const DevParams& P, const double* X, const double* Y, const double* Z, const double* u,
+                                  const double* v, int wx0, int wy0, int wx1, int wy1, int cullsign, Tri& T)
 {
-    const double* __restrict__ s = P.soup;
-    const size_t n = (size_t)P.n_tri;
-    // all nine coalesced loads in flight together (one memory round trip per triangle, not three)
-    double vv[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) vv[k] = s[k * n + t];
-    __builtin_amdgcn_sched_barrier(0);
-    double X[3], Y[3], Z[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double vx = vv[3 * k + 0], vy = vv[3 * k + 1], vz = vv[3 * k + 2];
-        X[k] = ((Rt[0] * vx + Rt[1] * vy) + Rt[2] * vz) + Rt[9];
-        Y[k] = ((Rt[3] * vx + Rt[4] * vy) + Rt[5] * vz) + Rt[10];
-        Z[k] = ((Rt[6] * vx + Rt[7] * vy) + Rt[8] * vz) + Rt[11];
-    }
     if (!(Z[0] > 0.0 && Z[1] > 0.0 && Z[2] > 0.0)) return false;
-    double u[3], v[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double iz = div_f64(1.0, Z[k]);
-        u[k] = P.fx * (X[k] * iz) + P.cx;
-        v[k] = P.fy * (Y[k] * iz) + P.cy;
-    }
     // bbox first: most sub-pixel triangles contain no integer sample point and leave here
     // (pure reordering of independent operations -- values are unchanged)
     const double umin = fmin(fmin(u[0], u[1]), u[2]), umax = fmax(fmax(u[0], u[1]), u[2]);
@@ -501,6 +488,49 @@ __device__ inline bool tri_setup(const DevParams& P, int t, const double* __rest
     tri_filter(T, xlo_d, ylo_d);
 #endif
     return true;
+}
+
+// One vertex into camera space and onto the image plane: the oracle's operations in the oracle's
+// order (oracle/rbsensor_oracle.c raster_triangle()).  The division is carried out whatever Z is:
+// tri_finish rejects a triangle with a vertex at Z <= 0 before it looks at u, v.
+__device__ inline void vertex_project(const DevParams& P, const double* __restrict__ Rt, double vx, double vy, double vz,
+                                      double& X, double& Y, double& Z, double& u, double& v)
+{
+    X = ((Rt[0] * vx + Rt[1] * vy) + Rt[2] * vz) + Rt[9];
+    Y = ((Rt[3] * vx + Rt[4] * vy) + Rt[5] * vz) + Rt[10];
+    Z = ((Rt[6] * vx + Rt[7] * vy) + Rt[8] * vz) + Rt[11];
+    const double iz = div_f64(1.0, Z);
+    u = P.fx * (X * iz) + P.cx;
+    v = P.fy * (Y * iz) + P.cy;
+}
+
+__device__ inline bool tri_setup(const DevParams& P, int t, const double* __restrict__ Rt,
+                                 int wx0, int wy0, int wx1, int wy1, int cullsign, Tri& T)
+{
+    const double* __restrict__ s = P.soup;
+    const size_t n = (size_t)P.n_tri;
+    // all nine coalesced loads in flight together (one memory round trip per triangle, not three)
+    double vv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) vv[k] = s[k * n + t];
+    __builtin_amdgcn_sched_barrier(0);
+    double X[3], Y[3], Z[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double vx = vv[3 * k + 0], vy = vv[3 * k + 1], vz = vv[3 * k + 2];
+        X[k] = ((Rt[0] * vx + Rt[1] * vy) + Rt[2] * vz) + Rt[9];
+        Y[k] = ((Rt[3] * vx + Rt[4] * vy) + Rt[5] * vz) + Rt[10];
+        Z[k] = ((Rt[6] * vx + Rt[7] * vy) + Rt[8] * vz) + Rt[11];
+    }
+    if (!(Z[0] > 0.0 && Z[1] > 0.0 && Z[2] > 0.0)) return false;
+    double u[3], v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double iz = div_f64(1.0, Z[k]);
+        u[k] = P.fx * (X[k] * iz) + P.cx;
+        v[k] = P.fy * (Y[k] * iz) + P.cy;
+    }
+    return tri_finish(P, X, Y, Z, u, v, wx0, wy0, wx1, wy1, cullsign, T);
 }
 
 // The oracle's coverage rule on one integer sample point (px, py as doubles): all three edge
@@ -589,11 +619,14 @@ __device__ inline bool cluster_may_touch(const DevParams& P, const double* __res
 //   n.(p - eye) >= n.(c - eye) - rho >= |c| cos(psi + phi) - rho,   psi = angle(axis, c - eye),
 // so the cluster is back-facing when |c| (cos psi cos phi - sin psi sin phi) - rho > 0; a
 // margin of 1e-3 (|c| + rho) + 1e-4 absorbs the float rounding.  One cluster per lane.
-__device__ inline bool cluster_faces_away(const double* __restrict__ Rt, const floatx4 sph, const floatx4 cone4)
+// Returns +1: every triangle faces away (cull the cluster); -1: every triangle faces the camera
+// (nothing of it will be culled: no need to pre-test its triangles); 0: mixed or unknown.  The -1
+// verdict only chooses a code path -- the exact projected-area test still sees every triangle.
+__device__ inline int cluster_facing(const double* __restrict__ Rt, const floatx4 sph, const floatx4 cone4)
 {
     const float cone[4] = {cone4.x, cone4.y, cone4.z, cone4.w};
     const float m = cone[3];
-    if (!(m > 0.0f)) return false;
+    if (!(m > 0.0f)) return 0;
     const float r0 = (float)Rt[0], r1 = (float)Rt[1], r2 = (float)Rt[2], r3 = (float)Rt[3], r4 = (float)Rt[4],
                 r5 = (float)Rt[5], r6 = (float)Rt[6], r7 = (float)Rt[7], r8 = (float)Rt[8];
     const float X = r0 * sph.x + r1 * sph.y + r2 * sph.z + (float)Rt[9];
@@ -606,8 +639,15 @@ __device__ inline bool cluster_faces_away(const double* __restrict__ Rt, const f
     const float D = cone_sqrt(X * X + Y * Y + Z * Z);
     const float ad = ax * X + ay * Y + az * Z;           // |c| cos psi
     const float sp = cone_sqrt(fmaxf(D * D - ad * ad, 0.0f)); // |c| sin psi
-    const float lhs = ad * m - sp * cone_sqrt(fmaxf(1.0f - m * m, 0.0f)) - rho;
-    return lhs > 1e-3f * (D + rho) + 1e-4f;
+    const float spread = sp * cone_sqrt(fmaxf(1.0f - m * m, 0.0f)) + rho;
+    const float margin = 1e-3f * (D + rho) + 1e-4f;
+    if (ad * m - spread > margin) return 1;
+    if (-ad * m - spread > margin) return -1;    // the same bound with the axis reversed
+    return 0;
+}
+__device__ inline bool cluster_faces_away(const double* __restrict__ Rt, const floatx4 sph, const floatx4 cone4)
+{
+    return cluster_facing(Rt, sph, cone4) > 0;
 }
 
 // Back-face culling.  A body whose mesh is a closed, consistently oriented surface, every shell
@@ -628,16 +668,9 @@ __device__ inline int body_cullsign(const DevParams& P, const double* __restrict
     return (Z - P.sphere[b][3] > 1e-6) ? P.body_cull[b] : 0;
 }
 
-// One lane's triangle: setup, then its sample points (or the cooperative queue when it is big).
-__device__ inline void raster_lane_triangle(const DevParams& P, int t, const double* __restrict__ Rt, int wx0,
-                                            int wy0, int wx1, int wy1, int cullsign, unsigned* tile, int tw,
-                                            int* big, int* nbig RBS_TICK_PARAM)
+// A set-up triangle's sample points (or the cooperative queue when it is big).
+__device__ inline void raster_lane_samples(const Tri& T, int t, int wx0, int wy0, unsigned* tile, int tw, int* big, int* nbig)
 {
-    Tri T;
-    RBS_TICK(10);
-    const bool ok_ = tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, cullsign, T);
-    RBS_TICK(11);
-    if (!ok_) return;
 #ifdef RBS_EXP_SKIP_PIXELS   // profiling builds (tools/phase_timing.py): triangle setup only
     if (T.nv0 != 12345.678) return;
 #endif
@@ -676,6 +709,54 @@ __device__ inline void raster_lane_triangle(const DevParams& P, int t, const dou
         for (int col = T.xlo; col <= T.xhi; ++col)
             tri_pixel(T, col, row, tile, tw, wx0, wy0);
 #endif
+}
+
+// One lane's triangle: setup, then its sample points.
+__device__ inline void raster_lane_triangle(const DevParams& P, int t, const double* __restrict__ Rt, int wx0,
+                                            int wy0, int wx1, int wy1, int cullsign, unsigned* tile, int tw,
+                                            int* big, int* nbig RBS_TICK_PARAM)
+{
+    Tri T;
+    RBS_TICK(10);
+    const bool ok_ = tri_setup(P, t, Rt, wx0, wy0, wx1, wy1, cullsign, T);
+    RBS_TICK(11);
+    if (!ok_) return;
+    raster_lane_samples(T, t, wx0, wy0, tile, tw, big, nbig);
+}
+
+// A whole cluster whose triangles all go to the setup (a body that is not culled, or a cluster
+// whose normal cone faces the camera), with its VERTICES shared: a triangle's transform and
+// projection -- 99 of a setup's 175 instructions, three binary64 divisions among them -- are the
+// same for every triangle around a vertex, six on a closed mesh.  Lane v transforms and projects
+// the cluster's unique vertex v once (the oracle's operations in the oracle's order: the values
+// are those tri_setup computes), lane t fetches its triangle's three vertices from the lanes that
+// hold them (ds_bpermute: 30 cross-lane reads, no LDS space, no VALU) and finishes the setup.
+// nv = the cluster's unique vertices (<= 64).
+__device__ inline void raster_shared_cluster(const DevParams& P, int c, int nv, int t_end, const double* __restrict__ Rt,
+                                             int wx0, int wy0, int wx1, int wy1, int cullsign, unsigned* tile, int tw,
+                                             int* big, int* nbig RBS_TICK_PARAM)
+{
+    const int lane = threadIdx.x & 63;
+    RBS_TICK(10);
+    const double* __restrict__ cv = P.cluster_vtx + (size_t)c * 192;
+    const int vl = min(lane, nv - 1);                      // (lanes past the list repeat its last vertex: nobody fetches them)
+    const double vx = cv[vl], vy = cv[64 + vl], vz = cv[128 + vl];
+    const int t = (c << 6) + lane;
+    const unsigned packed = P.tri_local[t];
+    __builtin_amdgcn_sched_barrier(0);
+    double Xv, Yv, Zv, uv, vv;
+    vertex_project(P, Rt, vx, vy, vz, Xv, Yv, Zv, uv, vv);
+    double X[3], Y[3], Z[3], u[3], v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int src = (int)((packed >> (8 * k)) & 63u);
+        X[k] = __shfl(Xv, src, 64); Y[k] = __shfl(Yv, src, 64); Z[k] = __shfl(Zv, src, 64);
+        u[k] = __shfl(uv, src, 64); v[k] = __shfl(vv, src, 64);
+    }
+    Tri T;
+    const bool ok_ = t < t_end && packed != 0xffffffffu && tri_finish(P, X, Y, Z, u, v, wx0, wy0, wx1, wy1, cullsign, T);
+    RBS_TICK(11);
+    if (ok_) raster_lane_samples(T, t, wx0, wy0, tile, tw, big, nbig);
 }
 // (phase-timing builds: the time between a lane leaving its sample loop and the next tick is the
 // wave's sample phase -- lane 0 may leave early, so the caller ticks after reconvergence)
@@ -745,14 +826,32 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
                 sph = reinterpret_cast<const floatx4*>(P.cluster_sphere)[ci];
                 cone = reinterpret_cast<const floatx4*>(P.cluster_cone)[ci];
             }
-            const bool hit = ci < c1 && (!cull || cluster_may_touch(P, Rt, sph, wx0, wy0, wx1, wy1)) &&
-                             !(cullsign != 0 && cluster_faces_away(Rt, sph, cone));
+            const int facing = cullsign != 0 && ci < c1 ? cluster_facing(Rt, sph, cone) : 0;
+            const bool hit = ci < c1 && (!cull || cluster_may_touch(P, Rt, sph, wx0, wy0, wx1, wy1)) && facing <= 0;
             const unsigned long long mask = __ballot(hit);
             RBS_TICK(8);
             // this wave's share: the surviving clusters are dealt round-robin by their rank
             const int rank = taken + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
             unsigned long long mine = __ballot(hit && (rank % (kBlock / 64)) == wave);
             taken += __popcll(mask);
+#if RBS_SHARE_VERTICES
+            // Clusters all of whose triangles go to the setup -- every cluster of a body that is not
+            // culled, and the clusters whose normal cone faces the camera (4/5 of a closed body's
+            // surviving triangles) -- are set up with their vertices shared, straight from the
+            // cluster (no pre-test, no ring); the others (silhouette clusters, clusters with more
+            // than 64 unique vertices) take the per-triangle route below.
+            const int nvc = ci < c1 ? P.cluster_nv[ci] : 0;
+            unsigned long long whole = mine & __ballot(hit && nvc > 0 && (cullsign == 0 || facing < 0));
+            mine &= ~whole;
+            while (whole) {
+                const int bit = __builtin_ctzll(whole);
+                whole &= whole - 1;
+                const int nv = __shfl(nvc, bit, 64);
+                raster_shared_cluster(P, base + bit, __builtin_amdgcn_readfirstlane(nv), t_end, Rt, wx0, wy0, wx1, wy1, cullsign,
+                                      tile, tw, big, nbig RBS_TICK_ARG);
+                __builtin_amdgcn_wave_barrier(); RBS_TICK(12);
+            }
+#endif
             if (cullsign == 0) {   // nothing to pre-test: the clusters' lanes go straight to the setup
                 while (mine) {
                     const int bit = __builtin_ctzll(mine);
@@ -881,7 +980,12 @@ __global__ void frame_aux_kernel(const float* __restrict__ frame, double* __rest
 // log-likelihoods: 1e-9).
 struct MathTabs { const double* erfc; const double* logt; };
 
-__device__ inline double pixel_loglik(const DevParams& P, const MathTabs& M, int gi, float r, float prior, float& posterior)
+#ifdef RBS_NOINLINE_EVAL
+#define RBS_EVAL_INLINE __attribute__((noinline))
+#else
+#define RBS_EVAL_INLINE inline
+#endif
+__device__ RBS_EVAL_INLINE double pixel_loglik(const DevParams& P, const MathTabs& M, int gi, float r, float prior, float& posterior)
 {
     // the per-frame terms of this pixel, observation included: one 32-byte entry, one memory round trip
     typedef double doublex2 __attribute__((ext_vector_type(2)));

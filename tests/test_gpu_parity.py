@@ -887,7 +887,7 @@ def test_out_of_device_memory_is_an_error_not_a_wreck(gpu_lib, state_layout):
     free0 = torch.cuda.mem_get_info()[0]
     too_many = int(free0 // (640 * 480 * 4)) // 2 + 2000      # two buffers of this many planes do not fit
     with pytest.raises(RbSensorError) as e:
-        RbSensor(om, cam, P, max_particles=too_many)
+        RbSensor(om, cam, P, max_particles=too_many, slab_px=-1)   # whole planes (the library's own choice would be slabs)
     assert e.value.code == _capi.RBS_ERR_OUT_OF_MEMORY
     assert torch.cuda.mem_get_info()[0] > 0.9 * free0
     with RbSensor(om, cam, P, max_particles=4) as g:
