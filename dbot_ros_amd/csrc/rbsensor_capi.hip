@@ -178,6 +178,10 @@ struct rbs_handle {
     // refused with this message until rbs_reset (rbs_tracker_initialize) re-establishes a known state.
     bool poisoned = false;
     std::string poison_msg;
+    // test hook (tests/test_gpu_multidevice.py): RBS_TEST_FAULT="<shard>:<call>" read at rbs_create makes
+    // the group's <call>-th rbs_loglikes fail on shard <shard> after the shards before it were enqueued
+    int fault_shard = -1;
+    long fault_call = -1, group_calls = 0;
     // ---- several devices in one handle (rbs_config.n_devices > 1) ----
     // A GROUP handle owns one single-device handle ("shard") per device; global slot g lives on
     // shard g / shard_cap.  Every call is fanned out to the shards by the calling thread; a
@@ -1522,6 +1526,10 @@ int32_t create_group(const rbs_config* cfg, rbs_handle* g)
     }
     g->windowed = g->shards[0]->windowed;
     g->precision = g->shards[0]->precision;
+    if (const char* f = std::getenv("RBS_TEST_FAULT")) {
+        int a = -1; long c = -1;
+        if (std::sscanf(f, "%d:%ld", &a, &c) == 2) { g->fault_shard = a; g->fault_call = c; }
+    }
     // parents on another device are read in place
     for (int a = 0; a < nd; ++a) {
         RBS_HIP(g, hipSetDevice(devs[a]));
@@ -1652,8 +1660,13 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
                 if (hipEventRecord(h->ev_done, h->stream) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, "hipEventRecord failed"));
                 continue;
             }
+            if (k == g->fault_shard && g->group_calls == g->fault_call) {   // (test hook)
+                g->group_calls += 1;
+                return poison(g, gfail(g, h, fail(h, RBS_ERR_HIP, "injected fault (RBS_TEST_FAULT)")));
+            }
             if (int32_t rc = host_call(h, poses + stride * (size_t)lo, indices + lo, cnt, update != 0)) return poison(g, gfail(g, h, rc));
         }
+        g->group_calls += 1;
         bool overflow = false;
         for (int k = 0; k < nd; ++k) {
             rbs_handle* h = g->shards[k];

@@ -325,3 +325,48 @@ def test_device_pointer_entry_points_on_a_group_handle(gpu_lib, ids):
                     assert np.array_equal(one.get_occlusion(s_), grp.get_occlusion(s_))
                 idx = rng.integers(0, n, n).astype(np.int32)
             grp.synchronize()
+
+
+def test_a_fan_out_that_fails_half_way_poisons_the_handle_until_reset(gpu_lib, monkeypatch):
+    """a call that fails on shard k after shards 0..k-1 were enqueued leaves the shards
+    out of step.  (Injected with the library's test hook.)  The failing call reports its error,
+    everything enqueued is drained, every later call is REFUSED with the original message -- no
+    silently mismatched buffers -- and rbs_reset restores a working handle with the numbers of a
+    fresh one."""
+    from dbot_ros_amd.sensor import RbSensorError
+    n = 30
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    rng = np.random.default_rng(4)
+    monkeypatch.setenv("RBS_TEST_FAULT", "1:2")        # the group's third rbs_loglikes fails on its second shard
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", device_ids=[0, 0, 0]) as grp:
+        monkeypatch.delenv("RBS_TEST_FAULT")
+        with RbSensor(om, cam, P, max_particles=n, precision="f64") as one:
+            t = synth.truth_pose(1)
+            frame = synth.make_frame(one.render_depth(t), 120, 160, rng).astype(np.float32)
+            poses = synth.particle_poses(t, n, rng)
+
+            def step(s, idx):
+                s.set_observation(frame)
+                return s.loglikes_poses(poses, idx, update=True)
+
+            for s in (grp, one):
+                s.reset()
+            idx = np.zeros(n, np.int32)
+            for k in range(2):
+                a, b = step(grp, idx.copy()), step(one, idx.copy())
+                assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+                idx = rng.integers(0, n, n).astype(np.int32)
+            with pytest.raises(RbSensorError, match="injected fault"):
+                step(grp, idx.copy())
+            for call in (lambda: step(grp, idx.copy()), lambda: grp.set_observation(frame)):
+                with pytest.raises(RbSensorError, match="undefined state.*injected fault"):
+                    call()
+            for s in (grp, one):
+                s.reset()
+            idx = np.zeros(n, np.int32)
+            for k in range(3):
+                a, b = step(grp, idx.copy()), step(one, idx.copy())
+                assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+                idx = rng.integers(0, n, n).astype(np.int32)
+            for s_ in (0, n - 1):
+                assert np.array_equal(grp.get_occlusion(s_), one.get_occlusion(s_))
