@@ -68,7 +68,7 @@ struct rbs_handle {
     size_t plane_stride = 0;    // floats per slot: npx or slab_px
     int4* d_reg[2] = {nullptr, nullptr};   // [max_particles] stored region of each plane, per buffer
     int* d_err = nullptr;       // [2] device: [0] a region did not fit its slab, [1] the largest region asked for so far (px)
-    int* h_err = nullptr;       // pinned copy, fetched with the log-likelihoods
+    int* h_err = nullptr;       // pinned copy, fetched with the log-likelihoods ([2], [3]: the flags as they were BEFORE the call)
     bool slab_auto = false;     // the slab size is the library's choice (rbs_config.state_slab_px == 0 with many particles)
     int* d_bbox = nullptr;      // [4] scratch of rbs_import_plane / rbs_set_occlusion
     bool windowed = true;       // planes valid inside their window only (state_layout dense: whole plane)
@@ -1239,8 +1239,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMalloc(&h->d_occ[1], sizeof(float) * h->plane_stride * h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_err, 2 * sizeof(int)));
     RBS_HIP(h, hipMemset(h->d_err, 0, 2 * sizeof(int)));
-    RBS_HIP(h, hipHostMalloc(&h->h_err, 2 * sizeof(int), hipHostMallocDefault));
-    h->h_err[0] = h->h_err[1] = 0;
+    RBS_HIP(h, hipHostMalloc(&h->h_err, 4 * sizeof(int), hipHostMallocDefault));
+    h->h_err[0] = h->h_err[1] = h->h_err[2] = h->h_err[3] = 0;
     RBS_HIP(h, hipMalloc(&h->d_bbox, sizeof(int) * 4));
     if (h->slab_px) {
         RBS_HIP(h, hipMalloc(&h->d_reg[0], sizeof(int4) * (size_t)h->max_particles));
@@ -1578,6 +1578,9 @@ int32_t host_call(rbs_handle* h, const double* poses, const int32_t* indices, in
 {
     const bool copies = h->host_copies;
     const size_t pose_bytes = sizeof(double) * 12 * h->n_bodies * (size_t)n;
+    // slabs: the overflow flag as it stands BEFORE this call -- set, it belongs to an asynchronous call
+    // that has not been reported yet
+    if (h->slab_px) RBS_HIP(h, hipMemcpyAsync(h->h_err + 2, h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     std::memcpy(h->h_in, poses, pose_bytes);
     std::memcpy(h->h_in + h->in_idx_off, indices, sizeof(int) * (size_t)n);
     if (copies) {
@@ -2086,6 +2089,7 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
     const CallState before = save_call_state(h);
     if (int32_t rc = host_call(h, poses, indices, n, update != 0)) return rc;
     RBS_HIP(h, hipEventSynchronize(h->ev_out));
+    const bool stale_overflow = h->slab_px && h->h_err[2] != 0;   // of an earlier asynchronous call: reported below, once
     if (h->slab_px && h->h_err[0]) {
         // a region did not fit its slab: the planes this call read are intact (double buffer), so the
         // call is taken back, the slabs are enlarged to hold the largest region asked for, and the
@@ -2100,7 +2104,14 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
     std::memcpy(out_loglik, h->h_out, sizeof(double) * (size_t)n);
     if (update)
         for (int32_t i = 0; i < n; ++i) indices[i] = i;
-    return slab_housekeeping(h);
+    if (int32_t rc = slab_housekeeping(h)) return rc;
+    if (stale_overflow) {   // this call's results are good; an earlier rbs_loglikes_device's were not
+        h->h_err[0] = 1;
+        const int32_t rc = check_slab_error(h);
+        h->h_err[0] = 0;
+        return rc;
+    }
+    return RBS_OK;
 }
 
 int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t* d_indices,

@@ -282,3 +282,44 @@ def test_device_tracker_on_slabs(gpu_lib):
             assert tr.n_resamplings >= 1
             tr.close()
     assert np.array_equal(ests[0], ests[1])
+
+
+def test_a_synchronous_call_reports_an_earlier_asynchronous_overflow(gpu_lib):
+    """The overflow of an rbs_loglikes_device call that nobody has synchronised on yet is reported by
+    the next rbs_loglikes too -- once, with that call's own results intact (it runs, or is repeated,
+    on the enlarged slabs)."""
+    import ctypes as C
+    import torch
+    n = 8
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
+    rng = np.random.default_rng(0)
+    dev = torch.device("cuda", 0)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=16384) as g, \
+            RbSensor(om, cam, P, max_particles=n, precision="f64") as whole:
+        truth = synth.truth_pose(1)
+        frame = synth.make_frame(g.render_depth(truth), 480, 640, rng).astype(np.float32)
+        near = synth.particle_poses(truth, n, rng)
+        near[3, 0, 9:12] = (0.0, 0.0, 0.25)
+        for s in (g, whole):
+            s.reset()
+            s.set_observation(frame)
+        d_poses = torch.from_numpy(np.ascontiguousarray(near.reshape(n, -1))).to(dev)
+        d_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_out = torch.empty(n, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        g.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, True, d_out.data_ptr(), None)     # particle 3 overflows, contained
+        whole.loglikes_poses(near, np.zeros(n, np.int32), update=True)
+        whole.set_occlusion(3, np.full(640 * 480, whole.get_background(), np.float32))           # the same history: 3 starts over
+        for s in (g, whole):
+            s.set_observation(frame)
+        ref = whole.loglikes_poses(near, np.arange(n, dtype=np.int32), update=True)
+        idx, out = np.arange(n, dtype=np.int32), np.empty(n)
+        rc = g._lib.rbs_loglikes(g._h, near.reshape(n, -1).ctypes.data_as(C.POINTER(C.c_double)),
+                                 idx.ctypes.data_as(C.POINTER(C.c_int32)), n, 1, out.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == _capi.RBS_ERR_OUT_OF_MEMORY and b"already returned" in g._lib.rbs_last_error(g._h)
+        assert np.isnan(d_out.cpu().numpy()[3])                       # the asynchronous call's particle was contained ...
+        assert np.array_equal(out, ref)                                # ... this call's results are those of whole planes
+        for s in (g, whole):
+            s.set_observation(frame)
+        idx = rng.permutation(n).astype(np.int32)
+        assert np.array_equal(g.loglikes_poses(near, idx.copy(), update=True), whole.loglikes_poses(near, idx.copy(), update=True))
