@@ -445,7 +445,7 @@ def cpu_baseline(om, cam, P, truth, frame, seconds):
 
 
 # --------------------------------------------------------------------------------- host API from C++
-def write_host_workload(f, om, cam, P, frames, poses, parents, update):
+def write_host_workload(f, om, cam, P, frames, poses, parents, update, init=None):
     """The binary workload tests/cpp/host_bench.cpp reads (layout in its header comment)."""
     import struct
     frames = np.ascontiguousarray(frames, dtype=np.float32)
@@ -465,6 +465,8 @@ def write_host_workload(f, om, cam, P, frames, poses, parents, update):
     f.write(frames.tobytes())
     f.write(poses.tobytes())
     f.write(np.ascontiguousarray(parents, dtype=np.int32).tobytes())
+    if init is not None:
+        f.write(np.ascontiguousarray(init, dtype=np.float64).tobytes())
 
 
 def native_host_leg(a, om, cam, P, W, steps):
@@ -494,6 +496,40 @@ def native_host_leg(a, om, cam, P, W, steps):
         os.unlink(path)
 
 
+def native_tracker_leg(om, cam, P, frames, init, counts, precision):
+    """The device tracker driven from C++ (tests/cpp/host_bench --tracker): what the reference's own
+    node, which is C++, would see -- no interpreter between the frames.  {} when the binary is missing."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "cpp", "host_bench")
+    if not os.path.exists(exe):
+        return {}
+    nb = om.count_parts
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        path = f.name
+        write_host_workload(f, om, cam, P, np.stack(frames), np.zeros((len(frames), 1, 12 * nb)), np.zeros(1, np.int32), True, init=init)
+    out = {}
+    try:
+        env = dict(os.environ, RBS_PRECISION=precision)
+        for n in counts:
+            r = subprocess.run([exe, "--tracker", path, str(n)], capture_output=True, text=True, timeout=300, env=env)
+            line = next((l for l in r.stdout.splitlines() if l.startswith("tracker_bench ")), None)
+            if not line:
+                out["tracker_fps_native_note"] = "host_bench --tracker did not run: " + (r.stdout + r.stderr)[-200:]
+                break
+            tok = line.split()
+            out[f"tracker_fps_native_{n}"] = float(tok[4])
+            out[f"tracker_fps_native_pipelined_{n}"] = float(tok[6])
+        else:
+            out["tracker_fps_native_note"] = ("the same device tracker and frames driven from C++ through the C-ABI (tests/cpp/host_bench.cpp --tracker): "
+                                              "rbs_tracker_track frame by frame / rbs_tracker_submit + rbs_tracker_result with one frame of look-ahead")
+    except Exception as e:   # noqa: BLE001 -- a benchmark leg must not take the headline down
+        out["tracker_fps_native_note"] = "host_bench --tracker failed: %r" % (e,)
+    finally:
+        os.unlink(path)
+    return out
+
+
 # --------------------------------------------------------------------------------- tracker FPS
 def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30, precision=None):
     """Frames/s of the device tracker (rbs_tracker_*: transition, weights, KL, resampling and mean
@@ -518,6 +554,7 @@ def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30, precisi
                 Rt = synth.truth_pose(nb, frame=0)[b]
                 init[12 * b + 3:12 * b + 6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
                 init[12 * b:12 * b + 3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[b]
+            out["_native"] = (frames, init.copy())
             tr.initialize([init])
             tr.track(frames[0])  # warm-up
             t0 = time.perf_counter()
@@ -856,6 +893,8 @@ def main():
         from dbot_ros_amd import ObjectModel, synth
         meshes = [synth.mesh_m1(), synth.mesh_m2(), synth.mesh_m3()]
         om_c2 = ObjectModel([v for v, _ in meshes], [t for _, t in meshes], center=True)
+        nat_frames, nat_init = fps.pop("_native")
+        out.update(native_tracker_leg(om, cam, P, nat_frames, nat_init, (200, 2000, 20000), a.precision))
         c2 = tracker_fps(om_c2, cam, dev, counts=(20000,), precision=a.precision)[20000]
         out["tracker_fps_c2"] = c2["fps"]
         out["tracker_fps_pipelined_c2"] = c2["fps_pipelined"]

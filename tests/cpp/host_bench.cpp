@@ -6,10 +6,18 @@
 //   int32 rows, cols, n_objects, n, F, update; double K[9]; double params[7]
 //   (p_occluded_visible, p_occluded_occluded, initial_occlusion_prob, tail_weight, model_sigma,
 //   sigma_factor, delta_time); per object: int32 nv, nt; double v[3 nv]; int32 t[3 nt];
-//   float frames[F][rows*cols]; double poses[F][n][n_objects][12]; int32 parents[n]
+//   float frames[F][rows*cols]; double poses[F][n][n_objects][12]; int32 parents[n];
+//   double tracker_init[n_objects][12] (position, rotation vector, velocities: the model-frame state the
+//   device tracker starts from)
+//   host_bench --tracker <workload.bin> <particles>
+// the device tracker (rbs_tracker_*: transition, loglikes, weights, KL test, resampling, mean; device
+// RNG) over the workload's frames, frame by frame (rbs_tracker_track: one host synchronisation per
+// frame, the frame uploaded from host memory) and with one frame of look-ahead (rbs_tracker_submit /
+// rbs_tracker_result) -- what the reference's C++ node would see, no interpreter between the frames.
 // Prints one line: "host_bench particle-likelihoods/s <v> ms/step <t> checksum <sum of finite log-likelihoods of the last step>".
 #include <rbsensor_mi355x.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -22,7 +30,9 @@ static bool rd(std::FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: host_bench workload.bin steps [warmup]\n"); return 2; }
+    const bool tracker_mode = argc > 1 && !std::strcmp(argv[1], "--tracker");
+    if (tracker_mode) { --argc; ++argv; }
+    if (argc < 3) { std::fprintf(stderr, "usage: host_bench workload.bin steps [warmup] | host_bench --tracker workload.bin particles\n"); return 2; }
     std::FILE* f = std::fopen(argv[1], "rb");
     if (!f) { std::perror(argv[1]); return 2; }
     const int steps = std::atoi(argv[2]), warmup = argc > 3 ? std::atoi(argv[3]) : 10;
@@ -45,20 +55,59 @@ int main(int argc, char** argv)
     std::vector<double> poses(stride * F), out(n);
     std::vector<int32_t> parents(n), idx(n);
     if (!rd(f, frames.data(), frames.size()) || !rd(f, poses.data(), poses.size()) || !rd(f, parents.data(), (size_t)n)) return 2;
+    std::vector<double> init((size_t)12 * nobj, 0.0);
+    const bool have_init = rd(f, init.data(), init.size());
     std::fclose(f);
+    if (tracker_mode && !have_init) { std::fprintf(stderr, "host_bench --tracker: the workload holds no initial state\n"); return 2; }
 
     rbs_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = RBS_ABI_VERSION;
     cfg.rows = rows; cfg.cols = cols;
     std::memcpy(cfg.K, K, sizeof K);
-    cfg.max_particles = n; cfg.n_objects = nobj;
+    const int track_n = tracker_mode ? std::max(1, steps / nobj) : 0;   // (--tracker: argv[2] = evaluations per frame)
+    cfg.max_particles = tracker_mode ? track_n : n; cfg.n_objects = nobj;
     cfg.vertices = verts.data(); cfg.vertex_counts = vcnt.data();
     cfg.triangles = tris.data(); cfg.triangle_counts = tcnt.data();
     cfg.p_occluded_visible = prm[0]; cfg.p_occluded_occluded = prm[1]; cfg.initial_occlusion_prob = prm[2];
     cfg.tail_weight = prm[3]; cfg.model_sigma = prm[4]; cfg.sigma_factor = prm[5]; cfg.delta_time = prm[6];
     rbs_handle* h = nullptr;
     if (rbs_create(&cfg, &h) != RBS_OK) { std::printf("NO_DEVICE %s\n", h ? rbs_last_error(h) : "rbs_create failed"); return 0; }
+    if (tracker_mode) {
+        rbs_tracker_params tp;
+        std::memset(&tp, 0, sizeof tp);
+        for (int k = 0; k < 3; ++k) { tp.linear_sigma[k] = 0.0025; tp.angular_sigma[k] = 0.02; }   // R:config/particle_tracker.yaml:55-60
+        tp.velocity_factor = 0.8; tp.max_kl_divergence = 2.0; tp.n_particles = track_n;
+        rbs_tracker* t = nullptr;
+        if (rbs_tracker_create(h, &tp, &t) != RBS_OK) { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; }
+        std::vector<double> state((size_t)12 * nobj), state2((size_t)12 * nobj);
+        int32_t nres = 0;
+        auto fail = [&]() { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; };
+        // frame by frame
+        if (rbs_tracker_initialize(t, init.data())) return fail();
+        if (rbs_tracker_track(t, frames.data(), nullptr, nullptr, 1, state.data(), &nres)) return fail();   // warm-up
+        auto t0 = std::chrono::steady_clock::now();
+        for (int k = 1; k < F; ++k)
+            if (rbs_tracker_track(t, frames.data() + npx * k, nullptr, nullptr, 1, state.data(), &nres)) return fail();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        // one frame of look-ahead
+        if (rbs_tracker_initialize(t, init.data())) return fail();
+        if (rbs_tracker_track(t, frames.data(), nullptr, nullptr, 1, state2.data(), &nres)) return fail();
+        t0 = std::chrono::steady_clock::now();
+        if (rbs_tracker_submit(t, frames.data() + npx, nullptr, nullptr, 1)) return fail();
+        for (int k = 2; k < F; ++k) {
+            if (rbs_tracker_submit(t, frames.data() + npx * k, nullptr, nullptr, 1)) return fail();
+            if (rbs_tracker_result(t, state2.data(), &nres)) return fail();
+        }
+        if (rbs_tracker_result(t, state2.data(), &nres)) return fail();
+        const double dt2 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const bool same = std::memcmp(state.data(), state2.data(), sizeof(double) * state.size()) == 0;
+        std::printf("tracker_bench particles %d fps %.1f fps_pipelined %.1f resamplings %d identical %d state %.9g %.9g %.9g\n", track_n,
+                    (F - 1) / dt, (F - 1) / dt2, (int)nres, same ? 1 : 0, state[0], state[1], state[2]);
+        rbs_tracker_destroy(t);
+        rbs_destroy(h);
+        return 0;
+    }
     auto step = [&](int i) -> int32_t {
         const int k = i % F;
         if (int32_t rc = rbs_set_observation_f32(h, frames.data() + npx * k, npx)) return rc;
