@@ -2417,6 +2417,7 @@ struct rbs_tracker {
     double* h_state_dev[2] = {nullptr, nullptr};   // h_state / h_flags as the device addresses them
     int* h_flags_dev[2] = {nullptr, nullptr};
     int32_t res_rc[2] = {0, 0};       // (a handle over several devices runs submit synchronously)
+    int res_seq[2] = {0, 0};          // the frame number the kernel that finishes slot k's frame stores into h_flags[k][2]
     long submitted = 0, collected = 0;
     bool recentre_pending = false;    // T.part_old still holds the particles before the last frame's re-centring
     bool poisoned = false;            // a frame failed half-way (buffers partly swapped): rbs_tracker_initialize first
@@ -2519,7 +2520,7 @@ int32_t tracker_create_one(rbs_handle* sensor, const rbs_tracker_params* p, int 
         if (hipHostMalloc(&t->h_normals[k], sizeof(double) * n * P6, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc(&t->h_uniforms[k], sizeof(double) * n * T.parts, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc(&t->h_state[k], sizeof(double) * D, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(&t->h_flags[k], sizeof(int) * 2, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&t->h_flags[k], sizeof(int) * 4, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc(&t->h_serr[k], 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&t->ev_res[k], hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
@@ -2527,6 +2528,7 @@ int32_t tracker_create_one(rbs_handle* sensor, const rbs_tracker_params* p, int 
             return fail(sensor, RBS_ERR_OUT_OF_MEMORY, "tracker_create: pinned host memory");
         }
         t->h_serr[k][0] = t->h_serr[k][1] = 0;
+        t->h_flags[k][2] = 0;
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&t->h_state_dev[k]), t->h_state[k], 0) != hipSuccess ||
             hipHostGetDevicePointer(reinterpret_cast<void**>(&t->h_flags_dev[k]), t->h_flags[k], 0) != hipSuccess) {
             (void)hipGetLastError();
@@ -2616,6 +2618,7 @@ int32_t rbs_tracker_initialize(rbs_tracker* t, const double* default_state)
     RBT_HIP(t, hipGetLastError());
     RBT_HIP(t, hipStreamSynchronize(s));
     T.frame = 0;
+    for (int k = 0; k < 2; ++k) { t->h_flags[k][2] = 0; t->res_seq[k] = 0; }   // frame numbers start over
     return RBS_OK;
 }
 
@@ -2851,6 +2854,7 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
         if (h->slab_px) RBT_HIP(t, hipMemcpyAsync(t->h_serr[slot], h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         RBT_HIP(t, hipEventRecord(t->ev_res[slot], s));
     }
+    t->res_seq[slot] = (int)(T.frame + 1);
     T.frame += 1;
     t->res_rc[slot] = RBS_OK;
     t->submitted += 1;
@@ -2868,7 +2872,21 @@ int32_t rbs_tracker_result(rbs_tracker* t, double* out_state, int32_t* out_resam
     const int D = r->T.D;
     if (t->reps.empty()) {
         RBT_HIP(t, hipSetDevice(t->s->device));
-        RBT_HIP(t, hipEventSynchronize(t->ev_res[slot]));
+        // The kernel that finishes the frame stores the estimate into pinned (host-coherent) memory and
+        // the frame's number behind it with a system-scope release: spin on that number -- the signalling
+        // of the kernel's completion and the wake-up behind it cost several microseconds more.  The
+        // event is the fall-back (and the only way with slabs, whose error word arrives by a copy).
+        static const bool spin = [] { const char* e = std::getenv("RBS_TRACKER_SPIN"); return !(e && std::atoi(e) == 0); }();
+        bool seen = false;
+        if (spin && !t->s->slab_px && t->res_seq[slot] > 0) {
+            volatile int* seq = t->h_flags[slot] + 2;
+            for (long it = 0; it < 4000000 && !seen; ++it) {
+                seen = __atomic_load_n(seq, __ATOMIC_ACQUIRE) == t->res_seq[slot];
+                if (!seen && (it & 255) == 255 && hipEventQuery(t->ev_res[slot]) == hipSuccess) break;
+                if (!seen) __builtin_ia32_pause();
+            }
+        }
+        if (!seen) RBT_HIP(t, hipEventSynchronize(t->ev_res[slot]));
     }
     std::memcpy(out_state, r->h_state[slot], sizeof(double) * D);
     if (out_resamplings) *out_resamplings = r->h_flags[slot][1];
