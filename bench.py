@@ -646,7 +646,10 @@ def in_process_multi_device(a):
         fps = nf / (time.perf_counter() - t0)
         tr.close()
     alg_bytes = (2.0 if a.update else 1.0) * 4.0 * a.rows * a.cols * a.particles     # per device launch, SURVEY 8d
-    copy_dominant = bool(a.update) and copy_ms > raster_ms
+    # whole planes: the copy kernel is the dominant one and HBM bound.  Windowed planes: the raster kernel
+    # (the windowed copy kernel runs BESIDE it and moves ~1 % of the algorithmic bytes: pricing it with
+    # them would report several times the HBM peak)
+    copy_dominant = bool(a.update) and a.layout == "dense" and copy_ms > raster_ms
     roof, pmc_live, copy_traffic = roofline_for(a, a.particles, raster_ms, copy_ms, alg_bytes, copy_dominant, not a.no_pmc and not a.quick)
     roof.update({"counters_live": bool(pmc_live), "counters_note": "instruction counts from a single-device pass of the same per-device launch",
                  "kernel_launches_averaged": n_used, "raster_kernel_ms": raster_ms, "copy_kernel_ms": copy_ms,
@@ -764,7 +767,10 @@ def main():
         return
 
     alg_bytes = (2.0 if a.update else 1.0) * 4.0 * a.rows * a.cols * n  # per launch, SURVEY 8d
-    copy_dominant = bool(a.update) and copy_ms > raster_ms
+    # whole planes: the copy kernel is the dominant one and HBM bound.  Windowed planes: the raster kernel
+    # (the windowed copy kernel runs BESIDE it and moves ~1 % of the algorithmic bytes: pricing it with
+    # them would report several times the HBM peak)
+    copy_dominant = bool(a.update) and a.layout == "dense" and copy_ms > raster_ms
     out = {
         "metric": "particle-likelihoods/sec @640x480" if (a.cols, a.rows) == (640, 480)
                   else f"particle-likelihoods/sec @{a.cols}x{a.rows}",

@@ -271,3 +271,29 @@ def test_nccl_all_gather_smoke(gpu_lib):
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     assert '"n_gpus": 2' in r.stdout
+
+
+def test_bench_line_of_two_ranks_on_one_gpu(gpu_lib):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with
+    two ranks sharing the one GPU and a gloo rendezvous (RBS_BENCH_BACKEND: functional test, never used
+    for numbers): the line carries the contract's keys, the whole-job value, and the `roofline` of
+    rank 0's dominant kernel."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RBS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29100 + os.getpid() % 800),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--particles", "256"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 2 and line["dtype"] == "f64" and line["scaling"] == "weak" and line["steps"] == 5
+    assert abs(line["value"] - 2 * 256 * 5 / (line["ms_per_step"] * 5e-3)) <= 1e-6 * line["value"]
+    roof = line["roofline"]
+    assert roof["bound"] == "valu_issue" and roof["kernel_ms"] > 0 and "cpu_baseline" not in line
