@@ -796,6 +796,9 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
     if (threadIdx.x == 0) *nbig = 0;
     __syncthreads();
     asm volatile("" ::"s"(touch0), "s"(touch1));   // (the touches are not dead code)
+#ifdef RBS_EXP_NO_RASTER   // profiling builds: per-item overheads + tile clear + pixel scan only
+    return;
+#endif
     RBS_TICK_DECL;
     // surviving clusters so far: dealt round-robin to the block's waves (an LDS ticket per
     // cluster instead measured no better: the waves of a block finish within a few percent)
@@ -1193,6 +1196,9 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
         }                                                                                               \
     } while (0)
 
+#ifdef RBS_EXP_NO_SCAN     // profiling builds: no pixel pass at all
+    if (P.cols < 0)
+#endif
     if ((P.cols & 3) == 0) {
         // Four pixels per lane: rows of the tile, of both planes and of the frame are 16-byte
         // aligned (rectangles and windows move in float4 columns), so one ds_read_b128 + two
