@@ -871,6 +871,14 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     "need 0 < p_occluded_occluded - p_occluded_visible < 1");
     if (!(cfg->delta_time > 0.0)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "delta_time must be > 0");
+    // the pixel model: a density needs a positive noise level and a mixture weight in [0, 1) (with
+    // these the per-pixel arithmetic never meets a NaN of its own making: sigma > 0 for every finite o)
+    if (!(cfg->model_sigma > 0.0) || !(cfg->sigma_factor >= 0.0) || !std::isfinite(cfg->model_sigma) || !std::isfinite(cfg->sigma_factor))
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "need kinect.model_sigma > 0 and kinect.sigma_factor >= 0");
+    if (!(cfg->tail_weight >= 0.0) || !(cfg->tail_weight < 1.0))
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "need 0 <= kinect.tail_weight < 1");
+    if (!(cfg->initial_occlusion_prob >= 0.0) || !(cfg->initial_occlusion_prob <= 1.0))
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "need 0 <= occlusion.initial_occlusion_prob <= 1");
 
     (void)hipGetLastError();   // a stale error left by somebody else on this thread is not ours
     int ndev = 0;

@@ -81,6 +81,13 @@ def test_invalid_models_rejected():
     with pytest.raises(RbSensorError) as e:
         RbSensor(om, cam, P2, max_particles=4)
     assert e.value.code == _capi.RBS_ERR_INVALID_ARGUMENT
+    for field, value in (("model_sigma", 0.0), ("model_sigma", float("nan")), ("sigma_factor", -1e-3), ("tail_weight", 1.0),
+                         ("tail_weight", -0.1)):
+        P3 = RbSensorBuilder.Parameters(sample_count=4)
+        setattr(P3.kinect, field, value)          # a density needs sigma > 0 and a mixture weight in [0, 1)
+        with pytest.raises(RbSensorError) as e:
+            RbSensor(om, cam, P3, max_particles=4)
+        assert e.value.code == _capi.RBS_ERR_INVALID_ARGUMENT, (field, value)
     om.triangles[0][0, 0] = 10 ** 6
     with pytest.raises(RbSensorError) as e:
         RbSensor(om, cam, P, max_particles=4)

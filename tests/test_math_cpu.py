@@ -86,6 +86,10 @@ def test_log_f32(mlib):
     got, ref = _call(mlib, "rbsm_log_f32", x, np.float32), np.log(x.astype(np.float64))
     assert np.all(np.abs(got - ref) <= 2.5e-16 + np.spacing(np.abs(ref)))
     assert abs(_call(mlib, "rbsm_log_f32", [1.0], np.float32)[0]) <= 1e-17
+    # not a positive normal float: what log gives (never a finite number read off the exponent field)
+    odd = _call(mlib, "rbsm_log_f32", [0.0, np.inf, np.nan, -1.0, 1e-40], np.float32)
+    assert odd[0] == -np.inf and odd[1] == np.inf and np.isnan(odd[2]) and np.isnan(odd[3])
+    assert abs(odd[4] - np.log(np.float64(np.float32(1e-40)))) <= 1e-13
 
 
 def _pixels(n, seed):
