@@ -977,7 +977,7 @@ __global__ void frame_aux_kernel(const float* __restrict__ frame, double* __rest
 // rounded divisions); log in double.  The transcendentals are rbs_math.h's fixed-length binary64
 // sequences (exp to 4e-16 relative, erfc to 1e-16 absolute, log to 1e-16 absolute + its own
 // rounding) instead of ocml's general-purpose exp / erf / log: about 125 VALU instructions per 64
-// pixels instead of 250, no divergent ranges, no scratch.  The float roundings of a and b then
+// pixels instead of 250, no divergent ranges, nothing spilled.  The float roundings of a and b then
 // agree with the oracle's (libm) except where a term lies within ~1e-15 relative of a rounding
 // boundary -- about one pixel in 1e7 -- which tests/ bound (planes: <= 1e-4 of pixels at 1 ulp;
 // log-likelihoods: 1e-9).
@@ -1213,7 +1213,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
         // kScanUnroll quads per lane per trip: all their loads (the parent's values come from HBM --
         // another call wrote them -- and a dependent load per trip left the phase latency bound:
         // 13 % of the kernel) are issued before the first is used
-        // (binary64 likelihood: two quads per trip as well since it fits the budget without scratch:
+        // (binary64 likelihood: two quads per trip as well since it fits the budget without spilling in the loops:
         // raster kernel 0.179 -> 0.175 ms)
         constexpr int kScanUnroll = PREC ? RBS_SCAN_UNROLL : RBS_SCAN_UNROLL_F64;
         for (int q0 = wave * 64; q0 < nq; q0 += kBlock * kScanUnroll) {
@@ -1662,7 +1662,7 @@ void rbs_raster_kernel_f32(const DevParams P)
     raster_kernel_body<UPDATE, 1, SLAB>(P);
 }
 // The same budget for the binary64 likelihood: on rbs_math.h's functions it fits 160 registers
-// without scratch, so the windowed copy kernel runs beside it as well (C1 9.27 -> 9.72 M/s, C2 3.24
+// (a few kernel-lifetime dwords in scratch at most), so the windowed copy kernel runs beside it as well (C1 9.27 -> 9.72 M/s, C2 3.24
 // -> 3.45; ocml's exp / erf / log needed 168 + 72 spilled).  RBS_RASTER_VGPRS_F64=0: no budget.
 #ifndef RBS_RASTER_VGPRS_F64
 #define RBS_RASTER_VGPRS_F64 80
