@@ -2627,6 +2627,21 @@ int32_t rbs_tracker_initialize(rbs_tracker* t, const double* default_state)
     RBT_HIP(t, hipStreamSynchronize(s));
     T.frame = 0;
     for (int k = 0; k < 2; ++k) { t->h_flags[k][2] = 0; t->res_seq[k] = 0; }   // frame numbers start over
+    if (t->s->slab_px && !t->s->group) {
+        // Window-sized slabs: a tracker frame that overflows cannot be repeated, so the slabs are sized
+        // BEFORE the first frame -- one updating probe call of a single particle at the default pose
+        // measures the object's screen rectangle, the housekeeping enlarges the slabs to hold it with
+        // room to move, and the sensor is reset again.  From there on the regions grow a few pixels
+        // per frame and the housekeeping at every frame's result keeps ahead of them.
+        rbs_handle* h = t->s;
+        hipLaunchKernelGGL(rbt::default_pose_kernel, dim3(1), dim3(64), 0, s, T);
+        RBT_HIP(t, hipGetLastError());
+        if (int32_t rc = enqueue_loglikes(h, T.poses, T.idx, 1, true, T.ll_new, s)) return rc;
+        if (int32_t rc = drain(h, true)) return rc;
+        RBT_HIP(t, hipMemcpy(h->h_err, h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost));
+        if (int32_t rc = slab_housekeeping(h)) return rc;
+        if (int32_t rc = rbs_reset(h)) return rc;
+    }
     return RBS_OK;
 }
 

@@ -750,4 +750,17 @@ __global__ void init_kernel(const TrackerDev T)
     for (size_t k = i; k < (size_t)T.n * T.parts * 6; k += (size_t)gridDim.x * blockDim.x) T.noise[k] = 0.0;
 }
 
+// The default pose of every body as particle 0's absolute pose (zero delta): rbs_tracker_initialize's
+// probe call that sizes window-sized slabs before the first frame.
+__global__ void default_pose_kernel(const TrackerDev T)
+{
+    const int bb = threadIdx.x;
+    if (bb >= T.parts) return;
+    double R0[9];
+    rotvec_to_matrix(T.deflt + bb * kBody + 3, R0);
+    double* out = T.poses + (size_t)bb * 12;
+    for (int k = 0; k < 9; ++k) out[k] = R0[k];
+    for (int k = 0; k < 3; ++k) out[9 + k] = T.deflt[bb * kBody + k];
+}
+
 }  // namespace rbt

@@ -123,7 +123,8 @@ typedef struct rbs_config {
      * repaired -- rbs_loglikes_device, a frame of rbs_tracker_*: a region that outgrows its slab by
      * more than a quarter within one such call is contained (log-likelihood NaN, plane reset to the
      * background) and reported once, by the next synchronising call / that frame's result; the slabs
-     * have been enlarged when that call returns. */
+     * have been enlarged when that call returns.  rbs_tracker_initialize sizes the slabs for the object
+     * at its default pose with a probe call, so a tracker does not start on slabs that are too small. */
     int32_t state_slab_px;
     int32_t reserved0;
 } rbs_config;

@@ -323,3 +323,35 @@ def test_a_synchronous_call_reports_an_earlier_asynchronous_overflow(gpu_lib):
             s.set_observation(frame)
         idx = rng.permutation(n).astype(np.int32)
         assert np.array_equal(g.loglikes_poses(near, idx.copy(), update=True), whole.loglikes_poses(near, idx.copy(), update=True))
+
+
+def test_device_tracker_on_slabs_that_start_too_small(gpu_lib):
+    """A tracker frame cannot be repeated, so rbs_tracker_initialize sizes the slabs with a probe call at
+    the default pose, and every frame's result enlarges them ahead of the regions: a slab of 4 096 px
+    -- smaller than the object's own rectangle -- never overflows, and the estimates are those of whole
+    planes, bit for bit, while the object comes closer."""
+    from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
+    n = 400
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
+    rng = np.random.default_rng(3)
+    ests = []
+    for slab in (-1, 4096):
+        with RbSensor(om, cam, P, max_particles=n, slab_px=slab) as s:
+            if not ests:
+                frames = []
+                for k in range(1, 41):
+                    t = synth.truth_pose(1, frame=k)
+                    t[0, 11] -= 0.006 * k                      # 0.7 m -> 0.46 m: the footprint more than doubles
+                    frames.append(synth.make_frame(s.render_depth(t), 480, 640, rng, occluder=False).astype(np.float32))
+                randomness = [(rng.standard_normal((1, n, 6)), rng.random((1, n))) for _ in frames]
+            trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters()).build()
+            tr = DeviceParticleTracker(trans, s, om, ParticleTrackerBuilder.Parameters(evaluation_count=n), np.random.default_rng(5))
+            init = np.zeros(12)
+            Rt = synth.truth_pose(1, frame=0)[0]
+            init[3:6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+            init[0:3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0]
+            tr.initialize([init])
+            ests.append(np.array([tr.track(f, nz, u) for f, (nz, u) in zip(frames, randomness)]))
+            assert tr.n_resamplings >= 1
+            tr.close()
+    assert np.isfinite(ests[1]).all() and np.array_equal(ests[0], ests[1])

@@ -39,6 +39,7 @@ def truth_state(k):
 
 CONFIGS = {"window": dict(state_layout="window"), "dense": dict(state_layout="dense"),
            "slabs": dict(state_layout="window", slab_px=cols * rows // 8),
+           "slabs_growing": dict(state_layout="window", slab_px=4096),     # far too small: the slabs must grow in time
            "shards": dict(state_layout="window", device_ids=[0, 0])}
 
 
@@ -75,7 +76,7 @@ def run(layout):
 
 a = run("window")
 worst = 0.0
-for other in ("dense", "slabs", "shards"):
+for other in ("dense", "slabs", "slabs_growing", "shards"):
     b = run(other)
     d = np.abs(a - b).max(axis=1)
     worst = max(worst, float(d.max()))
