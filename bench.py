@@ -67,6 +67,14 @@ REPEATS = 5                   # the headline is the median of this many timed re
 WORKLOAD_FLAGS = ("particles", "cols", "rows", "mesh", "parents", "update", "sequence", "precision", "layout", "slab_px")
 
 
+# BASELINE.json's configurations as single-GPU workloads (C3 / C4: the 1/8 slice one GPU of the 8 carries)
+PRESETS = {"c1": {}, "c1_readonly": {"update": 0},
+           "c2": {"mesh": "m1,m2,m3", "particles": 6666, "steps": 50},
+           "c3_slice": {"particles": 25000, "steps": 20, "warmup": 3},
+           "c4_slice": {"mesh": "m4", "cols": 1280, "rows": 960, "particles": 6250, "steps": 5, "warmup": 2},
+           "default_res": {"cols": 80, "rows": 60}}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +104,7 @@ def parse():
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the opt-in float32-likelihood comparison run")
     ap.add_argument("--no-host-leg", action="store_true")
     ap.add_argument("--no-tracker-fps", action="store_true")
+    ap.add_argument("--no-configs-leg", action="store_true", help="skip the C2 / C3-slice / C4-slice / read-only / 80x60 runs")
     ap.add_argument("--no-pmc", action="store_true", help="no live rocprofv3 counter passes (roofline falls back to profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -105,15 +114,10 @@ def parse():
                          "without torch.distributed.run; with --gpus 1 the same steps on a plain handle, for comparison)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the process rocprofv3 wraps
     a = ap.parse_args()
-    presets = {"c1": {}, "c1_readonly": {"update": 0},
-               "c2": {"mesh": "m1,m2,m3", "particles": 6666, "steps": 50},
-               "c3_slice": {"particles": 25000, "steps": 20, "warmup": 3},
-               "c4_slice": {"mesh": "m4", "cols": 1280, "rows": 960, "particles": 6250, "steps": 5, "warmup": 2},
-               "default_res": {"cols": 80, "rows": 60}}
-    for k, v in presets.get(a.config, {}).items():
+    for k, v in PRESETS.get(a.config, {}).items():
         setattr(a, k, v)
     if a.quick or a.config not in (None, "c1"):
-        a.no_dense_leg = a.no_f32_leg = a.no_host_leg = a.no_tracker_fps = a.no_cpu_baseline = True
+        a.no_dense_leg = a.no_f32_leg = a.no_host_leg = a.no_tracker_fps = a.no_cpu_baseline = a.no_configs_leg = True
         a.no_pmc = a.no_pmc or a.quick
     return a
 
@@ -233,6 +237,41 @@ def prime(sensor, a, W):
         fill_planes(sensor, a)
     sensor.set_observation(W.frames[0])
     sensor.synchronize()
+
+
+def configs_leg(a, dev, stream, names=("c1_readonly", "c2", "c3_slice", "c4_slice", "default_res")):
+    """The other BASELINE configurations on this GPU, same clock as the headline (inputs resident
+    in HBM, the 30-frame sequence): flat `<config>_value` / `_ms_per_step` / `_raster_kernel_ms` keys."""
+    import copy
+    res = {}
+    for name in names:
+        b = copy.copy(a)
+        for k, v in PRESETS[name].items():
+            setattr(b, k, v)
+        b.steps = max(b.steps, 20) if name != "c1_readonly" and name != "default_res" else 300
+        om, cam, P, n_tri, nb = build_scene(b)
+        W = Workload(b, om, cam, P, nb, dev, 0)
+        d_out = torch.empty(b.particles, dtype=torch.float64, device=dev)
+        s = make_sensor(b, om, cam, P, dev)
+        prime(s, b, W)
+        run = ResidentRun(b, W, s, stream, d_out)
+        el = run.timed(b.steps, max(3, min(b.warmup, 10)))
+        if not np.isfinite(d_out.cpu().numpy()).all():
+            raise SystemExit(f"non-finite log-likelihoods in the {name} leg")
+        raster_ms, copy_ms, _, _ = run.kernel_times(64)
+        s.close()
+        res[f"{name}_value"] = b.particles * b.steps / el
+        res[f"{name}_ms_per_step"] = el / b.steps * 1e3
+        res[f"{name}_raster_kernel_ms"] = raster_ms
+        if b.update:
+            res[f"{name}_copy_kernel_ms"] = copy_ms
+        del W, d_out
+        torch.cuda.empty_cache()
+    res["configs_note"] = ("the same timed loop on BASELINE's other configurations, one GPU, precision " + a.precision + ": c1_readonly = "
+                           "loglikes(update=false); c2 = 6 666 particles x (M1, M2, M3), particle-likelihoods/s (x3 = body renders/s); "
+                           "c3_slice = 25 000 particles (1/8 of C3); c4_slice = 6 250 particles, mesh M4 (50 880 triangles), 1280x960 "
+                           "(1/8 of C4); default_res = C1 at 80x60 (downsampling_factor 8)")
+    return res
 
 
 # --------------------------------------------------------------------------------- PMC child passes
@@ -841,6 +880,8 @@ def main():
         if other == "f32":
             out["f32_note"] = ("opt-in rbs_config.likelihood_precision = F32: float32 likelihood over binary64 geometry; within 1e-5 of the "
                                "reference semantics only for well-conditioned sums, parent indices not reproduced at large particle counts")
+    if single and not a.no_configs_leg and a.config in (None, "c1"):
+        out.update(configs_leg(a, dev, stream))
     # ---- host-pointer API: frame upload + pose upload + log-likelihood download inside the clock
     if single and not a.no_host_leg:
         hs = make_sensor(a, om, cam, P, dev)
