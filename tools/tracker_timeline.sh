@@ -25,4 +25,7 @@ for s, e, name in rows[lo:hi]:
     print("%9.1f us  dur %7.1f  gap %6.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, 0.0 if prev_end is None else (s - prev_end) / 1e3, name))
     prev_end = max(e, prev_end or 0)
 print("frame period: %.1f us" % ((rows[hi][0] - rows[lo][0]) / 4e3))
+with open(out + "/all.txt", "w") as f:   # the whole run, for a look at the other legs (pipelined, host filter)
+    for s, e, name in rows:
+        f.write("%12.1f %8.1f %s\n" % ((s - rows[0][0]) / 1e3, (e - s) / 1e3, name))
 PY
