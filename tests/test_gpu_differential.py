@@ -250,3 +250,32 @@ def test_results_do_not_depend_on_the_raster_grid(gpu_lib, monkeypatch, precisio
     finally:
         for s in sensors:
             s.close()
+
+
+def test_host_frame_sent_in_pieces_arrives_whole(gpu_lib, monkeypatch):
+    """A caller's host frame is staged and sent in pieces while the device is quiet (RBS_UPLOAD_CHUNKS,
+    default 2; floats and doubles take different routes): whatever the number of pieces and wherever
+    their boundaries fall -- frame sizes that are no multiple of the piece granularity included --
+    the observation the device holds is the frame, and the log-likelihoods are those of one piece."""
+    for cols, rows in ((640, 480), (324, 244), (80, 60)):
+        n = 24
+        om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+        truth = synth.truth_pose(1, frame=3)
+        poses = synth.particle_poses(truth, n, np.random.default_rng(4)).reshape(n, 1, 12)
+        runs = {}
+        for chunks in ("1", "2", "3", "16"):
+            monkeypatch.setenv("RBS_UPLOAD_CHUNKS", chunks)      # read when the handle is created
+            rng = np.random.default_rng(5)
+            with RbSensor(om, cam, P, max_particles=n) as s:
+                idx = np.arange(n, dtype=np.int32)
+                lls = []
+                for k in range(6):
+                    frame = rng.uniform(0.4, 1.2, rows * cols).astype(np.float32)
+                    frame[rng.random(frame.size) < 0.03] = np.nan
+                    # (k = 0: nothing has run yet -- one piece; afterwards the synchronous call before it left the device quiet)
+                    s.set_observation(frame if k % 2 == 0 else frame.astype(np.float64))
+                    np.testing.assert_array_equal(s.get_observation(), frame)
+                    lls.append(s.loglikes_poses(poses, idx.copy(), update=True))
+                runs[chunks] = np.stack(lls)
+            assert np.isfinite(runs[chunks]).all()
+            np.testing.assert_array_equal(runs[chunks], runs["1"])
