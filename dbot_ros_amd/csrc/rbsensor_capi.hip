@@ -131,6 +131,8 @@ struct rbs_handle {
     size_t in_idx_off = 0;             // byte offset of the indices inside h_in / d_in
     hipEvent_t ev_out = nullptr;
     float* h_frames[2] = {nullptr, nullptr};   // pinned frame staging, alternating
+    float* h_frames_dev[2] = {nullptr, nullptr};   // ... as the device addresses them
+    size_t frame_pull_bytes = 128 * 1024;      // frames up to this size are read from the staging buffer by a kernel (RBS_FRAME_PULL_BYTES)
     hipEvent_t ev_frame[2] = {nullptr, nullptr};   // the upload out of h_frames[k] into d_fin[k] has finished
     int frame_slot = 0;
     // Host frames travel on their own stream into one of two device staging buffers, and the launch
@@ -152,9 +154,6 @@ struct rbs_handle {
     bool frame_ingest = false;                     // RBS_FRAME_INGEST=1: host frames are copied into d_frame by the ingest kernel
     bool host_copies = false;                      // RBS_HOST_STAGED_COPIES=1: poses / results travel as H2D / D2H copies
     float* h_frame = nullptr;   // = h_frames[frame_slot]
-    float* h_native = nullptr;  // pinned staging for full-resolution frames
-    float* d_native = nullptr;
-    size_t native_cap = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // the copy kernel runs here, beside the raster kernel
     hipEvent_t ev_fork = nullptr;
@@ -770,8 +769,6 @@ void release(rbs_handle* h)
     if (h->h_out) (void)hipHostFree(h->h_out);
     (void)hipFree(h->d_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
-    if (h->h_native) (void)hipHostFree(h->h_native);
-    (void)hipFree(h->d_native);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int i = 0; i < rbs_handle::kRing; ++i) {
         if (h->ev_start[i]) (void)hipEventDestroy(h->ev_start[i]);
@@ -817,6 +814,12 @@ int32_t upload_frame(rbs_handle* h, const float* src, const float* pageable = nu
     if (k == h->cur_slot)
         if (int32_t rc = release_frame_slot(h)) return rc;
     RBS_HIP(h, hipStreamWaitEvent(h->up_stream, h->ev_used[k], 0));   // d_fin[k]: read by the ingest kernel two frames ago
+    // A SMALL frame (the reference's default operating point is 80x60: 19 KB) is not worth a transfer: a copy-engine
+    // job costs ~11 us before it moves a byte and ~9 more until a kernel behind it starts.  The kernel that computes
+    // the frame's model terms reads it where the host staged it (this handle's pinned buffer, over PCIe) and leaves
+    // the observation in d_fin[k] as it goes (precision F32: that copy is all it does).
+    const bool pull = h->frame_pull_bytes > 0 && n * sizeof(float) <= h->frame_pull_bytes && h->h_frames_dev[k] && !h->frame_ingest &&
+                      (pageable || pageable_f64 || src == h->h_frames[k]);
     if (pageable || pageable_f64) {
         float* stage = h->h_frames[k];
         // (a frame of doubles takes the host ~4x as long to stage as a frame of floats: twice the pieces)
@@ -827,12 +830,17 @@ int32_t upload_frame(rbs_handle* h, const float* src, const float* pageable = nu
             const size_t len = std::min(per, n - off);
             if (pageable) std::memcpy(stage + off, pageable + off, len * sizeof(float));
             else for (size_t p = off; p < off + len; ++p) stage[p] = (float)pageable_f64[p];   // dbot hands a vector of doubles
-            RBS_HIP(h, hipMemcpyAsync(h->d_fin[k] + off, stage + off, len * sizeof(float), hipMemcpyHostToDevice, h->up_stream));
+            if (!pull) RBS_HIP(h, hipMemcpyAsync(h->d_fin[k] + off, stage + off, len * sizeof(float), hipMemcpyHostToDevice, h->up_stream));
         }
-    } else {
+    } else if (!pull) {
         RBS_HIP(h, hipMemcpyAsync(h->d_fin[k], src, n * sizeof(float), hipMemcpyHostToDevice, h->up_stream));
     }
-    if (h->d_aux && !h->frame_ingest) {
+    if (pull) {
+        hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->up_stream,
+                           h->h_frames_dev[k], h->d_aux ? h->d_aux_slot[k] : (double*)nullptr, h->d_pbg, h->npx, h->base.tw,
+                           h->base.ms, h->base.sf, h->base.lambda, h->d_fin[k]);
+        RBS_HIP(h, hipGetLastError());
+    } else if (h->d_aux && !h->frame_ingest) {
         // precision F64: the frame's per-pixel model terms are computed right behind the copy, on the
         // upload stream, into the slot's own table -- the launch stream does not wait for the frame
         // until the raster kernel needs it, so a caller's transition and the rectangles kernel run
@@ -1337,10 +1345,12 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         B.vtx = reinterpret_cast<const rbs::floatx4*>(h->d_vtx);
     }
     if (const char* e = std::getenv("RBS_FRAME_INGEST")) h->frame_ingest = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RBS_FRAME_PULL_BYTES")) h->frame_pull_bytes = (size_t)std::max(0L, std::atol(e));
     if (const char* e = std::getenv("RBS_HOST_STAGED_COPIES")) h->host_copies = std::atoi(e) != 0;
     RBS_HIP(h, hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k) {
         RBS_HIP(h, hipHostMalloc(&h->h_frames[k], plane, hipHostMallocPortable));   // (every device of a group uploads from shard 0's)
+        if (hipHostGetDevicePointer((void**)&h->h_frames_dev[k], h->h_frames[k], 0) != hipSuccess) { (void)hipGetLastError(); h->h_frames_dev[k] = nullptr; }
         RBS_HIP(h, hipEventCreateWithFlags(&h->ev_frame[k], hipEventDisableTiming));
         RBS_HIP(h, hipEventCreateWithFlags(&h->ev_used[k], hipEventDisableTiming));
         if (k == 0) RBS_HIP(h, hipEventCreateWithFlags(&h->ev_reader, hipEventDisableTiming));
@@ -2039,26 +2049,20 @@ int32_t rbs_set_observation_native_f32(rbs_handle* h, const float* native, int32
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
                     fmt("set_observation_native: %dx%d / %d does not give the evaluated %dx%d", width,
                         height, f, h->cols, h->rows));
+    if (f == 1) return rbs_set_observation_f32(h, native, (size_t)h->npx);
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
-    RBS_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer reuse
-    if (int32_t rc = release_frame_slot(h)) return rc;
-    const size_t n = (size_t)width * height;
-    if (n > h->native_cap) {
-        if (h->h_native) (void)hipHostFree(h->h_native);
-        (void)hipFree(h->d_native);
-        h->h_native = nullptr; h->d_native = nullptr; h->native_cap = 0;
-        RBS_HIP(h, hipHostMalloc(&h->h_native, n * sizeof(float), hipHostMallocDefault));
-        RBS_HIP(h, hipMalloc(&h->d_native, n * sizeof(float)));
-        h->native_cap = n;
+    if (int32_t rc = next_frame_staging(h)) return rc;
+    // The reference's rule (R:source/dbot_ros/util/ros_interface.h:152-168): evaluated(r, c) =
+    // native(r f, c f) -- applied while the frame is staged, so that only the rows*cols values the
+    // sensor evaluates are copied and sent (1/f^2 of the driver's frame: 19 KB of 1.2 MB at the
+    // reference's default factor 8) and the frame then travels like any other host frame.
+    for (int r = 0; r < h->rows; ++r) {
+        const float* src = native + (size_t)r * f * width;
+        float* dst = h->h_frame + (size_t)r * h->cols;
+        for (int c = 0; c < h->cols; ++c) dst[c] = src[(size_t)c * f];
     }
-    std::memcpy(h->h_native, native, n * sizeof(float));
-    RBS_HIP(h, hipMemcpyAsync(h->d_native, h->h_native, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(rbs::rbs_subsample_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0,
-                       h->stream, h->d_native, width, f, h->d_frame, h->rows, h->cols);
-    RBS_HIP(h, hipGetLastError());
-    h->lazy_frame = h->d_frame;   // per-pixel terms: with the next loglikes launch
-    h->lazy_stream = h->stream;
+    if (int32_t rc = upload_frame(h, h->h_frame)) return rc;
     h->pending_frames += 1;
     return RBS_OK;
 }

@@ -1947,16 +1947,6 @@ __global__ __launch_bounds__(kBlock) void rbs_render_kernel(const DevParams P, f
         }
 }
 
-// eval(row, col) = native(row*f, col*f)  (ri::to_eigen_vector's sub-sampling rule)
-__global__ void rbs_subsample_kernel(const float* __restrict__ native, int native_w, int f,
-                                     float* __restrict__ out, int rows, int cols)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cols) return;
-    const int r = i / cols, c = i - r * cols;
-    out[i] = native[(size_t)(r * f) * native_w + (size_t)c * f];
-}
-
 __global__ void rbs_fill_kernel(float* __restrict__ p, size_t n, float v)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
