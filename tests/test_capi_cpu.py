@@ -148,3 +148,54 @@ def test_register_budgets_the_kernels_overlap_depends_on():
                  "rbs_raster_kernel_f64ILb0ELb1EE"):
         vgprs, spills = usage(name)        # precision F64 (the default): the same budget; a kernel-lifetime value or two
         assert vgprs <= 160 and spills <= 4, (name, vgprs, spills)   # parked in scratch at most (ocml's functions spilled 72)
+
+
+def test_create_survives_arbitrary_configs():
+    """rbs_create on arbitrary field values (negative / huge sizes, NaN and infinite parameters, null
+    and valid mesh pointers, bad enums, device lists): an error code and a message, or -- with a GPU --
+    a handle that is destroyed again; never a crash, never a handle behind an error."""
+    lib = _capi.load()
+    rng = np.random.default_rng(11)
+    verts = np.array([[0, 0, 0], [0.1, 0, 0], [0, 0.1, 0], [0, 0, 0.1]], dtype=np.float64)
+    tris = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]], dtype=np.int32)
+    vc = (C.c_int32 * 1)(4)
+    tc = (C.c_int32 * 1)(4)
+    ids = (C.c_int32 * 4)(0, 0, 7, -1)
+    weird_f = [0.0, -1.0, 1.0, 0.5, 1e-300, 1e300, float("nan"), float("inf"), -float("inf"), 0.1, 0.7, 1 / 30]
+    weird_i = [0, 1, -1, 2, 3, 4, 60, 80, 640, 8193, 2 ** 31 - 1, -2 ** 31]
+    outcomes = set()
+    for _ in range(400):
+        cfg = _capi.RbsConfig()
+        cfg.abi_version = _capi.RBS_ABI_VERSION if rng.random() < 0.9 else int(rng.choice(weird_i))
+        cfg.device_id = int(rng.choice([0, 0, 0, -1, 99]))
+        cfg.rows = int(rng.choice([60, 60, 48, 0, -3, 9000]))
+        cfg.cols = int(rng.choice([80, 80, 64, 0, -3, 9000, 81]))
+        K = [70.0, 0, 40.0, 0, 70.0, 30.0, 0, 0, 1.0]
+        if rng.random() < 0.3:
+            K[int(rng.integers(9))] = float(rng.choice(weird_f))
+        cfg.K = (C.c_double * 9)(*K)
+        cfg.max_particles = int(rng.choice([4, 4, 1, 0, -1, 2 ** 31 - 1]))
+        cfg.n_objects = int(rng.choice([1, 1, 1, 0, -1, 17]))
+        if rng.random() < 0.85:
+            cfg.vertices = verts.ctypes.data_as(C.POINTER(C.c_double))
+            cfg.vertex_counts = vc
+            cfg.triangles = tris.ctypes.data_as(C.POINTER(C.c_int32))
+            cfg.triangle_counts = tc
+        for name, good in (("p_occluded_visible", 0.1), ("p_occluded_occluded", 0.7), ("initial_occlusion_prob", 0.1),
+                           ("tail_weight", 0.01), ("model_sigma", 0.003), ("sigma_factor", 0.0014247), ("delta_time", 1 / 30)):
+            setattr(cfg, name, good if rng.random() < 0.85 else float(rng.choice(weird_f)))
+        cfg.likelihood_precision = int(rng.choice([0, 1, 2, 3, -1]))
+        cfg.state_layout = int(rng.choice([0, 1, 2, 3, -1]))
+        cfg.n_devices = int(rng.choice([0, 0, 1, 2, 4, 9, -1]))
+        cfg.device_ids = ids if rng.random() < 0.5 else None
+        cfg.state_slab_px = int(rng.choice([0, 0, -1, 16, 4800, -7, 2 ** 31 - 1]))
+        h = C.c_void_p()
+        rc = lib.rbs_create(C.byref(cfg), C.byref(h))
+        outcomes.add(rc)
+        if rc == _capi.RBS_OK:
+            assert h.value
+            lib.rbs_destroy(h)
+        else:
+            assert rc < 0 and not h.value, (rc, h.value)
+            assert lib.rbs_last_error(None), rc
+    assert _capi.RBS_ERR_INVALID_ARGUMENT in outcomes
