@@ -375,9 +375,12 @@ __device__ inline void publish_result(const TrackerDev& T)
     __syncthreads();
     for (int k = threadIdx.x; k < T.D; k += blockDim.x) T.host_state[k] = T.deflt[k];
     if (threadIdx.x < 2) T.host_flags[threadIdx.x] = T.flag[threadIdx.x];
-    // ... and the frame's number behind them (system-scope release): the host may take the estimate
-    // as soon as it sees the number, without waiting for this kernel's completion to be signalled
-    __threadfence_system();
+    // ... and the frame's number behind them: the host may take the estimate as soon as it sees the
+    // number, without waiting for this kernel's completion to be signalled.  The block's stores are
+    // ordered before thread 0 by the barrier (workgroup scope) and before the number by thread 0's
+    // system-scope release (cumulative) -- ONE wave writes the L2 back, not all sixteen (a system
+    // fence per thread here cost the kernel several microseconds behind a raster kernel's dirty L2)
+    __threadfence_block();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(T.host_flags + 2, (int)(T.frame + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
