@@ -594,12 +594,17 @@ def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30, precisi
                 init[12 * b + 3:12 * b + 6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
                 init[12 * b:12 * b + 3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[b]
             out["_native"] = (frames, init.copy())
-            tr.initialize([init])
-            tr.track(frames[0])  # warm-up
-            t0 = time.perf_counter()
-            for k in range(1, n_frames + 1):
-                est = tr.track(frames[k])
-            dt = time.perf_counter() - t0
+            # the median of three passes over the sequence (a pass is 6 ms at 200 particles: one pass alone
+            # moved by 25 % with whatever else the host was doing)
+            dts = []
+            for _rep in range(3):
+                tr.initialize([init])
+                tr.track(frames[0])  # warm-up
+                t0 = time.perf_counter()
+                for k in range(1, n_frames + 1):
+                    est = tr.track(frames[k])
+                dts.append(time.perf_counter() - t0)
+            dt = float(np.median(dts))
             Rt = synth.truth_pose(nb, frame=n_frames)[0]
             err = float(np.linalg.norm(est[0:3] - (Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0])))
             out[n] = {"fps": n_frames / dt, "ms_per_frame": dt / n_frames * 1e3, "resamplings": tr.n_resamplings,
@@ -607,15 +612,18 @@ def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30, precisi
             # the same sequence with one frame of look-ahead (rbs_tracker_submit / _result): frame k+1's
             # host copy and upload run beside frame k's kernels -- dataset replay, or a camera
             # ahead of its consumer
-            tr.initialize([init])
-            tr.track(frames[0])
-            t0 = time.perf_counter()
-            tr.submit(frames[1])
-            for k in range(2, n_frames + 1):
-                tr.submit(frames[k])
-                tr.result()
-            est2 = tr.result()
-            dt = time.perf_counter() - t0
+            dts = []
+            for _rep in range(3):
+                tr.initialize([init])
+                tr.track(frames[0])
+                t0 = time.perf_counter()
+                tr.submit(frames[1])
+                for k in range(2, n_frames + 1):
+                    tr.submit(frames[k])
+                    tr.result()
+                est2 = tr.result()
+                dts.append(time.perf_counter() - t0)
+            dt = float(np.median(dts))
             out[n]["fps_pipelined"] = n_frames / dt
             out[n]["pipelined_equals_synchronous"] = bool(np.array_equal(est, est2))
             tr.close()
