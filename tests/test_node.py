@@ -69,6 +69,38 @@ def test_rosparam_tree_and_subsampling(tmp_path):
     assert sub.shape == (60 * 80,) and sub[1] == img[0, 8] and sub[80] == img[8, 0]
 
 
+REFERENCE_CONFIG = "/root/reference/config"
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REFERENCE_CONFIG),
+                    reason="the reference's own config files exist only in the build container (never on the GPU box)")
+def test_the_references_own_yaml_files_parse_unchanged():
+    """SURVEY 8b "rosparam keys must keep working verbatim": the files the reference's launch file loads
+    (R:launch/particle_tracker.launch:13-15 -> R:config/particle_tracker.yaml, camera.yaml, object.yaml),
+    read where they lie, give every parameter object of the node assembly its values -- no key renamed,
+    none missing.  (Values below are the reference's shipped defaults.)"""
+    import os
+    from dbot_ros_amd import CameraData, RbSensorBuilder
+    from dbot_ros_amd.tracker import ObjectTransitionBuilder, ParticleTrackerBuilder
+    tree = node.load_rosparams(*(os.path.join(REFERENCE_CONFIG, f) for f in ("particle_tracker.yaml", "camera.yaml", "object.yaml")))
+    ps = RbSensorBuilder.Parameters.from_rosparam(tree)
+    assert ps.use_gpu is True and ps.sample_count == tree["particle_filter"]["gpu"]["sample_count"] == 2000
+    assert (ps.occlusion.p_occluded_visible, ps.occlusion.p_occluded_occluded, ps.occlusion.initial_occlusion_prob) == (0.1, 0.7, 0.1)
+    assert (ps.kinect.tail_weight, ps.kinect.model_sigma, ps.kinect.sigma_factor) == (0.01, 0.003, 0.0014247)
+    assert ps.use_custom_shaders is False and ps.geometry_shader_file == "none"      # accepted and ignored
+    tree["particle_filter"]["use_gpu"] = False
+    assert RbSensorBuilder.Parameters.from_rosparam(tree).sample_count == tree["particle_filter"]["cpu"]["sample_count"]
+    pt = ObjectTransitionBuilder.Parameters.from_rosparam(tree, part_count=len(tree["object"]["meshes"]))
+    assert (pt.linear_sigma_x, pt.angular_sigma_z, pt.velocity_factor) == (0.0025, 0.02, tree["particle_filter"]["object_transition"]["velocity_factor"])
+    pk = ParticleTrackerBuilder.Parameters.from_rosparam(tree, ps.sample_count)
+    assert pk.evaluation_count == 2000 and pk.max_kl_divergence == tree["particle_filter"]["max_kl_divergence"]
+    assert pk.center_object_frame is True and pk.moving_average_update_rate == 1.0
+    f = int(tree["downsampling_factor"])
+    cam = CameraData.from_native(synth.camera_matrix(640, 480), int(tree["resolution"]["width"]), int(tree["resolution"]["height"]), f)
+    assert f == 8 and (cam.cols, cam.rows) == (80, 60)
+    assert tree["object"]["package"] and tree["object"]["directory"] and len(tree["object"]["meshes"]) >= 1
+
+
 @pytest.mark.gpu
 def test_node_assembly_tracks_at_the_reference_operating_point(tmp_path, gpu_lib):
     paths = _write(tmp_path)
