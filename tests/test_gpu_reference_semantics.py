@@ -1,0 +1,243 @@
+"""Reference-semantics parity at BASELINE sizes: the HIP path against the LAZY oracle.
+
+The reference CPU model (use_gpu:false, R:source/dbot_ros/tracker/particle_tracker_node.cpp:165) keeps
+a per-pixel time stamp and propagates a pixel's occlusion by its own elapsed time in double
+(constants R:...particle_tracker_node.cpp:176-189, delta_time :189) -- the oracle's
+LAZY mode.  The device advances every stored value on every updating call with one float FMA and
+snaps values within 2^-18 of the never-covered level onto it (the oracle's EAGER mode, DESIGN ledger
+L8 / L9).  The other full-size tests compare with the EAGER oracle (to 1e-9); the tests here hold the
+device to north_star's bar against the LAZY one, at the sizes BASELINE.json names:
+
+  * every particle of C1 (2 000, 640x480, M1) on every frame of a 30-frame tracked sequence with
+    KL-triggered multinomial resampling:  |d ll| <= 1e-5 max(1, |ll|);
+  * the PARENT INDICES each resampling of that sequence draws from the device's log-likelihoods
+    against those it draws from the LAZY oracle's, same uniforms, same history (after counting, both
+    sides continue with the oracle's parents, so every resampling is compared on identical inputs):
+    the number of children whose parent differs is printed and bounded, and every such child must be
+    a uniform within 1e-7 of a step of the cumulative weights (it drew the neighbouring parent, parents
+    of weight ~0 aside);
+  * the same at 20 000 particles (the reference's default 80x60 operating point, where the CPU
+    oracle can follow 20 000 particles);
+  * the device's occlusion planes after the 30 frames against orc_get_occlusion_now (LAZY);
+  * C1 (all 2 000) and C2 (a random 1 000 of 6 666 x 3 bodies) in the two-frame full-size harness of
+    test_gpu_fullsize.py with the LAZY oracle as the checker;
+  * rbs_tracker_* at 20 000 particles against oracle/tracker_oracle.c over the LAZY sensor.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scenarios as sc
+from dbot_ros_amd import RbSensor, filter as flt, pose, synth
+from dbot_ros_amd.pose import pack_Rt, rotvec_to_matrix
+
+pytestmark = pytest.mark.gpu
+
+TOL_LAZY = 1e-5          # north_star: "within 1e-5 float tolerance"
+CDF_DELTA = 1e-7         # a child whose parent differs drew a uniform this close to a cdf step
+PLANE_TOL = 6e-6         # |device plane - LAZY plane "as of now"|: the snap (2^-18 = 3.8e-6, once) + float steps
+
+
+def rel_err(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+def _poses_around(truth, dl, da):
+    """Particles at R = R(da) R_truth, t = t_truth + dl (one body)."""
+    truth = np.asarray(truth).reshape(-1, 12)
+    R0 = truth[:, :9].reshape(1, 3, 3)
+    return pack_Rt(rotvec_to_matrix(da[:, None, :]) @ R0[None], truth[None, :, 9:12] + dl[:, None, :])
+
+
+def _lockstep(meshes, cols, rows, n, n_frames, seed, plane_slots):
+    """The filter step (log-weights, KL test, multinomial resampling from host-supplied uniforms:
+    dbot_ros_amd/filter.py) driven twice on identical inputs: once from the device's
+    log-likelihoods, once from the LAZY oracle's.  Particles are a random walk around the moving
+    ground truth and are inherited by the children.  Returns per-resampling mismatch counts, the worst
+    log-likelihood error and the worst plane difference."""
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    lazy = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
+    threads = sc.usable_threads()
+    rng = np.random.default_rng(seed)
+    dl = rng.normal(0.0, 0.0025, size=(n, 3))
+    da = rng.normal(0.0, 0.02, size=(n, 3))
+    idx_g, idx_o = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    logw = [np.zeros(n), np.zeros(n)]     # device, oracle
+    ll_prev = [np.zeros(n), np.zeros(n)]
+    mismatches, worst_ll, n_children = [], 0.0, 0
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        g.reset()
+        lazy.reset(threads=threads)
+        for k in range(n_frames):
+            truth = synth.truth_pose(1, frame=k)
+            frame = synth.make_frame(lazy.render_depth(truth), rows, cols, rng)
+            poses = _poses_around(truth, dl, da)
+            g.set_observation(frame)
+            lazy.set_observation(frame)
+            ll = [g.loglikes_poses(poses, idx_g, update=True),
+                  lazy.loglikes_poses(poses, idx_o, update=True, threads=threads)]
+            e = rel_err(ll[0], ll[1])
+            assert e.max() <= TOL_LAZY, (k, int(e.argmax()), float(e.max()))      # EVERY particle
+            worst_ll = max(worst_ll, float(e.max()))
+            w, kl = [], []
+            for s in range(2):
+                logw[s] += ll[s] - ll_prev[s]
+                ll_prev[s] = ll[s]
+                w.append(flt.normalized_weights(logw[s]))
+                kl.append(flt.kl_to_uniform(w[s]))
+            assert (kl[0] > 2.0) == (kl[1] > 2.0), (k, kl)
+            if kl[1] > 2.0:
+                u = rng.random(n)
+                pg, po = flt.multinomial_resample(w[0], u), flt.multinomial_resample(w[1], u)
+                bad = np.nonzero(pg != po)[0]
+                mismatches.append(len(bad))
+                n_children += n
+                if len(bad):
+                    # each one drew a uniform within CDF_DELTA of the cumulative weights of EVERY parent between
+                    # the two answers (neighbours, or neighbours but for parents of weight ~0 between them)
+                    c = np.cumsum(w[1])
+                    c /= c[-1]
+                    a, b = np.minimum(pg[bad], po[bad]), np.maximum(pg[bad], po[bad])
+                    worst = np.maximum(np.abs(u[bad] - c[a]), np.abs(u[bad] - c[b - 1]))
+                    assert (worst <= CDF_DELTA).all(), (k, pg[bad], po[bad], worst)
+                # both sides continue with the REFERENCE-semantics parents: identical histories
+                dl, da = dl[po], da[po]
+                idx_g, idx_o = po.copy(), po.copy()
+                for s in range(2):
+                    ll_prev[s] = ll_prev[s][po]
+                    logw[s] = np.zeros(n)
+            dl = 0.8 * dl + rng.normal(0.0, 0.0025, size=(n, 3))
+            da = 0.8 * da + rng.normal(0.0, 0.02, size=(n, 3))
+        # the planes the next frame would start from: device (stored, eager) against LAZY "as of now"
+        worst_plane, n_diff = 0.0, 0
+        for slot in rng.choice(n, size=min(plane_slots, n), replace=False):
+            d = np.abs(g.get_occlusion(int(slot)) - lazy.get_occlusion(int(slot), now=True))
+            worst_plane = max(worst_plane, float(d.max()))
+            n_diff += int((d > 1e-6).sum())
+    lazy.close()
+    return mismatches, n_children, worst_ll, worst_plane, n_diff
+
+
+def test_c1_sequence_every_particle_and_parents_vs_lazy_oracle(gpu_lib):
+    """BASELINE C1 (2 000 particles, M1, 640x480), 30 frames."""
+    mism, children, worst_ll, worst_plane, n_diff = _lockstep(("m1",), 640, 480, 2000, 30, seed=41, plane_slots=200)
+    print(f"\nC1 vs LAZY oracle: worst |d ll| / max(1,|ll|) = {worst_ll:.3e}; {len(mism)} resamplings, "
+          f"parent mismatches per resampling {mism} = {sum(mism)} of {children} children; "
+          f"planes: worst |d| = {worst_plane:.3e}, {n_diff} pixels above 1e-6 in 200 planes")
+    assert len(mism) >= 5
+    # measured (round 4): 0 of 60 000 children over 30 resamplings
+    assert max(mism) <= 2 and sum(mism) <= max(2, children // 10000), mism
+    assert worst_plane <= PLANE_TOL, worst_plane
+
+
+def test_20000_particles_parents_vs_lazy_oracle(gpu_lib):
+    """20 000 particles at the reference's default 80x60 (R:config/camera.yaml: downsampling 8), 30 frames."""
+    mism, children, worst_ll, worst_plane, n_diff = _lockstep(("m1_l2",), 80, 60, 20000, 30, seed=43, plane_slots=500)
+    print(f"\n20 000 particles vs LAZY oracle: worst |d ll| / max(1,|ll|) = {worst_ll:.3e}; {len(mism)} resamplings, "
+          f"parent mismatches per resampling {mism} = {sum(mism)} of {children} children; "
+          f"planes: worst |d| = {worst_plane:.3e}, {n_diff} pixels above 1e-6 in 500 planes")
+    assert len(mism) >= 5
+    # measured (round 4): 16 of 600 000 children over 30 resamplings, at most 5 in one
+    assert max(mism) <= 12 and sum(mism) <= children // 10000, mism
+    assert worst_plane <= PLANE_TOL, worst_plane
+
+
+def _two_frames(meshes, cols, rows, n, k_oracle, blocks_readonly, chunk):
+    """test_gpu_fullsize._full_size_case's two-frame run with the LAZY oracle as the checker."""
+    nb = len(meshes)
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    render = ob.Oracle(om, cam, P, max_particles=1, mode=ob.LAZY)
+    rng = np.random.default_rng(21)
+    truth = synth.truth_pose(nb)
+    frame = synth.make_frame(render.render_depth(truth), rows, cols, rng)
+    render.close()
+    poses = synth.particle_poses(truth, n, rng, scale=2.0)
+    with RbSensor(om, cam, P, max_particles=n) as g:
+        g.reset()
+        g.set_observation(frame)
+        idx = np.zeros(n, np.int32)
+        out = [g.loglikes_poses(poses, idx.copy(), update=False) for _ in range(blocks_readonly)]
+        out.append(g.loglikes_poses(poses, idx, update=True))
+        g.set_observation(frame)
+        out.append(g.loglikes_poses(poses, np.arange(n, dtype=np.int32), update=True))
+    sel = np.arange(n) if k_oracle >= n else np.sort(rng.choice(n, size=k_oracle, replace=False))
+    threads = sc.usable_threads()
+    worst = 0.0
+    for lo in range(0, len(sel), chunk):
+        part = sel[lo:lo + chunk]
+        k = len(part)
+        orc = ob.Oracle(om, cam, P, max_particles=k, mode=ob.LAZY)
+        orc.reset(threads=threads)
+        orc.set_observation(frame)
+        io = np.zeros(k, np.int32)
+        r = [orc.loglikes_poses(poses[part], io.copy(), update=False, threads=threads) for _ in range(blocks_readonly)]
+        r.append(orc.loglikes_poses(poses[part], io, update=True, threads=threads))
+        orc.set_observation(frame)
+        r.append(orc.loglikes_poses(poses[part], np.arange(k, dtype=np.int32), update=True, threads=threads))
+        orc.close()
+        for x, y in zip(out, r):
+            e = rel_err(x[part], y)
+            assert e.max() <= TOL_LAZY, float(e.max())
+            worst = max(worst, float(e.max()))
+    return worst
+
+
+def test_c1_full_size_every_particle_vs_lazy_oracle(gpu_lib):
+    worst = _two_frames(("m1",), 640, 480, 2000, 2000, 0, 500)
+    print(f"\nC1, all 2 000 particles vs LAZY oracle: {worst:.3e}")
+
+
+def test_c2_full_size_random_1000_vs_lazy_oracle(gpu_lib):
+    """BASELINE C2: 6 666 particles x meshes [M1, M2, M3] (R:config/object.yaml:3-5 lists several meshes),
+    two read-only blocks and the updating one per frame; a random 1 000 against the LAZY oracle."""
+    worst = _two_frames(("m1", "m2", "m3"), 640, 480, 6666, 1000, 2, 500)
+    print(f"\nC2, a random 1 000 particles vs LAZY oracle: {worst:.3e}")
+
+
+def test_device_tracker_20000_particles_vs_lazy_oracle_tracker(gpu_lib):
+    """rbs_tracker_* (default precision F64) at 20 000 particles against oracle/tracker_oracle.c over
+    the LAZY (reference-semantics) sensor, same host-supplied randomness.  As long as every earlier
+    resampling drew identical parents the two runs have identical histories and the parents of the
+    next one are compared child by child (count printed and bounded); after a first difference -- one
+    child with the neighbouring parent shifts every later cumulative weight by ~1/n, so indices stop
+    being comparable -- the estimates are only held to the spread of the particle cloud (2e-3: the two
+    runs are then two draws of the same filter); before it, to 1e-6."""
+    from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
+    n, cols, rows = 20000, 80, 60
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    tp = ParticleTrackerBuilder.Parameters(evaluation_count=n, center_object_frame=False)
+    orc = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
+    trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters()).build()
+    ref = ob.OracleTracker(orc, n, trans.sigma, trans.vf, tp.max_kl_divergence)
+    init = np.zeros(12)
+    Rt = synth.truth_pose(1, frame=0)[0]
+    init[3:6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+    init[0:3] = Rt[9:]
+    counts, same_history, worst = [], True, [0.0, 0.0]
+    with RbSensor(om, cam, P, max_particles=n) as s:
+        dev = DeviceParticleTracker(trans, s, om, tp, np.random.default_rng(2))
+        dev.initialize([init])
+        ref.initialize(init)
+        rng = np.random.default_rng(10)
+        nres_prev = 0
+        for k in range(1, 9):
+            frame = synth.make_frame(orc.render_depth(synth.truth_pose(1, frame=k)), rows, cols, rng, occluder=False)
+            normals, uniforms = dev.draw_randomness()
+            ed = dev.track(frame, normals, uniforms)
+            er, nres = ref.track(frame, normals, uniforms)
+            assert dev.n_resamplings == nres, (k, dev.n_resamplings, nres)
+            err = float(np.abs(ed - er).max())
+            if same_history and nres > nres_prev:
+                _, _, idd = dev.get_state()
+                _, _, idr = ref.get_state()
+                bad = int((idd != idr).sum())
+                counts.append(bad)
+                same_history = bad == 0
+            worst[0 if same_history else 1] = max(worst[0 if same_history else 1], err)
+            assert err <= (1e-6 if same_history else 2e-3), (k, same_history, err)
+            nres_prev = nres
+        dev.close()
+    print(f"\ndevice tracker vs LAZY oracle tracker, 20 000 particles: parent mismatches per resampling "
+          f"(identical histories up to the first difference) {counts}; estimates differ by <= {worst[0]:.2e} "
+          f"up to it, <= {worst[1]:.2e} after")
+    assert len(counts) >= 1 and max(counts) <= 12, counts
