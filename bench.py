@@ -55,14 +55,22 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-# VALU issue ceilings of this chip, MEASURED (tools/valu_bench.hip, profiles/r03_valu_issue_microbench.txt:
-# chip-wide G wave64-instructions/s with 3 waves per SIMD, the raster kernel's occupancy): a binary64
-# add / mul / fma issues at 0.62x the rate of a float32 / integer instruction, a binary64 transcendental
-# (v_rcp_f64: every division) at 0.19x.  Round 2 priced every instruction at 614.4 G/s (4 cycles at
-# 2.4 GHz): too high for the binary64 half of this kernel, too low for the rest.
-VALU_PEAK_F32_GINST = 735.0
-VALU_PEAK_F64_GINST = 454.0
-VALU_PEAK_TRANS_F64_GINST = 142.0
+# VALU issue ceilings of this chip in G wave64-instructions/s, chip-wide (1 024 SIMDs).
+# MEASURED (tools/valu_bench.hip, profiles/r04_valu_issue_microbench.txt: kernels of 6-55 ms, every block's
+# start / end and cycle count logged, 1..8 waves per SIMD; wall-clock rates cross-checked against the chip's own
+# counters, SQ_INSTS_VALU / (SQ_BUSY_CYCLES / 32 / clock): profiles/r04_valu_issue_pmc.txt, profiles/README.md):
+# the rates SATURATE at -- float32 / integer add 1 000-1 023 (v_fma_f32 868-1 074), binary64 add / mul / fma / min
+# 576-592, v_rcp_f64 (every division) 151.  (Round 3 quoted 735 / 454 / 142 from 60-180 us kernels whose launch and
+# ramp were a sixth of the measurement.)  The SIMD issues its OLDEST wave first: pure-VALU waves finish staggered,
+# which is why round 3's per-wave cycle counts did not add up to the wall clock.
+VALU_PEAK_F32_GINST = 1020.0
+VALU_PEAK_F64_GINST = 590.0
+VALU_PEAK_TRANS_F64_GINST = 151.0
+# The guide's figures (MI355X_MICROARCH.md, per-instruction cycle constants): v_fma_f32 wave64 = 2 cycles per SIMD,
+# binary64 at half rate = 4, at 2.4 GHz; a binary64 transcendental holds the pipe 16 cycles (measured, above).
+GUIDE_PEAK_F32_GINST = 1024 * 2.4 / 2.0      # 1 228.8
+GUIDE_PEAK_F64_GINST = 1024 * 2.4 / 4.0      # 614.4
+GUIDE_PEAK_TRANS_F64_GINST = 1024 * 2.4 / 16.0   # 153.6
 REPEATS = 5                   # the headline is the median of this many timed regions of --steps steps each
 WORKLOAD_FLAGS = ("particles", "cols", "rows", "mesh", "parents", "update", "sequence", "precision", "layout", "slab_px")
 
@@ -361,7 +369,7 @@ def roofline_for(a, n, raster_ms, copy_ms, alg_bytes, copy_dominant, live):
                 "traffic": copy_traffic, "kernel": copy_kernel, "kernel_ms": copy_ms}
     else:
         ginst = (valu / (raster_ms * 1e-3) / 1e9) if valu else None
-        peak = frac = f64_share = None
+        peak = frac = f64_share = peak_guide = n64 = ntr = None
         if valu and "SQ_INSTS_VALU_FMA_F64" in rmix:
             n64 = rmix["SQ_INSTS_VALU_FMA_F64"] + rmix.get("SQ_INSTS_VALU_MUL_F64", 0.0) + rmix.get("SQ_INSTS_VALU_ADD_F64", 0.0)
             ntr = rmix.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
@@ -369,10 +377,17 @@ def roofline_for(a, n, raster_ms, copy_ms, alg_bytes, copy_dominant, live):
             t_min = (n64 / VALU_PEAK_F64_GINST + ntr / VALU_PEAK_TRANS_F64_GINST + rest / VALU_PEAK_F32_GINST) / 1e9   # s: nothing but issue
             peak = valu / t_min / 1e9
             frac = ginst / peak
+            t_guide = (n64 / GUIDE_PEAK_F64_GINST + ntr / GUIDE_PEAK_TRANS_F64_GINST + rest / GUIDE_PEAK_F32_GINST) / 1e9
+            peak_guide = valu / t_guide / 1e9
             f64_share = (n64 + ntr) / valu
         roof = {"bound": "valu_issue", "achieved": ginst, "peak": peak, "unit": "G wave-instructions/s", "frac": frac,
-                "peak_note": "issue ceiling of THIS kernel's instruction mix from measured per-class rates (binary64 454, binary64 "
-                             "transcendental 142, other 735 G wave-instructions/s: profiles/r03_valu_issue_microbench.txt)",
+                "peak_note": "issue ceiling of THIS kernel's instruction mix from MEASURED saturated per-class rates (binary64 590, binary64 "
+                             "transcendental 151, other 1 020 G wave-instructions/s: profiles/r04_valu_issue_microbench.txt)",
+                "peak_guide": peak_guide, "frac_vs_guide_peak": (ginst / peak_guide) if (ginst and peak_guide) else None,
+                "peak_guide_note": "the same mix at the guide's issue costs: 2 cycles float32 / integer, 4 binary64, 16 binary64 transcendental, "
+                                   "wave64 at 2.4 GHz x 1 024 SIMDs (MI355X_MICROARCH.md)",
+                "valu_instr_f64": (n64 if valu and "SQ_INSTS_VALU_FMA_F64" in rmix else None),
+                "valu_instr_trans_f64": (ntr if valu and "SQ_INSTS_VALU_FMA_F64" in rmix else None),
                 "traffic": raster_traffic, "kernel": "rbs_raster_kernel", "kernel_ms": raster_ms,
                 "f64_share_of_valu_instructions": f64_share,
                 "valu_wave_instructions_per_launch": valu,

@@ -18,6 +18,7 @@ RBS_ERR_NO_DEVICE = -2
 RBS_ERR_OUT_OF_MEMORY = -3
 RBS_ERR_HIP = -4
 RBS_ERR_UNSUPPORTED = -5
+RBS_IPC_BLOB_BYTES = 512
 RBS_PRECISION_DEFAULT, RBS_PRECISION_F64, RBS_PRECISION_F32 = 0, 1, 2
 RBS_STATE_DEFAULT, RBS_STATE_WINDOWED, RBS_STATE_DENSE = 0, 1, 2
 PRECISIONS = {None: 0, "default": 0, "f64": 1, "f32": 2}
@@ -31,6 +32,7 @@ EXPORTS = (
     "rbs_acquire_frame_buffer", "rbs_commit_frame_buffer",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_export_plane", "rbs_import_plane",
+    "rbs_export_window", "rbs_import_window", "rbs_stream_join", "rbs_ipc_export", "rbs_ipc_attach", "rbs_stage_windows",
     "rbs_get_window", "rbs_get_background", "rbs_raster_kernel_ms", "rbs_set_timing_every",
     "rbs_render_depth",
     "rbs_last_kernel_ms", "rbs_timing_summary",
@@ -154,6 +156,18 @@ def load():
     lib.rbs_export_plane.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rbs_import_plane.restype = C.c_int32
     lib.rbs_import_plane.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rbs_export_window.restype = C.c_int32
+    lib.rbs_export_window.argtypes = [H, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.rbs_import_window.restype = C.c_int32
+    lib.rbs_import_window.argtypes = [H, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]
+    lib.rbs_stream_join.restype = C.c_int32
+    lib.rbs_stream_join.argtypes = [H, C.c_void_p]
+    lib.rbs_ipc_export.restype = C.c_int32
+    lib.rbs_ipc_export.argtypes = [H, C.c_void_p]
+    lib.rbs_ipc_attach.restype = C.c_int32
+    lib.rbs_ipc_attach.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
+    lib.rbs_stage_windows.restype = C.c_int32
+    lib.rbs_stage_windows.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rbs_render_depth.restype = C.c_int32
     lib.rbs_render_depth.argtypes = [H, dp, fp]
     lib.rbs_last_kernel_ms.restype = C.c_int32

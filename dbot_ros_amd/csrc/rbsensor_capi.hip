@@ -196,6 +196,13 @@ struct rbs_handle {
     int shard_cap = 0;                 // global slots per device
     hipEvent_t ev_done = nullptr;      // shard: its last loglikes call has finished, planes included
     struct Rccl* rccl = nullptr;       // group: communicators for the log-likelihood all-gather (device tracker)
+    // ---- particle sharding across PROCESSES (rbs_ipc_attach): the other ranks' plane buffers, window and
+    // region tables mapped into this process; rank r owns global slots [r * max_particles, ...)
+    int peer_world = 0, peer_rank = 0;
+    const float* peer_occ[rbs::kMaxDevices][2] = {};
+    const int4* peer_win[rbs::kMaxDevices][2] = {};
+    const int4* peer_reg[rbs::kMaxDevices][2] = {};
+    void* peer_mapped[rbs::kMaxDevices][6] = {};    // what hipIpcCloseMemHandle gets back
     const float* snap_occ[rbs::kMaxDevices] = {};   // group: every shard's CURRENT planes / windows as of the start
     const int4* snap_win[rbs::kMaxDevices] = {};    //   of the call being fanned out (shards flip buffers one by one)
     const int4* snap_reg[rbs::kMaxDevices] = {};
@@ -356,6 +363,16 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             P.occ_src_dev[k] = g->snap_occ[k];
             P.win_src_dev[k] = g->snap_win[k];
             P.reg_src_dev[k] = g->snap_reg[k];
+        }
+    }
+    if (h->peer_world > 1) {   // the same table, the other devices being other PROCESSES' handles (every rank flips its buffers in step)
+        P.n_dev = h->peer_world;
+        P.shard_cap = h->max_particles;
+        P.slots = h->peer_world * h->max_particles;
+        for (int k = 0; k < P.n_dev; ++k) {
+            P.occ_src_dev[k] = k == h->peer_rank ? h->d_occ[h->cur] : h->peer_occ[k][h->cur];
+            P.win_src_dev[k] = k == h->peer_rank ? h->d_win[h->cur] : h->peer_win[k][h->cur];
+            P.reg_src_dev[k] = k == h->peer_rank ? h->d_reg[h->cur] : h->peer_reg[k][h->cur];
         }
     }
     P.out = d_out;
@@ -646,6 +663,12 @@ int32_t grow_slabs(rbs_handle* h, int new_slab)
 {
     new_slab = std::min(h->npx, (new_slab + 1023) & ~1023);
     if (new_slab <= h->slab_px) return RBS_OK;
+    if (h->peer_world > 1)   // the other ranks address these slabs with a fixed stride through their mappings
+        return h->h_err[0] ? fail(h, RBS_ERR_OUT_OF_MEMORY,
+                                  fmt("a region of %d px does not fit the slab of %d px, and slabs cannot grow once the handle is "
+                                      "attached to other ranks (rbs_ipc_attach): create the handles with a larger state_slab_px",
+                                      h->h_err[1], h->slab_px))
+                           : RBS_OK;
     float* nb[2] = {nullptr, nullptr};
     const size_t bytes = sizeof(float) * (size_t)new_slab * h->max_particles;
     for (int k = 0; k < 2; ++k)
@@ -673,7 +696,9 @@ CallState save_call_state(const rbs_handle* h) { return {h->cur, h->pending_fram
 void restore_call_state(rbs_handle* h, const CallState& c) { h->cur = c.cur; h->pending_frames = c.pending_frames; h->background = c.background; }
 
 // Slab size that holds a region of `need` px with room to move.
-int slab_for(const rbs_handle* h, int need) { return (int)std::min<long>(h->npx, (long)need + need / 4 + 1024); }
+// (1.5 x: a slab enlarged for `need` is at most two thirds full, below the three quarters that trigger the next
+// enlargement -- with 1.25 x the trigger stayed true after growing and every synchronising call drained the handle: ADVICE r3)
+int slab_for(const rbs_handle* h, int need) { return (int)std::min<long>(h->npx, (long)need + need / 2 + 1024); }
 
 // After a synchronising call on an idle handle: enlarge the slabs BEFORE a region fills one (the
 // regions move a few pixels per frame; three quarters full is the trigger).  Clears the flag.
@@ -681,7 +706,11 @@ int32_t slab_housekeeping(rbs_handle* h)
 {
     if (!h->slab_px) return RBS_OK;
     const bool overflowed = h->h_err[0] != 0;
-    if (overflowed || (long)h->h_err[1] * 4 > (long)h->slab_px * 3) {
+    // drain (a host synchronisation of both streams) only when the slabs will really be reallocated: h_err[1] is a
+    // sticky maximum, and a slab that is already the whole frame, or large enough for it, has nothing to gain
+    const int target = (int)std::min<long>(h->npx, ((long)slab_for(h, h->h_err[1]) + 1023) & ~1023L);
+    const bool grow = (long)h->h_err[1] * 4 > (long)h->slab_px * 3 && target > h->slab_px && h->peer_world <= 1;
+    if (overflowed || grow) {
         if (int32_t rc = drain(h, true)) return rc;
         if (int32_t rc = grow_slabs(h, slab_for(h, h->h_err[1]))) return rc;
     }
@@ -714,6 +743,9 @@ void release(rbs_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    for (auto& rank_bufs : h->peer_mapped)
+        for (void*& p : rank_bufs)
+            if (p) { (void)hipIpcCloseMemHandle(p); p = nullptr; }
     (void)hipFree(h->d_soup);
     (void)hipFree(h->d_frame);
     (void)hipFree(h->d_aux);
@@ -1660,7 +1692,10 @@ int32_t group_grow_slabs(rbs_handle* g, const std::vector<CallState>* before)
     int need = 0;
     bool overflowed = false;
     for (rbs_handle* h : g->shards) { need = std::max(need, h->h_err[1]); overflowed = overflowed || h->h_err[0] != 0; }
-    if (!before && !overflowed && (long)need * 4 <= (long)s0->slab_px * 3) return RBS_OK;
+    if (!before && !overflowed) {   // housekeeping: act (and drain every shard) only when the slabs will really be reallocated
+        const int would = (int)std::min<long>(s0->npx, ((long)slab_for(s0, need) + 1023) & ~1023L);
+        if ((long)need * 4 <= (long)s0->slab_px * 3 || would <= s0->slab_px) return RBS_OK;
+    }
     for (size_t k = 0; k < g->shards.size(); ++k) {
         rbs_handle* h = g->shards[k];
         RBS_HIP(g, hipSetDevice(h->device));
@@ -2112,11 +2147,12 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
     if (!poses || !indices || !out_loglik)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, "loglikes: null pointer");
     if (!h->shards.empty()) return group_loglikes(h, poses, indices, n, update, out_loglik);
+    const int32_t slots_total = h->peer_world > 1 ? h->peer_world * h->max_particles : h->max_particles;   // (attached: parents are global slots)
     for (int32_t i = 0; i < n; ++i)
-        if (indices[i] < 0 || indices[i] >= h->max_particles)
+        if (indices[i] < 0 || indices[i] >= slots_total)
             return fail(h, RBS_ERR_INVALID_ARGUMENT,
                         fmt("loglikes: indices[%d] = %d outside 0..%d", i, indices[i],
-                            h->max_particles - 1));
+                            slots_total - 1));
     RBS_HIP(h, hipSetDevice(h->device));
     // the call waits for the log-likelihoods only -- the occlusion planes are finished by the second
     // stream and joined by the next call
@@ -2136,8 +2172,10 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
         if (h->h_err[0]) return check_slab_error(h);   // (cannot happen: a region is never larger than the frame)
     }
     std::memcpy(out_loglik, h->h_out, sizeof(double) * (size_t)n);
-    if (update)
-        for (int32_t i = 0; i < n; ++i) indices[i] = i;
+    if (update) {
+        const int32_t first = h->peer_world > 1 ? h->peer_rank * h->max_particles : 0;
+        for (int32_t i = 0; i < n; ++i) indices[i] = first + i;
+    }
     if (int32_t rc = slab_housekeeping(h)) return rc;
     h->quiet = !h->async_outstanding;   // (everything on the handle's stream has run; the copy kernel's last blocks are short)
     if (stale_overflow) {   // this call's results are good; an earlier rbs_loglikes_device's were not
@@ -2299,6 +2337,219 @@ int32_t rbs_import_plane(rbs_handle* h, int32_t slot, const void* d_src, void* s
                            make_int4(0, 0, h->cols, h->rows));
         RBS_HIP(h, hipGetLastError());
     }
+    return RBS_OK;
+}
+
+int32_t rbs_stream_join(rbs_handle* h, void* stream)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty()) {
+        for (rbs_handle* sh_ : h->shards)
+            if (int32_t rc = rbs_stream_join(sh_, stream)) return gfail(h, sh_, rc);
+        return RBS_OK;
+    }
+    RBS_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    return RBS_OK;
+}
+
+// A slot's window as the host needs it for the window-sized transport (one 16-byte read-back).
+static int32_t window_of(rbs_handle* h, int slot, hipStream_t s, int box[4])
+{
+    if (!h->windowed) { box[0] = 0; box[1] = 0; box[2] = h->cols; box[3] = h->rows; return RBS_OK; }
+    RBS_HIP(h, hipMemcpyAsync(box, h->d_win[h->cur] + slot, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    RBS_HIP(h, hipStreamSynchronize(s));
+    if (box[2] <= box[0] || box[3] <= box[1]) { box[0] = h->cols; box[1] = h->rows; box[2] = 0; box[3] = 0; }
+    return RBS_OK;
+}
+
+int32_t rbs_export_window(rbs_handle* h, int32_t slot, int32_t rect_out[4], void* d_payload, size_t capacity_floats, void* stream)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_SLOT(h, slot, rbs_export_window(sh_, l_, rect_out, d_payload, capacity_floats, stream));
+    if (slot < 0 || slot >= h->max_particles || !rect_out)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("export_window: bad slot %d", slot));
+    RBS_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    int box[4];
+    if (int32_t rc = window_of(h, slot, s, box)) return rc;
+    for (int k = 0; k < 4; ++k) rect_out[k] = box[k];
+    const int w = box[2] - box[0], hh = box[3] - box[1];
+    if (w <= 0 || hh <= 0) return RBS_OK;   // all background: nothing to carry
+    if ((size_t)w * (size_t)hh > capacity_floats || !d_payload)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("export_window: the window of slot %d holds %d x %d values, the buffer %zu", slot, w, hh, capacity_floats));
+    // where the window's first value is stored, and the stored row length
+    const float* base = h->d_occ[h->cur] + (size_t)slot * h->plane_stride;
+    size_t src_pitch = sizeof(float) * (size_t)h->cols;
+    if (h->slab_px) {
+        int reg[4];
+        RBS_HIP(h, hipMemcpyAsync(reg, h->d_reg[h->cur] + slot, sizeof(reg), hipMemcpyDeviceToHost, s));
+        RBS_HIP(h, hipStreamSynchronize(s));
+        src_pitch = sizeof(float) * (size_t)(reg[2] - reg[0]);
+        base += (size_t)(box[1] - reg[1]) * (size_t)(reg[2] - reg[0]) + (size_t)(box[0] - reg[0]);
+    } else {
+        base += (size_t)box[1] * h->cols + box[0];
+    }
+    RBS_HIP(h, hipMemcpy2DAsync(d_payload, sizeof(float) * (size_t)w, base, src_pitch, sizeof(float) * (size_t)w, (size_t)hh,
+                                hipMemcpyDeviceToDevice, s));
+    return RBS_OK;
+}
+
+int32_t rbs_import_window(rbs_handle* h, int32_t slot, const int32_t rect[4], const void* d_payload, void* stream)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_SLOT(h, slot, rbs_import_window(sh_, l_, rect, d_payload, stream));
+    if (slot < 0 || slot >= h->max_particles || !rect)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("import_window: bad slot %d", slot));
+    RBS_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    int4 r = make_int4(rect[0], rect[1], rect[2], rect[3]);
+    const bool empty = r.z <= r.x || r.w <= r.y;
+    if (empty) r = make_int4(h->cols, h->rows, 0, 0);
+    else if (r.x < 0 || r.y < 0 || r.z > h->cols || r.w > h->rows || (h->windowed && ((r.x | r.z) & 3)) || !d_payload)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("import_window: bad rectangle (%d, %d, %d, %d)", rect[0], rect[1], rect[2], rect[3]));
+    const int w = r.z - r.x, hh = r.w - r.y;
+    float* dst = h->d_occ[h->cur] + (size_t)slot * h->plane_stride;
+    if (!h->windowed) {
+        // whole planes without windows: the background has to be written out
+        hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(256), dim3(256), 0, s, dst, (size_t)h->npx, h->background);
+        RBS_HIP(h, hipGetLastError());
+        if (!empty)
+            RBS_HIP(h, hipMemcpy2DAsync(dst + (size_t)r.y * h->cols + r.x, sizeof(float) * (size_t)h->cols, d_payload, sizeof(float) * (size_t)w,
+                                        sizeof(float) * (size_t)w, (size_t)hh, hipMemcpyDeviceToDevice, s));
+        return RBS_OK;
+    }
+    if (h->slab_px) {
+        if (!empty && (long)w * hh > (long)h->slab_px)
+            return fail(h, RBS_ERR_OUT_OF_MEMORY, fmt("import_window: a window of %d x %d values does not fit a slab of %d px (state_slab_px)", w, hh, h->slab_px));
+        if (!empty)   // the slot's stored region becomes the window itself, packed
+            RBS_HIP(h, hipMemcpyAsync(dst, d_payload, sizeof(float) * (size_t)w * (size_t)hh, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_reg[h->cur] + slot, 1, r);
+    } else if (!empty) {
+        RBS_HIP(h, hipMemcpy2DAsync(dst + (size_t)r.y * h->cols + r.x, sizeof(float) * (size_t)h->cols, d_payload, sizeof(float) * (size_t)w,
+                                    sizeof(float) * (size_t)w, (size_t)hh, hipMemcpyDeviceToDevice, s));
+    }
+    hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_win[h->cur] + slot, 1, r);
+    RBS_HIP(h, hipGetLastError());
+    return RBS_OK;
+}
+
+// ---- one process per GPU: the handles of the other ranks, mapped (include/rbsensor_mi355x.h) ----
+namespace {
+struct IpcBlob {
+    uint32_t magic;
+    int32_t device, max_particles, rows, cols, slab_px, windowed, cur;
+    int64_t plane_stride;
+    hipIpcMemHandle_t mem[6];   // occ[0], occ[1], win[0], win[1], reg[0], reg[1] (reg: slabs only)
+};
+static_assert(sizeof(IpcBlob) <= RBS_IPC_BLOB_BYTES, "RBS_IPC_BLOB_BYTES");
+constexpr uint32_t kIpcMagic = 0x52425331u;
+}
+
+int32_t rbs_ipc_export(rbs_handle* h, void* blob_out)
+{
+    if (!h || !blob_out) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty()) return fail(h, RBS_ERR_UNSUPPORTED, "ipc_export: a handle over several devices already shares its planes in-process");
+    RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = drain(h, true)) return rc;
+    std::memset(blob_out, 0, RBS_IPC_BLOB_BYTES);
+    IpcBlob b{};
+    b.magic = kIpcMagic;
+    b.device = h->device; b.max_particles = h->max_particles; b.rows = h->rows; b.cols = h->cols;
+    b.slab_px = h->slab_px; b.windowed = h->windowed ? 1 : 0; b.cur = h->cur; b.plane_stride = (int64_t)h->plane_stride;
+    void* bufs[6] = {h->d_occ[0], h->d_occ[1], h->d_win[0], h->d_win[1], h->d_reg[0], h->d_reg[1]};
+    for (int k = 0; k < 6; ++k)
+        if (bufs[k]) RBS_HIP(h, hipIpcGetMemHandle(&b.mem[k], bufs[k]));
+    std::memcpy(blob_out, &b, sizeof(b));
+    return RBS_OK;
+}
+
+int32_t rbs_ipc_attach(rbs_handle* h, int32_t rank, int32_t world, const void* blobs)
+{
+    if (!h || !blobs) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty()) return fail(h, RBS_ERR_UNSUPPORTED, "ipc_attach: a handle over several devices already shares its planes in-process");
+    if (world < 1 || world > rbs::kMaxDevices || rank < 0 || rank >= world)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("ipc_attach: rank %d of %d (at most %d ranks)", rank, world, rbs::kMaxDevices));
+    if (h->peer_world > 1) return fail(h, RBS_ERR_INVALID_ARGUMENT, "ipc_attach: already attached");
+    if ((long)world * h->max_particles > 0x7fffffffL) return fail(h, RBS_ERR_INVALID_ARGUMENT, "ipc_attach: too many global slots");
+    RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = drain(h, true)) return rc;
+    const unsigned char* raw = static_cast<const unsigned char*>(blobs);
+    for (int k = 0; k < world; ++k) {
+        IpcBlob b;
+        std::memcpy(&b, raw + (size_t)k * RBS_IPC_BLOB_BYTES, sizeof(b));
+        if (b.magic != kIpcMagic) return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("ipc_attach: blob %d is not an rbs_ipc_export", k));
+        if (b.max_particles != h->max_particles || b.rows != h->rows || b.cols != h->cols || b.slab_px != h->slab_px ||
+            b.windowed != (h->windowed ? 1 : 0) || b.plane_stride != (int64_t)h->plane_stride || b.cur != h->cur)
+            return fail(h, RBS_ERR_INVALID_ARGUMENT,
+                        fmt("ipc_attach: rank %d's handle differs (max_particles %d, %d x %d, slab %d px, %s planes, buffer %d) from this one "
+                            "(%d, %d x %d, %d, %s, %d): every rank must create the same handle and be at the same point of its call sequence",
+                            k, b.max_particles, b.cols, b.rows, b.slab_px, b.windowed ? "windowed" : "whole", b.cur, h->max_particles, h->cols,
+                            h->rows, h->slab_px, h->windowed ? "windowed" : "whole", h->cur));
+        if (k == rank) continue;
+        if (b.device != h->device) {   // another GPU of the node: read over xGMI
+            int can = 0;
+            RBS_HIP(h, hipDeviceCanAccessPeer(&can, h->device, b.device));
+            if (!can) return fail(h, RBS_ERR_UNSUPPORTED, fmt("ipc_attach: device %d cannot access device %d's memory (peer access)", h->device, b.device));
+            const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                (void)hipGetLastError();
+                return fail(h, RBS_ERR_HIP, fmt("hipDeviceEnablePeerAccess(%d -> %d): %s", h->device, b.device, hipGetErrorString(e)));
+            }
+            (void)hipGetLastError();
+        }
+        for (int m = 0; m < 6; ++m) {
+            if (m >= 4 && !h->slab_px) break;
+            void* p = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&p, b.mem[m], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(h, RBS_ERR_HIP, fmt("hipIpcOpenMemHandle(rank %d, buffer %d): %s", k, m, hipGetErrorString(e)));
+            }
+            h->peer_mapped[k][m] = p;
+        }
+        for (int c = 0; c < 2; ++c) {
+            h->peer_occ[k][c] = static_cast<const float*>(h->peer_mapped[k][c]);
+            h->peer_win[k][c] = static_cast<const int4*>(h->peer_mapped[k][2 + c]);
+            h->peer_reg[k][c] = static_cast<const int4*>(h->peer_mapped[k][4 + c]);
+        }
+    }
+    h->peer_world = world;
+    h->peer_rank = rank;
+    return RBS_OK;
+}
+
+int32_t rbs_stage_windows(rbs_handle* h, const int32_t* d_src_global, const int32_t* d_dst_local, int32_t n, void* stream)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty()) return fail(h, RBS_ERR_UNSUPPORTED, "stage_windows: a handle over several devices reads every parent in place");
+    if (!h->windowed || (h->cols & 3))
+        return fail(h, RBS_ERR_UNSUPPORTED, "stage_windows: windowed planes only (state_layout dense moves whole planes: rbs_export/import_plane)");
+    if (n < 0 || n > h->max_particles || (n > 0 && (!d_src_global || !d_dst_local)))
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("stage_windows: n = %d outside 0..%d, or a null pointer", n, h->max_particles));
+    if (n == 0) return RBS_OK;
+    RBS_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    DevParams P = h->base;
+    P.slots = h->max_particles; P.n_dev = 1; P.shard_cap = h->max_particles;
+    P.slab_px = h->slab_px; P.plane_stride = (int)h->plane_stride;
+    P.occ_src = h->d_occ[h->cur]; P.win_src = h->d_win[h->cur]; P.reg_src = h->d_reg[h->cur];
+    if (h->peer_world > 1) {
+        P.n_dev = h->peer_world;
+        P.slots = h->peer_world * h->max_particles;
+        for (int k = 0; k < P.n_dev; ++k) {
+            P.occ_src_dev[k] = k == h->peer_rank ? h->d_occ[h->cur] : h->peer_occ[k][h->cur];
+            P.win_src_dev[k] = k == h->peer_rank ? h->d_win[h->cur] : h->peer_win[k][h->cur];
+            P.reg_src_dev[k] = k == h->peer_rank ? h->d_reg[h->cur] : h->peer_reg[k][h->cur];
+        }
+    }
+    hipLaunchKernelGGL(rbs::rbs_stage_kernel, dim3((unsigned)n, 4), dim3(256), 0, s, P, d_src_global, d_dst_local, h->d_occ[h->cur],
+                       h->d_win[h->cur], h->d_reg[h->cur]);
+    RBS_HIP(h, hipGetLastError());
     return RBS_OK;
 }
 

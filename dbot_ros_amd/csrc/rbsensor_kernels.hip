@@ -1876,6 +1876,41 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
     }
 }
 
+// One process per GPU (rbs_ipc_attach): pull the windows of parents that live in OTHER ranks' handles into
+// local slots, one window-sized read over xGMI per staged plane -- for parents that several of this rank's
+// children share (a parent with one child here is read in place by that child's raster block instead).
+// Entry i: dst[i] < 0 -> nothing; else the plane of global slot src[i] -> local slot dst[i] of the CURRENT
+// buffer (what the next call reads its parents from).  blockIdx.x = entry, blockIdx.y = row chunk.
+__global__ __launch_bounds__(256) void rbs_stage_kernel(const DevParams P, const int* __restrict__ src, const int* __restrict__ dst,
+                                                       float* __restrict__ occ_cur, int4* __restrict__ win_cur, int4* __restrict__ reg_cur)
+{
+    const int e = (int)blockIdx.x;
+    const int d = dst[e];
+    if (d < 0 || d >= P.shard_cap) return;
+    const int g = src[e];
+    if ((unsigned)g >= (unsigned)P.slots) return;
+    const int4 w = parent_window(P, g);
+    const bool empty = w.z <= w.x || w.w <= w.y;
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+        const int4 r = empty ? make_int4(P.cols, P.rows, 0, 0) : w;
+        win_cur[d] = r;
+        if (P.slab_px) reg_cur[d] = r;   // the staged slab stores exactly the window, packed
+    }
+    if (empty) return;
+    const PlaneRef sref = parent_ref(P, g);
+    const float* __restrict__ sp = parent_plane(P, g);
+    float* __restrict__ dp = occ_cur + (size_t)d * P.plane_stride;
+    const int ww = w.z - w.x, hh = w.w - w.y, w4 = ww >> 2;
+    const int dstride = P.slab_px ? ww : P.cols, dx0 = P.slab_px ? w.x : 0, dy0 = P.slab_px ? w.y : 0;
+    const int rows_per = (hh + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int y0 = w.y + (int)blockIdx.y * rows_per, y1 = min(w.w, y0 + rows_per);
+    for (int k = threadIdx.x; k < (y1 - y0) * w4; k += 256) {   // float4 columns: windows move in multiples of four pixels
+        const int r = k / w4, y = y0 + r, x = w.x + ((k - r * w4) << 2);
+        const floatx4 v = *reinterpret_cast<const floatx4*>(sp + (size_t)(y - sref.y0) * sref.stride + (x - sref.x0));
+        *reinterpret_cast<floatx4*>(dp + (size_t)(y - dy0) * dstride + (x - dx0)) = v;
+    }
+}
+
 // Make one windowed plane dense in place: pixels outside its window become the background.
 // (The caller then marks the window full with rbs_set_window_kernel.)
 __global__ void rbs_materialize_kernel(float* __restrict__ plane, const int4* __restrict__ win,

@@ -4,10 +4,14 @@ block -- an all-gather of per-particle log-likelihoods (RCCL over xGMI with back
 gloo in the CPU tests) -- and, after resampling, migration of only those parent planes whose
 children could not be placed on the parent's own rank.
 
-Everything here is host logic over torch.distributed; the evaluator is any object with
-loglikes_poses / get_occlusion / set_occlusion (the product's RbSensor on GPUs; the CPU tests
-plug the oracle in).  Each rank's sensor is created with 2 x shard slots: [0, shard) own
-planes, [shard, 2*shard) staging for planes received from other ranks.
+Two forms.  ShardedSensor / ShardedRbSensor: host logic (numpy) over torch.distributed; the evaluator is
+any object with loglikes_poses / get_occlusion / set_occlusion (the product's RbSensor on GPUs; the CPU
+tests plug the oracle in).  Each rank's sensor is created with 2 x shard slots: [0, shard) own planes,
+[shard, 2*shard) staging for planes received from other ranks; on GPUs a plane travels as its window
+(rbs_export_window / rbs_import_window: rectangle + w x h values).
+PeerShardedStep (round 4, what bench.py --gpus N times): the ranks' handles are attached to each other
+(rbs_ipc_attach), parents on other ranks are read in place over xGMI, nothing migrates, the whole step is
+device-resident torch arithmetic + library calls on one stream.
 """
 import numpy as np
 import torch
@@ -177,33 +181,26 @@ class ShardedSensor:
                 for r in new:
                     cache[int(r[2])] = self.stage0 + len(cache)
                     moves.append((int(r[0]), int(dst), int(r[2])))
-        ops, keep, landed = [], [], []
         npx = self.sensor.rows * self.sensor.cols
-        on_device = self.device is not None and hasattr(self.sensor, "export_plane")
-        stream = torch.cuda.current_stream().cuda_stream if on_device else None
-        for src, dst, g in moves:
-            if src == self.rank:
-                if on_device:   # device-to-device out of the sensor, then RCCL straight from HBM
-                    t = torch.empty(npx, dtype=torch.float32, device=self.device)
-                    self.sensor.export_plane(g - self.lo, t.data_ptr(), stream)
-                else:
+        on_device = self.device is not None and hasattr(self.sensor, "export_window")
+        if on_device:
+            self._migrate_windows(moves)
+        else:
+            ops, keep, landed = [], [], []
+            for src, dst, g in moves:
+                if src == self.rank:
                     t = torch.from_numpy(np.ascontiguousarray(self.sensor.get_occlusion(g - self.lo)))
-                ops.append(dist.P2POp(dist.isend, t, dst, group=self.group))
-                keep.append(t)
-            elif dst == self.rank:
-                t = torch.empty(npx, dtype=torch.float32, device=self.device if on_device else None)
-                ops.append(dist.P2POp(dist.irecv, t, src, group=self.group))
-                landed.append((self.staged[self.rank][g], t))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for slot, t in landed:
-            if on_device:
-                self.sensor.import_plane(slot, t.data_ptr(), stream)
-            else:
-                self.sensor.set_occlusion(slot, t.cpu().numpy())
-        if on_device and landed:
-            torch.cuda.current_stream().synchronize()   # staging tensors die with this scope
+                    ops.append(dist.P2POp(dist.isend, t, dst, group=self.group))
+                    keep.append(t)
+                elif dst == self.rank:
+                    t = torch.empty(npx, dtype=torch.float32)
+                    ops.append(dist.P2POp(dist.irecv, t, src, group=self.group))
+                    landed.append((self.staged[self.rank][g], t))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for slot, t in landed:
+                self.sensor.set_occlusion(slot, t.numpy())
         new_layout = np.empty(self.n_total, dtype=np.int64)
         new_layout[self.bounds[child_rank] + child_slot] = np.arange(self.n_total)
         self.layout = new_layout
@@ -216,6 +213,41 @@ class ShardedSensor:
             slots[remote] = np.array([cache[int(x)] for x in g[remote]], dtype=np.int32)
         self.local_parent_slots = slots
         return moves
+
+
+    def _migrate_windows(self, moves):
+        """Device path (one process per GPU, RCCL): a plane travels as its WINDOW -- rectangle + w x h values,
+        about 3 % of rows x cols -- straight out of / into HBM (rbs_export_window / rbs_import_window).  Two
+        rounds of point-to-point transfers: the rectangles (16 bytes each; the receiver needs them to size its
+        buffers), then the payloads.  (Whole planes, round 3: 1.2 MB per move at 640x480.)"""
+        stream = torch.cuda.current_stream().cuda_stream
+        out, inc = [], []          # (dst, rect tensor, payload tensor), (src, slot, rect tensor)
+        for src, dst, g in moves:
+            if src == self.rank:
+                x0, y0, x1, y1 = self.sensor.get_window(g - self.lo)
+                area = max(0, x1 - x0) * max(0, y1 - y0)
+                pay = torch.empty(max(area, 1), dtype=torch.float32, device=self.device)
+                rect = self.sensor.export_window(g - self.lo, pay.data_ptr(), pay.numel(), stream)
+                out.append((dst, torch.tensor(rect, dtype=torch.int32, device=self.device), pay[:max(area, 1)]))
+            elif dst == self.rank:
+                inc.append((src, self.staged[self.rank][g], torch.empty(4, dtype=torch.int32, device=self.device)))
+        ops = [dist.P2POp(dist.isend, r, d, group=self.group) for d, r, _ in out]
+        ops += [dist.P2POp(dist.irecv, r, s_, group=self.group) for s_, _, r in inc]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        rects = [tuple(int(v) for v in r.cpu()) for _, _, r in inc]
+        pays = [torch.empty(max(1, max(0, r[2] - r[0]) * max(0, r[3] - r[1])), dtype=torch.float32, device=self.device) for r in rects]
+        ops = [dist.P2POp(dist.isend, p_, d, group=self.group) for d, _, p_ in out]
+        ops += [dist.P2POp(dist.irecv, p_, s_, group=self.group) for (s_, _, _), p_ in zip(inc, pays)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for (_, slot, _), r, p_ in zip(inc, rects, pays):
+            self.sensor.import_window(slot, r, p_.data_ptr(), stream)
+        self.window_floats_moved = getattr(self, "window_floats_moved", 0) + sum(int(p_.numel()) for _, _, p_ in out)
+        if inc or out:
+            torch.cuda.current_stream().synchronize()   # the transfer tensors die with this scope
 
 
 class ShardedRbSensor:
@@ -257,3 +289,102 @@ class ShardedRbSensor:
 
     def close(self):
         self.ss.sensor.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# One process per GPU with the other ranks' planes MAPPED (rbs_ipc_attach): no plane migrates.
+# Device-agnostic torch code (the CPU tests run the same functions on CPU tensors).
+
+def global_resample(ll_all, uniforms, temperature=1.0):
+    """Multinomial resampling over ALL ranks' particles (upper_bound of the cumulative normalised
+    weights at host-supplied uniforms), identical on every rank: the parent of each of the N children as an index
+    into the gathered log-likelihood vector, SORTED -- children are exchangeable, and in parent order the children
+    of rank r's particles are one contiguous run that mostly coincides with rank r's slots [r n, (r + 1) n):
+    slot g simply evaluates child g (a stable n-way partition without any bookkeeping)."""
+    w = torch.exp((ll_all - ll_all.max()) / temperature)   # (temperature > 1: flatter weights -- synthetic workloads only)
+    c = torch.cumsum(w, 0)
+    c = c / c[-1]
+    p = torch.searchsorted(c, uniforms, right=True).clamp_(max=ll_all.numel() - 1)
+    return torch.sort(p).values
+
+
+def plan_shard(parents_sorted, n, cap, rank, min_share=2):
+    """What rank `rank` does with its slice of the sorted parents (fixed-size tensor arithmetic, no host
+    synchronisation).  A parent on another rank is read IN PLACE by its child (over xGMI) -- unless at least
+    `min_share` of this rank's children share it: then its window is pulled once into a local staging slot
+    n + j and the children read that.  Returns
+      parent_idx [n] int32   global slot (rank_of_owner * cap + local slot) each local child inherits from,
+      stage_src / stage_dst [n] int32   entry i staged iff stage_dst[i] >= 0 (rbs_stage_windows),
+      counts [3] int64       children with a remote parent, of them served from staging, planes staged."""
+    dev = parents_sorted.device
+    mine = parents_sorted[rank * n:(rank + 1) * n]
+    owner = torch.div(mine, n, rounding_mode="floor")
+    remote = owner != rank
+    pg = owner * cap + (mine - owner * n)
+    new = torch.ones(n, dtype=torch.bool, device=dev)
+    new[1:] = mine[1:] != mine[:-1]
+    run = torch.cumsum(new.to(torch.int64), 0) - 1
+    runlen = torch.zeros(n, dtype=torch.int64, device=dev).scatter_add_(0, run, torch.ones(n, dtype=torch.int64, device=dev))
+    shared = remote & (runlen[run] >= min_share)
+    start = new & shared
+    sidx = torch.cumsum(start.to(torch.int64), 0) - 1
+    parent_idx = torch.where(shared, rank * cap + n + sidx, pg).to(torch.int32)
+    neg = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    stage_src = torch.where(start, pg, neg).to(torch.int32)
+    stage_dst = torch.where(start, n + sidx, neg).to(torch.int32)
+    counts = torch.stack([remote.sum(), shared.sum(), start.sum()])
+    return parent_idx, stage_src, stage_dst, counts
+
+
+def attach_peers(sensor, group=None):
+    """Exchange the ranks' rbs_ipc_export blobs (an all-gather of 512 bytes each) and attach."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    blobs = [None] * world
+    dist.all_gather_object(blobs, sensor.ipc_export(), group=group)
+    sensor.ipc_attach(rank, blobs)
+
+
+class PeerShardedStep:
+    """The filter step of SURVEY 8(e) across processes, everything on one stream, no host synchronisation:
+        loglikes(update) on this rank's n particles (parents = global slots; remote ones read in place)
+        -> rbs_stream_join -> all-gather of the log-likelihoods (RCCL) -> global_resample -> plan_shard
+        -> rbs_stage_windows (shared remote parents pulled once) -> the next step's parent indices.
+    The sensor has max_particles = cap >= 2 n (n own slots + staging) and is attached (attach_peers).
+    `evaluate(poses, parent_idx, out)` / `stage(src, dst)` / `all_gather(out, inp)` replace the three device
+    operations (the CPU tests drive the oracle through them; the one-GPU test gathers through gloo)."""
+
+    def __init__(self, sensor, n, cap, group=None, device=None, min_share=2, stream=None, evaluate=None, stage=None, all_gather=None,
+                 temperature=1.0):
+        self.sensor, self.n, self.cap, self.group, self.device, self.min_share = sensor, n, cap, group, device, min_share
+        self.temperature = temperature
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.N = self.world * n
+        self.stream = stream
+        self.d_out = torch.zeros(n, dtype=torch.float64, device=device)
+        self.d_all = torch.zeros(self.N, dtype=torch.float64, device=device)
+        self.parent_idx = torch.full((n,), self.rank * cap, dtype=torch.int32, device=device)   # after reset: any own slot
+        self.counts = torch.zeros(3, dtype=torch.int64, device=device)
+        self.children = 0
+        self._evaluate = evaluate or self._evaluate_device
+        self._stage = stage or (lambda src, dst: sensor.stage_windows(src.data_ptr(), dst.data_ptr(), n, self.stream))
+        self._all_gather = all_gather or (lambda out, inp: dist.all_gather_into_tensor(out, inp, group=group))
+        self._keep = None
+
+    def _evaluate_device(self, poses, parent_idx, out):
+        self.sensor.loglikes_device(poses.data_ptr(), parent_idx.data_ptr(), self.n, True, out.data_ptr(), self.stream)
+        self.sensor.stream_join(self.stream)
+
+    def step(self, poses, uniforms):
+        """One updating call + exchange + resampling.  poses: this rank's [n, 12 bodies] tensor; `uniforms` [N]
+        identical on every rank.  Returns the sorted global parents (indices into the gathered vector)."""
+        self._evaluate(poses, self.parent_idx, self.d_out)
+        self._all_gather(self.d_all, self.d_out)
+        ps = global_resample(self.d_all, uniforms, self.temperature)
+        self.last_parents = ps
+        parent_idx, src, dst, counts = plan_shard(ps, self.n, self.cap, self.rank, self.min_share)
+        self._stage(src, dst)
+        self._keep = (self.parent_idx, src, dst, poses)   # (alive until the kernels reading them are enqueued behind the next step's)
+        self.parent_idx = parent_idx
+        self.counts += counts
+        self.children += self.n
+        return ps

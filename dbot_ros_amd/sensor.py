@@ -336,6 +336,37 @@ class RbSensor:
     def import_plane(self, slot, d_src_ptr, stream=None):
         self._check(self._lib.rbs_import_plane(self._h, int(slot), d_src_ptr, stream))
 
+    def export_window(self, slot, d_payload_ptr, capacity_floats, stream=None):
+        """The slot's window (x0, y0, x1, y1) and, packed row-major into caller-owned device memory, its values:
+        the window-sized form of export_plane."""
+        r = (C.c_int32 * 4)()
+        self._check(self._lib.rbs_export_window(self._h, int(slot), r, d_payload_ptr, int(capacity_floats), stream))
+        return tuple(int(x) for x in r)
+
+    def import_window(self, slot, rect, d_payload_ptr, stream=None):
+        r = (C.c_int32 * 4)(*[int(x) for x in rect])
+        self._check(self._lib.rbs_import_window(self._h, int(slot), r, d_payload_ptr, stream))
+
+    def stream_join(self, stream=None):
+        """`stream` waits (on the device) for the planes of the last updating call, side stream included."""
+        self._check(self._lib.rbs_stream_join(self._h, stream))
+
+    def ipc_export(self):
+        buf = (C.c_ubyte * _capi.RBS_IPC_BLOB_BYTES)()
+        self._check(self._lib.rbs_ipc_export(self._h, buf))
+        return bytes(buf)
+
+    def ipc_attach(self, rank, blobs):
+        """blobs: every rank's ipc_export(), in rank order.  Afterwards parent indices are GLOBAL slots
+        (rank * max_particles + local slot) and parents of other ranks are read in place."""
+        raw = b"".join(blobs)
+        assert len(raw) == len(blobs) * _capi.RBS_IPC_BLOB_BYTES
+        self._check(self._lib.rbs_ipc_attach(self._h, int(rank), len(blobs), raw))
+        self.peer_rank, self.peer_world = int(rank), len(blobs)
+
+    def stage_windows(self, d_src_global_ptr, d_dst_local_ptr, n, stream=None):
+        self._check(self._lib.rbs_stage_windows(self._h, d_src_global_ptr, d_dst_local_ptr, int(n), stream))
+
     def occlusion_device_ptr(self, slot, next_buffer=False):
         p = C.c_void_p()
         fn = self._lib.rbs_occlusion_next_device_ptr if next_buffer else self._lib.rbs_occlusion_device_ptr

@@ -260,6 +260,60 @@ int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out);
  * RCCL send or recv of the caller's buffer), without staging through the host. */
 int32_t rbs_export_plane(rbs_handle* h, int32_t slot, void* d_dst, void* stream);
 int32_t rbs_import_plane(rbs_handle* h, int32_t slot, const void* d_src, void* stream);
+/* The same transport, WINDOW-SIZED (round 4): a plane is its window plus the background level, so what
+ * has to travel is the window's rectangle and its w x h values (about 3 % of a plane), not rows*cols
+ * floats.  rbs_export_window: rect_out = (x0, y0, x1, y1) of the slot's window -- (cols, rows, 0, 0) when
+ * the plane is all background -- and its values packed row-major, width x1 - x0, into d_payload
+ * (device memory of the handle's device, capacity_floats floats; too small: RBS_ERR_INVALID_ARGUMENT
+ * with nothing copied, rect_out still valid so the caller can size the buffer).  Waits for the
+ * rectangle (one 16-byte read-back); the payload copy is enqueued on `stream`.
+ * rbs_import_window: the slot's plane becomes "background everywhere, these values inside rect"
+ * (x0 and x1 multiples of 4, inside the frame); a slab that is too small for rect fails with
+ * RBS_ERR_OUT_OF_MEMORY like rbs_import_plane.  Both layouts, whole planes and slabs.
+ * Used by dbot_ros_amd/dist.py (one process per GPU) to migrate a parent's plane to the rank its
+ * surplus children were placed on: an RCCL send / recv of rect + payload. */
+int32_t rbs_export_window(rbs_handle* h, int32_t slot, int32_t rect_out[4], void* d_payload, size_t capacity_floats, void* stream);
+int32_t rbs_import_window(rbs_handle* h, int32_t slot, const int32_t rect[4], const void* d_payload, void* stream);
+/* `stream` waits (on the device, no host synchronisation) until the planes of the handle's last
+ * updating call are complete, the side stream's copy kernel included: what a caller enqueues on
+ * `stream` afterwards -- e.g. the collective that tells the other ranks "my step is done" -- is
+ * ordered after them. */
+int32_t rbs_stream_join(rbs_handle* h, void* stream);
+
+/* --- particle sharding ACROSS PROCESSES: one process per GPU (torch.distributed / RCCL) ------------
+ * SURVEY 8(e)'s partitioning with one handle per rank: rank r owns global slots
+ * [r * max_particles, (r + 1) * max_particles).  After rbs_ipc_attach the parent indices of
+ * rbs_loglikes / rbs_loglikes_device are GLOBAL slots: a parent that lives in another rank's handle
+ * is read IN PLACE over xGMI -- its window's ~3 % of a plane, once -- through that rank's buffers
+ * mapped into this process (hipIpcGetMemHandle / hipIpcOpenMemHandle), exactly as the shards of a
+ * multi-device handle read each other (rbs_config.n_devices).  No plane ever migrates; the only
+ * collective of a filter step is the all-gather of the log-likelihoods.
+ *   rbs_ipc_export   this handle's description (RBS_IPC_BLOB_BYTES bytes): memory handles of its two
+ *                    plane buffers, window and region tables, its device and geometry.  Single-device
+ *                    handles only; synchronises.
+ *   rbs_ipc_attach   blobs = world x RBS_IPC_BLOB_BYTES, rank-major, every rank's export (exchanged by
+ *                    the caller: an all-gather of bytes); rank = this handle's.  All handles must have
+ *                    the same geometry, layout, max_particles and slab size.  Afterwards children are
+ *                    still written to LOCAL slots 0..n-1 (global rank * max_particles + i); an updating
+ *                    rbs_loglikes returns indices[i] = rank * max_particles + i.
+ * ORDERING is the caller's: every rank performs the same sequence of rbs_reset / updating calls, and a
+ * rank may start step k+1 only when every rank has finished step k (it reads their planes and
+ * overwrites the buffer they were reading) -- enqueue rbs_stream_join and then the step's all-gather
+ * on the stream the next call is enqueued on (bench.py --gpus N, dbot_ros_amd/dist.py PeerShardedStep).
+ * Slabs do not grow once attached (the other ranks address them with a fixed stride): a region that
+ * does not fit is an error; size state_slab_px for the scene. */
+#define RBS_IPC_BLOB_BYTES 512
+int32_t rbs_ipc_export(rbs_handle* h, void* blob_out);
+int32_t rbs_ipc_attach(rbs_handle* h, int32_t rank, int32_t world, const void* blobs);
+/* Parents that SEVERAL of this rank's children share are better pulled once than read in place by every
+ * child: for i in [0, n) with d_dst_local[i] >= 0, the plane of global slot d_src_global[i] (any rank's)
+ * is copied -- its window only -- into local slot d_dst_local[i] of the current buffer, on `stream`, no
+ * host synchronisation (entries with d_dst_local[i] < 0 are skipped, so the arrays can have a fixed
+ * length).  The caller keeps local slots for this (max_particles > the particles it evaluates) and names
+ * the staged copy -- global slot rank * max_particles + d_dst_local[i] -- as the children's parent.
+ * Both arrays in device memory.  Works on an unattached handle as well (src = local slots). */
+int32_t rbs_stage_windows(rbs_handle* h, const int32_t* d_src_global, const int32_t* d_dst_local, int32_t n, void* stream);
+
 /* Rasterize one pose [n_objects][12] -> host float[rows*cols], +inf where uncovered. */
 int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out);
 /* Device time in milliseconds of the most recent rbs_loglikes* call (HIP events recorded on the

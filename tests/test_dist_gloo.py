@@ -237,3 +237,138 @@ def test_two_rank_sharded_tracker_matches_single_process(parts):
         assert nres == nres_ref and nres > 0
         assert np.abs(ests - ref).max() <= 1e-9, np.abs(ests - ref).max()
     assert got[0][3] == got[1][3] and got[0][3] > 0, "no plane migrated"
+
+
+# ---------------------------------------------------------------- the peer-read step (round 4)
+PN, PSTEPS = 6, 5   # 6 particles per rank
+
+
+def _peer_inputs(world):
+    import torch
+    n_all = PN * world
+    om, cam, P = sc.make_scene(("m1_l2",), 80, 60, max_particles=2 * n_all)
+    o = ob.Oracle(om, cam, P, max_particles=1)
+    frames = sc.make_frames(o, 1, PSTEPS, seed=16)
+    rng = np.random.default_rng(22)
+    poses = [synth.particle_poses(t, n_all, rng, scale=2.0).reshape(n_all, -1) for t, _ in frames]   # by SLOT
+    g = torch.Generator().manual_seed(5)
+    uniforms = [torch.rand(n_all, dtype=torch.float64, generator=g) for _ in frames]
+    return om, cam, P, frames, poses, uniforms
+
+
+def _peer_single(world):
+    import torch
+    om, cam, P, frames, poses, uniforms = _peer_inputs(world)
+    n_all = PN * world
+    o = ob.Oracle(om, cam, P, max_particles=n_all, mode=ob.EAGER)
+    o.reset()
+    idx = np.zeros(n_all, np.int32)
+    out = []
+    for k, (_, frame) in enumerate(frames):
+        o.set_observation(frame)
+        ll = o.loglikes_poses(poses[k], idx, update=True)
+        ps = rdist.global_resample(torch.from_numpy(ll), uniforms[k], temperature=30.0)
+        out.append((ll.copy(), ps.numpy().copy()))
+        idx = ps.numpy().astype(np.int32)
+    return out
+
+
+def _peer_worker(rank, world, port, q):
+    import torch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        om, cam, P, frames, poses, uniforms = _peer_inputs(world)
+        n, cap = PN, 2 * PN
+        o = _OracleWithImport(om, cam, P, max_particles=cap, mode=ob.EAGER)
+        o.reset()
+        sent = [0]
+
+        def evaluate(p, parent_idx, out):
+            # on the CPU every remote parent was staged (min_share = 1): all parents are local slots
+            local = (parent_idx.numpy() - rank * cap).astype(np.int32)
+            assert ((local >= 0) & (local < cap)).all()
+            out.copy_(torch.from_numpy(o.loglikes_poses(p.numpy(), local, update=True)))
+
+        def stage(src, dst):
+            # what rbs_stage_windows does by reading the owner's mapped planes, done here with messages:
+            # every rank knows every rank's plan, the owner sends, the stager stores
+            ops, landed, keep = [], [], []
+            for r in range(world):
+                _, s_r, d_r, _ = rdist.plan_shard(step.last_parents, n, cap, r, 1)
+                for sg, dl in zip(s_r.tolist(), d_r.tolist()):
+                    if dl < 0:
+                        continue
+                    owner, slot = divmod(sg, cap)
+                    assert owner != r and slot < n
+                    if owner == rank:
+                        t = torch.from_numpy(o.get_occlusion(slot).copy())
+                        ops.append(dist.P2POp(dist.isend, t, r))
+                        keep.append(t)
+                        sent[0] += 1
+                    elif r == rank:
+                        t = torch.empty(o.rows * o.cols, dtype=torch.float32)
+                        ops.append(dist.P2POp(dist.irecv, t, owner))
+                        landed.append((dl, t))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for dl, t in landed:
+                o.set_occlusion(dl, t.numpy())
+
+        def all_gather(out, inp):
+            parts = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(parts, inp)
+            out.copy_(torch.cat(parts))
+
+        step = rdist.PeerShardedStep(None, n, cap, min_share=1, evaluate=evaluate, stage=stage, all_gather=all_gather, temperature=30.0)
+        res = []
+        for k, (_, frame) in enumerate(frames):
+            o.set_observation(frame)
+            ps = step.step(torch.from_numpy(poses[k][rank * n:(rank + 1) * n].copy()), uniforms[k])
+            res.append((step.d_all.numpy().copy(), ps.numpy().copy()))
+        q.put((rank, res, sent[0], step.counts.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_step_matches_single_process(world):
+    """dist.PeerShardedStep (global resampling, children in parent order, shared remote parents staged) on gloo
+    ranks over oracle evaluators against ONE oracle holding all particles: the gathered log-likelihoods and the
+    global parents of every step.  (On GPUs remote parents are read through mapped memory; here every one is
+    staged, by message -- the index arithmetic under test is the same code.)"""
+    ref = _peer_single(world)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 23500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(g[2] for g in got) > 0, "the scenario must stage planes across ranks"
+    assert sum(g[3][0] for g in got) > 0
+    for _, res, _, _ in got:
+        for (ll_ref, ps_ref), (ll, ps) in zip(ref, res):
+            assert np.abs(ll - ll_ref).max() <= 1e-9 * max(1.0, np.abs(ll_ref).max()), np.abs(ll - ll_ref).max()
+            assert np.array_equal(ps, ps_ref)
+
+
+def test_plan_shard_indices():
+    """plan_shard by hand: 2 ranks x 4 particles, cap 8.  Sorted parents [1 1 2 5 | 5 5 6 7]: rank 0's child 3 has
+    the remote parent 5 alone (read in place: global slot 1 * 8 + 1); rank 1's children are all local."""
+    import torch
+    ps = torch.tensor([1, 1, 2, 5, 5, 5, 6, 7])
+    p0, s0, d0, c0 = rdist.plan_shard(ps, 4, 8, 0, 2)
+    assert p0.tolist() == [1, 1, 2, 9] and d0.tolist() == [-1] * 4 and c0.tolist() == [1, 0, 0]
+    p1, s1, d1, c1 = rdist.plan_shard(ps, 4, 8, 1, 2)
+    assert p1.tolist() == [9, 9, 10, 11] and c1.tolist() == [0, 0, 0]
+    # [0 0 0 0 | 0 0 3 6]: rank 1 has two children of rank 0's particle 0 -> staged once at local slot 4 (global 12),
+    # one child of rank 0's particle 3 -> in place
+    ps = torch.tensor([0, 0, 0, 0, 0, 0, 3, 6])
+    p1, s1, d1, c1 = rdist.plan_shard(ps, 4, 8, 1, 2)
+    assert p1.tolist() == [12, 12, 3, 10] and s1.tolist() == [0, -1, -1, -1] and d1.tolist() == [4, -1, -1, -1]
+    assert c1.tolist() == [3, 2, 1]
