@@ -120,6 +120,8 @@ def parse():
     ap.add_argument("--in-process", action="store_true",
                     help="ONE process, one handle over --gpus devices through the host-pointer API (the default for --gpus > 1 "
                          "without torch.distributed.run; with --gpus 1 the same steps on a plain handle, for comparison)")
+    ap.add_argument("--resample-temperature", type=float, default=1.0,
+                    help="several ranks: weights = exp((ll - max) / T) in the global resampling of every step (1 = the filter's own weights)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the process rocprofv3 wraps
     a = ap.parse_args()
     for k, v in PRESETS.get(a.config, {}).items():
@@ -230,6 +232,105 @@ class ResidentRun:
         raster_ms = self.sensor.raster_kernel_ms(launches)
         self.sensor.set_timing_every(8)
         return raster_ms, copy_ms, call_ms, n_used
+
+
+class PeerRun(ResidentRun):
+    """world > 1, one process per GPU: SURVEY 8(e)'s step with its hard part inside the clock --
+    set_observation_device + loglikes_device(update) on this rank's shard with GLOBAL parent slots (parents in
+    other ranks' handles are read in place over xGMI through HIP-IPC mappings; parents that several local
+    children share are pulled once by rbs_stage_windows), the all-gather of the log-likelihoods (RCCL), and a
+    multinomial resampling over ALL ranks' particles (device-resident torch arithmetic, identical on every rank)
+    that produces the next step's parents.  dbot_ros_amd/dist.py PeerShardedStep; nothing touches the host."""
+
+    def __init__(self, a, W, sensor, stream, step, uniforms):
+        super().__init__(a, W, sensor, stream, step.d_out)
+        self.step, self.uniforms = step, uniforms
+        self.distinct = torch.zeros(1, dtype=torch.int64, device=step.d_out.device)
+        self.steps_done = 0
+
+    def launch(self):
+        a, W = self.a, self.W
+        k = W.order[self.count % len(W.order)]
+        u = self.uniforms[self.count % len(self.uniforms)]
+        self.count += 1
+        if a.sequence > 0:
+            self.sensor.set_observation_device(W.d_frames.data_ptr() + k * W.frame_bytes, self.stream.cuda_stream)
+        ps = self.step.step(W.d_poses[k], u)
+        self.distinct += (ps[1:] != ps[:-1]).sum() + 1
+        self.steps_done += 1
+
+    def reset_stats(self):
+        self.step.counts.zero_()
+        self.step.children = 0
+        self.distinct.zero_()
+        self.steps_done = 0
+
+    def stats(self):
+        c = self.step.counts.cpu().numpy().astype(np.float64)
+        ch = max(1, self.step.children)
+        return {"remote_parent_frac": c[0] / ch, "remote_children_served_from_staging_frac": (c[1] / c[0]) if c[0] else 0.0,
+                "planes_staged_per_step_per_rank": c[2] / max(1, self.steps_done),
+                "distinct_parents_per_step": float(self.distinct.item()) / max(1, self.steps_done)}
+
+
+def setup_peer_run(a, om, cam, P, W, dev, stream, dist, backend, world):
+    """One rank's handle (n own slots + n staging slots), attached to the other ranks', and its PeerRun."""
+    from dbot_ros_amd import dist as rdist
+    n = a.particles
+    sensor = make_sensor(a, om, cam, P, dev, n=2 * n)
+    prime(sensor, a, W)
+    rdist.attach_peers(sensor)
+
+    def gather(out_t, inp_t):
+        if backend == "nccl":
+            dist.all_gather_into_tensor(out_t, inp_t)      # RCCL over xGMI, on `stream`
+        else:                                              # (functional tests on a box with fewer GPUs than ranks)
+            host = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(host, inp_t.cpu())
+            out_t.copy_(torch.cat(host))
+
+    pstep = rdist.PeerShardedStep(sensor, n, 2 * n, device=dev, min_share=2, stream=stream.cuda_stream, all_gather=gather,
+                                  temperature=a.resample_temperature)
+    gen = torch.Generator().manual_seed(1234)        # the same uniforms on every rank
+    uniforms = [torch.rand(n * world, dtype=torch.float64, generator=gen).to(dev) for _ in range(16)]
+    return sensor, PeerRun(a, W, sensor, stream, pstep, uniforms)
+
+
+def peer_configs_leg(a, dev, stream, dist, backend, world, rank, names=("c3_slice", "c4_slice")):
+    """BASELINE C3 / C4 at their real per-GPU sizes (25 000 / 6 250 particles per rank) through the same multi-rank
+    step: whole-job particle-likelihoods/s (MAX over ranks of the elapsed time) and where the parents were."""
+    import copy
+    res = {}
+    for name in names:
+        b = copy.copy(a)
+        for k, v in PRESETS[name].items():
+            setattr(b, k, v)
+        b.steps = max(b.steps, 10)
+        om, cam, P, n_tri, nb = build_scene(b)
+        W = Workload(b, om, cam, P, nb, dev, rank)
+        s, run = setup_peer_run(b, om, cam, P, W, dev, stream, dist, backend, world)
+        el = run.timed(b.steps, 3, barrier=dist.barrier)
+        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        ok = bool(torch.isfinite(run.step.d_all).all().item())
+        st = run.stats()
+        torch.cuda.synchronize()
+        dist.barrier()                     # nobody frees planes a peer may still be reading
+        s.close()
+        if not ok:
+            raise SystemExit(f"non-finite log-likelihoods in the {name} leg")
+        key = name.replace("_slice", "")
+        res[f"{key}_value"] = b.particles * world * b.steps / el
+        res[f"{key}_ms_per_step"] = el / b.steps * 1e3
+        res[f"{key}_particles_total"] = b.particles * world
+        for k_, v_ in st.items():
+            res[f"{key}_{k_}"] = v_
+        del W, run
+        torch.cuda.empty_cache()
+    res["configs_note"] = (f"BASELINE C3 ({25000 * world} particles, M1, 640x480) and C4 ({6250 * world} particles, M4 = 50 880 triangles, "
+                           f"1280x960) over {world} ranks: the same step as the headline (global resampling every step), whole-job rates")
+    return res
 
 
 def make_sensor(a, om, cam, P, device, precision=None, layout=None, n=None):
@@ -736,6 +837,9 @@ def in_process_multi_device(a):
 
 # --------------------------------------------------------------------------------- main
 def main():
+    if os.environ.get("RBS_BENCH_WATCHDOG"):    # diagnostics: dump every thread's stack and exit after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["RBS_BENCH_WATCHDOG"]), exit=True)
     a = parse()
     if (a.gpus > 1 or a.in_process) and "WORLD_SIZE" not in os.environ and not a.pmc_child:
         if not torch.cuda.is_available():
@@ -778,31 +882,25 @@ def main():
     d_out.zero_()                  # first submission creates the stream's hardware queue: setup, not a step
     torch.cuda.synchronize()
 
-    sensor = make_sensor(a, om, cam, P, dev)
-    prime(sensor, a, W)
-    run = ResidentRun(a, W, sensor, stream, d_out)
+    if world > 1:
+        sensor, run = setup_peer_run(a, om, cam, P, W, dev, stream, dist, backend, world)
+        d_out, d_all = run.step.d_out, run.step.d_all
+    else:
+        sensor = make_sensor(a, om, cam, P, dev)
+        prime(sensor, a, W)
+        run = ResidentRun(a, W, sensor, stream, d_out)
 
     if a.pmc_child:                # wrapped by rocprofv3: a few steps, no output
         run.timed(a.steps, a.warmup)
         sensor.close()
         return
 
-    def exchange():
-        # the weight exchange before resampling: every rank gets all N*world log-likelihoods
-        if backend == "nccl":
-            dist.all_gather_into_tensor(d_all, d_out)      # RCCL over xGMI, on `stream`
-        else:
-            host = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
-            dist.all_gather(host, d_out.cpu())
-            d_all.copy_(torch.cat(host))
-
     # REPEATS timed regions of exactly --steps steps each (every one bracketed by barrier +
     # synchronize on both sides, the MAX over ranks taken per region); the headline is the MEDIAN
     # region -- a 20-step region is 4 ms, and one region alone moved by 7 % between runs
     regions = []
     for rep in range(REPEATS):
-        el = run.timed(a.steps, a.warmup if rep == 0 else 0, after=exchange if world > 1 else None,
-                       barrier=dist.barrier if world > 1 else None)
+        el = run.timed(a.steps, a.warmup if rep == 0 else 0, barrier=dist.barrier if world > 1 else None)
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -821,11 +919,33 @@ def main():
     raster_ms, copy_ms, call_ms, n_used = run.kernel_times(512)
     windows = np.array([sensor.get_window(s_) for s_ in range(0, n, max(1, n // 64))])
     win_frac = float(np.mean(np.maximum(0, windows[:, 2] - windows[:, 0]) * np.maximum(0, windows[:, 3] - windows[:, 1]))) / (a.rows * a.cols)
+    peer_stats, peer_legs = None, {}
+    if world > 1:
+        peer_stats = run.stats()
+        # the same step with FLATTENED weights (temperature = the spread of the log-likelihoods): many distinct parents,
+        # a large share of them on other ranks and unshared -- the case that exercises the in-place reads over xGMI
+        # (the filter's own weights on these synthetic poses leave one or two survivors per step)
+        run.reset_stats()
+        run.step.temperature = max(1.0, float(d_all.std().item()))
+        run.timed(a.warmup + 3, 0, barrier=dist.barrier)
+        run.reset_stats()
+        el2 = run.timed(a.steps, 0, barrier=dist.barrier)
+        t2 = torch.tensor([el2], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        peer_stats.update({"spread_parents_" + k_: v_ for k_, v_ in run.stats().items()})
+        peer_stats["spread_parents_value"] = n * world * a.steps / float(t2.item())
+        peer_stats["spread_parents_temperature"] = run.step.temperature
+        torch.cuda.synchronize()
+        dist.barrier()                     # every rank is done reading its peers' planes: handles may go
+        sensor.close()
+        if not a.no_configs_leg and a.config in (None, "c1"):
+            peer_legs = peer_configs_leg(a, dev, stream, dist, backend, world, rank)
 
     if rank != 0:
-        sensor.close()
         if world > 1:
             dist.destroy_process_group()
+        else:
+            sensor.close()
         return
 
     alg_bytes = (2.0 if a.update else 1.0) * 4.0 * a.rows * a.cols * n  # per launch, SURVEY 8d
@@ -852,6 +972,15 @@ def main():
                    "particles_per_gpu": n, "resolution": [a.cols, a.rows], "triangles": int(n_tri),
                    "sharding": f"particles/{world}" + (" + RCCL all-gather of log-likelihoods" if world > 1 else "")},
     }
+    if world > 1:
+        out["config"]["workload"] = (f"C1 per GPU: {n} particles/GPU ({n * world} in all) x [loglikes(update=true) with GLOBAL parents + RCCL all-gather of "
+                                     f"the log-likelihoods + multinomial resampling over all ranks' particles (weights exp((ll - max) / {a.resample_temperature:g}))], "
+                                     f"{a.cols}x{a.rows} synthetic depth frame, mesh {a.mesh} ({n_tri} triangles), {max(1, a.sequence)}-frame moving-object "
+                                     f"sequence, likelihood precision {a.precision}, {a.layout} planes, inputs resident in HBM")
+        out["config"]["sharding"] = (f"particles/{world}: one process per GPU, handles attached over HIP IPC (parents on other ranks read in place over "
+                                     "xGMI, shared ones pulled once), one RCCL all-gather per step, no plane migration, no host synchronisation")
+        out.update(peer_stats)
+        out.update(peer_legs)
     single = world == 1
     # (several ranks: rank 0's device; live counter passes only on request -- the other ranks would
     # wait minutes at the next collective -- otherwise the committed counters of the same launch)
@@ -863,7 +992,8 @@ def main():
                  "state_layout": a.layout, "stored_window_fraction_of_plane": win_frac,
                  "algorithmic_bytes_per_launch": alg_bytes})
     out["roofline"] = roof
-    sensor.close()
+    if world == 1:
+        sensor.close()
 
     # ---- the same steps on whole planes: the copy kernel is dominant there and HBM bound
     if single and a.update and a.layout == "window" and not a.no_dense_leg:

@@ -659,6 +659,15 @@ int32_t check_slab_error(rbs_handle* h)
 // its first float, so the planes move with one strided copy; the regions' tables stay as they are.
 // Only the CURRENT buffer holds state (the other one is written from scratch by the next updating
 // call).  The caller has drained the handle.
+// Bytes to ask hipMalloc for when `bytes` are needed for a plane buffer.  A buffer whose size has bit 31 set
+// (2-4 GiB, 6-8 GiB, ...) cannot be imported by another process on ROCm 7.2: hipIpcOpenMemHandle never
+// returns (measured, tools/dbg/ipc_attach_notorch.py: 13 900 x 38 400 px opens at once, 14 500 x 38 400 hangs,
+// 30 000 x 38 400 opens, 50 000 x 38 400 hangs).  Such sizes are rounded up to the next multiple of 4 GiB.
+size_t occ_alloc_bytes(size_t bytes)
+{
+    return (bytes & 0x80000000ull) ? ((bytes >> 32) + 1) << 32 : bytes;
+}
+
 int32_t grow_slabs(rbs_handle* h, int new_slab)
 {
     new_slab = std::min(h->npx, (new_slab + 1023) & ~1023);
@@ -672,7 +681,7 @@ int32_t grow_slabs(rbs_handle* h, int new_slab)
     float* nb[2] = {nullptr, nullptr};
     const size_t bytes = sizeof(float) * (size_t)new_slab * h->max_particles;
     for (int k = 0; k < 2; ++k)
-        if (hipMalloc(&nb[k], bytes) != hipSuccess) {
+        if (hipMalloc(&nb[k], occ_alloc_bytes(bytes)) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(nb[0]);
             return fail(h, RBS_ERR_OUT_OF_MEMORY, fmt("enlarging the occlusion slabs from %d to %d px per slot needs 2 x %zu bytes more", h->slab_px, new_slab, bytes));
@@ -1307,8 +1316,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     }
     if (h->slab_px >= h->npx) h->slab_px = 0;
     h->plane_stride = h->slab_px ? (size_t)h->slab_px : (size_t)h->npx;
-    RBS_HIP(h, hipMalloc(&h->d_occ[0], sizeof(float) * h->plane_stride * h->max_particles));
-    RBS_HIP(h, hipMalloc(&h->d_occ[1], sizeof(float) * h->plane_stride * h->max_particles));
+    RBS_HIP(h, hipMalloc(&h->d_occ[0], occ_alloc_bytes(sizeof(float) * h->plane_stride * h->max_particles)));
+    RBS_HIP(h, hipMalloc(&h->d_occ[1], occ_alloc_bytes(sizeof(float) * h->plane_stride * h->max_particles)));
     RBS_HIP(h, hipMalloc(&h->d_err, 2 * sizeof(int)));
     RBS_HIP(h, hipMemset(h->d_err, 0, 2 * sizeof(int)));
     RBS_HIP(h, hipHostMalloc(&h->h_err, 4 * sizeof(int), hipHostMallocDefault));
@@ -2476,6 +2485,7 @@ int32_t rbs_ipc_attach(rbs_handle* h, int32_t rank, int32_t world, const void* b
     if (h->peer_world > 1) return fail(h, RBS_ERR_INVALID_ARGUMENT, "ipc_attach: already attached");
     if ((long)world * h->max_particles > 0x7fffffffL) return fail(h, RBS_ERR_INVALID_ARGUMENT, "ipc_attach: too many global slots");
     RBS_HIP(h, hipSetDevice(h->device));
+    if (std::getenv("RBS_DEBUG_IPC")) std::fprintf(stderr, "[rbs ipc] rank %d attach: draining\n", rank);
     if (int32_t rc = drain(h, true)) return rc;
     const unsigned char* raw = static_cast<const unsigned char*>(blobs);
     for (int k = 0; k < world; ++k) {
@@ -2504,7 +2514,9 @@ int32_t rbs_ipc_attach(rbs_handle* h, int32_t rank, int32_t world, const void* b
         for (int m = 0; m < 6; ++m) {
             if (m >= 4 && !h->slab_px) break;
             void* p = nullptr;
+            if (std::getenv("RBS_DEBUG_IPC")) std::fprintf(stderr, "[rbs ipc] rank %d opens rank %d buffer %d\n", rank, k, m);
             const hipError_t e = hipIpcOpenMemHandle(&p, b.mem[m], hipIpcMemLazyEnablePeerAccess);
+            if (std::getenv("RBS_DEBUG_IPC")) std::fprintf(stderr, "[rbs ipc] rank %d opened rank %d buffer %d -> %p (%d)\n", rank, k, m, p, (int)e);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
                 return fail(h, RBS_ERR_HIP, fmt("hipIpcOpenMemHandle(rank %d, buffer %d): %s", k, m, hipGetErrorString(e)));

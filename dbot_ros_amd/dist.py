@@ -341,7 +341,12 @@ def attach_peers(sensor, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     blobs = [None] * world
     dist.all_gather_object(blobs, sensor.ipc_export(), group=group)
-    sensor.ipc_attach(rank, blobs)
+    # one rank at a time: two processes importing each other's large buffers at the same moment were seen to
+    # block each other inside hipIpcOpenMemHandle for ever (3 GB slabs, ROCm 7.2)
+    for r in range(world):
+        if r == rank:
+            sensor.ipc_attach(rank, blobs)
+        dist.barrier(group=group)
 
 
 class PeerShardedStep:

@@ -286,7 +286,8 @@ def test_bench_line_of_two_ranks_on_one_gpu(gpu_lib):
     env = dict(os.environ, RBS_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", str(29100 + os.getpid() % 800),
-                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--particles", "256"],
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--particles", "256",
+                        "--no-configs-leg", "--resample-temperature", "40"],
                        capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -297,3 +298,6 @@ def test_bench_line_of_two_ranks_on_one_gpu(gpu_lib):
     assert abs(line["value"] - 2 * 256 * 5 / (line["ms_per_step"] * 5e-3)) <= 1e-6 * line["value"]
     roof = line["roofline"]
     assert roof["bound"] == "valu_issue" and roof["kernel_ms"] > 0 and "cpu_baseline" not in line
+    # the step resamples over BOTH ranks' particles: some children inherit from the other rank
+    assert 0.0 < line["remote_parent_frac"] < 1.0 and line["distinct_parents_per_step"] > 4
+    assert "global" in line["config"]["workload"].lower() and "IPC" in line["config"]["sharding"]
