@@ -642,9 +642,16 @@ def native_host_leg(a, om, cam, P, W, steps):
         if not line:
             return {"host_api_native_note": "host_bench did not run: " + (r.stdout + r.stderr)[-200:]}
         tok = line.split()
-        return {"host_api_native_value": float(tok[2]), "host_api_native_ms_per_step": float(tok[4]),
-                "host_api_native_note": "the host-pointer step (rbs_set_observation_f32 + rbs_loglikes, synchronous) called from C++ "
-                                        "(tests/cpp/host_bench.cpp), frames cycling forwards through the sequence"}
+        res = {"host_api_native_value": float(tok[2]), "host_api_native_ms_per_step": float(tok[4]),
+               "host_api_native_note": "the host-pointer step (rbs_set_observation_f32 + rbs_loglikes, synchronous) called from C++ "
+                                       "(tests/cpp/host_bench.cpp), frames cycling forwards through the sequence"}
+        r2 = subprocess.run([exe, "--prefetch", path, str(steps), "10"], capture_output=True, text=True, timeout=300, env=env)
+        line2 = next((l for l in r2.stdout.splitlines() if l.startswith("host_bench ")), None)
+        if line2:
+            t2 = line2.split()
+            res.update({"host_api_native_prefetch_value": float(t2[2]), "host_api_native_prefetch_ms_per_step": float(t2[4]),
+                        "host_api_native_prefetch_checksum_equal": t2[6] == tok[6] if len(t2) > 6 and len(tok) > 6 else None})
+        return res
     except Exception as e:   # noqa: BLE001 -- a benchmark leg must not take the headline down
         return {"host_api_native_note": "host_bench failed: %r" % (e,)}
     finally:
@@ -1073,13 +1080,35 @@ def main():
         for i in range(hsteps):
             staged_step(i)
         ts = time.perf_counter() - t0
+        # the same with the NEXT frame handed over with each call (rbs_loglikes_prefetch): its staging copy and transfer
+        # pass behind the call's kernels; rbs_set_observation_prefetched then costs nothing.  Still every frame from
+        # host memory, every pose up and every log-likelihood down inside the clock.
+        def ahead_step(i):
+            k, k1 = W.order[i % len(W.order)], W.order[(i + 1) % len(W.order)]
+            ll_ = hs.loglikes_poses_prefetch(W.poses[k], W.parents.copy(), W.frames[k1], update=bool(a.update))
+            hs.set_observation_prefetched()
+            return ll_
+
+        hs.set_observation(W.frames[W.order[0]])
+        for i in range(10):
+            ahead_step(i)
+        t0 = time.perf_counter()
+        for i in range(10, 10 + hsteps):
+            ahead_step(i)
+        tp = time.perf_counter() - t0
         hs.close()
+        out["host_api_prefetch_value"] = n * hsteps / tp
+        out["host_api_prefetch_ms_per_step"] = tp / hsteps * 1e3
         out["host_api_staged_frame_value"] = n * hsteps / ts
         out["host_api_value"] = n * hsteps / th
         out["host_api_ms_per_step"] = th / hsteps * 1e3
         out["host_api_loglikes_only_value"] = n * hsteps / tl
         out["host_api_note"] = ("rbs_set_observation_f32 (1.2 MB frame from host memory) + rbs_loglikes (poses + parent indices "
-                                "from host memory, log-likelihoods back to host memory, synchronous), called through ctypes")
+                                "from host memory, log-likelihoods back to host memory, synchronous), called through ctypes; "
+                                "host_api_prefetch_*: the same frames, poses and results through rbs_loglikes_prefetch + "
+                                "rbs_set_observation_prefetched (frame k+1 handed over with call k: a recorded dataset, or a driver one frame ahead); "
+                                "host_api_loglikes_only_value = SURVEY 8(d)'s definition of the metric to the letter (pose upload and "
+                                "log-likelihood download inside the clock, no frame)")
         # the same step driven from C++ through the C-ABI (tests/cpp/host_bench.cpp): what the
         # reference's own filter, which is C++, would pay -- no interpreter between the calls
         nat = native_host_leg(a, om, cam, P, W, hsteps)

@@ -29,7 +29,7 @@ EXPORTS = (
     "rbs_abi_version", "rbs_device_count", "rbs_create", "rbs_destroy", "rbs_last_error",
     "rbs_reset", "rbs_set_observation", "rbs_set_observation_f32",
     "rbs_set_observation_native_f32", "rbs_set_observation_device", "rbs_get_observation", "rbs_loglikes",
-    "rbs_acquire_frame_buffer", "rbs_commit_frame_buffer",
+    "rbs_acquire_frame_buffer", "rbs_commit_frame_buffer", "rbs_loglikes_prefetch", "rbs_set_observation_prefetched",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_export_plane", "rbs_import_plane",
     "rbs_export_window", "rbs_import_window", "rbs_stream_join", "rbs_ipc_export", "rbs_ipc_attach", "rbs_stage_windows",
@@ -156,6 +156,11 @@ def load():
     lib.rbs_export_plane.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rbs_import_plane.restype = C.c_int32
     lib.rbs_import_plane.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rbs_loglikes_prefetch.restype = C.c_int32
+    lib.rbs_loglikes_prefetch.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_double),
+                                          C.POINTER(C.c_float), C.c_size_t]
+    lib.rbs_set_observation_prefetched.restype = C.c_int32
+    lib.rbs_set_observation_prefetched.argtypes = [H]
     lib.rbs_export_window.restype = C.c_int32
     lib.rbs_export_window.argtypes = [H, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_size_t, C.c_void_p]
     lib.rbs_import_window.restype = C.c_int32

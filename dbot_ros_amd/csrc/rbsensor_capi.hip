@@ -177,6 +177,7 @@ struct rbs_handle {
     int join_pending = -1;      // ring slot whose copy kernel later work on the planes must wait for
     std::string err;
     bool frame_acquired = false;       // rbs_acquire_frame_buffer without its rbs_commit_frame_buffer yet
+    int prefetched_slot = -1;          // staging slot holding a frame uploaded ahead of its turn (rbs_loglikes_prefetch), -1: none
     // A call that failed half-way through a fan-out (some shards enqueued, others not) or between a
     // tracker's buffer swaps leaves the handle's double buffers out of step: every later call is
     // refused with this message until rbs_reset (rbs_tracker_initialize) re-establishes a known state.
@@ -850,6 +851,7 @@ int32_t upload_frame(rbs_handle* h, const float* src, const float* pageable = nu
 {
     const int k = h->frame_slot;
     const size_t n = (size_t)h->npx;
+    h->prefetched_slot = -1;   // (a frame uploaded ahead of its turn that another frame overtakes is abandoned)
     // (the two staging images alternate, so k is never the image that serves as the observation --
     // should it be, its readers are recorded first: the wait below must not be on a stale event)
     if (k == h->cur_slot)
@@ -916,6 +918,32 @@ int32_t next_frame_staging(rbs_handle* h)
     h->frame_slot ^= 1;
     h->h_frame = h->h_frames[h->frame_slot];
     RBS_HIP(h, hipEventSynchronize(h->ev_frame[h->frame_slot]));
+    return RBS_OK;
+}
+
+// The NEXT frame, uploaded while the current one is still the observation (rbs_loglikes_prefetch: called between
+// the launch of a call's kernels and the wait for its results, so the host's staging copy and the transfer pass
+// behind the raster kernel): staged into the other pinned image, sent on the upload stream, its model terms
+// (precision F64) computed behind it -- everything upload_frame does except making it the observation.
+int32_t prefetch_frame(rbs_handle* h, const float* depth)
+{
+    if (h->frame_ingest)   // (frames ingested on the launch stream: RBS_FRAME_INGEST tooling mode)
+        return fail(h, RBS_ERR_UNSUPPORTED, "loglikes_prefetch: not with RBS_FRAME_INGEST");
+    if (int32_t rc = next_frame_staging(h)) return rc;
+    const int k = h->frame_slot;
+    const size_t n = (size_t)h->npx;
+    if (k == h->cur_slot) return fail(h, RBS_ERR_HIP, "loglikes_prefetch: the staging images did not alternate");
+    RBS_HIP(h, hipStreamWaitEvent(h->up_stream, h->ev_used[k], 0));   // d_fin[k]: its readers were enqueued two frames ago
+    std::memcpy(h->h_frames[k], depth, n * sizeof(float));
+    RBS_HIP(h, hipMemcpyAsync(h->d_fin[k], h->h_frames[k], n * sizeof(float), hipMemcpyHostToDevice, h->up_stream));
+    if (h->d_aux) {
+        hipLaunchKernelGGL(rbs::frame_aux_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->up_stream,
+                           h->d_fin[k], h->d_aux_slot[k], h->d_pbg, h->npx, h->base.tw, h->base.ms, h->base.sf,
+                           h->base.lambda, (float*)nullptr);
+        RBS_HIP(h, hipGetLastError());
+    }
+    RBS_HIP(h, hipEventRecord(h->ev_frame[k], h->up_stream));
+    h->prefetched_slot = k;
     return RBS_OK;
 }
 
@@ -2144,8 +2172,48 @@ int32_t rbs_get_observation(rbs_handle* h, float* out)
     return RBS_OK;
 }
 
+static int32_t loglikes_impl(rbs_handle* h, const double* poses, int32_t* indices, int32_t n, int32_t update, double* out_loglik,
+                             const float* next_depth);
+
 int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32_t n,
                      int32_t update, double* out_loglik)
+{
+    return loglikes_impl(h, poses, indices, n, update, out_loglik, nullptr);
+}
+
+int32_t rbs_loglikes_prefetch(rbs_handle* h, const double* poses, int32_t* indices, int32_t n, int32_t update, double* out_loglik,
+                              const float* next_depth, size_t next_n)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty()) return fail(h, RBS_ERR_UNSUPPORTED, "loglikes_prefetch: single-device handles (a handle over several devices: rbs_acquire/commit_frame_buffer)");
+    if (!next_depth || next_n != (size_t)h->npx)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("loglikes_prefetch: expected a next frame of %d pixels, got %zu", h->npx, next_n));
+    if (n <= 0) return fail(h, RBS_ERR_INVALID_ARGUMENT, "loglikes_prefetch: n must be positive");
+    return loglikes_impl(h, poses, indices, n, update, out_loglik, next_depth);
+}
+
+int32_t rbs_set_observation_prefetched(rbs_handle* h)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_REFUSE_POISONED(h);
+    if (h->prefetched_slot < 0)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_observation_prefetched: no frame was uploaded ahead (rbs_loglikes_prefetch), or another frame has been set since");
+    RBS_HIP(h, hipSetDevice(h->device));
+    h->frame_acquired = false;
+    if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
+    const int k = h->prefetched_slot;
+    h->prefetched_slot = -1;
+    if (int32_t rc = release_frame_slot(h)) return rc;   // the readers of the frame it replaces are on the launch stream by now
+    h->cur_frame = h->d_fin[k];
+    h->cur_aux = h->d_aux ? h->d_aux_slot[k] : nullptr;
+    h->cur_slot = k;
+    h->frame_wait = k;
+    h->pending_frames += 1;
+    return RBS_OK;
+}
+
+static int32_t loglikes_impl(rbs_handle* h, const double* poses, int32_t* indices, int32_t n, int32_t update, double* out_loglik,
+                             const float* next_depth)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
     RBS_REFUSE_POISONED(h);
@@ -2167,6 +2235,8 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
     // stream and joined by the next call
     const CallState before = save_call_state(h);
     if (int32_t rc = host_call(h, poses, indices, n, update != 0)) return rc;
+    if (next_depth)   // the next frame travels while this call's kernels run
+        if (int32_t rc = prefetch_frame(h, next_depth)) return rc;
     RBS_HIP(h, hipEventSynchronize(h->ev_out));
     const bool stale_overflow = h->slab_px && h->h_err[2] != 0;   // of an earlier asynchronous call: reported below, once
     if (h->slab_px && h->h_err[0]) {

@@ -284,6 +284,21 @@ class RbSensor:
             out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def loglikes_poses_prefetch(self, poses, indices, next_image, update=False):
+        """loglikes_poses with the NEXT frame (float32 [rows*cols]) uploaded behind the call's kernels;
+        set_observation_prefetched() then makes it the observation."""
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, self.n_bodies * 12)
+        n = poses.shape[0]
+        nxt = np.ascontiguousarray(next_image, dtype=np.float32).ravel()
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.rbs_loglikes_prefetch(
+            self._h, poses.ctypes.data_as(C.POINTER(C.c_double)), indices.ctypes.data_as(C.POINTER(C.c_int32)), n, int(bool(update)),
+            out.ctypes.data_as(C.POINTER(C.c_double)), nxt.ctypes.data_as(C.POINTER(C.c_float)), nxt.size))
+        return out
+
+    def set_observation_prefetched(self):
+        self._check(self._lib.rbs_set_observation_prefetched(self._h))
+
     def set_observation_device(self, d_depth_ptr, stream=None):
         """Frame already on the device (float32 [rows*cols], raw address); asynchronous."""
         self._check(self._lib.rbs_set_observation_device(self._h, d_depth_ptr, stream))

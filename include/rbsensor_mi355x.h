@@ -192,6 +192,18 @@ int32_t rbs_get_observation(rbs_handle* h, float* out);
 int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32_t n,
                      int32_t update, double* out_loglik);
 
+/* rbs_loglikes with the NEXT frame travelling behind it (a recorded dataset, or a driver that is a frame ahead:
+ * the reference's tracker takes its frames from a mailbox, R:source/dbot_ros/object_tracker_ros.hpp:69-84, :44-49).
+ * Same call, same results; between launching its kernels and waiting for them the library stages next_depth
+ * (float32 metres, rows*cols, the layout of rbs_set_observation_f32) into its other pinned image and sends it on
+ * the upload stream, the per-pixel model terms behind it -- the 1.2 MB copy and transfer of a 640x480 frame pass
+ * while the raster kernel runs.  The current observation is unchanged.  rbs_set_observation_prefetched then makes
+ * that frame the observation at no cost (one frame per call, as rbs_set_observation_f32 does: the model clock
+ * advances by delta_time); any other rbs_set_observation* in between abandons it.  Single-device handles. */
+int32_t rbs_loglikes_prefetch(rbs_handle* h, const double* poses, int32_t* indices, int32_t n, int32_t update,
+                              double* out_loglik, const float* next_depth, size_t next_n);
+int32_t rbs_set_observation_prefetched(rbs_handle* h);
+
 /* Device-pointer variant: poses/indices/out_loglik are device memory on the handle's device,
  * work is enqueued on `stream` (a hipStream_t, NULL = the handle's own stream) and the call
  * returns without synchronising.  indices is read-only and read in `stream` order only (the

@@ -1,7 +1,8 @@
 // host_bench.cpp -- the host-pointer step (rbs_set_observation_f32 + rbs_loglikes) driven from
 // C++ through the C-ABI, the way the reference's own (C++) filter would call it; bench.py's
 // host_api_* leg goes through Python/ctypes and pays the interpreter per call.
-//   host_bench <workload.bin> <steps> [warmup]
+//   host_bench [--prefetch] <workload.bin> <steps> [warmup]
+//   (--prefetch: rbs_loglikes_prefetch + rbs_set_observation_prefetched, the next frame uploaded behind each call's kernels)
 // workload.bin (written by bench.py, native endianness):
 //   int32 rows, cols, n_objects, n, F, update; double K[9]; double params[7]
 //   (p_occluded_visible, p_occluded_occluded, initial_occlusion_prob, tail_weight, model_sigma,
@@ -31,7 +32,8 @@ static bool rd(std::FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n
 int main(int argc, char** argv)
 {
     const bool tracker_mode = argc > 1 && !std::strcmp(argv[1], "--tracker");
-    if (tracker_mode) { --argc; ++argv; }
+    const bool prefetch_mode = argc > 1 && !std::strcmp(argv[1], "--prefetch");   // the next frame travels behind each call's kernels
+    if (tracker_mode || prefetch_mode) { --argc; ++argv; }
     if (argc < 3) { std::fprintf(stderr, "usage: host_bench workload.bin steps [warmup] | host_bench --tracker workload.bin particles\n"); return 2; }
     std::FILE* f = std::fopen(argv[1], "rb");
     if (!f) { std::perror(argv[1]); return 2; }
@@ -121,11 +123,19 @@ int main(int argc, char** argv)
         idx = parents;
         return rbs_loglikes(h, poses.data() + stride * k, idx.data(), n, update, out.data());
     };
+    // --prefetch: rbs_loglikes_prefetch hands frame i + 1 over with step i's call, rbs_set_observation_prefetched makes it current
+    auto step_ahead = [&](int i) -> int32_t {
+        const int k = i % F, k1 = (i + 1) % F;
+        idx = parents;
+        if (int32_t rc = rbs_loglikes_prefetch(h, poses.data() + stride * k, idx.data(), n, update, out.data(), frames.data() + npx * k1, npx)) return rc;
+        return rbs_set_observation_prefetched(h);
+    };
+    if (prefetch_mode && rbs_set_observation_f32(h, frames.data(), npx)) { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; }
     for (int i = 0; i < warmup; ++i)
-        if (step(i)) { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; }
+        if (prefetch_mode ? step_ahead(i) : step(i)) { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; }
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < steps; ++i)
-        if (step(i)) { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; }
+        if (prefetch_mode ? step_ahead(warmup + i) : step(warmup + i)) { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     double sum = 0.0;
     for (double v : out) if (std::isfinite(v)) sum += v;

@@ -1010,3 +1010,44 @@ def test_sharded_tracker_matches_the_single_gpu_tracker(gpu_lib, state_layout):
     assert out[1]["estimate_digest"] == out[2]["estimate_digest"]
     assert out[2]["planes_migrated"] > 0 and out[1]["planes_migrated"] == 0
     assert out[2]["final_position_error_m"] < 0.01
+
+
+def test_prefetched_frames_give_the_same_numbers(gpu_lib):
+    """rbs_loglikes_prefetch hands frame k+1 over with call k (uploaded behind the call's kernels),
+    rbs_set_observation_prefetched makes it the observation: log-likelihoods, planes and the model clock are those of
+    rbs_set_observation_f32 + rbs_loglikes, bit for bit, in both precisions; a prefetched frame that another
+    set_observation overtakes is abandoned, and a second activation is refused."""
+    from dbot_ros_amd.sensor import RbSensorError
+    n = 24
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    orc = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    frames = sc.make_frames(orc, 1, 6, seed=31)
+    rng = np.random.default_rng(8)
+    poses = [synth.particle_poses(t, n, rng, scale=2.0) for t, _ in frames]
+    parents = [rng.integers(0, n, n).astype(np.int32) for _ in frames]
+    for precision in ("f64", "f32"):
+        with RbSensor(om, cam, P, max_particles=n, precision=precision) as a, RbSensor(om, cam, P, max_particles=n, precision=precision) as b:
+            a.reset(); b.reset()
+            idx_a, idx_b = np.zeros(n, np.int32), np.zeros(n, np.int32)
+            b.set_observation(frames[0][1].astype(np.float32))
+            for k in range(len(frames)):
+                a.set_observation(frames[k][1].astype(np.float32))
+                la = a.loglikes_poses(poses[k], idx_a, update=True)
+                if k + 1 < len(frames):
+                    lb = b.loglikes_poses_prefetch(poses[k], idx_b, frames[k + 1][1], update=True)
+                    b.set_observation_prefetched()
+                else:
+                    lb = b.loglikes_poses(poses[k], idx_b, update=True)
+                assert np.array_equal(la, lb), (precision, k)
+                idx_a, idx_b = parents[k].copy(), parents[k].copy()
+            for slot in (0, n // 2, n - 1):
+                assert np.array_equal(a.get_occlusion(slot), b.get_occlusion(slot))
+            assert a.get_background() == b.get_background()
+            with pytest.raises(RbSensorError):
+                b.set_observation_prefetched()                                   # nothing uploaded ahead
+            b.loglikes_poses_prefetch(poses[0], idx_b.copy(), frames[1][1], update=False)
+            b.set_observation(frames[2][1].astype(np.float32))                    # overtakes the prefetched frame
+            with pytest.raises(RbSensorError):
+                b.set_observation_prefetched()
+            a.set_observation(frames[2][1].astype(np.float32))
+            assert np.array_equal(a.loglikes_poses(poses[2], idx_a.copy(), update=False), b.loglikes_poses(poses[2], idx_b.copy(), update=False))
