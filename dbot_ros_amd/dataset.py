@@ -14,8 +14,9 @@ restates the published bag v2.0 container (records = <header_len><header><data_l
 header = <field_len>name=value ..., op 0x03 bag header padded to 4 096 bytes, 0x05 chunk,
 0x07 connection, 0x02 message data, 0x04 index data, 0x06 chunk info) and the ROS1 wire
 serialisation of the two message types; there is no upstream bag in the reference tree to pin
-it against (the repo ships none), so the round trip writer -> reader of this module is what
-the tests pin.
+it against (the repo ships none).  The tests pin the reader two ways: the round trip through this
+module's own writer, and tests/golden/dataset_fixture/ -- a bag assembled byte by byte from the
+published format by a script that does not import this module (tests/golden/make_bag_fixture.py).
 
 Host-side data plumbing only: frames come out as float32 [rows*cols] in the layout
 ``RbSensor.set_observation`` takes (row-major, metres, NaN = no reading), K as the 3x3 matrix

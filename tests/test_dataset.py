@@ -179,3 +179,45 @@ def test_messages_are_replayed_in_receipt_time_order(tmp_path):
     in_file = [m[2][0] for m in ds.read_bag(str(path), time_order=False)]
     in_time = [m[2][0] for m in ds.read_bag(str(path))]
     assert in_file == [12, 10, 11] and in_time == [10, 11, 12]
+
+
+def test_hand_assembled_bag_fixture_is_read_without_this_modules_writer():
+    """tests/golden/dataset_fixture/ was laid down byte by byte from the published bag v2.0 description by
+    tests/golden/make_bag_fixture.py, which does not import dbot_ros_amd.dataset (a reader bug mirrored
+    in the module's own writer is invisible to a round trip).  One chunk, one connection per topic -- the reference's topic
+    and file names, R:source/dbot_ros/util/tracking_dataset.cpp:92-99 --, two frames, index and chunk-info records, the
+    4 096-byte bag header; ground_truth.txt in StoreTextFile's text (:326-360)."""
+    import os
+    import struct
+    from dbot_ros_amd import dataset as ds
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_fixture")
+    raw = open(os.path.join(here, "measurements.bag"), "rb").read()
+    assert raw.startswith(b"#ROSBAG V2.0\n") and len(raw) == 6616
+    # the fixture really has the structure it claims: the bag header's index_pos points at the first record behind the chunk's index
+    hlen = struct.unpack_from("<I", raw, 13)[0]
+    fields = ds._parse_header(raw[17:17 + hlen])
+    index_pos = struct.unpack("<Q", fields["index_pos"])[0]
+    assert struct.unpack("<I", fields["conn_count"])[0] == 2 and struct.unpack("<I", fields["chunk_count"])[0] == 1
+    tail = list(ds._records(raw, index_pos))
+    assert [h["op"][0] for h, _ in tail] == [7, 7, 6]
+    d = ds.TrackingDataset(here)
+    assert d.size() == 2
+    want0 = np.array([0.50, 0.75, 1.00, 1.25, 1.50, np.nan, 2.00, 2.25, 2.50, 2.75, 3.00, 3.25], np.float32)
+    want1 = np.array([0.625, 0.875, np.nan, 1.375, 1.625, 1.875, 2.125, 2.375, 2.625, 2.875, 3.125, 3.375], np.float32)
+    for k, want in enumerate((want0, want1)):
+        v = d.frame_vector(k)
+        assert v.dtype == np.float32 and v.shape == (12,)
+        assert np.array_equal(np.isnan(v), np.isnan(want)) and np.array_equal(v[~np.isnan(v)], want[~np.isnan(want)])
+        assert (d.get_image(k).height, d.get_image(k).width) == (3, 4) and d.get_image(k).seq == k
+        assert d.get_info(k).distortion_model == "plumb_bob" and len(d.get_info(k).D) == 5
+    assert d.get_image(0).stamp == ds.Stamp(1400000000, 250000000) and str(d.get_image(1).stamp) == "1400000000.283333333"
+    assert np.array_equal(d.get_camera_matrix(), np.array([[570.25, 0, 1.5], [0, 571.5, 1.0], [0, 0, 1.0]]))
+    assert np.allclose(d.get_ground_truth(0), [0.01, -0.02, 0.70, 0.3, -0.5, 0.2, 0, 0, 0, 0, 0, 0])
+    assert np.allclose(d.get_ground_truth(1), [0.012, -0.02, 0.70, 0.3, -0.4825, 0.2, 0.06, 0, 0, 0, 0.5236, 0])
+    # the reference's own LoadTextFile reads ONE line: frame 1 then has no ground truth
+    d1 = ds.TrackingDataset(here, load=False)
+    d1.load(first_line_only=True)
+    assert d1.get_ground_truth(0).size == 12 and d1.get_ground_truth(1).size == 0
+    # file order is message order here; reading by time gives the same sequence
+    msgs = ds.read_bag(os.path.join(here, "measurements.bag"))
+    assert [m[0] for m in msgs] == ["XTION/depth/image", "XTION/depth/camera_info"] * 2
