@@ -70,6 +70,7 @@ struct rbs_handle {
     int* d_err = nullptr;       // [2] device: [0] a region did not fit its slab, [1] the largest region asked for so far (px)
     int* h_err = nullptr;       // pinned copy, fetched with the log-likelihoods ([2], [3]: the flags as they were BEFORE the call)
     bool slab_auto = false;     // the slab size is the library's choice (rbs_config.state_slab_px == 0 with many particles)
+    bool slab_probed = false;   // ... and has been checked against a first call's regions (rbs_loglikes_device, probe_auto_slabs)
     int* d_bbox = nullptr;      // [4] scratch of rbs_import_plane / rbs_set_occlusion
     bool windowed = true;       // planes valid inside their window only (state_layout dense: whole plane)
     // windowed planes whose windows have grown to a large part of the frame are served like whole
@@ -183,7 +184,7 @@ struct rbs_handle {
     // refused with this message until rbs_reset (rbs_tracker_initialize) re-establishes a known state.
     bool poisoned = false;
     std::string poison_msg;
-    // test hook (tests/test_gpu_multidevice.py): RBS_TEST_FAULT="<shard>:<call>" read at rbs_create makes
+    // test hook, builds with -DRBS_TEST_HOOKS only (tests/test_gpu_multidevice.py): RBS_TEST_FAULT="<shard>:<call>" read at rbs_create makes
     // the group's <call>-th rbs_loglikes fail on shard <shard> after the shards before it were enqueued
     int fault_shard = -1;
     long fault_call = -1, group_calls = 0;
@@ -616,6 +617,9 @@ int32_t slab_expand(rbs_handle* h, int slot, float* d_full, hipStream_t s)
 // Slabs: store a whole plane (device, npx floats) into a slot: its stored region and window become
 // the float4-aligned bounding box of the values that differ from the background.  Synchronises
 // (the box is needed on the host to check that it fits).
+int32_t drain(rbs_handle* h, bool host_sync);
+int32_t grow_slabs(rbs_handle* h, int new_slab);
+int slab_for(const rbs_handle* h, int need);
 int32_t slab_store(rbs_handle* h, int slot, const float* d_full, hipStream_t s)
 {
     const int init[4] = {h->cols, h->rows, 0, 0};
@@ -629,9 +633,17 @@ int32_t slab_store(rbs_handle* h, int slot, const float* d_full, hipStream_t s)
     int4 r = make_int4(box[0], box[1], std::min(box[2], h->cols), box[3]);
     if (r.z <= r.x || r.w <= r.y) r = make_int4(h->cols, h->rows, 0, 0);   // all background
     const long area = r.z > r.x ? (long)(r.z - r.x) * (r.w - r.y) : 0;
-    if (area > (long)h->slab_px)
-        return fail(h, RBS_ERR_OUT_OF_MEMORY,
-                    fmt("a plane whose values differ from the background over %ld px does not fit a slab of %d px (state_slab_px)", area, h->slab_px));
+    if (area > (long)h->slab_px) {
+        // the slabs grow for a plane handed in from outside as they do for a region a call asks for -- on
+        // a handle of its own; the shards of a group and attached ranks must keep one size among them
+        if (h->group || h->peer_world > 1)
+            return fail(h, RBS_ERR_OUT_OF_MEMORY,
+                        fmt("a plane whose values differ from the background over %ld px does not fit a slab of %d px (state_slab_px)", area, h->slab_px));
+        if (int32_t rc = drain(h, true)) return rc;
+        if (int32_t rc = grow_slabs(h, slab_for(h, (int)std::min<long>(area, h->npx)))) return rc;
+        if (area > (long)h->slab_px)
+            return fail(h, RBS_ERR_OUT_OF_MEMORY, fmt("a plane of %ld px does not fit a slab of %d px (state_slab_px)", area, h->slab_px));
+    }
     if (area > 0) {
         hipLaunchKernelGGL(rbs::rbs_pack_kernel, dim3((unsigned)((area + 255) / 256)), dim3(256), 0, s, d_full, r, h->cols,
                            h->d_occ[h->cur] + (size_t)slot * h->plane_stride);
@@ -975,8 +987,10 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     // these the per-pixel arithmetic never meets a NaN of its own making: sigma > 0 for every finite o)
     if (!(cfg->model_sigma > 0.0) || !(cfg->sigma_factor >= 0.0) || !std::isfinite(cfg->model_sigma) || !std::isfinite(cfg->sigma_factor))
         return fail(h, RBS_ERR_INVALID_ARGUMENT, "need kinect.model_sigma > 0 and kinect.sigma_factor >= 0");
-    if (!(cfg->tail_weight >= 0.0) || !(cfg->tail_weight < 1.0))
-        return fail(h, RBS_ERR_INVALID_ARGUMENT, "need 0 <= kinect.tail_weight < 1");
+    // tail_weight > 0: the library's erfc / exp are accurate in ABSOLUTE terms (1e-16), which is all the mixture can see
+    // next to tw / max_depth; with tw = 0 the far tails would be priced by that floor instead of the decaying value
+    if (!(cfg->tail_weight > 0.0) || !(cfg->tail_weight < 1.0))
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "need 0 < kinect.tail_weight < 1");
     if (!(cfg->initial_occlusion_prob >= 0.0) || !(cfg->initial_occlusion_prob <= 1.0))
         return fail(h, RBS_ERR_INVALID_ARGUMENT, "need 0 <= occlusion.initial_occlusion_prob <= 1");
 
@@ -1637,10 +1651,12 @@ int32_t create_group(const rbs_config* cfg, rbs_handle* g)
     }
     g->windowed = g->shards[0]->windowed;
     g->precision = g->shards[0]->precision;
+#ifdef RBS_TEST_HOOKS   // (librbsensor_mi355x_hooks.so, `make hooks`: the release library carries no fault injection -- ADVICE r3)
     if (const char* f = std::getenv("RBS_TEST_FAULT")) {
         int a = -1; long c = -1;
         if (std::sscanf(f, "%d:%ld", &a, &c) == 2) { g->fault_shard = a; g->fault_call = c; }
     }
+#endif
     // parents on another device are read in place
     for (int a = 0; a < nd; ++a) {
         RBS_HIP(g, hipSetDevice(devs[a]));
@@ -1765,6 +1781,7 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
     std::vector<CallState> before;
     for (rbs_handle* h : g->shards) before.push_back(save_call_state(h));
     const size_t stride = (size_t)12 * g->n_bodies;
+    bool stale_overflow = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         // from here on a failure leaves some shards advanced and others not: the group is poisoned
         if (int32_t rc = group_begin_call(g, nullptr)) return poison(g, rc);
@@ -1777,10 +1794,12 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
                 if (hipEventRecord(h->ev_done, h->stream) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, "hipEventRecord failed"));
                 continue;
             }
+#ifdef RBS_TEST_HOOKS
             if (k == g->fault_shard && g->group_calls == g->fault_call) {   // (test hook)
                 g->group_calls += 1;
                 return poison(g, gfail(g, h, fail(h, RBS_ERR_HIP, "injected fault (RBS_TEST_FAULT)")));
             }
+#endif
             if (int32_t rc = host_call(h, poses + stride * (size_t)lo, indices + lo, cnt, update != 0)) return poison(g, gfail(g, h, rc));
         }
         g->group_calls += 1;
@@ -1793,6 +1812,9 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
                 return poison(g, fail(g, RBS_ERR_HIP, fmt("device %d: waiting for the log-likelihoods failed", h->device)));
             std::memcpy(out + lo, h->h_out, sizeof(double) * (size_t)cnt);
             overflow = overflow || (h->slab_px && h->h_err[0]);
+            // the flag as it stood BEFORE this call (host_call fetches it): set, it belongs to an asynchronous call whose
+            // results were NaN and which has not been reported yet -- repaired below like this call's own, but REPORTED
+            if (attempt == 0 && h->slab_px && h->h_err[2]) stale_overflow = true;
         }
         if (!overflow) break;
         if (attempt == 1) return gfail(g, g->shards[0], check_slab_error(g->shards[0]));
@@ -1803,7 +1825,15 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
     }
     if (update)
         for (int32_t i = 0; i < n; ++i) indices[i] = i;
-    return group_grow_slabs(g, nullptr);   // (housekeeping: enlarge before a region fills a slab)
+    if (int32_t rc = group_grow_slabs(g, nullptr)) return rc;   // (housekeeping: enlarge before a region fills a slab)
+    if (stale_overflow) {   // this call's numbers are good; an earlier asynchronous call's were not (single-device path: the same, once)
+        rbs_handle* s0 = g->shards[0];
+        s0->h_err[0] = 1;
+        const int32_t rc = check_slab_error(s0);
+        s0->h_err[0] = 0;
+        return gfail(g, s0, rc);
+    }
+    return RBS_OK;
 }
 
 // rbs_set_observation_device on a group: `d_depth` lives on the handle's FIRST device; every shard
@@ -2280,6 +2310,26 @@ int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t*
     if (!h->shards.empty()) return group_loglikes_device(h, d_poses, d_indices, n, update, d_out_loglik, static_cast<hipStream_t>(stream));
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    if (h->slab_auto && !h->slab_probed && update && h->peer_world <= 1) {
+        // slabs the LIBRARY chose (state_slab_px = 0, more than 8 192 particles): an asynchronous call cannot be taken
+        // back, so the first one is preceded by a look at the regions it will store -- one small kernel and ONE host
+        // synchronisation in the handle's lifetime -- and the slabs are enlarged first if they would be three
+        // quarters full (a default-config handle must not answer its first call with NaNs)
+        h->slab_probed = true;
+        DevParams P = h->base;
+        P.poses = d_poses; P.indices = d_indices; P.n = n;
+        P.slots = h->max_particles; P.n_dev = 1; P.shard_cap = h->max_particles;
+        P.win_src = h->d_win[h->cur];
+        P.rect_align = h->windowed ? h->rect_align : rbs::kRectAlign;
+        if (int32_t rc = drain(h, false)) return rc;
+        int* d_max = h->d_err + 1;   // (the sticky maximum the rectangles kernel keeps: the probe only raises it early)
+        hipLaunchKernelGGL(rbs::rbs_region_probe_kernel, dim3((unsigned)((n + rbs::kPrepPerBlock - 1) / rbs::kPrepPerBlock)),
+                           dim3(64 * rbs::kPrepPerBlock), 0, s, P, d_max);
+        RBS_HIP(h, hipGetLastError());
+        RBS_HIP(h, hipMemcpyAsync(h->h_err, h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        RBS_HIP(h, hipStreamSynchronize(s));
+        if (int32_t rc = slab_housekeeping(h)) return rc;
+    }
     h->async_outstanding = true;
     return enqueue_loglikes(h, d_poses, d_indices, n, update != 0, d_out_loglik, s);
 }

@@ -1911,6 +1911,25 @@ __global__ __launch_bounds__(256) void rbs_stage_kernel(const DevParams P, const
     }
 }
 
+// The largest region an updating call with these poses and parents would store (bbox of the parent's window and the
+// particle's rectangle: what prep_particles records in err[1]) WITHOUT running the call: the library sizes slabs
+// it chose itself with it before the first asynchronous call (which could not be repaired afterwards).
+__global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_region_probe_kernel(const DevParams P, int* __restrict__ out_max)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = (int)blockIdx.x * kPrepPerBlock + w;
+    if (i >= P.n) return;
+    const Rect r = particle_rect(P, P.poses + (size_t)i * 12 * P.n_bodies);
+    if (lane != 0) return;
+    int4 u = r.x1 > r.x0 ? make_int4(r.x0, r.y0, r.x1, r.y1) : make_int4(P.cols, P.rows, 0, 0);
+    const int parent = P.indices[i];
+    if ((unsigned)parent < (unsigned)P.slots) {
+        const int4 pw = parent_window(P, parent);
+        u = make_int4(min(pw.x, u.x), min(pw.y, u.y), max(pw.z, u.z), max(pw.w, u.w));
+    }
+    if (u.z > u.x && u.w > u.y) atomicMax(out_max, (u.z - u.x) * (u.w - u.y));
+}
+
 // Make one windowed plane dense in place: pixels outside its window become the background.
 // (The caller then marks the window full with rbs_set_window_kernel.)
 __global__ void rbs_materialize_kernel(float* __restrict__ plane, const int4* __restrict__ win,

@@ -132,7 +132,15 @@ typedef struct rbs_config {
      * more than a quarter within one such call is contained (log-likelihood NaN, plane reset to the
      * background) and reported once, by the next synchronising call / that frame's result; the slabs
      * have been enlarged when that call returns.  rbs_tracker_initialize sizes the slabs for the object
-     * at its default pose with a probe call, so a tracker does not start on slabs that are too small. */
+     * at its default pose with a probe call, so a tracker does not start on slabs that are too small;
+     * slabs the LIBRARY chose (0) are checked the same way in front of a handle's first updating
+     * rbs_loglikes_device (one small kernel, one host synchronisation, once).  Planes handed in from
+     * outside (rbs_set_occlusion, rbs_import_plane / _window) enlarge the slabs when they do not fit.
+     * With slabs -- chosen by the caller or by the library -- two hooks are RBS_ERR_UNSUPPORTED, because a slot
+     * is not a plane any more: rbs_occlusion_device_ptr and rbs_occlusion_next_device_ptr (use
+     * rbs_export_plane / rbs_export_window); RBS_SLAB_WHOLE_PLANES keeps them.  The shards of a handle over
+     * several devices and ranks attached with rbs_ipc_attach keep ONE slab size among them: a group grows all its
+     * shards together (synchronous calls), attached ranks do not grow. */
     int32_t state_slab_px;
     int32_t reserved0;
 } rbs_config;

@@ -82,9 +82,9 @@ def test_invalid_models_rejected():
         RbSensor(om, cam, P2, max_particles=4)
     assert e.value.code == _capi.RBS_ERR_INVALID_ARGUMENT
     for field, value in (("model_sigma", 0.0), ("model_sigma", float("nan")), ("sigma_factor", -1e-3), ("tail_weight", 1.0),
-                         ("tail_weight", -0.1)):
+                         ("tail_weight", -0.1), ("tail_weight", 0.0)):   # (0: the far tails would be priced by erfc's absolute floor)
         P3 = RbSensorBuilder.Parameters(sample_count=4)
-        setattr(P3.kinect, field, value)          # a density needs sigma > 0 and a mixture weight in [0, 1)
+        setattr(P3.kinect, field, value)          # a density needs sigma > 0 and a mixture weight in (0, 1)
         with pytest.raises(RbSensorError) as e:
             RbSensor(om, cam, P3, max_particles=4)
         assert e.value.code == _capi.RBS_ERR_INVALID_ARGUMENT, (field, value)
@@ -199,3 +199,11 @@ def test_create_survives_arbitrary_configs():
             assert rc < 0 and not h.value, (rc, h.value)
             assert lib.rbs_last_error(None), rc
     assert _capi.RBS_ERR_INVALID_ARGUMENT in outcomes
+
+
+def test_release_library_carries_no_fault_injection_hook():
+    """RBS_TEST_FAULT is read by the test build (librbsensor_mi355x_hooks.so, -DRBS_TEST_HOOKS) only."""
+    lib = os.path.join(ROOT, "dbot_ros_amd", "lib")
+    assert b"RBS_TEST_FAULT" not in open(os.path.join(lib, "librbsensor_mi355x.so"), "rb").read()
+    hooks = os.path.join(lib, "librbsensor_mi355x_hooks.so")
+    assert os.path.exists(hooks) and b"RBS_TEST_FAULT" in open(hooks, "rb").read()

@@ -177,7 +177,7 @@ def test_native_host_bench_computes_what_python_computes(tmp_path, gpu_lib, monk
         frames = np.stack([synth.make_frame(s.render_depth(t), rows, cols, rng) for t in truths]).astype(np.float32)
         poses = np.stack([synth.particle_poses(t, n, rng).reshape(n, -1) for t in truths])
         parents = rng.permutation(n).astype(np.int32)
-        for i in list(range(warm)) + list(range(steps)):
+        for i in range(warm + steps):
             s.set_observation(frames[i % F])
             ll = s.loglikes_poses(poses[i % F], parents.copy(), update=True)
     path = tmp_path / "w.bin"
@@ -188,3 +188,6 @@ def test_native_host_bench_computes_what_python_computes(tmp_path, gpu_lib, monk
     assert tok[0] == "host_bench", out
     want = float(ll[np.isfinite(ll)].sum())
     assert abs(float(tok[6]) - want) <= 1e-8 * max(1.0, abs(want)), (tok[6], want)
+    # the same steps with each next frame handed over ahead (rbs_loglikes_prefetch / rbs_set_observation_prefetched): the same numbers
+    out2 = subprocess.run([exe, "--prefetch", str(path), str(steps), str(warm)], capture_output=True, text=True, check=True).stdout
+    assert out2.split()[6] == tok[6], (out2, out)

@@ -334,6 +334,19 @@ def test_a_fan_out_that_fails_half_way_poisons_the_handle_until_reset(gpu_lib, m
     silently mismatched buffers -- and rbs_reset restores a working handle with the numbers of a
     fresh one."""
     from dbot_ros_amd.sensor import RbSensorError
+    import os
+    import subprocess
+    import sys
+    from dbot_ros_amd import _capi
+    hooks = os.path.join(os.path.dirname(_capi.LIB_PATH), "librbsensor_mi355x_hooks.so")
+    if os.path.abspath(_capi.LIB_PATH) != os.path.abspath(hooks):
+        # the hook is compiled into the test build of the library only (`make hooks`): run this test in a process that loads it
+        assert os.path.exists(hooks), "build() makes librbsensor_mi355x_hooks.so"
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                            __file__ + "::test_a_fan_out_that_fails_half_way_poisons_the_handle_until_reset"],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, RBS_LIB_PATH=hooks))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        return
     n = 30
     om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
     rng = np.random.default_rng(4)

@@ -209,12 +209,44 @@ def test_plane_hooks_on_slabs(gpu_lib):
         g.set_occlusion(5, planes[0])
         assert np.array_equal(g.get_occlusion(5), planes[0])
         assert g.get_window(5) == g.get_window(0) or g.get_window(0)[2] - g.get_window(0)[0] >= g.get_window(5)[2] - g.get_window(5)[0]
-        full = np.full(160 * 120, 0.5, np.float32)                      # differs from the background everywhere
-        with pytest.raises(RbSensorError) as e:
-            g.set_occlusion(1, full)
-        assert e.value.code == _capi.RBS_ERR_OUT_OF_MEMORY
+        full = np.full(160 * 120, 0.5, np.float32)                      # differs from the background everywhere:
+        g.set_occlusion(1, full)                                        # the slabs grow for it (round 3: OUT_OF_MEMORY)
+        assert np.array_equal(g.get_occlusion(1), full) and g.get_window(1) == (0, 0, 160, 120)
+        assert np.array_equal(g.get_occlusion(4), planes[2])            # the other slots moved with the reallocation
+        idx = np.array([1, 4, 0, 1, 2, 3], np.int32)
+        poses = synth.particle_poses(frames[-1][0], n, np.random.default_rng(3))
+        assert np.isfinite(g.loglikes_poses(poses, idx, update=True)).all()
         with pytest.raises(RbSensorError):
             g.occlusion_device_ptr(0, next_buffer=True)
+
+
+def test_library_chosen_slabs_are_sized_before_the_first_asynchronous_call(gpu_lib):
+    """state_slab_px = 0 with more than 8 192 particles: the library picks slabs of rows*cols/8 floats.  An object whose
+    region is larger than that must not turn a default-config handle's FIRST rbs_loglikes_device into NaNs:
+    the regions are probed in front of that call and the slabs enlarged; the numbers are those of whole planes."""
+    import torch
+    n = 8200
+    om, cam, P = sc.make_scene(("m1",), 320, 240, max_particles=n)
+    truth = synth.truth_pose(1, z=0.22)                                 # close: the object's rectangle is ~200 x 160 px > 9 600 px
+    rng = np.random.default_rng(5)
+    poses = synth.particle_poses(truth, n, rng)
+    with RbSensor(om, cam, P, max_particles=n) as auto, RbSensor(om, cam, P, max_particles=n, slab_px=-1) as whole:
+        frame = synth.make_frame(whole.render_depth(truth), 240, 320, rng)
+        assert np.isfinite(frame).any()
+        d_poses = torch.from_numpy(poses.reshape(n, -1)).cuda()
+        d_idx = torch.zeros(n, dtype=torch.int32, device="cuda")
+        out = []
+        for s_ in (auto, whole):
+            s_.reset()
+            s_.set_observation(frame)
+            d_out = torch.empty(n, dtype=torch.float64, device="cuda")
+            s_.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, True, d_out.data_ptr())
+            s_.synchronize()                                            # (would report a contained overflow)
+            out.append(d_out.cpu().numpy())
+        assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
+        x0, y0, x1, y1 = whole.get_window(0)
+        assert (x1 - x0) * (y1 - y0) > 320 * 240 // 8, "the scenario must need more than the library's first choice"
+        assert np.array_equal(auto.get_occlusion(17), whole.get_occlusion(17))
 
 
 def test_slabs_in_a_handle_over_several_shards(gpu_lib):
