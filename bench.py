@@ -693,7 +693,7 @@ def native_tracker_leg(om, cam, P, frames, init, counts, precision):
 
 
 # --------------------------------------------------------------------------------- tracker FPS
-def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30, precision=None):
+def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30, precision=None, device_ids=None):
     """Frames/s of the device tracker (rbs_tracker_*: transition, weights, KL, resampling and mean
     on the GPU, device RNG, one host sync per frame; the frame is uploaded from host memory every
     frame) on the 30-frame sequence.  Second half of BASELINE.json's metric."""
@@ -704,7 +704,9 @@ def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30, precisi
     frames = None
     for n in counts:
         P = RbSensorBuilder.Parameters(sample_count=n)
-        with RbSensor(om, cam, P, device_id=device.index, max_particles=max(1, n // nb), precision=precision) as s:
+        # device_ids: the tracker SHARDED over several devices inside one handle (all states on every device, the sensor
+        # call split, one RCCL all-gather of the log-likelihoods per sampling block)
+        with RbSensor(om, cam, P, device_id=device.index, max_particles=max(1, n // nb), precision=precision, device_ids=device_ids) as s:
             if frames is None:
                 rng = np.random.default_rng(0)
                 frames = [synth.make_frame(s.render_depth(synth.truth_pose(nb, frame=k)), cam.rows, cam.cols, rng,
@@ -947,6 +949,23 @@ def main():
         sensor.close()
         if not a.no_configs_leg and a.config in (None, "c1"):
             peer_legs = peer_configs_leg(a, dev, stream, dist, backend, world, rank)
+        # tracker FPS over the job's GPUs: the device tracker sharded inside ONE handle (rank 0 drives every device; the
+        # other ranks wait) -- the reference's node is one process (R:source/dbot_ros/tracker/particle_tracker_node.cpp:277-284)
+        if not a.no_tracker_fps and os.environ.get("RBS_BENCH_SHARDED_TRACKER", "1") != "0":
+            if rank == 0:
+                ids = [0] * world if backend != "nccl" else list(range(world))
+                try:
+                    fps = tracker_fps(om, cam, dev, precision=a.precision, device_ids=ids)
+                    fps.pop("_native", None)
+                    for k_, v_ in fps.items():
+                        peer_legs[f"tracker_fps_sharded_{k_}"] = v_["fps"]
+                        peer_legs[f"tracker_fps_sharded_pipelined_{k_}"] = v_["fps_pipelined"]
+                    peer_legs["tracker_fps_sharded_note"] = (f"rbs_tracker_* over one handle on devices {ids} (rbs_config.n_devices): every device holds all "
+                                                             "particle states, the sensor call is sharded, RCCL all-gather of the log-likelihoods per sampling "
+                                                             "block; frame uploaded from host memory every frame; driven by rank 0 while the other ranks wait")
+                except Exception as e:     # noqa: BLE001 -- a leg must not take the headline down
+                    peer_legs["tracker_fps_sharded_note"] = "sharded tracker leg failed: %r" % (e,)
+            dist.barrier()
 
     if rank != 0:
         if world > 1:
