@@ -267,6 +267,24 @@ public:
     /// inherits from, set to identity when update is true.  Returns log-likelihoods.
     RealArray loglikes(const StateArray& deltas, IntArray& indices, const bool& update = false)
     {
+        return loglikes_with_next_frame(deltas, indices, update, nullptr, 0);
+    }
+    /// The same call with the NEXT frame handed over: its staging copy and transfer pass behind this call's kernels
+    /// (rbs_loglikes_prefetch); use_next_frame() then makes it the observation at no cost.  For a replayed dataset, or a
+    /// driver that is a frame ahead of the tracker.
+    RealArray loglikes(const StateArray& deltas, IntArray& indices, const bool& update, const float* next_depth, size_t next_n)
+    {
+        return loglikes_with_next_frame(deltas, indices, update, next_depth, next_n);
+    }
+    void use_next_frame() { check(rbs_set_observation_prefetched(handle_)); }
+
+    State& integrated_poses() { return integrated_poses_; }
+    const State& integrated_poses() const { return integrated_poses_; }
+    rbs_handle* handle() { return handle_; }
+
+private:
+    RealArray loglikes_with_next_frame(const StateArray& deltas, IntArray& indices, bool update, const float* next_depth, size_t next_n)
+    {
         const size_t n = deltas.size();
         if (indices.size() != n) throw std::runtime_error("RbSensor::loglikes: indices.size() != deltas.size()");
         poses_.resize(n * static_cast<size_t>(n_bodies_) * 12);
@@ -284,16 +302,14 @@ public:
                     out[9 + k] = deltas[i].position(b)[k] + integrated_poses_.position(b)[k];
             }
         RealArray ll(n);
-        check(rbs_loglikes(handle_, poses_.data(), indices.data(), static_cast<int32_t>(n), update ? 1 : 0,
-                           ll.data()));
+        if (next_depth)
+            check(rbs_loglikes_prefetch(handle_, poses_.data(), indices.data(), static_cast<int32_t>(n), update ? 1 : 0, ll.data(),
+                                        next_depth, next_n));
+        else
+            check(rbs_loglikes(handle_, poses_.data(), indices.data(), static_cast<int32_t>(n), update ? 1 : 0, ll.data()));
         return ll;
     }
 
-    State& integrated_poses() { return integrated_poses_; }
-    const State& integrated_poses() const { return integrated_poses_; }
-    rbs_handle* handle() { return handle_; }
-
-private:
     void check(int32_t rc) const
     {
         if (rc != RBS_OK) throw std::runtime_error(std::string("RbSensor: ") + rbs_last_error(handle_));
