@@ -44,6 +44,10 @@ l2, _ = per_dispatch(os.path.join(src, "l2", "l2_counter_collection.csv"))
 out = {"tag": tag, "units": "FETCH_SIZE/WRITE_SIZE in KiB per dispatch (average over dispatches)",
        "kernels": {}, "calibration": {}}
 KNOWN = 2000 * 640 * 480 * 4  # bytes read == bytes written by one copybench flat_copy launch
+# the profiled workload, when it is not the default C1 step (tools/profile_round.sh with BENCH_ARGS="--config c2" ...)
+N_PART = int(os.environ.get("RBS_PROFILE_N", "2000"))
+NPX = int(os.environ.get("RBS_PROFILE_NPX", str(640 * 480)))
+WORKLOAD = os.environ.get("RBS_PROFILE_WORKLOAD", "bench.py default (C1: 2000 particles, 640x480, update=true, 30-frame sequence)")
 cal_f = os.path.join(src, "cal_fetch", "cal_counter_collection.csv")
 fetch_scale, write_scale = 2.0, 1.0
 if os.path.exists(cal_f):
@@ -72,15 +76,16 @@ for (k, c), v in sorted(fetch.items()):
                              "l2_hit_rate": (hit / (hit + miss)) if hit is not None and (hit + miss) > 0 else None}
         total += b
 out["hbm_bytes_per_loglikes_call"] = total
-out["algorithmic_bytes_per_loglikes_call"] = 2.0 * KNOWN
-out["traffic_over_algorithmic"] = total / (2.0 * KNOWN)
+out["algorithmic_bytes_per_loglikes_call"] = 2.0 * 4.0 * NPX * N_PART
+out["traffic_over_algorithmic"] = total / (2.0 * 4.0 * NPX * N_PART)
+out["workload"] = WORKLOAD
 out["state_layout"] = layout
 # roofline.traffic in bench.py is per launch of the dominant kernel: the raster kernel on windowed
 # planes, the copy kernel on whole planes
 dom = "rbs_raster_kernel" if layout == "window" else "rbs_copy_rows_kernel"
 dom_bytes = sum(v["hbm_bytes_per_dispatch_corrected"] for k, v in out["kernels"].items() if dom in k)
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
-if layout == "window":
+if layout == "window" and "RBS_PROFILE_N" not in os.environ:
     json.dump({"state_layout": layout, "kernel": dom, "hbm_bytes_per_launch": dom_bytes,
                "hbm_bytes_per_loglikes_call_all_kernels": total, "source": f"profiles/{tag}_pmc_hbm.json",
                "workload": "bench.py default (C1: 2000 particles, 640x480, update=true, 30-frame sequence)"},
@@ -93,11 +98,11 @@ if os.path.exists(sq_path):
         k = k[0]
         g = lambda c: sq.get((k, c), 0.0)
         # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves
-        summary = {"precision": os.environ.get("RBS_PROFILE_PRECISION", "f64"), "state_layout": layout, "kernel": k, "workload": "bench.py default step (raster kernel of loglikes(update=true), 2000 particles)",
+        summary = {"precision": os.environ.get("RBS_PROFILE_PRECISION", "f64"), "state_layout": layout, "kernel": k, "workload": WORKLOAD,
                    "per_dispatch": {c: g(c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
                                                       "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
                                                       "SQ_BUSY_CYCLES", "SQ_INSTS_SALU")},
-                   "valu_instructions_per_particle": g("SQ_INSTS_VALU") / 2000.0,
+                   "valu_instructions_per_particle": g("SQ_INSTS_VALU") / float(N_PART),
                    "cycles_per_valu_instruction": 4.0 * g("SQ_ACTIVE_INST_VALU") / max(g("SQ_INSTS_VALU"), 1.0),
                    "fraction_of_wave_time_issuing_valu": g("SQ_ACTIVE_INST_VALU") / max(g("SQ_WAVE_CYCLES"), 1.0),
                    "fraction_waiting": g("SQ_WAIT_ANY") / max(g("SQ_WAVE_CYCLES"), 1.0),
