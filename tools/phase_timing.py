@@ -8,15 +8,18 @@ from dbot_ros_amd import CameraData, ObjectModel, RbSensor, RbSensorBuilder, syn
 upd = int(sys.argv[sys.argv.index("--update") + 1]) if "--update" in sys.argv else 0
 names = sys.argv[sys.argv.index("--mesh") + 1].split(",") if "--mesh" in sys.argv else ["m1"]
 n = int(sys.argv[sys.argv.index("--particles") + 1]) if "--particles" in sys.argv else 2000
+cols = int(sys.argv[sys.argv.index("--cols") + 1]) if "--cols" in sys.argv else 640
+rows = cols * 3 // 4
+zdist = float(sys.argv[sys.argv.index("--z") + 1]) if "--z" in sys.argv else 0.7
 fns = {"m1": synth.mesh_m1, "m2": synth.mesh_m2, "m3": synth.mesh_m3, "m4": synth.mesh_m4}
 ms_ = [fns[k]() for k in names]
-om = ObjectModel([v for v, _ in ms_], [t for _, t in ms_]); cam = CameraData(synth.camera_matrix(), 480, 640)
+om = ObjectModel([v for v, _ in ms_], [t for _, t in ms_]); cam = CameraData(synth.camera_matrix(cols, rows), rows, cols)
 P = RbSensorBuilder.Parameters(sample_count=n)
 with RbSensor(om, cam, P, max_particles=n) as s:
     lib = _capi.load()
     rng = np.random.default_rng(0)
-    truth = synth.truth_pose(len(names))
-    s.set_observation(synth.make_frame(s.render_depth(truth), 480, 640, rng))
+    truth = synth.truth_pose(len(names), z=zdist)
+    s.set_observation(synth.make_frame(s.render_depth(truth), rows, cols, rng))
     poses = synth.particle_poses(truth, n, rng)
     idx = rng.permutation(n).astype(np.int32)
     out = (C.c_ulonglong * 16)()
