@@ -452,7 +452,7 @@ def roofline_for(a, n, raster_ms, copy_ms, alg_bytes, copy_dominant, live):
     pmc_live = sq is not None and "rbs_raster_kernel" in sq
     if not pmc_live:               # a box without counters: the committed summary of this command
         try:
-            j = json.load(open(os.path.join(ROOT, "profiles", "r03_raster_sq.json")))
+            j = json.load(open(os.path.join(ROOT, "profiles", "r04_raster_sq.json")))
             if j.get("precision") == a.precision and j.get("state_layout") == a.layout:
                 sq = {"rbs_raster_kernel": j["per_dispatch"]}
                 mix = sq
