@@ -952,6 +952,9 @@ def main():
         # tracker FPS over the job's GPUs: the device tracker sharded inside ONE handle (rank 0 drives every device; the
         # other ranks wait) -- the reference's node is one process (R:source/dbot_ros/tracker/particle_tracker_node.cpp:277-284)
         if not a.no_tracker_fps and os.environ.get("RBS_BENCH_SHARDED_TRACKER", "1") != "0":
+            # (the other ranks wait on the rendezvous STORE, on the host: a collective barrier would park a spinning RCCL
+            # kernel on every GPU rank 0 is about to time)
+            store = dist.distributed_c10d._get_default_store()
             if rank == 0:
                 ids = [0] * world if backend != "nccl" else list(range(world))
                 try:
@@ -965,7 +968,9 @@ def main():
                                                              "block; frame uploaded from host memory every frame; driven by rank 0 while the other ranks wait")
                 except Exception as e:     # noqa: BLE001 -- a leg must not take the headline down
                     peer_legs["tracker_fps_sharded_note"] = "sharded tracker leg failed: %r" % (e,)
-            dist.barrier()
+                store.set("rbs_sharded_tracker_done", "1")
+            else:
+                store.wait(["rbs_sharded_tracker_done"])
 
     if rank != 0:
         if world > 1:
