@@ -123,6 +123,7 @@ def parse():
     ap.add_argument("--resample-temperature", type=float, default=1.0,
                     help="several ranks: weights = exp((ll - max) / T) in the global resampling of every step (1 = the filter's own weights)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the process rocprofv3 wraps
+    ap.add_argument("--sharded-tracker-child", action="store_true", help=argparse.SUPPRESS)   # one handle over --device-ids: tracker frames/s
     a = ap.parse_args()
     for k, v in PRESETS.get(a.config, {}).items():
         setattr(a, k, v)
@@ -247,6 +248,7 @@ class PeerRun(ResidentRun):
         self.step, self.uniforms = step, uniforms
         self.distinct = torch.zeros(1, dtype=torch.int64, device=step.d_out.device)
         self.steps_done = 0
+        self.reduce = None                 # sums a small int64 tensor over the ranks (setup_peer_run)
 
     def launch(self):
         a, W = self.a, self.W
@@ -256,7 +258,8 @@ class PeerRun(ResidentRun):
         if a.sequence > 0:
             self.sensor.set_observation_device(W.d_frames.data_ptr() + k * W.frame_bytes, self.stream.cuda_stream)
         ps = self.step.step(W.d_poses[k], u)
-        self.distinct += (ps[1:] != ps[:-1]).sum() + 1
+        if not self.step.fused:            # (the library kernel counts the distinct parents of this rank's children itself)
+            self.distinct += (ps[1:] != ps[:-1]).sum() + 1
         self.steps_done += 1
 
     def reset_stats(self):
@@ -266,11 +269,40 @@ class PeerRun(ResidentRun):
         self.steps_done = 0
 
     def stats(self):
-        c = self.step.counts.cpu().numpy().astype(np.float64)
-        ch = max(1, self.step.children)
+        """Job-wide: the ranks' counters summed (every rank calls this at the same point)."""
+        c = self.step.counts.to(torch.int64).clone()
+        if self.step.fused:
+            runs = c[3:4]
+        else:
+            runs = self.distinct.clone()
+            c = c[:3]
+        t = torch.cat([c[:3], runs, torch.tensor([self.step.children], dtype=torch.int64, device=c.device)])
+        if self.reduce is not None:
+            t = self.reduce(t)
+        c = t.cpu().numpy().astype(np.float64)
+        ch = max(1.0, c[4])
+        world = max(1, self.step.world)
+        steps = max(1, self.steps_done)
         return {"remote_parent_frac": c[0] / ch, "remote_children_served_from_staging_frac": (c[1] / c[0]) if c[0] else 0.0,
-                "planes_staged_per_step_per_rank": c[2] / max(1, self.steps_done),
-                "distinct_parents_per_step": float(self.distinct.item()) / max(1, self.steps_done)}
+                "planes_staged_per_step_per_rank": c[2] / steps / world,
+                # (fused: runs of equal parents per rank, summed -- a parent whose children straddle two ranks counts twice;
+                #  tensor path: distinct parents of the whole job as every rank sees them, hence / world)
+                "distinct_parents_per_step": c[3] / steps / (1 if self.step.fused else world)}
+
+
+class LocalShardRun(ResidentRun):
+    """The multi-rank step WITHOUT cross-rank parents (every rank's children inherit from its own slots) + the
+    all-gather of the log-likelihoods: what bench.py --gpus N falls back to when the ranks' handles cannot be
+    attached to each other (rbs_ipc_attach); the line says so (`peer_step`)."""
+
+    def __init__(self, a, W, sensor, stream, d_out, d_all, gather):
+        super().__init__(a, W, sensor, stream, d_out)
+        self.d_all, self.gather = d_all, gather
+
+    def launch(self):
+        super().launch()
+        self.sensor.stream_join(self.stream.cuda_stream)
+        self.gather(self.d_all, self.d_out)
 
 
 def setup_peer_run(a, om, cam, P, W, dev, stream, dist, backend, world):
@@ -289,11 +321,28 @@ def setup_peer_run(a, om, cam, P, W, dev, stream, dist, backend, world):
             dist.all_gather(host, inp_t.cpu())
             out_t.copy_(torch.cat(host))
 
+    # resampling + this rank's plan in ONE library launch (rbs_peer_resample) at sorted uniforms; RBS_BENCH_TENSOR_RESAMPLE=1:
+    # the same arithmetic as ~45 tensor kernels (dist.global_resample + dist.plan_shard), for comparison
+    fused = os.environ.get("RBS_BENCH_TENSOR_RESAMPLE") != "1"
     pstep = rdist.PeerShardedStep(sensor, n, 2 * n, device=dev, min_share=2, stream=stream.cuda_stream, all_gather=gather,
-                                  temperature=a.resample_temperature)
+                                  temperature=a.resample_temperature, fused=fused)
     gen = torch.Generator().manual_seed(1234)        # the same uniforms on every rank
-    uniforms = [torch.rand(n * world, dtype=torch.float64, generator=gen).to(dev) for _ in range(16)]
-    return sensor, PeerRun(a, W, sensor, stream, pstep, uniforms)
+    uniforms = [torch.rand(n * world, dtype=torch.float64, generator=gen) for _ in range(16)]
+    if fused:
+        uniforms = [u.sort().values for u in uniforms]
+    uniforms = [u.to(dev) for u in uniforms]
+    run = PeerRun(a, W, sensor, stream, pstep, uniforms)
+
+    def reduce(t):
+        if backend == "nccl":
+            dist.all_reduce(t)
+            return t
+        h = t.cpu()
+        dist.all_reduce(h)
+        return h
+
+    run.reduce = reduce
+    return sensor, run
 
 
 def peer_configs_leg(a, dev, stream, dist, backend, world, rank, names=("c3_slice", "c4_slice")):
@@ -845,11 +894,50 @@ def in_process_multi_device(a):
 
 
 # --------------------------------------------------------------------------------- main
+def sharded_tracker_child(a):
+    """A process of its own (bench.py --gpus N under torch.distributed.run starts it from rank 0 with a time limit:
+    a leg that hangs must not take the headline down): the device tracker over ONE handle on --device-ids."""
+    om, cam, P, n_tri, nb = build_scene(a)
+    ids = [int(x) for x in a.device_ids.split(",")]
+    dev = torch.device("cuda", ids[0])
+    torch.cuda.set_device(dev)
+    fps = tracker_fps(om, cam, dev, precision=a.precision, device_ids=ids)
+    fps.pop("_native", None)
+    print("SHARDED_TRACKER " + json.dumps({str(k): {"fps": v["fps"], "fps_pipelined": v["fps_pipelined"]} for k, v in fps.items()}), flush=True)
+
+
+def sharded_tracker_leg(a, ids, timeout=420):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-tracker-child", "--gpus", str(len(ids)), "--device-ids", ",".join(map(str, ids)),
+           "--precision", a.precision]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"tracker_fps_sharded_note": f"sharded tracker leg did not finish within {timeout} s (stopped)"}
+    for line in r.stdout.splitlines():
+        if line.startswith("SHARDED_TRACKER "):
+            d = json.loads(line[len("SHARDED_TRACKER "):])
+            out = {}
+            for k_, v_ in d.items():
+                out[f"tracker_fps_sharded_{k_}"] = v_["fps"]
+                out[f"tracker_fps_sharded_pipelined_{k_}"] = v_["fps_pipelined"]
+            out["tracker_fps_sharded_note"] = (f"rbs_tracker_* over one handle on devices {ids} (rbs_config.n_devices): every device holds all "
+                                               "particle states, the sensor call is sharded, RCCL all-gather of the log-likelihoods per sampling "
+                                               "block; frame uploaded from host memory every frame; a process of its own started by rank 0 while "
+                                               "the ranks wait")
+            return out
+    return {"tracker_fps_sharded_note": "sharded tracker leg failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+
+
 def main():
     if os.environ.get("RBS_BENCH_WATCHDOG"):    # diagnostics: dump every thread's stack and exit after that many seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["RBS_BENCH_WATCHDOG"]), exit=True)
     a = parse()
+    if a.sharded_tracker_child:
+        return sharded_tracker_child(a)
     if (a.gpus > 1 or a.in_process) and "WORLD_SIZE" not in os.environ and not a.pmc_child:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
@@ -891,9 +979,27 @@ def main():
     d_out.zero_()                  # first submission creates the stream's hardware queue: setup, not a step
     torch.cuda.synchronize()
 
+    peer_ok, peer_msg = world > 1, None
     if world > 1:
-        sensor, run = setup_peer_run(a, om, cam, P, W, dev, stream, dist, backend, world)
-        d_out, d_all = run.step.d_out, run.step.d_all
+        try:
+            sensor, run = setup_peer_run(a, om, cam, P, W, dev, stream, dist, backend, world)
+            d_out, d_all = run.step.d_out, run.step.d_all
+        except RuntimeError as e:          # (dist.attach_peers raises on EVERY rank when any rank could not attach)
+            peer_ok, peer_msg = False, str(e)
+            if rank == 0:
+                print("# bench.py: " + peer_msg + " -- falling back to shards with local parents + all-gather", file=sys.stderr)
+            sensor = make_sensor(a, om, cam, P, dev)
+            prime(sensor, a, W)
+
+            def gather(out_t, inp_t):
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(out_t, inp_t)
+                else:
+                    host = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(host, inp_t.cpu())
+                    out_t.copy_(torch.cat(host))
+
+            run = LocalShardRun(a, W, sensor, stream, d_out, d_all, gather)
     else:
         sensor = make_sensor(a, om, cam, P, dev)
         prime(sensor, a, W)
@@ -929,8 +1035,14 @@ def main():
     windows = np.array([sensor.get_window(s_) for s_ in range(0, n, max(1, n // 64))])
     win_frac = float(np.mean(np.maximum(0, windows[:, 2] - windows[:, 0]) * np.maximum(0, windows[:, 3] - windows[:, 1]))) / (a.rows * a.cols)
     peer_stats, peer_legs = None, {}
-    if world > 1:
+    if world > 1 and not peer_ok:
+        peer_stats = {"peer_step": "FAILED, local parents only: " + (peer_msg or "")}
+        torch.cuda.synchronize()
+        dist.barrier()
+        sensor.close()
+    if world > 1 and peer_ok:
         peer_stats = run.stats()
+        peer_stats["peer_step"] = "ok"
         # the same step with FLATTENED weights (temperature = the spread of the log-likelihoods): many distinct parents,
         # a large share of them on other ranks and unshared -- the case that exercises the in-place reads over xGMI
         # (the filter's own weights on these synthetic poses leave one or two survivors per step)
@@ -948,7 +1060,10 @@ def main():
         dist.barrier()                     # every rank is done reading its peers' planes: handles may go
         sensor.close()
         if not a.no_configs_leg and a.config in (None, "c1"):
-            peer_legs = peer_configs_leg(a, dev, stream, dist, backend, world, rank)
+            try:
+                peer_legs = peer_configs_leg(a, dev, stream, dist, backend, world, rank)
+            except RuntimeError as e:      # (attach_peers: raised on every rank alike)
+                peer_legs = {"configs_note": "C3 / C4 legs failed: " + str(e)}
         # tracker FPS over the job's GPUs: the device tracker sharded inside ONE handle (rank 0 drives every device; the
         # other ranks wait) -- the reference's node is one process (R:source/dbot_ros/tracker/particle_tracker_node.cpp:277-284)
         if not a.no_tracker_fps and os.environ.get("RBS_BENCH_SHARDED_TRACKER", "1") != "0":
@@ -957,17 +1072,7 @@ def main():
             store = dist.distributed_c10d._get_default_store()
             if rank == 0:
                 ids = [0] * world if backend != "nccl" else list(range(world))
-                try:
-                    fps = tracker_fps(om, cam, dev, precision=a.precision, device_ids=ids)
-                    fps.pop("_native", None)
-                    for k_, v_ in fps.items():
-                        peer_legs[f"tracker_fps_sharded_{k_}"] = v_["fps"]
-                        peer_legs[f"tracker_fps_sharded_pipelined_{k_}"] = v_["fps_pipelined"]
-                    peer_legs["tracker_fps_sharded_note"] = (f"rbs_tracker_* over one handle on devices {ids} (rbs_config.n_devices): every device holds all "
-                                                             "particle states, the sensor call is sharded, RCCL all-gather of the log-likelihoods per sampling "
-                                                             "block; frame uploaded from host memory every frame; driven by rank 0 while the other ranks wait")
-                except Exception as e:     # noqa: BLE001 -- a leg must not take the headline down
-                    peer_legs["tracker_fps_sharded_note"] = "sharded tracker leg failed: %r" % (e,)
+                peer_legs.update(sharded_tracker_leg(a, ids))
                 store.set("rbs_sharded_tracker_done", "1")
             else:
                 store.wait(["rbs_sharded_tracker_done"])
@@ -1009,7 +1114,12 @@ def main():
                                      f"{a.cols}x{a.rows} synthetic depth frame, mesh {a.mesh} ({n_tri} triangles), {max(1, a.sequence)}-frame moving-object "
                                      f"sequence, likelihood precision {a.precision}, {a.layout} planes, inputs resident in HBM")
         out["config"]["sharding"] = (f"particles/{world}: one process per GPU, handles attached over HIP IPC (parents on other ranks read in place over "
-                                     "xGMI, shared ones pulled once), one RCCL all-gather per step, no plane migration, no host synchronisation")
+                                     "xGMI, shared ones pulled once), one RCCL all-gather per step, resampling + plan in one library launch "
+                                     "(rbs_peer_resample), no plane migration, no host synchronisation")
+        if not peer_ok:
+            out["config"]["workload"] = (f"C1 per GPU: {n} particles/GPU ({n * world} in all) x [loglikes(update=true), parents on the rank's own GPU + "
+                                         f"RCCL all-gather of the log-likelihoods] -- the ranks' handles could not be attached to each other, see peer_step")
+            out["config"]["sharding"] = f"particles/{world}: one process per GPU, local parents, one RCCL all-gather per step"
         out.update(peer_stats)
         out.update(peer_legs)
     single = world == 1

@@ -32,7 +32,7 @@ EXPORTS = (
     "rbs_acquire_frame_buffer", "rbs_commit_frame_buffer", "rbs_loglikes_prefetch", "rbs_set_observation_prefetched",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_export_plane", "rbs_import_plane",
-    "rbs_export_window", "rbs_import_window", "rbs_stream_join", "rbs_ipc_export", "rbs_ipc_attach", "rbs_stage_windows",
+    "rbs_export_window", "rbs_import_window", "rbs_stream_join", "rbs_ipc_export", "rbs_ipc_attach", "rbs_stage_windows", "rbs_peer_resample",
     "rbs_get_window", "rbs_get_background", "rbs_raster_kernel_ms", "rbs_set_timing_every",
     "rbs_render_depth",
     "rbs_last_kernel_ms", "rbs_timing_summary",
@@ -173,6 +173,9 @@ def load():
     lib.rbs_ipc_attach.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
     lib.rbs_stage_windows.restype = C.c_int32
     lib.rbs_stage_windows.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.rbs_peer_resample.restype = C.c_int32
+    lib.rbs_peer_resample.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rbs_render_depth.restype = C.c_int32
     lib.rbs_render_depth.argtypes = [H, dp, fp]
     lib.rbs_last_kernel_ms.restype = C.c_int32

@@ -10,6 +10,7 @@
 // There is no CPU path in this library.
 #include "rbsensor_kernels.hip"
 #include "rbsensor_tracker.hip"
+#include "rbsensor_peers.hip"
 
 #include "../../include/rbsensor_mi355x.h"
 
@@ -205,6 +206,8 @@ struct rbs_handle {
     const int4* peer_win[rbs::kMaxDevices][2] = {};
     const int4* peer_reg[rbs::kMaxDevices][2] = {};
     void* peer_mapped[rbs::kMaxDevices][6] = {};    // what hipIpcCloseMemHandle gets back
+    void* d_peer_scratch = nullptr;                 // rbs_peer_resample: cdf [N] doubles + 2 x [n] ints
+    size_t peer_scratch_bytes = 0;
     const float* snap_occ[rbs::kMaxDevices] = {};   // group: every shard's CURRENT planes / windows as of the start
     const int4* snap_win[rbs::kMaxDevices] = {};    //   of the call being fanned out (shards flip buffers one by one)
     const int4* snap_reg[rbs::kMaxDevices] = {};
@@ -792,6 +795,7 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_reg[1]);
     (void)hipFree(h->d_err);
     (void)hipFree(h->d_bbox);
+    (void)hipFree(h->d_peer_scratch);
     if (h->h_err) (void)hipHostFree(h->h_err);
     (void)hipFree(h->d_item_range);
     (void)hipFree(h->d_item_particle);
@@ -2681,6 +2685,49 @@ int32_t rbs_stage_windows(rbs_handle* h, const int32_t* d_src_global, const int3
     }
     hipLaunchKernelGGL(rbs::rbs_stage_kernel, dim3((unsigned)n, 4), dim3(256), 0, s, P, d_src_global, d_dst_local, h->d_occ[h->cur],
                        h->d_win[h->cur], h->d_reg[h->cur]);
+    RBS_HIP(h, hipGetLastError());
+    return RBS_OK;
+}
+
+int32_t rbs_peer_resample(rbs_handle* h, const double* d_loglik_all, const double* d_uniforms_sorted, int32_t n_total, int32_t n_local,
+                          int32_t rank, int32_t min_share, double temperature, int32_t* d_parent_idx, int32_t* d_stage_src,
+                          int32_t* d_stage_dst, int32_t* d_parents_local, int64_t* d_counts, void* stream)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty()) return fail(h, RBS_ERR_UNSUPPORTED, "peer_resample: a handle over several devices resamples inside rbs_tracker_*");
+    if (n_local <= 0 || n_total < n_local || n_total % n_local != 0 || rank < 0 || rank >= n_total / n_local)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("peer_resample: n_total = %d is not world x n_local = %d with rank %d inside it", n_total, n_local, rank));
+    if (2 * (long)n_local > (long)h->max_particles)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("peer_resample: n_local = %d needs max_particles >= %d (own slots + staging slots), have %d",
+                                                      n_local, 2 * n_local, h->max_particles));
+    if (h->peer_world > 1 && (h->peer_world != n_total / n_local || h->peer_rank != rank))
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("peer_resample: rank %d of %d, but the handle is attached as rank %d of %d", rank, n_total / n_local,
+                                                      h->peer_rank, h->peer_world));
+    if (!d_loglik_all || !d_uniforms_sorted || !d_parent_idx || !d_stage_src || !d_stage_dst || !d_counts)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "peer_resample: null pointer");
+    if (!(temperature > 0.0) || min_share < 1) return fail(h, RBS_ERR_INVALID_ARGUMENT, "peer_resample: temperature must be > 0, min_share >= 1");
+    RBS_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    const size_t need = sizeof(double) * (size_t)n_total + 2 * sizeof(int) * (size_t)n_local;
+    if (need > h->peer_scratch_bytes) {   // (first call, or a larger job: the only synchronising path)
+        RBS_HIP(h, hipStreamSynchronize(s));
+        (void)hipFree(h->d_peer_scratch);
+        h->d_peer_scratch = nullptr;
+        h->peer_scratch_bytes = 0;
+        RBS_HIP(h, hipMalloc(&h->d_peer_scratch, need));
+        h->peer_scratch_bytes = need;
+    }
+    rbp::PeerPlan Q;
+    Q.ll_all = d_loglik_all; Q.uniforms = d_uniforms_sorted;
+    Q.N = n_total; Q.n = n_local; Q.rank = rank; Q.cap = h->max_particles; Q.min_share = min_share;
+    Q.temperature = temperature;
+    Q.cdf = static_cast<double*>(h->d_peer_scratch);
+    Q.mine = reinterpret_cast<int*>(Q.cdf + n_total);
+    Q.aux = Q.mine + n_local;
+    Q.parent_idx = d_parent_idx; Q.stage_src = d_stage_src; Q.stage_dst = d_stage_dst;
+    Q.parents_local = d_parents_local;
+    Q.counts = reinterpret_cast<long long*>(d_counts);
+    hipLaunchKernelGGL(rbp::peer_resample_kernel, dim3(1), dim3(rbp::kThreads), 0, s, Q);
     RBS_HIP(h, hipGetLastError());
     return RBS_OK;
 }

@@ -337,16 +337,32 @@ def plan_shard(parents_sorted, n, cap, rank, min_share=2):
 
 
 def attach_peers(sensor, group=None):
-    """Exchange the ranks' rbs_ipc_export blobs (an all-gather of 512 bytes each) and attach."""
+    """Exchange the ranks' rbs_ipc_export blobs (an all-gather of 512 bytes each) and attach.  A failure on any
+    rank (export or attach) is raised on EVERY rank, after all of them have left the hand-shake: nobody is left
+    waiting at a barrier for a rank that has given up."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    err = None
+    try:
+        mine = sensor.ipc_export()
+    except Exception as e:   # noqa: BLE001 -- reported to every rank below
+        mine, err = None, e
     blobs = [None] * world
-    dist.all_gather_object(blobs, sensor.ipc_export(), group=group)
+    dist.all_gather_object(blobs, mine, group=group)
+    usable = all(b is not None for b in blobs)
     # one rank at a time: two processes importing each other's large buffers at the same moment were seen to
     # block each other inside hipIpcOpenMemHandle for ever (3 GB slabs, ROCm 7.2)
     for r in range(world):
-        if r == rank:
-            sensor.ipc_attach(rank, blobs)
+        if r == rank and usable and err is None:
+            try:
+                sensor.ipc_attach(rank, blobs)
+            except Exception as e:   # noqa: BLE001
+                err = e
         dist.barrier(group=group)
+    said = [None] * world
+    dist.all_gather_object(said, None if err is None else repr(err), group=group)
+    bad = [f"rank {r}: {m}" for r, m in enumerate(said) if m]
+    if bad:
+        raise RuntimeError("attach_peers failed -- " + "; ".join(bad))
 
 
 class PeerShardedStep:
@@ -356,24 +372,31 @@ class PeerShardedStep:
         -> rbs_stage_windows (shared remote parents pulled once) -> the next step's parent indices.
     The sensor has max_particles = cap >= 2 n (n own slots + staging) and is attached (attach_peers).
     `evaluate(poses, parent_idx, out)` / `stage(src, dst)` / `all_gather(out, inp)` replace the three device
-    operations (the CPU tests drive the oracle through them; the one-GPU test gathers through gloo)."""
+    operations (the CPU tests drive the oracle through them; the one-GPU test gathers through gloo).
+    fused=True: global_resample + plan_shard as ONE library kernel (rbs_peer_resample) instead of ~45 tensor
+    kernels; the step's uniforms must then be SORTED ascending (children are exchangeable: the parents come out
+    sorted either way, and they are the same parents), step() returns this rank's slice of the sorted parents."""
 
     def __init__(self, sensor, n, cap, group=None, device=None, min_share=2, stream=None, evaluate=None, stage=None, all_gather=None,
-                 temperature=1.0):
+                 temperature=1.0, fused=False):
         self.sensor, self.n, self.cap, self.group, self.device, self.min_share = sensor, n, cap, group, device, min_share
         self.temperature = temperature
+        self.fused = fused
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.N = self.world * n
         self.stream = stream
         self.d_out = torch.zeros(n, dtype=torch.float64, device=device)
         self.d_all = torch.zeros(self.N, dtype=torch.float64, device=device)
         self.parent_idx = torch.full((n,), self.rank * cap, dtype=torch.int32, device=device)   # after reset: any own slot
-        self.counts = torch.zeros(3, dtype=torch.int64, device=device)
+        self.counts = torch.zeros(4 if fused else 3, dtype=torch.int64, device=device)
         self.children = 0
         self._evaluate = evaluate or self._evaluate_device
         self._stage = stage or (lambda src, dst: sensor.stage_windows(src.data_ptr(), dst.data_ptr(), n, self.stream))
         self._all_gather = all_gather or (lambda out, inp: dist.all_gather_into_tensor(out, inp, group=group))
         self._keep = None
+        if fused:   # two sets of plan buffers: a step's plan is read by kernels enqueued behind the next step's
+            self._plans = [tuple(torch.full((n,), -1, dtype=torch.int32, device=device) for _ in range(4)) for _ in range(2)]
+            self._flip = 0
 
     def _evaluate_device(self, poses, parent_idx, out):
         self.sensor.loglikes_device(poses.data_ptr(), parent_idx.data_ptr(), self.n, True, out.data_ptr(), self.stream)
@@ -381,9 +404,22 @@ class PeerShardedStep:
 
     def step(self, poses, uniforms):
         """One updating call + exchange + resampling.  poses: this rank's [n, 12 bodies] tensor; `uniforms` [N]
-        identical on every rank.  Returns the sorted global parents (indices into the gathered vector)."""
+        identical on every rank (fused: ascending).  Returns the sorted global parents (indices into the gathered
+        vector) -- fused: this rank's n of them."""
         self._evaluate(poses, self.parent_idx, self.d_out)
         self._all_gather(self.d_all, self.d_out)
+        if self.fused:
+            parent_idx, src, dst, mine = self._plans[self._flip]
+            self._flip ^= 1
+            self.sensor.peer_resample(self.d_all.data_ptr(), uniforms.data_ptr(), self.N, self.n, self.rank, self.min_share,
+                                      self.temperature, parent_idx.data_ptr(), src.data_ptr(), dst.data_ptr(), mine.data_ptr(),
+                                      self.counts.data_ptr(), self.stream)
+            self._stage(src, dst)
+            self._keep = (self.parent_idx, poses, uniforms)
+            self.parent_idx = parent_idx
+            self.last_parents = mine
+            self.children += self.n
+            return mine
         ps = global_resample(self.d_all, uniforms, self.temperature)
         self.last_parents = ps
         parent_idx, src, dst, counts = plan_shard(ps, self.n, self.cap, self.rank, self.min_share)

@@ -382,6 +382,14 @@ class RbSensor:
     def stage_windows(self, d_src_global_ptr, d_dst_local_ptr, n, stream=None):
         self._check(self._lib.rbs_stage_windows(self._h, d_src_global_ptr, d_dst_local_ptr, int(n), stream))
 
+    def peer_resample(self, d_loglik_all_ptr, d_uniforms_sorted_ptr, n_total, n_local, rank, min_share, temperature,
+                      d_parent_idx_ptr, d_stage_src_ptr, d_stage_dst_ptr, d_parents_local_ptr, d_counts_ptr, stream=None):
+        """rbs_peer_resample: multinomial resampling over all ranks' particles at SORTED uniforms + this rank's plan
+        (parents, what to stage) in one launch; device pointers, nothing synchronises after the first call."""
+        self._check(self._lib.rbs_peer_resample(self._h, d_loglik_all_ptr, d_uniforms_sorted_ptr, int(n_total), int(n_local), int(rank),
+                                                int(min_share), float(temperature), d_parent_idx_ptr, d_stage_src_ptr, d_stage_dst_ptr,
+                                                d_parents_local_ptr, d_counts_ptr, stream))
+
     def occlusion_device_ptr(self, slot, next_buffer=False):
         p = C.c_void_p()
         fn = self._lib.rbs_occlusion_next_device_ptr if next_buffer else self._lib.rbs_occlusion_device_ptr

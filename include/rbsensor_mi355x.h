@@ -333,6 +333,32 @@ int32_t rbs_ipc_attach(rbs_handle* h, int32_t rank, int32_t world, const void* b
  * the staged copy -- global slot rank * max_particles + d_dst_local[i] -- as the children's parent.
  * Both arrays in device memory.  Works on an unattached handle as well (src = local slots). */
 int32_t rbs_stage_windows(rbs_handle* h, const int32_t* d_src_global, const int32_t* d_dst_local, int32_t n, void* stream);
+/* The resampling half of the filter step across processes in ONE launch on `stream` (no host synchronisation
+ * after the first call, which allocates scratch): what dbot_ros_amd/dist.py global_resample + plan_shard
+ * compute with ~45 tensor kernels.  d_loglik_all [n_total = world * n_local]: the all-gathered
+ * log-likelihoods, rank-major.  d_uniforms_sorted [n_total]: the step's uniforms in [0, 1), identical on
+ * every rank and ASCENDING -- multinomial resampling (parent = upper_bound(cumulative normalised
+ * weights, u); weights exp((ll - max) / temperature), temperature 1 = the filter's own) draws exchangeable
+ * children, and u -> parent is monotone, so sorted uniforms give the children sorted by parent: child g of
+ * the job is evaluated by rank g / n_local, and in that order the children of rank r's particles are one
+ * contiguous run that mostly coincides with rank r's slots.  A NaN log-likelihood (a contained particle)
+ * weighs nothing.  Outputs, all in device memory, [n_local] each unless noted:
+ *   d_parent_idx     the GLOBAL slot local child k inherits from -- owner * max_particles + local slot --
+ *                    or, for a parent on another rank that at least min_share of this rank's children
+ *                    share, the local staging slot rank * max_particles + n_local + j
+ *   d_stage_src/dst  the arguments of rbs_stage_windows(h, src, dst, n_local, stream), which the caller
+ *                    enqueues next: entry k pulls global slot src[k] into local slot dst[k] iff dst[k] >= 0
+ *   d_parents_local  (may be null) each local child's parent as an index into d_loglik_all
+ *   d_counts [4]     int64, ACCUMULATED: children with a parent on another rank, of them served from
+ *                    staging, windows staged, distinct parents among this rank's children
+ * The handle needs max_particles >= 2 * n_local (own slots + staging slots); an attached handle must be
+ * rank `rank` of n_total / n_local.  Deterministic: every rank derives the same parents bit for bit.
+ * Replaces nothing in the reference (its filter is one process: R:source/dbot_ros/tracker/
+ * particle_tracker_node.cpp:277-284); it is the step north_star's "RCCL all-reduce of log-weights before
+ * resampling" leaves to each rank. */
+int32_t rbs_peer_resample(rbs_handle* h, const double* d_loglik_all, const double* d_uniforms_sorted, int32_t n_total, int32_t n_local,
+                          int32_t rank, int32_t min_share, double temperature, int32_t* d_parent_idx, int32_t* d_stage_src,
+                          int32_t* d_stage_dst, int32_t* d_parents_local, int64_t* d_counts, void* stream);
 
 /* Rasterize one pose [n_objects][12] -> host float[rows*cols], +inf where uncovered. */
 int32_t rbs_render_depth(rbs_handle* h, const double* pose, float* out);

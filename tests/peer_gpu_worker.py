@@ -53,7 +53,7 @@ def single(slab_px):
     return out
 
 
-def worker(rank, world, port, slab_px, q):
+def worker(rank, world, port, slab_px, q, fused=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -73,12 +73,13 @@ def worker(rank, world, port, slab_px, q):
                 out.copy_(torch.cat(parts))
 
             step = rdist.PeerShardedStep(s, n, cap, device=dev, min_share=2, stream=stream.cuda_stream, all_gather=all_gather,
-                                         temperature=TEMP)
+                                         temperature=TEMP, fused=fused)
             res = []
             for k, (_, frame) in enumerate(frames):
                 s.set_observation(frame)
                 d_poses = torch.from_numpy(poses[k][rank * n:(rank + 1) * n].copy()).to(dev)
-                ps = step.step(d_poses, uniforms[k].to(dev))
+                u = uniforms[k].sort().values if fused else uniforms[k]    # (fused: one launch, sorted uniforms; the same parents)
+                ps = step.step(d_poses, u.to(dev))
                 res.append((step.d_all.cpu().numpy().copy(), ps.cpu().numpy().copy()))
             torch.cuda.synchronize()
             dist.barrier()     # nobody unmaps while a peer may still be reading
@@ -90,10 +91,10 @@ def worker(rank, world, port, slab_px, q):
 
 def main():
     port = int(sys.argv[1])
-    for slab_px in (0, 4096):
+    for slab_px, fused in ((0, False), (4096, False), (0, True), (4096, True)):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
-        procs = [ctx.Process(target=worker, args=(r, WORLD, port, slab_px, q)) for r in range(WORLD)]
+        procs = [ctx.Process(target=worker, args=(r, WORLD, port, slab_px, q, fused)) for r in range(WORLD)]
         for p in procs:
             p.start()
         got = [q.get(timeout=300) for _ in procs]
@@ -104,11 +105,11 @@ def main():
         remote = sum(g[2][0] for g in got)
         from_staging = sum(g[2][1] for g in got)
         staged = sum(g[2][2] for g in got)
-        print(f"slab_px={slab_px}: children with a remote parent {remote}, of them served from staging {from_staging}, planes staged {staged}")
+        print(f"slab_px={slab_px} fused={fused}: children with a remote parent {remote}, of them served from staging {from_staging}, planes staged {staged}")
         assert remote > from_staging > 0 and staged > 0, "the scenario must exercise in-place remote reads AND staging"
-        for _, res, _ in got:
+        for rk, res, _ in got:
             for k, ((ll_ref, ps_ref), (ll, ps)) in enumerate(zip(ref, res)):
-                assert np.array_equal(ps, ps_ref), k
+                assert np.array_equal(ps, ps_ref[rk * PN:(rk + 1) * PN] if fused else ps_ref), k
                 assert np.array_equal(ll, ll_ref), (k, np.abs(ll - ll_ref).max())
         port += 7
     print("PEERS_OK")

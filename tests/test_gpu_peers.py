@@ -81,3 +81,48 @@ def test_ipc_attach_refuses_mismatched_handles(gpu_lib):
         assert "differs" in str(e.value)
         with pytest.raises(RbSensorError):
             a.ipc_attach(0, [b"\0" * 512, b"\0" * 512])
+
+
+@pytest.mark.parametrize("world,n,min_share,temp,spread", [
+    (2, 48, 2, 1.0, 3.0),          # a handful of survivors
+    (4, 500, 2, 1.0, 0.05),        # many distinct parents, most children alone with theirs
+    (8, 2000, 2, 50.0, 30.0),      # BASELINE C1 over eight ranks, flattened weights
+    (3, 1111, 3, 1.0, 1.0),        # chunks that do not divide evenly, min_share 3
+    (2, 25000, 2, 1.0, 200.0),     # one survivor: every child of the other rank shares a remote parent
+    (1, 64, 2, 1.0, 1.0),          # a single rank: nothing is remote
+])
+def test_peer_resample_matches_tensor_arithmetic(gpu_lib, world, n, min_share, temp, spread):
+    """rbs_peer_resample (one launch) against dist.global_resample + dist.plan_shard (the same step as tensor
+    arithmetic, here on the CPU): identical parents, identical plan and counts, for every rank of the job."""
+    from dbot_ros_amd import dist as rdist
+    N = world * n
+    rng = np.random.default_rng(world * 1000 + n)
+    ll = rng.normal(-3000.0, spread, N)
+    ll[rng.integers(0, N, 3)] = np.nan if n > 100 else ll[0]     # contained particles weigh nothing
+    g = torch.Generator().manual_seed(n)
+    u_sorted = torch.sort(torch.rand(N, dtype=torch.float64, generator=g)).values
+    ll_ref = torch.from_numpy(np.where(np.isnan(ll), -np.inf, ll))
+    ps = rdist.global_resample(ll_ref, u_sorted, temp)
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=2 * n)
+    with RbSensor(om, cam, P, max_particles=2 * n) as s:
+        d_ll = torch.from_numpy(ll).cuda()
+        d_u = u_sorted.cuda()
+        for rank in range(world):
+            out = [torch.full((n,), -7, dtype=torch.int32, device="cuda") for _ in range(4)]
+            counts = torch.zeros(4, dtype=torch.int64, device="cuda")
+            for _ in range(2):      # twice: the counts accumulate
+                s.peer_resample(d_ll.data_ptr(), d_u.data_ptr(), N, n, rank, min_share, temp, out[0].data_ptr(), out[1].data_ptr(),
+                                out[2].data_ptr(), out[3].data_ptr(), counts.data_ptr())
+            s.synchronize()
+            torch.cuda.synchronize()
+            pidx, src, dst, cnt = rdist.plan_shard(ps, n, 2 * n, rank, min_share)
+            mine = ps[rank * n:(rank + 1) * n]
+            assert np.array_equal(out[3].cpu().numpy(), mine.numpy()), rank
+            assert np.array_equal(out[0].cpu().numpy(), pidx.numpy()), rank
+            assert np.array_equal(out[1].cpu().numpy(), src.numpy()), rank
+            assert np.array_equal(out[2].cpu().numpy(), dst.numpy()), rank
+            runs = int((mine[1:] != mine[:-1]).sum()) + 1
+            assert counts.cpu().tolist() == [2 * int(c) for c in cnt] + [2 * runs], rank
+        with pytest.raises(RbSensorError):       # the staging slots must exist
+            s.peer_resample(d_ll.data_ptr(), d_u.data_ptr(), N * 2, 2 * n, 0, 2, 1.0, out[0].data_ptr(), out[1].data_ptr(),
+                            out[2].data_ptr(), 0, counts.data_ptr())
