@@ -469,7 +469,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipMemcpyAsync(h->h_area, h->d_area, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         RBS_HIP(h, hipEventRecord(h->ev_area, s));
         h->area_pending = true;
-        h->area_n = n;
+        h->area_n = (n + 7) / 8;    // (the rectangles kernel adds every 8th particle's region)
     }
     if (update) {
         // fork: the copy kernel runs on the handle's second stream, concurrently with the

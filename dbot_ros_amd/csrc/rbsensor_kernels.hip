@@ -1512,7 +1512,10 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
         }
         P.win_used[i] = u;
         P.win_dst[i] = seed;
-        if (P.area_sum && u.z > u.x && u.w > u.y)
+        // (every 8th particle: the sum only feeds an estimate of the stored fraction of a plane, and one atomic per
+        // particle on one address serialises at ~12 ns each -- 24 us of a sampled call's rectangles kernel at 2 000
+        // particles, 250 us at 20 000)
+        if (P.area_sum && (i & 7) == 0 && u.z > u.x && u.w > u.y)
             atomicAdd(P.area_sum, (unsigned long long)(u.z - u.x) * (unsigned long long)(u.w - u.y));
     }
 }
