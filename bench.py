@@ -311,7 +311,15 @@ def setup_peer_run(a, om, cam, P, W, dev, stream, dist, backend, world):
     n = a.particles
     sensor = make_sensor(a, om, cam, P, dev, n=2 * n)
     prime(sensor, a, W)
-    rdist.attach_peers(sensor)
+    try:
+        if os.environ.get("RBS_BENCH_FAIL_ATTACH") == "1":      # (tests: the fallback of a job whose handles cannot attach)
+            raise RuntimeError("attach_peers failed -- RBS_BENCH_FAIL_ATTACH=1")
+        rdist.attach_peers(sensor)
+    except RuntimeError:
+        torch.cuda.synchronize()
+        dist.barrier()
+        sensor.close()
+        raise
 
     def gather(out_t, inp_t):
         if backend == "nccl":

@@ -372,3 +372,55 @@ def test_plan_shard_indices():
     p1, s1, d1, c1 = rdist.plan_shard(ps, 4, 8, 1, 2)
     assert p1.tolist() == [12, 12, 3, 10] and s1.tolist() == [0, -1, -1, -1] and d1.tolist() == [4, -1, -1, -1]
     assert c1.tolist() == [3, 2, 1]
+
+
+class _FakeSensor:
+    """What attach_peers needs of a sensor; `fail` = the step that raises on this rank."""
+
+    def __init__(self, rank, fail=None):
+        self.rank, self.fail, self.attached = rank, fail, None
+
+    def ipc_export(self):
+        if self.fail == "export":
+            raise RuntimeError("export refused on rank %d" % self.rank)
+        return bytes([self.rank]) * 512
+
+    def ipc_attach(self, rank, blobs):
+        if self.fail == "attach":
+            raise RuntimeError("attach refused on rank %d" % self.rank)
+        self.attached = [b[0] for b in blobs]
+
+
+def _attach_worker(rank, world, port, fail_rank, fail, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = _FakeSensor(rank, fail if rank == fail_rank else None)
+        try:
+            rdist.attach_peers(s)
+            q.put((rank, "ok", s.attached))
+        except RuntimeError as e:
+            q.put((rank, "raised", str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [None, "export", "attach"])
+def test_attach_peers_fails_on_every_rank_alike(fail):
+    """A rank that cannot export or attach must not leave the others waiting at a barrier: attach_peers raises the
+    same RuntimeError on EVERY rank (bench.py --gpus N then falls back to shards with local parents)."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 25100 + (os.getpid() % 1500) + (0 if fail is None else len(fail))
+    procs = [ctx.Process(target=_attach_worker, args=(r, world, port, 1, fail, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if fail is None:
+        assert all(g[1] == "ok" and g[2] == [0, 1, 2] for g in got), got
+    else:
+        assert all(g[1] == "raised" and "rank 1" in g[2] and "refused" in g[2] for g in got), got

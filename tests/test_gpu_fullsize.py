@@ -301,3 +301,25 @@ def test_bench_line_of_two_ranks_on_one_gpu(gpu_lib):
     # the step resamples over BOTH ranks' particles: some children inherit from the other rank
     assert 0.0 < line["remote_parent_frac"] < 1.0 and line["distinct_parents_per_step"] > 4
     assert "global" in line["config"]["workload"].lower() and "IPC" in line["config"]["sharding"]
+
+
+def test_bench_line_when_the_ranks_cannot_attach(gpu_lib):
+    """bench.py --gpus 2 whose handles fail to attach to each other (RBS_BENCH_FAIL_ATTACH: the hand-shake raises on every
+    rank) still prints the contract's line -- shards with local parents + the all-gather -- and says what happened."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RBS_BENCH_BACKEND="gloo", RBS_BENCH_FAIL_ATTACH="1", RBS_BENCH_SHARDED_TRACKER="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29950 + os.getpid() % 40),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--particles", "256",
+                        "--no-configs-leg"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["peer_step"].startswith("FAILED") and "RBS_BENCH_FAIL_ATTACH" in line["peer_step"]
+    assert "could not be attached" in line["config"]["workload"] and "local parents" in line["config"]["sharding"]
+    assert line["value"] > 0 and "roofline" in line
+    assert abs(line["value"] - 2 * 256 * 5 / (line["ms_per_step"] * 5e-3)) <= 1e-6 * line["value"]
