@@ -475,20 +475,11 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         // fork: the copy kernel runs on the handle's second stream, concurrently with the
         // persistent raster kernel; it needs this call's rectangles only
         RBS_HIP(h, hipEventRecord(h->ev_fork, s));
-        RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
-        if (h->windowed && !wide) {
-            // the windowed copy goes first: its one-wave blocks (32 VGPRs) then run beside the
-            // persistent raster blocks (3 x 160 VGPRs per SIMD: precision F32; the binary64
-            // likelihood's 3 x 168 leave it the ramp-up and the tail only)
-            if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
-            const int ny = std::min(n, 32768);
-            const dim3 wg((unsigned)h->win_chunks, (unsigned)ny, (unsigned)((n + ny - 1) / ny));
-            if (h->slab_px) hipLaunchKernelGGL(rbs::rbs_copy_window_kernel<true>, wg, dim3(64), 0, h->copy_stream, P);
-            else hipLaunchKernelGGL(rbs::rbs_copy_window_kernel<false>, wg, dim3(64), 0, h->copy_stream, P);
-            RBS_HIP(h, hipGetLastError());
-            if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_stop[tslot], h->copy_stream));
-            RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
-        }
+        // (the windowed copy kernel itself is launched BEHIND the raster kernel's launch, below: its one-wave blocks
+        // (32 VGPRs) run beside the persistent raster blocks (3 x 160 VGPRs per SIMD) whichever of the two reaches the
+        // device first, and the three runtime calls it takes -- 10-15 us of host time -- are then not in front of the
+        // raster kernel when the host is what the device waits for: a tracker frame by frame, the host-pointer calls)
+        if (!(h->windowed && !wide)) RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
     }
     // deferred join: the raster kernel reads planes the previous updating call's copy kernel
     // may still be writing; everything before this point overlapped with that copy's tail
@@ -527,7 +518,15 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
         if (timed && (!h->windowed || wide)) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
         if (h->windowed && !wide) {
-            // launched above, ahead of the raster kernel
+            RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
+            if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
+            const int ny = std::min(n, 32768);
+            const dim3 wg((unsigned)h->win_chunks, (unsigned)ny, (unsigned)((n + ny - 1) / ny));
+            if (h->slab_px) hipLaunchKernelGGL(rbs::rbs_copy_window_kernel<true>, wg, dim3(64), 0, h->copy_stream, P);
+            else hipLaunchKernelGGL(rbs::rbs_copy_window_kernel<false>, wg, dim3(64), 0, h->copy_stream, P);
+            RBS_HIP(h, hipGetLastError());
+            if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_stop[tslot], h->copy_stream));
+            RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
         } else if (wide) {
             const int W4 = P.cols >> 2;
             const int nseg = (W4 + 63) / 64;
