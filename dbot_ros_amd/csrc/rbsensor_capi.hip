@@ -432,7 +432,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.done = h->d_done;
     P.partial = h->d_partial;
 #ifdef RBS_PHASE_TIMING
-    if (!h->d_phase) { RBS_HIP(h, hipMalloc(&h->d_phase, 128)); RBS_HIP(h, hipMemset(h->d_phase, 0, 128)); }
+    if (!h->d_phase) { RBS_HIP(h, hipMalloc(&h->d_phase, 256)); RBS_HIP(h, hipMemset(h->d_phase, 0, 256)); }
     P.phase = h->d_phase;
 #endif
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_start[tslot], s));
@@ -2761,8 +2761,8 @@ int32_t rbs_debug_phase_cycles(rbs_handle* h, unsigned long long* out8)
 {
     if (!h || !h->d_phase) return RBS_ERR_INVALID_ARGUMENT;
     RBS_HIP(h, hipDeviceSynchronize());
-    RBS_HIP(h, hipMemcpy(out8, h->d_phase, 128, hipMemcpyDeviceToHost));   // 16 counters
-    RBS_HIP(h, hipMemset(h->d_phase, 0, 128));
+    RBS_HIP(h, hipMemcpy(out8, h->d_phase, 256, hipMemcpyDeviceToHost));   // 16 cycle counters + 16 event counters
+    RBS_HIP(h, hipMemset(h->d_phase, 0, 256));
     return RBS_OK;
 }
 #endif

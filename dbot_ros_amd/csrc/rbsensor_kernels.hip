@@ -216,18 +216,20 @@ struct DevParams {
     double* partial;               // [items] partial log-likelihood per work item
     int* done;                     // [n] finished work items per particle (the last one sums them)
 #ifdef RBS_PHASE_TIMING
-    unsigned long long* phase;     // [8] accumulated wave-0 cycles per phase (profiling builds only)
+    unsigned long long* phase;     // [32] accumulated wave-0 cycles per phase and event counts (profiling builds only)
 #endif
 };
 #ifdef RBS_PHASE_TIMING
 // (accumulated in LDS, flushed once per block: a global atomic per tick serialised the blocks)
-__shared__ unsigned long long g_phase_lds[16];
+__shared__ unsigned long long g_phase_lds[32];   // [0, 16): cycles per phase, [16, 32): event counts (RBS_COUNT)
 #define RBS_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); g_phase_lds[k] += t_ - tick_; tick_ = t_; } } while (0)
+#define RBS_COUNT(k, v) do { if (threadIdx.x == 0) g_phase_lds[k] += (unsigned long long)(v); } while (0)
 #define RBS_TICK_DECL unsigned long long tick_ = clock64()
 #define RBS_TICK_PARAM , unsigned long long& tick_
 #define RBS_TICK_ARG , tick_
 #else
 #define RBS_TICK(k) do {} while (0)
+#define RBS_COUNT(k, v) do {} while (0)
 #define RBS_TICK_DECL do {} while (0)
 #define RBS_TICK_PARAM
 #define RBS_TICK_ARG
@@ -833,6 +835,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
             const bool hit = ci < c1 && (!cull || cluster_may_touch(P, Rt, sph, wx0, wy0, wx1, wy1)) && facing <= 0;
             const unsigned long long mask = __ballot(hit);
             RBS_TICK(8);
+            RBS_COUNT(16, min(64, c1 - base)); RBS_COUNT(17, __popcll(mask));
             // this wave's share: the surviving clusters are dealt round-robin by their rank
             const int rank = taken + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
             unsigned long long mine = __ballot(hit && (rank % (kBlock / 64)) == wave);
@@ -852,7 +855,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
                 const int nv = __shfl(nvc, bit, 64);
                 raster_shared_cluster(P, base + bit, __builtin_amdgcn_readfirstlane(nv), t_end, Rt, wx0, wy0, wx1, wy1, cullsign,
                                       tile, tw, big, nbig RBS_TICK_ARG);
-                __builtin_amdgcn_wave_barrier(); RBS_TICK(12);
+                __builtin_amdgcn_wave_barrier(); RBS_TICK(12); RBS_COUNT(18, 1); RBS_COUNT(19, 1);
             }
 #endif
             if (cullsign == 0) {   // nothing to pre-test: the clusters' lanes go straight to the setup
@@ -899,7 +902,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
                     qh = (qh + 64) & (kTq - 1);
                     qn -= 64;
                     raster_lane_triangle(P, t64, Rt, wx0, wy0, wx1, wy1, cullsign, tile, tw, big, nbig RBS_TICK_ARG);
-                    __builtin_amdgcn_wave_barrier(); RBS_TICK(12);
+                    __builtin_amdgcn_wave_barrier(); RBS_TICK(12); RBS_COUNT(18, 1);
                 }
             }
         }
@@ -910,13 +913,14 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
                 raster_lane_triangle(P, tt, Rt, wx0, wy0, wx1, wy1, cullsign, tile, tw, big, nbig RBS_TICK_ARG);
             }
             __builtin_amdgcn_wave_barrier();
-            RBS_TICK(12);
+            RBS_TICK(12); RBS_COUNT(18, 1); RBS_COUNT(23, qn);
         }
     }
     RBS_TICK(9);   // pre-test, compaction, loop bookkeeping (what 8, 10, 11, 12 do not claim)
     __syncthreads();
     RBS_TICK(13);  // waiting for the block's other waves
     const int nb = min(*nbig, kBigCap);
+    RBS_COUNT(20, nb); RBS_COUNT(21, 1);
     if (nb == 0) return;   // block-uniform; the usual case (a barrier costs an item about 1 %)
     for (int e = 0; e < nb; ++e) {
         const int t = big[e];
@@ -1567,7 +1571,7 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
     }
 #ifdef RBS_PHASE_TIMING
     const unsigned long long c0_ = clock64(), w0_ = wall_clock64();
-    if (threadIdx.x < 16) g_phase_lds[threadIdx.x] = 0;
+    if (threadIdx.x < 32) g_phase_lds[threadIdx.x] = 0;
 #endif
     RBS_TICK_DECL;
     // The first round is dealt statically (block b takes item b): 768 blocks drawing their first
@@ -1648,7 +1652,7 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
     }
 #ifdef RBS_PHASE_TIMING
     if (threadIdx.x == 0) {   // block lifetime in shader cycles (clock64) and in 100 MHz wall ticks
-        for (int k = 0; k < 16; ++k)
+        for (int k = 0; k < 32; ++k)
             if (k != 5 && k != 6) atomicAdd(&P.phase[k], g_phase_lds[k]);
         atomicAdd(&P.phase[5], clock64() - c0_);
         atomicAdd(&P.phase[6], wall_clock64() - w0_);

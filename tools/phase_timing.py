@@ -22,7 +22,7 @@ with RbSensor(om, cam, P, max_particles=n) as s:
     s.set_observation(synth.make_frame(s.render_depth(truth), rows, cols, rng))
     poses = synth.particle_poses(truth, n, rng)
     idx = rng.permutation(n).astype(np.int32)
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 32)()
     for rep in range(3):
         s.loglikes_poses(poses, idx.copy(), update=bool(upd))
         lib.rbs_debug_phase_cycles(s._h, out)
@@ -35,4 +35,9 @@ with RbSensor(om, cam, P, max_particles=n) as s:
                                            ((8, "cluster cull"), (9, "pre-test+queue"), (10, "before setup"), (11, "setup"), (12, "sample loops"),
                                             (13, "barrier wait"), (14, "big triangles"))},
               "\n   per item, cycles: ticket %.0f, descriptor %.0f, pose + eye %.0f, cluster cull %.0f" % (c[7] / n, c[15] / n, c[0] / n, c[8] / n),
+              "\n   per item (wave 0 of four; clusters are tested by every wave): clusters tested %.1f, surviving the cull %.1f (%.0f %%), "
+              "setup batches of wave 0 %.2f (of them whole clusters with shared vertices %.2f), triangles of its last partial batches %.1f, "
+              "triangles handed to the block-wide path %.2f" % (c[16] / max(c[21], 1), c[17] / max(c[21], 1), 100 * c[17] / max(c[16], 1), c[18] / max(c[21], 1),
+                                                             c[19] / max(c[21], 1), c[23] / max(c[21], 1), c[20] / max(c[21], 1)),
+              "\n   items per particle %.2f" % (c[21] / n),
               "\n   | block lifetime: %.0f cycles, %.1f us wall -> %.2f GHz shader clock" % (c[5] / 768, c[6] / 768 / 100.0, c[5] / max(c[6], 1) * 0.1))
