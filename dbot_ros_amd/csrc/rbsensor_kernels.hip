@@ -72,6 +72,9 @@ namespace rbs {
 #ifndef RBS_EDGE_FILTER
 #define RBS_EDGE_FILTER 0
 #endif
+#ifndef RBS_PIN_EDGES
+#define RBS_PIN_EDGES 1        // raster_lane_samples: the edge components stay in registers across the sample loops
+#endif
 #ifndef RBS_SHARE_VERTICES
 #define RBS_SHARE_VERTICES 1   // raster_shared_cluster (0: every triangle transforms its own three vertices)
 #endif
@@ -707,9 +710,20 @@ __device__ inline void raster_lane_samples(const Tri& T, int t, int wx0, int wy0
         }
     }
 #else
+#if RBS_PIN_EDGES
+    // (the six edge components opaque to the optimiser, so that none of them is re-derived from the vertices inside the
+    // loop: left alone the compiler re-materialises one of them per trip -- a binary64 subtraction it deems cheaper than two
+    // registers; C2 / C4 +0.5-0.7 %, C1 +0.2 %, same bits)
+    Tri U = T;
+    asm volatile("" : "+v"(U.e01u), "+v"(U.e01v), "+v"(U.e12u), "+v"(U.e12v), "+v"(U.e20u), "+v"(U.e20v));
+    for (int row = U.ylo; row <= U.yhi; ++row)
+        for (int col = U.xlo; col <= U.xhi; ++col)
+            tri_pixel(U, col, row, tile, tw, wx0, wy0);
+#else
     for (int row = T.ylo; row <= T.yhi; ++row)
         for (int col = T.xlo; col <= T.xhi; ++col)
             tri_pixel(T, col, row, tile, tw, wx0, wy0);
+#endif
 #endif
 }
 
