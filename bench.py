@@ -27,9 +27,13 @@ in HBM before the timed region, device-pointer API.  The same JSON line carries,
   cpu_baseline    the CPU oracle (reference CPU-path semantics) on this host: 1 thread (as dbot's
                   CPU model runs) and all cores
 
-With `torch.distributed.run` (--gpus N, one rank per GPU) each rank evaluates its own 2 000-particle
-shard (weak scaling) and the per-particle log-likelihoods are all-gathered over RCCL every step
-(the weight exchange before resampling); only the headline is measured then.
+With `torch.distributed.run` (--gpus N, one rank per GPU) a step is SURVEY 8(e)'s whole exchange: each rank's
+2 000-particle shard (weak scaling) evaluated with GLOBAL parent slots -- the ranks' handles are attached to each
+other over HIP IPC, a parent on another GPU is read in place over xGMI --, the RCCL all-gather of the
+log-likelihoods, multinomial resampling over all ranks' particles and this rank's plan in one library launch
+(rbs_peer_resample), shared remote parents staged once; then the same step at C3 / C4's per-GPU sizes and the
+one-handle tracker over the job's devices (a time-limited child process).  Ranks that cannot attach fall back to
+shards with local parents + the all-gather, and the line says so (`peer_step`).
 
 `python bench.py --gpus N` WITHOUT torch.distributed.run (WORLD_SIZE unset) measures the other
 multi-GPU form: ONE process, one handle over N devices (rbs_config.n_devices; --device-ids to
