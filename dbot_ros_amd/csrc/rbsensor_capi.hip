@@ -99,7 +99,8 @@ struct rbs_handle {
     int cu_count = 256;
     int smalln_target = 768;    // few particles: aim at about this many work items per call
     int rect_align = 4;         // windowed planes: rectangles move in float4 columns
-    int win_chunks = 8;         // row chunks (blocks) per particle of the windowed copy kernel
+    int win_chunks = 8;         // row chunks (blocks) per particle of the windowed copy kernel (several bodies: it walks the whole window)
+    int win_chunks_single = 2;  // ... one body: it enumerates only the cells outside the rectangle, a tenth of the window
     int upload_chunks = 2;      // pieces a caller's host frame is staged and sent in (RBS_UPLOAD_CHUNKS) ...
     bool quiet = false;         // ... while nothing long of this handle's is running on the device (set by the entry points that
                                 // wait for results, cleared by every launch): behind a running raster kernel the second piece's
@@ -521,9 +522,15 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
             if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
             const int ny = std::min(n, 32768);
-            const dim3 wg((unsigned)h->win_chunks, (unsigned)ny, (unsigned)((n + ny - 1) / ny));
-            if (h->slab_px) hipLaunchKernelGGL(rbs::rbs_copy_window_kernel<true>, wg, dim3(64), 0, h->copy_stream, P);
-            else hipLaunchKernelGGL(rbs::rbs_copy_window_kernel<false>, wg, dim3(64), 0, h->copy_stream, P);
+            const dim3 wg((unsigned)(P.groups || !RBS_COPY_STRIPS ? h->win_chunks : h->win_chunks_single), (unsigned)ny, (unsigned)((n + ny - 1) / ny));
+            const bool strips = RBS_COPY_STRIPS && !P.groups;
+            if (h->slab_px) {
+                if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, true>), wg, dim3(64), 0, h->copy_stream, P);
+                else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, false>), wg, dim3(64), 0, h->copy_stream, P);
+            } else {
+                if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, true>), wg, dim3(64), 0, h->copy_stream, P);
+                else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, false>), wg, dim3(64), 0, h->copy_stream, P);
+            }
             RBS_HIP(h, hipGetLastError());
             if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_stop[tslot], h->copy_stream));
             RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
@@ -1328,7 +1335,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         if (const char* m = std::getenv("RBS_WIDE_ENTER")) { h->wide_enter = std::atof(m); h->wide_leave = h->wide_enter * 0.67; }
         if (const char* m = std::getenv("RBS_RECT_ALIGN")) h->rect_align = std::atoi(m) >= 16 ? 16 : (std::atoi(m) >= 8 ? 8 : 4);
         if (const char* m = std::getenv("RBS_TIMING_EVERY")) h->timing_every = std::max(1, std::atoi(m));
-        if (const char* m = std::getenv("RBS_WIN_CHUNKS")) h->win_chunks = std::min(1024, std::max(1, std::atoi(m)));
+        if (const char* m = std::getenv("RBS_WIN_CHUNKS")) h->win_chunks = h->win_chunks_single = std::min(1024, std::max(1, std::atoi(m)));
         if (const char* m = std::getenv("RBS_UPLOAD_CHUNKS")) h->upload_chunks = std::min(16, std::max(1, std::atoi(m)));
         if (h->cols & 3) h->windowed = false;   // windows move whole float4s
         h->base.rect_align = h->windowed ? h->rect_align : rbs::kRectAlign;

@@ -1816,8 +1816,13 @@ __global__ __launch_bounds__(64) void rbs_wide_window_kernel(const DevParams P, 
 #ifndef RBS_WIN_UNROLL
 #define RBS_WIN_UNROLL 2
 #endif
+#ifndef RBS_COPY_STRIPS
+#define RBS_COPY_STRIPS 1      // (0: one body takes the walk-everything form as well -- A/B)
+#endif
 constexpr int kWinUnroll = RBS_WIN_UNROLL;
-template <bool SLAB>
+// STRIPS: one rectangle per particle (P.groups == nullptr) -- only the cells outside it are enumerated; otherwise the
+// whole window is walked and the cells the raster kernel writes are skipped (several bodies: up to kMaxGroups rectangles).
+template <bool SLAB, bool STRIPS>
 __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
 {
     const int particle = (int)blockIdx.y + (int)blockIdx.z * (int)gridDim.y;
@@ -1834,8 +1839,8 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
     const int w4 = (u.z - u.x) >> 2, ux4 = u.x >> 2, W4 = P.cols >> 2;
     const int rpc = (u.w - u.y + (int)gridDim.x - 1) / (int)gridDim.x;
     const int ry0 = u.y + (int)blockIdx.x * rpc, ry1 = min(u.w, ry0 + rpc);
-    if (ry0 >= ry1) return;
-    const int n4 = (ry1 - ry0) * w4;
+    if (!STRIPS && ry0 >= ry1) return;   // (STRIPS: the blocks share CELLS, not rows -- below)
+    const int n4 = max(ry1 - ry0, 0) * w4;
     const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(parent_plane(P, parent));
     floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(P.occ_dst + (size_t)particle * P.plane_stride);
     // float4 index of pixel (col, row) in the parent's / the child's plane (whole planes: row W4 + col/4;
@@ -1845,10 +1850,62 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
     const int ds4 = SLAB ? w4 : W4, dx4 = SLAB ? ux4 : 0, dy0 = SLAB ? u.y : 0;
     const float alpha = P.alpha, beta = P.beta, bg_new = P.bg_new;
     const int lane = (int)threadIdx.x;
+    int bx0 = P.cols, by0 = P.rows, bx1 = 0, by1 = 0;
+    if (STRIPS) {
+        // One rectangle: the region this kernel writes is u minus the rectangle -- a band of rows above it, one below
+        // and two strips beside it, a tenth of u on a moving object (92 x 70 px of window around 88 x 65 of rectangle) --
+        // and ONLY those cells are enumerated (the generic loop below walks all of u and skips nine lanes in ten: every
+        // instruction of it is issued on SIMDs the persistent raster blocks are using).  Cell = one float4.
+        const bool has = q.z > q.x;
+        const int ty1 = has ? q.y : u.w, tby0 = has ? q.w : u.w;
+        const int left4 = has ? (q.x - u.x) >> 2 : 0, right4 = has ? (u.z - q.z) >> 2 : 0, m = left4 + right4;
+        const int rjump = has ? (q.z - u.x) >> 2 : 0;
+        const int n_top = (ty1 - u.y) * w4, n_mid = (tby0 - ty1) * m, L = n_top + n_mid + (u.w - tby0) * w4;
+        const int per = (L + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int lo = (int)blockIdx.x * per, hi = min(L, lo + per);
+        for (int base = lo; base < hi; base += 64 * kWinUnroll) {
+            floatx4 v[kWinUnroll];
+            int pk[kWinUnroll];    // state << 28 | row << 14 | float4 column (rows and columns <= 8 192: create refuses more)
+#pragma unroll
+            for (int k = 0; k < kWinUnroll; ++k) {
+                const int idx = base + k * 64 + lane;
+                const bool live = idx < hi;
+                int row, c4;
+                if (idx < n_top) { const int r = idx / w4; row = u.y + r; c4 = idx - r * w4; }
+                else if (idx < n_top + n_mid) {
+                    const int j = idx - n_top, r = j / max(m, 1), kk = j - r * m;
+                    row = ty1 + r; c4 = kk < left4 ? kk : kk - left4 + rjump;
+                } else { const int j = idx - n_top - n_mid, r = j / w4; row = tby0 + r; c4 = j - r * w4; }
+                const int col = (ux4 + c4) << 2;
+                const bool stored = live && col >= pw.x && col < pw.z && row >= pw.y && row < pw.w;
+                pk[k] = ((live ? (stored ? 2 : 1) : 0) << 28) | (row << 14) | (ux4 + c4);
+                if (stored) v[k] = __builtin_nontemporal_load(&s4[(row - sy0) * ss4 + (ux4 + c4 - sx4)]);
+            }
+#pragma unroll
+            for (int k = 0; k < kWinUnroll; ++k) {
+                const int st_ = pk[k] >> 28, row_ = (pk[k] >> 14) & 0x3fff, at_ = pk[k] & 0x3fff;
+                if (!st_) continue;
+                floatx4 w;
+                if (st_ == 2) {
+                    w.x = occ_step(alpha, beta, v[k].x, bg_new);
+                    w.y = occ_step(alpha, beta, v[k].y, bg_new);
+                    w.z = occ_step(alpha, beta, v[k].z, bg_new);
+                    w.w = occ_step(alpha, beta, v[k].w, bg_new);
+                } else {
+                    w.x = w.y = w.z = w.w = bg_new;
+                }
+                __builtin_nontemporal_store(w, &d4[(row_ - dy0) * ds4 + (at_ - dx4)]);
+                if (w.x != bg_new || w.y != bg_new || w.z != bg_new || w.w != bg_new) {
+                    const int col = at_ << 2;
+                    bx0 = min(bx0, col); bx1 = max(bx1, col + 4);
+                    by0 = min(by0, row_); by1 = max(by1, row_ + 1);
+                }
+            }
+        }
+    } else {
     const int qstep = 64 / w4, rstep = 64 - qstep * w4;
     int row = ry0 + lane / w4;
     int c4 = lane - (lane / w4) * w4;
-    int bx0 = P.cols, by0 = P.rows, bx1 = 0, by1 = 0;
     for (int base = 0; base < n4; base += 64 * kWinUnroll) {
         floatx4 v[kWinUnroll];
         int st[kWinUnroll], at[kWinUnroll], rr[kWinUnroll];
@@ -1884,6 +1941,7 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
                 by0 = min(by0, rr[k]); by1 = max(by1, rr[k] + 1);
             }
         }
+    }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
