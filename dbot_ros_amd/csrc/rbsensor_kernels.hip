@@ -1423,8 +1423,16 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
     const bool live = i < P.n;
     Rect r = {0, 0, 0, 0};
     int cnt = 0;
-    Groups G;
-    G.n = 0;
+    // (the per-body rectangles and the particle's groups live in LDS, one set per wave: indexed at run time, arrays of the
+    // function's own went to scratch -- 384 bytes per lane, and every step of the merge below a round trip to memory:
+    // the rectangles kernel of C2's three bodies took 76 us)
+    __shared__ int4 gr_s[kPrepPerBlock][kMaxBodies];
+    __shared__ unsigned gm_s[kPrepPerBlock][kMaxBodies];
+    __shared__ Groups G_s[kPrepPerBlock];
+    int4* const gr = gr_s[w];
+    unsigned* const gm = gm_s[w];
+    Groups& G = G_s[w];
+    if (lane == 0) G.n = 0;
     const int cap_px = min(P.tile_w * P.tile_h, P.tile_px);
     if (P.poses_src && live) {
         // a host-pointer call: the particle's pose is pulled from pinned host memory (one PCIe read of
@@ -1443,44 +1451,59 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
     } else if (live) {
         // several bodies: one rectangle per body, overlapping ones merged (all lanes hold the same
         // values and take the same branches)
-        Rect gr[kMaxBodies];
-        unsigned gm[kMaxBodies];
+        // (int4 = x0, y0, x1, y1; every lane of the wave runs the same steps on the same values: LDS reads are broadcasts,
+        // writes go through lane 0 with the wave's other lanes waiting at the barrier behind them)
         int ng = 0;
         for (int b = 0; b < P.n_bodies; ++b) {
             const Rect br = bodies_rect(P, P.poses + (size_t)i * 12 * P.n_bodies, b, b + 1);
-            if (br.x1 > br.x0) { gr[ng] = br; gm[ng] = 1u << b; ++ng; }
+            if (br.x1 > br.x0) {
+                if (lane == 0) { gr[ng] = make_int4(br.x0, br.y0, br.x1, br.y1); gm[ng] = 1u << b; }
+                ++ng;
+            }
         }
+        __builtin_amdgcn_wave_barrier();
         for (bool changed = true; changed;) {
             changed = false;
             for (int a = 0; a < ng && !changed; ++a)
-                for (int c = a + 1; c < ng && !changed; ++c)
-                    if (gr[a].x0 < gr[c].x1 && gr[c].x0 < gr[a].x1 && gr[a].y0 < gr[c].y1 && gr[c].y0 < gr[a].y1) {
-                        gr[a].x0 = min(gr[a].x0, gr[c].x0); gr[a].y0 = min(gr[a].y0, gr[c].y0);
-                        gr[a].x1 = max(gr[a].x1, gr[c].x1); gr[a].y1 = max(gr[a].y1, gr[c].y1);
-                        gm[a] |= gm[c];
-                        gr[c] = gr[ng - 1]; gm[c] = gm[ng - 1];
+                for (int c = a + 1; c < ng && !changed; ++c) {
+                    const int4 A = gr[a], C = gr[c];
+                    if (A.x < C.z && C.x < A.z && A.y < C.w && C.y < A.w) {
+                        const int4 last = gr[ng - 1];
+                        const unsigned ma = gm[a], mc = gm[c], ml = gm[ng - 1];
+                        __builtin_amdgcn_wave_barrier();          // (every lane has read before lane 0 writes)
+                        if (lane == 0) {
+                            gr[a] = make_int4(min(A.x, C.x), min(A.y, C.y), max(A.z, C.z), max(A.w, C.w));
+                            gm[a] = ma | mc;
+                            if (c != ng - 1) { gr[c] = last; gm[c] = ml; }
+                        }
+                        __builtin_amdgcn_wave_barrier();
                         --ng;
                         changed = true;
                     }
+                }
         }
         if (ng > kMaxGroups) {   // more separate objects than groups: one union rectangle
+            int4 U = gr[0];
+            unsigned mu = gm[0];
             for (int c = 1; c < ng; ++c) {
-                gr[0].x0 = min(gr[0].x0, gr[c].x0); gr[0].y0 = min(gr[0].y0, gr[c].y0);
-                gr[0].x1 = max(gr[0].x1, gr[c].x1); gr[0].y1 = max(gr[0].y1, gr[c].y1);
-                gm[0] |= gm[c];
+                const int4 C = gr[c];
+                U = make_int4(min(U.x, C.x), min(U.y, C.y), max(U.z, C.z), max(U.w, C.w));
+                mu |= gm[c];
             }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) { gr[0] = U; gm[0] = mu; }
+            __builtin_amdgcn_wave_barrier();
             ng = 1;
         }
-        G.n = ng;
-        if (ng > 0) r = gr[0];
+        if (lane == 0) G.n = ng;
+        if (ng > 0) { const int4 g0 = gr[0]; r = Rect{g0.x, g0.y, g0.z, g0.w}; }
         for (int g = 0; g < ng; ++g) {
-            const TileGrid tg = tile_grid(gr[g].x1 - gr[g].x0, gr[g].y1 - gr[g].y0, P.tile_w, cap_px);
-            G.rect[g] = make_int4(gr[g].x0, gr[g].y0, gr[g].x1, gr[g].y1);
-            G.mask[g] = gm[g];
-            G.first[g] = cnt;
+            const int4 R = gr[g];
+            const TileGrid tg = tile_grid(R.z - R.x, R.w - R.y, P.tile_w, cap_px);
+            if (lane == 0) { G.rect[g] = R; G.mask[g] = gm[g]; G.first[g] = cnt; }
             cnt += tg.nx * tg.ny;
-            r.x0 = min(r.x0, gr[g].x0); r.y0 = min(r.y0, gr[g].y0);
-            r.x1 = max(r.x1, gr[g].x1); r.y1 = max(r.y1, gr[g].y1);
+            r.x0 = min(r.x0, R.x); r.y0 = min(r.y0, R.y);
+            r.x1 = max(r.x1, R.z); r.y1 = max(r.y1, R.w);
         }
         if (ng == 0) cnt = 1;
     }
