@@ -171,7 +171,8 @@ __device__ inline void propagate_body(const TrackerDev& T, int b, int i, int bb,
 // recentre: the re-centring of the previous frame's particles (recentre_kernel's work) has been
 // deferred into this launch -- one launch and one kernel boundary less per frame; the thread owns
 // particle i, so it re-centres the old particle in place first (same operations, same bits).
-__global__ void propagate_kernel(const TrackerDev T, int b, int recentre)
+__global__ __launch_bounds__(256) void propagate_kernel(const TrackerDev T, int b, int recentre)   // (launched with 256: without the bound the
+                                                                                              //  compiler budgets for 1 024 and spills 20 registers)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T.n) return;
@@ -618,7 +619,7 @@ __device__ inline void recentre_one(const TrackerDev& T, double* __restrict__ pa
     for (int b = 0; b < T.parts; ++b) recentre_body(T, part_new + (size_t)i * T.D + b * kBody, b);
 }
 
-__global__ void recentre_kernel(const TrackerDev T, double* __restrict__ particles)
+__global__ __launch_bounds__(256) void recentre_kernel(const TrackerDev T, double* __restrict__ particles)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < T.n) recentre_one(T, particles, i);
