@@ -30,7 +30,7 @@ in HBM before the timed region, device-pointer API.  The same JSON line carries,
 With `torch.distributed.run` (--gpus N, one rank per GPU) a step is SURVEY 8(e)'s whole exchange: each rank's
 2 000-particle shard (weak scaling) evaluated with GLOBAL parent slots -- the ranks' handles are attached to each
 other over HIP IPC, a parent on another GPU is read in place over xGMI --, the RCCL all-gather of the
-log-likelihoods, multinomial resampling over all ranks' particles and this rank's plan in one library launch
+log-likelihoods, multinomial resampling over all ranks' particles and this rank's plan in one library call
 (rbs_peer_resample), shared remote parents staged once; then the same step at C3 / C4's per-GPU sizes and the
 one-handle tracker over the job's devices (a time-limited child process).  Ranks that cannot attach fall back to
 shards with local parents + the all-gather, and the line says so (`peer_step`).
@@ -1126,7 +1126,7 @@ def main():
                                      f"{a.cols}x{a.rows} synthetic depth frame, mesh {a.mesh} ({n_tri} triangles), {max(1, a.sequence)}-frame moving-object "
                                      f"sequence, likelihood precision {a.precision}, {a.layout} planes, inputs resident in HBM")
         out["config"]["sharding"] = (f"particles/{world}: one process per GPU, handles attached over HIP IPC (parents on other ranks read in place over "
-                                     "xGMI, shared ones pulled once), one RCCL all-gather per step, resampling + plan in one library launch "
+                                     "xGMI, shared ones pulled once), one RCCL all-gather per step, resampling + plan in one library call "
                                      "(rbs_peer_resample), no plane migration, no host synchronisation")
         if not peer_ok:
             out["config"]["workload"] = (f"C1 per GPU: {n} particles/GPU ({n * world} in all) x [loglikes(update=true), parents on the rank's own GPU + "

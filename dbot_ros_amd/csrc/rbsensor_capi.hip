@@ -207,7 +207,7 @@ struct rbs_handle {
     const int4* peer_win[rbs::kMaxDevices][2] = {};
     const int4* peer_reg[rbs::kMaxDevices][2] = {};
     void* peer_mapped[rbs::kMaxDevices][6] = {};    // what hipIpcCloseMemHandle gets back
-    void* d_peer_scratch = nullptr;                 // rbs_peer_resample: cdf [N] doubles + 2 x [n] ints
+    void* d_peer_scratch = nullptr;                 // rbs_peer_resample: cdf [N] + 2 x [tiles] doubles + 2 x [n] ints
     size_t peer_scratch_bytes = 0;
     const float* snap_occ[rbs::kMaxDevices] = {};   // group: every shard's CURRENT planes / windows as of the start
     const int4* snap_win[rbs::kMaxDevices] = {};    //   of the call being fanned out (shards flip buffers one by one)
@@ -2714,7 +2714,9 @@ int32_t rbs_peer_resample(rbs_handle* h, const double* d_loglik_all, const doubl
     if (!(temperature > 0.0) || min_share < 1) return fail(h, RBS_ERR_INVALID_ARGUMENT, "peer_resample: temperature must be > 0, min_share >= 1");
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
-    const size_t need = sizeof(double) * (size_t)n_total + 2 * sizeof(int) * (size_t)n_local;
+    const int tiles = (n_total + rbp::kTile - 1) / rbp::kTile;
+    if (tiles > rbp::kMaxTiles) return fail(h, RBS_ERR_UNSUPPORTED, fmt("peer_resample: n_total = %d exceeds %d particles", n_total, rbp::kMaxTiles * rbp::kTile));
+    const size_t need = sizeof(double) * ((size_t)n_total + 2 * (size_t)tiles) + 2 * sizeof(int) * (size_t)n_local;
     if (need > h->peer_scratch_bytes) {   // (first call, or a larger job: the only synchronising path)
         RBS_HIP(h, hipStreamSynchronize(s));
         (void)hipFree(h->d_peer_scratch);
@@ -2728,11 +2730,15 @@ int32_t rbs_peer_resample(rbs_handle* h, const double* d_loglik_all, const doubl
     Q.N = n_total; Q.n = n_local; Q.rank = rank; Q.cap = h->max_particles; Q.min_share = min_share;
     Q.temperature = temperature;
     Q.cdf = static_cast<double*>(h->d_peer_scratch);
-    Q.mine = reinterpret_cast<int*>(Q.cdf + n_total);
+    Q.tile_max = Q.cdf + n_total;
+    Q.tile_total = Q.tile_max + tiles;
+    Q.mine = reinterpret_cast<int*>(Q.tile_total + tiles);
     Q.aux = Q.mine + n_local;
     Q.parent_idx = d_parent_idx; Q.stage_src = d_stage_src; Q.stage_dst = d_stage_dst;
     Q.parents_local = d_parents_local;
     Q.counts = reinterpret_cast<long long*>(d_counts);
+    hipLaunchKernelGGL(rbp::peer_max_kernel, dim3(tiles), dim3(rbp::kThreads), 0, s, Q);
+    hipLaunchKernelGGL(rbp::peer_weights_kernel, dim3(tiles), dim3(rbp::kThreads), 0, s, Q);
     hipLaunchKernelGGL(rbp::peer_resample_kernel, dim3(1), dim3(rbp::kThreads), 0, s, Q);
     RBS_HIP(h, hipGetLastError());
     return RBS_OK;

@@ -1,6 +1,6 @@
 // rbsensor_peers.hip -- the resampling half of the filter step across PROCESSES (one rank per GPU,
 // SURVEY 8(e); dbot_ros_amd/dist.py PeerShardedStep): everything between the all-gather of the
-// log-likelihoods and the next step's parent indices in ONE launch.
+// log-likelihoods and the next step's parent indices in three launches (two over the chip, one block for the plan).
 //
 // Every rank holds the gathered log-likelihoods of all N = world * n particles and the same N uniforms,
 // SORTED ascending (children are exchangeable: sorting the uniforms is sorting the children by parent,
@@ -26,13 +26,19 @@
 namespace rbp {
 
 constexpr int kThreads = 1024;
+constexpr int kTileShift = 11, kTile = 1 << kTileShift;   // particles per block of the two elementwise passes: two per thread
+constexpr int kMaxTiles = 1024;                            // (their totals sit in the plan kernel's LDS: N <= 2 M particles)
+constexpr int kSamples = 2048;                             // cdf values kept in LDS to start a search from
+constexpr int kLdsChildren = 4096;                         // a rank's children's parents stay in LDS up to this many
 
 struct PeerPlan {
     const double* ll_all;     // [N] gathered log-likelihoods, rank-major
     const double* uniforms;   // [N] ascending
     int N, n, rank, cap, min_share;
     double temperature;
-    double* cdf;              // [N] scratch
+    double* cdf;              // [N] scratch: cumulative weights WITHIN a tile of kTile particles (peer_weights_kernel)
+    double* tile_max;         // [tiles] scratch: the largest log-likelihood of a tile (peer_max_kernel)
+    double* tile_total;       // [tiles] scratch: the weight of a tile
     int* mine;                // [n] scratch: this rank's children's parents (indices into ll_all)
     int* aux;                 // [n] scratch
     int32_t* parent_idx;      // [n]
@@ -72,56 +78,120 @@ __device__ inline T block_exscan(T v, T ident, Op op, T* sh, T* total)
     return op(base, exc);
 }
 
-__global__ __launch_bounds__(kThreads) void peer_resample_kernel(const PeerPlan Q)
+// The cdf over all N particles, spread over the chip (one CU took 3.6 ns per particle for the exponentials and the
+// scan: 57 us of N = 16 000, 720 us of N = 200 000): the largest log-likelihood per tile ...
+__global__ __launch_bounds__(kThreads) void peer_max_kernel(const PeerPlan Q)
 {
     __shared__ double shd[kThreads / 64];
-    __shared__ int shi[kThreads / 64];
-    const int t = (int)threadIdx.x, N = Q.N, n = Q.n;
-
-    // ---- weights exp((ll - max) / T), their cumulative sums, normalised: the cdf
+    const int i0 = (int)blockIdx.x * kTile + 2 * (int)threadIdx.x;
     double m = -INFINITY;
-    for (int i = t; i < N; i += kThreads) m = fmax(m, Q.ll_all[i]);      // (fmax drops NaN: a contained particle weighs nothing)
+    if (i0 < Q.N) m = fmax(m, Q.ll_all[i0]);              // (fmax drops NaN: a contained particle weighs nothing)
+    if (i0 + 1 < Q.N) m = fmax(m, Q.ll_all[i0 + 1]);
+    double tot;
+    (void)block_exscan(m, -(double)INFINITY, OpMax(), shd, &tot);
+    if (threadIdx.x == 0) Q.tile_max[blockIdx.x] = tot;
+}
+
+// ... then the weights exp((ll - max) / T) and their cumulative sums inside each tile, and each tile's total.
+__global__ __launch_bounds__(kThreads) void peer_weights_kernel(const PeerPlan Q)
+{
+    __shared__ double shd[kThreads / 64];
+    const int t = (int)threadIdx.x, tiles = (int)gridDim.x;
+    double m = -INFINITY;
+    for (int k = t; k < tiles; k += kThreads) m = fmax(m, Q.tile_max[k]);
     {
         double tot;
         (void)block_exscan(m, -(double)INFINITY, OpMax(), shd, &tot);
         m = tot;
     }
-    const int L = (N + kThreads - 1) / kThreads;
-    const int lo = min(N, t * L), hi = min(N, lo + L);
-    double run = 0.0;
-    for (int i = lo; i < hi; ++i) {
-        const double l = Q.ll_all[i];
-        const double w = l == l ? exp((l - m) / Q.temperature) : 0.0;
-        run += w;
-        Q.cdf[i] = run;
-    }
-    double total;
-    const double before = block_exscan(run, 0.0, OpAdd(), shd, &total);
-    for (int i = lo; i < hi; ++i) Q.cdf[i] = (before + Q.cdf[i]) / total;
     __syncthreads();
+    const int i0 = (int)blockIdx.x * kTile + 2 * t;
+    double w0 = 0.0, w1 = 0.0;
+    if (i0 < Q.N)     { const double l = Q.ll_all[i0];     w0 = l == l ? exp((l - m) / Q.temperature) : 0.0; }
+    if (i0 + 1 < Q.N) { const double l = Q.ll_all[i0 + 1]; w1 = l == l ? exp((l - m) / Q.temperature) : 0.0; }
+    double tile_total;
+    const double before = block_exscan(w0 + w1, 0.0, OpAdd(), shd, &tile_total);
+    if (i0 < Q.N)     Q.cdf[i0] = before + w0;
+    if (i0 + 1 < Q.N) Q.cdf[i0 + 1] = before + (w0 + w1);
+    if (t == 0) Q.tile_total[blockIdx.x] = tile_total;
+}
 
-    // ---- this rank's children: parent = upper_bound(cdf, u), clamped (the last cdf value is 1 up to rounding)
-    const int Ln = (n + kThreads - 1) / kThreads;
-    const int klo = min(n, t * Ln), khi = min(n, klo + Ln);
-    for (int k = klo; k < khi; ++k) {
-        const double u = Q.uniforms[(size_t)Q.rank * n + k];
-        int a = 0, b = N;
+// One block: the tiles' totals scanned in LDS (cdf value i = (weight of the tiles before i's + cumulative weight
+// inside the tile) / total, formed where it is read), this rank's children's parents, and the plan.
+__global__ __launch_bounds__(kThreads) void peer_resample_kernel(const PeerPlan Q)
+{
+    __shared__ double shd[kThreads / 64];
+    __shared__ int shi[kThreads / 64];
+    __shared__ double tile_before[kMaxTiles];
+    const int t = (int)threadIdx.x, N = Q.N, n = Q.n;
+    const int tiles = (N + kTile - 1) >> kTileShift;
+    double total;
+    {
+        double carry = 0.0;
+        for (int base = 0; base < tiles; base += kThreads) {
+            const int k = base + t;
+            const double v = k < tiles ? Q.tile_total[k] : 0.0;
+            double part;
+            const double before = block_exscan(v, 0.0, OpAdd(), shd, &part);
+            if (k < tiles) tile_before[k] = carry + before;
+            carry += part;
+        }
+        total = carry;
+    }
+    __syncthreads();
+    auto cdf_at = [&](int i) { return (tile_before[i >> kTileShift] + Q.cdf[i]) / total; };
+
+    // kSamples evenly spaced cdf values in LDS: a search narrows to one stretch of `stride` particles there, and
+    // only the last few probes go to memory (a probe is a dependent L2 read: eighteen of them were 12 us).
+    __shared__ double sample[kSamples];
+    const int stride = (N + kSamples - 1) / kSamples, stretches = (N + stride - 1) / stride;
+    for (int j = t; j < stretches; j += kThreads) sample[j] = cdf_at(min(N, (j + 1) * stride) - 1);
+    // (the plan's two work arrays: in LDS when this rank's children fit)
+    __shared__ int mine_s[kLdsChildren], aux_s[kLdsChildren];
+    int* __restrict__ const mine = n <= kLdsChildren ? mine_s : Q.mine;
+    int* __restrict__ const aux = n <= kLdsChildren ? aux_s : Q.aux;
+    __syncthreads();
+    auto upper_bound = [&](double u) {               // first particle with cdf > u (N: none)
+        int a = 0, b = stretches;
         while (a < b) {
             const int mid = (a + b) >> 1;
-            if (Q.cdf[mid] <= u) a = mid + 1; else b = mid;
+            if (sample[mid] <= u) a = mid + 1; else b = mid;
         }
-        const int p = min(a, N - 1);
-        Q.mine[k] = p;
-        if (Q.parents_local) Q.parents_local[k] = p;
+        if (a == stretches) return N;
+        int lo = a * stride, hi = min(N, (a + 1) * stride) - 1;     // cdf(hi) > u, and cdf(lo - 1) <= u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf_at(mid) <= u) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+
+    // ---- this rank's children: parent = upper_bound(cdf, u), clamped (the last cdf value is 1 up to rounding).  The
+    // uniforms are ascending, so are the parents: a thread's chunk of consecutive children searches ONCE, then walks
+    // the cdf forwards, searching again only past sixteen steps (a long stretch of weightless particles).
+    const int Ln = (n + kThreads - 1) / kThreads;
+    const int klo = min(n, t * Ln), khi = min(n, klo + Ln);
+    {
+        int p = 0;
+        for (int k = klo; k < khi; ++k) {
+            const double u = Q.uniforms[(size_t)Q.rank * n + k];
+            int steps = 0;
+            if (k != klo)
+                while (p < N && steps < 16 && cdf_at(p) <= u) { ++p; ++steps; }
+            if (k == klo || (steps == 16 && p < N && cdf_at(p) <= u)) p = upper_bound(u);
+            const int pc = min(p, N - 1);
+            mine[k] = pc;
+            if (Q.parents_local) Q.parents_local[k] = pc;
+        }
     }
     __syncthreads();
 
     // ---- runs of equal parents: where each child's run starts ...
     int last_start = -1;
     for (int k = klo; k < khi; ++k) {
-        const bool nw = k == 0 || Q.mine[k] != Q.mine[k - 1];
+        const bool nw = k == 0 || mine[k] != mine[k - 1];
         if (nw) last_start = k;
-        Q.aux[k] = last_start;                       // (-1: the run began in an earlier thread's chunk)
+        aux[k] = last_start;                       // (-1: the run began in an earlier thread's chunk)
     }
     int dummy;
     const int start_before = block_exscan(last_start, -1, OpMax(), shi, &dummy);
@@ -130,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void peer_resample_kernel(const PeerPlan 
     const int rlo = min(n, rt * Ln), rhi = min(n, rlo + Ln);
     int first_end = n;                               // smallest end position at or after the chunk's first child
     for (int k = rhi - 1; k >= rlo; --k)
-        if (k == n - 1 || Q.mine[k + 1] != Q.mine[k]) first_end = k;
+        if (k == n - 1 || mine[k + 1] != mine[k]) first_end = k;
     const int end_after = block_exscan(first_end, n, OpMin(), shi, &dummy);   // over the chunks that FOLLOW this thread's reverse chunk
     // (hand the reverse pass's result to the thread that owns the chunk in the forward pass)
     __shared__ int end_of_chunk[kThreads];
@@ -144,23 +214,23 @@ __global__ __launch_bounds__(kThreads) void peer_resample_kernel(const PeerPlan 
     {
         int next_end = my_end_after;
         for (int k = khi - 1; k >= klo; --k) {       // backwards: the end of k's run
-            if (k == n - 1 || Q.mine[k + 1] != Q.mine[k]) next_end = k;
-            const int s = Q.aux[k] >= 0 ? Q.aux[k] : start_before;
+            if (k == n - 1 || mine[k + 1] != mine[k]) next_end = k;
+            const int s = aux[k] >= 0 ? aux[k] : start_before;
             const int len = next_end - s + 1;
-            const int p = Q.mine[k], owner = p / n;
+            const int p = mine[k], owner = p / n;
             const bool shared = owner != Q.rank && len >= Q.min_share;
-            Q.aux[k] = shared ? (s == k ? 2 : 1) : 0;   // 2: the run's first child (stages the window)
+            aux[k] = shared ? (s == k ? 2 : 1) : 0;   // 2: the run's first child (stages the window)
             starts += shared && s == k;
         }
     }
     const int starts_before = block_exscan(starts, 0, OpAdd(), shi, &dummy);
     int sidx = starts_before - 1;
     for (int k = klo; k < khi; ++k) {
-        const int p = Q.mine[k], owner = p / n;
+        const int p = mine[k], owner = p / n;
         const int pg = owner * Q.cap + (p - owner * n);
-        const int f = Q.aux[k];
+        const int f = aux[k];
         if (f == 2) ++sidx;
-        const bool nw = k == 0 || Q.mine[k] != Q.mine[k - 1];
+        const bool nw = k == 0 || mine[k] != mine[k - 1];
         Q.parent_idx[k] = f ? Q.rank * Q.cap + n + sidx : pg;
         Q.stage_src[k] = f == 2 ? pg : -1;
         Q.stage_dst[k] = f == 2 ? n + sidx : -1;

@@ -90,9 +90,11 @@ def test_ipc_attach_refuses_mismatched_handles(gpu_lib):
     (3, 1111, 3, 1.0, 1.0),        # chunks that do not divide evenly, min_share 3
     (2, 25000, 2, 1.0, 200.0),     # one survivor: every child of the other rank shares a remote parent
     (1, 64, 2, 1.0, 1.0),          # a single rank: nothing is remote
+    (4, 3000, 2, 1.0, 6.0),        # some dozens of survivors, long weightless stretches between them
+    (8, 25000, 2, 1.0, 2.0),       # BASELINE C3 over eight ranks
 ])
 def test_peer_resample_matches_tensor_arithmetic(gpu_lib, world, n, min_share, temp, spread):
-    """rbs_peer_resample (one launch) against dist.global_resample + dist.plan_shard (the same step as tensor
+    """rbs_peer_resample (one call) against dist.global_resample + dist.plan_shard (the same step as tensor
     arithmetic, here on the CPU): identical parents, identical plan and counts, for every rank of the job."""
     from dbot_ros_amd import dist as rdist
     N = world * n
