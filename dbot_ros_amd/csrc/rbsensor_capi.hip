@@ -74,6 +74,7 @@ struct rbs_handle {
     bool slab_probed = false;   // ... and has been checked against a first call's regions (rbs_loglikes_device, probe_auto_slabs)
     int* d_bbox = nullptr;      // [4] scratch of rbs_import_plane / rbs_set_occlusion
     bool windowed = true;       // planes valid inside their window only (state_layout dense: whole plane)
+    bool many_clusters = false; // a body of more than 256 clusters: the rbs_raster_many_kernel_* instantiations (shared cluster cull)
     // windowed planes whose windows have grown to a large part of the frame are served like whole
     // planes (streaming copy kernel beside two raster blocks per CU); the stored area is sampled
     // on the device every timing_every-th updating call and read back without blocking
@@ -314,11 +315,11 @@ int32_t flush_lazy_frame(rbs_handle* h, hipStream_t then)
     return RBS_OK;
 }
 
-// The eight instantiations of the raster kernel: updating or read-only call, likelihood precision,
-// whole planes or slabs.
+// The instantiations of the raster kernel: updating or read-only call, likelihood precision,
+// whole planes or slabs, and the same eight again for object models with a body of many clusters.
 void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size_t smem, hipStream_t s, const DevParams& P)
 {
-    const int key = (update ? 4 : 0) | (h->precision == RBS_PRECISION_F32 ? 2 : 0) | (h->slab_px ? 1 : 0);
+    const int key = (h->many_clusters ? 8 : 0) | (update ? 4 : 0) | (h->precision == RBS_PRECISION_F32 ? 2 : 0) | (h->slab_px ? 1 : 0);
     switch (key) {
         case 0: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f64<false, false>), grid, block, smem, s, P); break;
         case 1: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f64<false, true>), grid, block, smem, s, P); break;
@@ -327,7 +328,15 @@ void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size
         case 4: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f64<true, false>), grid, block, smem, s, P); break;
         case 5: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f64<true, true>), grid, block, smem, s, P); break;
         case 6: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f32<true, false>), grid, block, smem, s, P); break;
-        default: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f32<true, true>), grid, block, smem, s, P); break;
+        case 7: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f32<true, true>), grid, block, smem, s, P); break;
+        case 8: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f64<false, false>), grid, block, smem, s, P); break;
+        case 9: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f64<false, true>), grid, block, smem, s, P); break;
+        case 10: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f32<false, false>), grid, block, smem, s, P); break;
+        case 11: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f32<false, true>), grid, block, smem, s, P); break;
+        case 12: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f64<true, false>), grid, block, smem, s, P); break;
+        case 13: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f64<true, true>), grid, block, smem, s, P); break;
+        case 14: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f32<true, false>), grid, block, smem, s, P); break;
+        default: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f32<true, true>), grid, block, smem, s, P); break;
     }
 }
 
@@ -513,7 +522,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     if (h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
     if (update) {
-        launch_raster(h, true, rgrid, block, rbs::smem_bytes(P.tile_px, f64), s, P);
+        launch_raster(h, true, rgrid, block, rbs::smem_bytes(P.tile_px, f64, h->many_clusters), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
@@ -569,7 +578,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
         }
     } else {
-        launch_raster(h, false, rgrid, block, rbs::smem_bytes(P.tile_px, f64), s, P);
+        launch_raster(h, false, rgrid, block, rbs::smem_bytes(P.tile_px, f64, h->many_clusters), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
     }
@@ -1065,6 +1074,10 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     }
     for (int b = h->n_bodies; b < rbs::kMaxBodies; ++b) B.tri_begin[b + 1] = (int)n_tri;
     for (int b = 0; b < rbs::kMaxBodies; ++b) B.tri_end[b] = B.tri_begin[b];
+    for (int b = 0; b < h->n_bodies; ++b) {
+        const int clusters = (B.tri_begin[b + 1] - B.tri_begin[b]) >> 6;
+        h->many_clusters |= clusters > 64 * (rbs::kBlock / 64);   // (more steps of 64 clusters than the block has waves)
+    }
     if (n_tri > (1L << 30)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "too many triangles");
     B.n_tri = (int)n_tri;
     const size_t n_alloc = (size_t)(n_tri > 0 ? n_tri : 64);
@@ -1468,9 +1481,13 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<false, true>),
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<false, true>),
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<true, true>),
-            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<true, true>)};
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<true, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f64<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f64<false, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f32<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f32<false, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f64<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f64<true, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f32<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f32<true, true>)};
         for (const void* k : kernels)
-            RBS_HIP(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig, false)));
+            RBS_HIP(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig, false, true)));
     }
     RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_render_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig, false)));

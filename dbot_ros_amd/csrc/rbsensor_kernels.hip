@@ -118,6 +118,11 @@ constexpr int kTq = kQPlanes_ * kEvalQueue;  // the same LDS during the raster p
 #endif
 constexpr int kPre = RBS_PRETEST_CLUSTERS;  // clusters pre-tested per step
 static_assert(kPre * 64 + 63 <= kTq && (kTq & (kTq - 1)) == 0, "the triangle ring must hold a step's survivors");
+// Meshes of many clusters (M4: 795; the rbs_raster_many_kernel_* instantiations, MANY): the cluster cull -- the same for
+// every wave of the block -- is dealt to the block's waves by steps of 64 clusters and the verdicts shared through LDS
+// (two masks per step): C4 slice +6 %.  Kernels of their own: the same code compiled into the one kernel cost C1 0.8 %.
+constexpr int kCullSteps = 28;              // steps of 64 clusters culled between two barriers: 448 B of verdicts, what the LDS block had
+                                            // left below the next 1 280-byte step (three blocks per CU, RBS_TILE_PX)
 constexpr int kQPlanes = kQPlanes_;                 // ints per queued pixel: index, depth, prior, observation (F32 precision)
 constexpr int kRectAlign = 16;              // whole planes: rectangle x-alignment in pixels (64 B)
 constexpr float kSnapTau = 0x1p-18f;         // background snap of the occlusion process (oracle ORC_SNAP_TAU)
@@ -793,9 +798,10 @@ __device__ inline void raster_shared_cluster(const DevParams& P, int c, int nv, 
 // Small triangles are rasterized by their lane; triangles whose clipped bbox exceeds kBigThresh
 // pixels are queued in LDS and rasterized by the whole block, pixel-parallel.
 // Clears the tile first; on return the tile is complete and synchronised.
+template <bool MANY = false>
 __device__ inline void raster_window(const DevParams& P, const double* __restrict__ pose,
                                      int wx0, int wy0, int wx1, int wy1, bool cull, unsigned* tile,
-                                     int* big, int* nbig, int* tq, unsigned body_mask)
+                                     int* big, int* nbig, int* tq, unsigned body_mask, unsigned long long* cullm = nullptr)
 {
     const int tw = wx1 - wx0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -837,16 +843,45 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
         if (threadIdx.x == 0 && eps + fsign == -12345.f) P.out[0] = 0.0;   // (waits for the pose)
         RBS_TICK(0);    // the body's pose and what is derived from it
 #endif
-        for (int base = c0; base < c1; base += 64) {
+        // MANY: the cull of up to kCullSteps steps of 64 clusters is dealt to the block's waves, the verdicts meet in
+        // LDS (two barriers per stretch -- the first keeps a wave that still reads the previous verdicts safe);
+        // otherwise one stretch = the whole body, every wave culling every step for itself.
+        for (int cbase = c0, cend = c1; cbase < c1; cbase = cend) {
+        cend = MANY ? min(c1, cbase + 64 * kCullSteps) : c1;
+        if (MANY) {
+            __syncthreads();
+            for (int it = wave; cbase + (it << 6) < cend; it += kBlock / 64) {
+                const int ci = cbase + (it << 6) + lane;
+                floatx4 sph = floatx4{0.f, 0.f, 0.f, 0.f}, cone = sph;
+                if (ci < c1) {
+                    sph = reinterpret_cast<const floatx4*>(P.cluster_sphere)[ci];
+                    cone = reinterpret_cast<const floatx4*>(P.cluster_cone)[ci];
+                }
+                const int facing = cullsign != 0 && ci < c1 ? cluster_facing(Rt, sph, cone) : 0;
+                const bool hit = ci < c1 && (!cull || cluster_may_touch(P, Rt, sph, wx0, wy0, wx1, wy1)) && facing <= 0;
+                const unsigned long long hitm = __ballot(hit), toward = __ballot(facing < 0);
+                if (lane == 0) { cullm[2 * it] = hitm; cullm[2 * it + 1] = toward; }
+            }
+            __syncthreads();
+        }
+        for (int base = cbase; base < cend; base += 64) {
             // 64 clusters culled at once, one per lane (every wave computes the same mask)
             const int ci = base + lane;
-            floatx4 sph = floatx4{0.f, 0.f, 0.f, 0.f}, cone = sph;
-            if (ci < c1) {
-                sph = reinterpret_cast<const floatx4*>(P.cluster_sphere)[ci];
-                cone = reinterpret_cast<const floatx4*>(P.cluster_cone)[ci];
+            int facing;
+            bool hit;
+            if (MANY) {
+                const int it = (base - cbase) >> 6;
+                hit = (cullm[2 * it] >> lane) & 1ull;
+                facing = (cullm[2 * it + 1] >> lane) & 1ull ? -1 : 0;
+            } else {
+                floatx4 sph = floatx4{0.f, 0.f, 0.f, 0.f}, cone = sph;
+                if (ci < c1) {
+                    sph = reinterpret_cast<const floatx4*>(P.cluster_sphere)[ci];
+                    cone = reinterpret_cast<const floatx4*>(P.cluster_cone)[ci];
+                }
+                facing = cullsign != 0 && ci < c1 ? cluster_facing(Rt, sph, cone) : 0;
+                hit = ci < c1 && (!cull || cluster_may_touch(P, Rt, sph, wx0, wy0, wx1, wy1)) && facing <= 0;
             }
-            const int facing = cullsign != 0 && ci < c1 ? cluster_facing(Rt, sph, cone) : 0;
-            const bool hit = ci < c1 && (!cull || cluster_may_touch(P, Rt, sph, wx0, wy0, wx1, wy1)) && facing <= 0;
             const unsigned long long mask = __ballot(hit);
             RBS_TICK(8);
             RBS_COUNT(16, min(64, c1 - base)); RBS_COUNT(17, __popcll(mask));
@@ -919,6 +954,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
                     __builtin_amdgcn_wave_barrier(); RBS_TICK(12); RBS_COUNT(18, 1);
                 }
             }
+        }
         }
         if (qn > 0) {   // the body's last, partly filled batch
             __builtin_amdgcn_wave_barrier();
@@ -1118,8 +1154,9 @@ __device__ inline double block_reduce_sum(double v, double* red)
 struct Smem {
     unsigned* tile; int* big; double* red; int* nbig; int* item; int* evalq;
     double* mtab;   // precision F64: the erfc and log tables of rbs_math.h (kMathTabDoubles doubles)
+    unsigned long long* cull;   // MANY: [kCullSteps][2] verdicts of the shared cluster cull (raster_window)
 };
-__device__ inline Smem carve(unsigned char* smem, int kTilePx)
+__device__ inline Smem carve(unsigned char* smem, int kTilePx, bool math_tables)
 {
     Smem m;
     m.tile = reinterpret_cast<unsigned*>(smem);
@@ -1129,12 +1166,14 @@ __device__ inline Smem carve(unsigned char* smem, int kTilePx)
     m.item = m.nbig + 1;
     m.evalq = m.nbig + 4;   // per wave: kQPlanes planes of kEvalQueue ints
     m.mtab = reinterpret_cast<double*>(m.evalq + kQPlanes * (kBlock / 64) * kEvalQueue);   // (16-byte aligned: everything before it is)
+    // (last, so that nothing else moves: shifting the rings and the tables by these 448 bytes cost C1 0.6 %)
+    m.cull = reinterpret_cast<unsigned long long*>(m.mtab + (math_tables ? kMathTabDoubles : 0));
     return m;
 }
 
 // One (particle, tile) work item: rasterize the tile window, evaluate its pixels, return the
 // block-reduced partial log-likelihood (valid in thread 0).
-template <bool UPDATE, int PREC, bool SLAB>
+template <bool UPDATE, int PREC, bool SLAB, bool MANY = false>
 __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect r, int tile_id,
                                           const Smem& m, unsigned body_mask, bool draw, int& ticket)
 {
@@ -1156,8 +1195,8 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
 
     RBS_TICK_DECL;
     // a rectangle that is a single tile was sized from the same spheres: nothing to cull
-    raster_window(P, pose, wx0, wy0, wx1, wy1, !whole || (body_mask & (body_mask - 1u)) != 0u, m.tile, m.big, m.nbig,
-                  m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue, body_mask);   // the eval queue is idle during the raster phase
+    raster_window<MANY>(P, pose, wx0, wy0, wx1, wy1, !whole || (body_mask & (body_mask - 1u)) != 0u, m.tile, m.big, m.nbig,
+                  m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue, body_mask, m.cull);   // the eval queue is idle during the raster phase
     RBS_TICK(2);
 
     // (SLAB is a template parameter: whole planes pay neither the registers nor the index arithmetic;
@@ -1594,11 +1633,11 @@ __global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_frame_prep_kernel(cons
 // Persistent: a fixed number of raster blocks per CU keeps its LDS/VGPR share for the whole
 // launch (never starved by the many small copy blocks) and pulls (particle, tile) items from
 // an atomic queue.
-template <bool UPDATE, int PREC, bool SLAB>
+template <bool UPDATE, int PREC, bool SLAB, bool MANY = false>
 __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Smem m = carve(smem, P.tile_px);
+    const Smem m = carve(smem, P.tile_px, PREC == 0 && RBS_MATH_LDS);
     const int total = P.ctr_this[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr_next[0] = 0; P.ctr_next[1] = 0; }
     if (PREC == 0 && RBS_MATH_LDS) {   // once per persistent block (the first item's tile clear ends in a barrier)
@@ -1637,7 +1676,7 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
         RBS_TICK(15);   // the item's descriptor
 #endif
         if (P.groups == nullptr) {
-            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC, SLAB>(P, particle, r, item - first, m, 0xffffffffu, draw, ticket);
+            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC, SLAB, MANY>(P, particle, r, item - first, m, 0xffffffffu, draw, ticket);
         } else {   // several bodies: the item belongs to one group of bodies with its own rectangle
             const Groups* G = P.groups + particle;
             const int k = item - first, ng = __builtin_amdgcn_readfirstlane(G->n);
@@ -1647,7 +1686,7 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
                 const int4 gq = G->rect[g];
                 const Rect gr = {__builtin_amdgcn_readfirstlane(gq.x), __builtin_amdgcn_readfirstlane(gq.y),
                                  __builtin_amdgcn_readfirstlane(gq.z), __builtin_amdgcn_readfirstlane(gq.w)};
-                part = raster_eval_tile<UPDATE, PREC, SLAB>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
+                part = raster_eval_tile<UPDATE, PREC, SLAB, MANY>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
                                                       (unsigned)__builtin_amdgcn_readfirstlane((int)G->mask[g]), draw, ticket);
             }
         }
@@ -1720,6 +1759,18 @@ template <bool UPDATE, bool SLAB>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_kernel_f64(const DevParams P)
 {
     raster_kernel_body<UPDATE, 0, SLAB>(P);
+}
+// ... and the same two for object models with a body of more than 256 clusters (MANY: the shared cluster cull).
+template <bool UPDATE, bool SLAB>
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) __attribute__((amdgpu_num_vgpr(RBS_RASTER_VGPRS)))
+void rbs_raster_many_kernel_f32(const DevParams P)
+{
+    raster_kernel_body<UPDATE, 1, SLAB, true>(P);
+}
+template <bool UPDATE, bool SLAB>
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_many_kernel_f64(const DevParams P)
+{
+    raster_kernel_body<UPDATE, 0, SLAB, true>(P);
 }
 
 template <int VEC>
@@ -2085,7 +2136,7 @@ __global__ void rbs_set_window_kernel(int4* __restrict__ win, int n, int4 value)
 __global__ __launch_bounds__(kBlock) void rbs_render_kernel(const DevParams P, float* out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Smem m = carve(smem, P.tile_px);
+    const Smem m = carve(smem, P.tile_px, false);
     const Rect r = particle_rect(P, P.poses);
     if (r.x1 <= r.x0) return;
     const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
@@ -2109,11 +2160,12 @@ __global__ void rbs_fill_kernel(float* __restrict__ p, size_t n, float v)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
-constexpr size_t smem_bytes(int tile_px, bool math_tables)
+constexpr size_t smem_bytes(int tile_px, bool math_tables, bool many = false)
 {
-    return sizeof(unsigned) * (size_t)tile_px + sizeof(int) * kBigCap + sizeof(double) * (kBlock / 64) + 16 +
+    return sizeof(unsigned) * (size_t)tile_px + sizeof(int) * kBigCap + sizeof(double) * (kBlock / 64) + 16 + (many ? 16 * kCullSteps : 0) +
            sizeof(int) * kQPlanes * (kBlock / 64) * kEvalQueue + (math_tables ? sizeof(double) * kMathTabDoubles : 0);
 }
 static_assert(smem_bytes(kTilePxF64, true) <= smem_bytes(kTilePx, false) && smem_bytes(kTilePxBigF64, true) <= smem_bytes(kTilePxBig, false),
               "the F64 kernel's LDS block must not be larger than the F32 kernel's: the same number of blocks per CU");
+static_assert(3 * ((smem_bytes(kTilePx, false, true) + 1279) / 1280 * 1280) <= 160 * 1024, "three raster blocks per CU: LDS is granted in 1 280-byte steps");
 }  // namespace rbs

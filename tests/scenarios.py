@@ -5,7 +5,9 @@ from dbot_ros_amd import CameraData, ObjectModel, RbSensorBuilder, synth
 import oracle_binding as ob
 
 MESHES = {"m1": synth.mesh_m1, "m2": synth.mesh_m2, "m3": synth.mesh_m3, "m4": synth.mesh_m4,
-          "box12": synth.mesh_box12, "m1_l2": lambda: synth.mesh_m1(level=2)}
+          "box12": synth.mesh_box12, "m1_l2": lambda: synth.mesh_m1(level=2),
+          # 134 680 triangles = 2 105 clusters: more than one stretch of the shared cluster cull (kCullSteps x 64 clusters)
+          "m4_fine": lambda: synth.mesh_m4(260, 260)}
 
 
 def usable_threads():

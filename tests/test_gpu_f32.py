@@ -47,7 +47,7 @@ def assert_f32_close(ll, ref, S, what=""):
                                                  (("m1",), 80, 60, 64), (("box12",), 640, 480, 8),
                                                  (("m1", "m2", "m3"), 640, 480, 12),
                                                  (("m1_l2",), 322, 241, 16),
-                                                 (("m4",), 1280, 960, 4)])
+                                                 (("m4",), 1280, 960, 4), (("m1", "m4", "m2"), 640, 480, 6)])
 def test_f32_sequence_matches_oracle(gpu_lib, state_layout, meshes, cols, rows, n):
     om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
     nb = len(meshes)

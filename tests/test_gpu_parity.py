@@ -89,7 +89,10 @@ def test_render_edge_poses(gpu_lib, pose_case):
                                                  (("m1",), 80, 60, 64), (("box12",), 640, 480, 8),
                                                  (("m1", "m2", "m3"), 640, 480, 12),
                                                  (("m1_l2",), 322, 241, 16),
-                                                 (("m4",), 1280, 960, 4)])
+                                                 (("m4",), 1280, 960, 4),
+                                                 # the rbs_raster_many_kernel_* instantiations (a body of > 256 clusters): with small
+                                                 # bodies beside it, and a body of more clusters than one stretch of the shared cull
+                                                 (("m1", "m4", "m2"), 640, 480, 6), (("m4_fine",), 640, 480, 3)])
 def test_sequence_matches_oracle(gpu_lib, meshes, cols, rows, n):
     """set_observation -> loglikes(update) -> resample, 4 frames; eager and lazy oracles."""
     om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
