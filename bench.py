@@ -403,6 +403,8 @@ def make_sensor(a, om, cam, P, device, precision=None, layout=None, n=None):
 
 def prime(sensor, a, W):
     sensor.reset()
+    if os.environ.get("RBS_BENCH_PRINT_PTRS") == "1":     # (tools/dbg/bimodal.sh: does a run's speed follow where its planes lie?)
+        sys.stderr.write("# planes at 0x%x / 0x%x\n" % (sensor.occlusion_device_ptr(0), sensor.occlusion_device_ptr(0, next_buffer=True)))
     if a.fill_planes is not None:
         fill_planes(sensor, a)
     sensor.set_observation(W.frames[0])

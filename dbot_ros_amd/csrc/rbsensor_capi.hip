@@ -74,7 +74,7 @@ struct rbs_handle {
     bool slab_probed = false;   // ... and has been checked against a first call's regions (rbs_loglikes_device, probe_auto_slabs)
     int* d_bbox = nullptr;      // [4] scratch of rbs_import_plane / rbs_set_occlusion
     bool windowed = true;       // planes valid inside their window only (state_layout dense: whole plane)
-    bool many_clusters = false; // a body of more than 256 clusters: the rbs_raster_many_kernel_* instantiations (shared cluster cull)
+    bool many_clusters = false; // a body of more than 256 clusters: the rbs_raster_kernel_many_* instantiations (shared cluster cull)
     // windowed planes whose windows have grown to a large part of the frame are served like whole
     // planes (streaming copy kernel beside two raster blocks per CU); the stored area is sampled
     // on the device every timing_every-th updating call and read back without blocking
@@ -329,14 +329,14 @@ void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size
         case 5: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f64<true, true>), grid, block, smem, s, P); break;
         case 6: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f32<true, false>), grid, block, smem, s, P); break;
         case 7: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f32<true, true>), grid, block, smem, s, P); break;
-        case 8: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f64<false, false>), grid, block, smem, s, P); break;
-        case 9: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f64<false, true>), grid, block, smem, s, P); break;
-        case 10: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f32<false, false>), grid, block, smem, s, P); break;
-        case 11: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f32<false, true>), grid, block, smem, s, P); break;
-        case 12: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f64<true, false>), grid, block, smem, s, P); break;
-        case 13: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f64<true, true>), grid, block, smem, s, P); break;
-        case 14: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f32<true, false>), grid, block, smem, s, P); break;
-        default: hipLaunchKernelGGL((rbs::rbs_raster_many_kernel_f32<true, true>), grid, block, smem, s, P); break;
+        case 8: hipLaunchKernelGGL((rbs::rbs_raster_kernel_many_f64<false, false>), grid, block, smem, s, P); break;
+        case 9: hipLaunchKernelGGL((rbs::rbs_raster_kernel_many_f64<false, true>), grid, block, smem, s, P); break;
+        case 10: hipLaunchKernelGGL((rbs::rbs_raster_kernel_many_f32<false, false>), grid, block, smem, s, P); break;
+        case 11: hipLaunchKernelGGL((rbs::rbs_raster_kernel_many_f32<false, true>), grid, block, smem, s, P); break;
+        case 12: hipLaunchKernelGGL((rbs::rbs_raster_kernel_many_f64<true, false>), grid, block, smem, s, P); break;
+        case 13: hipLaunchKernelGGL((rbs::rbs_raster_kernel_many_f64<true, true>), grid, block, smem, s, P); break;
+        case 14: hipLaunchKernelGGL((rbs::rbs_raster_kernel_many_f32<true, false>), grid, block, smem, s, P); break;
+        default: hipLaunchKernelGGL((rbs::rbs_raster_kernel_many_f32<true, true>), grid, block, smem, s, P); break;
     }
 }
 
@@ -1482,10 +1482,10 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<false, true>),
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f64<true, true>),
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_f32<true, true>),
-            reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f64<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f64<false, true>),
-            reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f32<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f32<false, true>),
-            reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f64<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f64<true, true>),
-            reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f32<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_many_kernel_f32<true, true>)};
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f64<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f64<false, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<false, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f64<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f64<true, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<true, true>)};
         for (const void* k : kernels)
             RBS_HIP(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig, false, true)));
     }

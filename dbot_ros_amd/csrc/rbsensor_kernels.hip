@@ -118,7 +118,7 @@ constexpr int kTq = kQPlanes_ * kEvalQueue;  // the same LDS during the raster p
 #endif
 constexpr int kPre = RBS_PRETEST_CLUSTERS;  // clusters pre-tested per step
 static_assert(kPre * 64 + 63 <= kTq && (kTq & (kTq - 1)) == 0, "the triangle ring must hold a step's survivors");
-// Meshes of many clusters (M4: 795; the rbs_raster_many_kernel_* instantiations, MANY): the cluster cull -- the same for
+// Meshes of many clusters (M4: 795; the rbs_raster_kernel_many_* instantiations, MANY): the cluster cull -- the same for
 // every wave of the block -- is dealt to the block's waves by steps of 64 clusters and the verdicts shared through LDS
 // (two masks per step): C4 slice +6 %.  Kernels of their own: the same code compiled into the one kernel cost C1 0.8 %.
 constexpr int kCullSteps = 28;              // steps of 64 clusters culled between two barriers: 448 B of verdicts, what the LDS block had
@@ -850,17 +850,26 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
         cend = MANY ? min(c1, cbase + 64 * kCullSteps) : c1;
         if (MANY) {
             __syncthreads();
-            for (int it = wave; cbase + (it << 6) < cend; it += kBlock / 64) {
-                const int ci = cbase + (it << 6) + lane;
-                floatx4 sph = floatx4{0.f, 0.f, 0.f, 0.f}, cone = sph;
-                if (ci < c1) {
-                    sph = reinterpret_cast<const floatx4*>(P.cluster_sphere)[ci];
-                    cone = reinterpret_cast<const floatx4*>(P.cluster_cone)[ci];
+            for (int it0 = wave; cbase + (it0 << 6) < cend; it0 += 4 * (kBlock / 64)) {   // four of the wave's steps at a time:
+                floatx4 sph[4], cone[4];                                                      // one memory latency, not four
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ci = cbase + ((it0 + u * (kBlock / 64)) << 6) + lane;
+                    sph[u] = floatx4{0.f, 0.f, 0.f, 0.f}; cone[u] = sph[u];
+                    if (ci < cend) {
+                        sph[u] = reinterpret_cast<const floatx4*>(P.cluster_sphere)[ci];
+                        cone[u] = reinterpret_cast<const floatx4*>(P.cluster_cone)[ci];
+                    }
                 }
-                const int facing = cullsign != 0 && ci < c1 ? cluster_facing(Rt, sph, cone) : 0;
-                const bool hit = ci < c1 && (!cull || cluster_may_touch(P, Rt, sph, wx0, wy0, wx1, wy1)) && facing <= 0;
-                const unsigned long long hitm = __ballot(hit), toward = __ballot(facing < 0);
-                if (lane == 0) { cullm[2 * it] = hitm; cullm[2 * it + 1] = toward; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int it = it0 + u * (kBlock / 64), ci = cbase + (it << 6) + lane;
+                    if (cbase + (it << 6) >= cend) break;   // wave-uniform
+                    const int facing = cullsign != 0 && ci < cend ? cluster_facing(Rt, sph[u], cone[u]) : 0;
+                    const bool hit = ci < cend && (!cull || cluster_may_touch(P, Rt, sph[u], wx0, wy0, wx1, wy1)) && facing <= 0;
+                    const unsigned long long hitm = __ballot(hit), toward = __ballot(facing < 0);
+                    if (lane == 0) { cullm[2 * it] = hitm; cullm[2 * it + 1] = toward; }
+                }
             }
             __syncthreads();
         }
@@ -889,6 +898,7 @@ __device__ inline void raster_window(const DevParams& P, const double* __restric
             const int rank = taken + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
             unsigned long long mine = __ballot(hit && (rank % (kBlock / 64)) == wave);
             taken += __popcll(mask);
+            if (MANY && mine == 0) continue;   // (nine clusters in ten of a large body are culled: most steps leave this wave nothing)
 #if RBS_SHARE_VERTICES
             // Clusters all of whose triangles go to the setup -- every cluster of a body that is not
             // culled, and the clusters whose normal cone faces the camera (4/5 of a closed body's
@@ -1763,12 +1773,12 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET voi
 // ... and the same two for object models with a body of more than 256 clusters (MANY: the shared cluster cull).
 template <bool UPDATE, bool SLAB>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) __attribute__((amdgpu_num_vgpr(RBS_RASTER_VGPRS)))
-void rbs_raster_many_kernel_f32(const DevParams P)
+void rbs_raster_kernel_many_f32(const DevParams P)
 {
     raster_kernel_body<UPDATE, 1, SLAB, true>(P);
 }
 template <bool UPDATE, bool SLAB>
-__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_many_kernel_f64(const DevParams P)
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_kernel_many_f64(const DevParams P)
 {
     raster_kernel_body<UPDATE, 0, SLAB, true>(P);
 }

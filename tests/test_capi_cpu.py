@@ -148,10 +148,10 @@ def test_register_budgets_the_kernels_overlap_depends_on():
                  "rbs_raster_kernel_f64ILb0ELb1EE"):
         vgprs, spills = usage(name)        # precision F64 (the default): the same budget; a kernel-lifetime value or two
         assert vgprs <= 160 and spills <= 4, (name, vgprs, spills)   # parked in scratch at most (ocml's functions spilled 72)
-    for name in ("rbs_raster_many_kernel_f64ILb1ELb0EE", "rbs_raster_many_kernel_f64ILb1ELb1EE", "rbs_raster_many_kernel_f32ILb1ELb0EE",
-                 "rbs_raster_many_kernel_f32ILb1ELb1EE"):
+    for name in ("rbs_raster_kernel_many_f64ILb1ELb0EE", "rbs_raster_kernel_many_f64ILb1ELb1EE", "rbs_raster_kernel_many_f32ILb1ELb0EE",
+                 "rbs_raster_kernel_many_f32ILb1ELb1EE"):
         vgprs, spills = usage(name)        # object models with a body of more than 256 clusters: the shared cluster cull
-        assert vgprs <= 160 and spills <= 4, (name, vgprs, spills)
+        assert vgprs <= 160 and spills <= 6, (name, vgprs, spills)   # (kernel-lifetime values again: nothing spilled in the loops)
 
 
 def test_create_survives_arbitrary_configs():

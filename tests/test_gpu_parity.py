@@ -90,7 +90,7 @@ def test_render_edge_poses(gpu_lib, pose_case):
                                                  (("m1", "m2", "m3"), 640, 480, 12),
                                                  (("m1_l2",), 322, 241, 16),
                                                  (("m4",), 1280, 960, 4),
-                                                 # the rbs_raster_many_kernel_* instantiations (a body of > 256 clusters): with small
+                                                 # the rbs_raster_kernel_many_* instantiations (a body of > 256 clusters): with small
                                                  # bodies beside it, and a body of more clusters than one stretch of the shared cull
                                                  (("m1", "m4", "m2"), 640, 480, 6), (("m4_fine",), 640, 480, 3)])
 def test_sequence_matches_oracle(gpu_lib, meshes, cols, rows, n):
