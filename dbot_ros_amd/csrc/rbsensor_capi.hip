@@ -1078,6 +1078,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         const int clusters = (B.tri_begin[b + 1] - B.tri_begin[b]) >> 6;
         h->many_clusters |= clusters > 64 * (rbs::kBlock / 64);   // (more steps of 64 clusters than the block has waves)
     }
+    if (const char* e = std::getenv("RBS_SHARED_CULL")) h->many_clusters = std::atoi(e) != 0;   // (A/B: the other set of kernels)
     if (n_tri > (1L << 30)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "too many triangles");
     B.n_tri = (int)n_tri;
     const size_t n_alloc = (size_t)(n_tri > 0 ? n_tri : 64);
