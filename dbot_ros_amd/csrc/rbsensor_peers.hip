@@ -1,6 +1,6 @@
 // rbsensor_peers.hip -- the resampling half of the filter step across PROCESSES (one rank per GPU,
 // SURVEY 8(e); dbot_ros_amd/dist.py PeerShardedStep): everything between the all-gather of the
-// log-likelihoods and the next step's parent indices in three launches (two over the chip, one block for the plan).
+// log-likelihoods and the next step's parent indices in four launches (three over the chip, one block for the plan).
 //
 // Every rank holds the gathered log-likelihoods of all N = world * n particles and the same N uniforms,
 // SORTED ascending (children are exchangeable: sorting the uniforms is sorting the children by parent,
@@ -116,12 +116,15 @@ __global__ __launch_bounds__(kThreads) void peer_weights_kernel(const PeerPlan Q
     if (t == 0) Q.tile_total[blockIdx.x] = tile_total;
 }
 
-// One block: the tiles' totals scanned in LDS (cdf value i = (weight of the tiles before i's + cumulative weight
-// inside the tile) / total, formed where it is read), this rank's children's parents, and the plan.
-__global__ __launch_bounds__(kThreads) void peer_resample_kernel(const PeerPlan Q)
+// This rank's children's parents, a child per thread over ceil(n / kThreads) blocks: each block scans the tiles' totals
+// in LDS (cdf value i = (weight of the tiles before i's + cumulative weight inside the tile) / total, formed where it
+// is read, so the cdf is never rewritten) and keeps kSamples evenly spaced cdf values there -- a search narrows to one
+// stretch of `stride` particles in LDS and only its last log2(stride) probes go to memory.  parent =
+// upper_bound(cdf, u), clamped (the last cdf value is 1 up to rounding).  (One block walking the cdf for all of the
+// rank's children was bound by its CU's load path: 190 us of 25 000 children with flat weights.)
+__global__ __launch_bounds__(kThreads) void peer_search_kernel(const PeerPlan Q)
 {
     __shared__ double shd[kThreads / 64];
-    __shared__ int shi[kThreads / 64];
     __shared__ double tile_before[kMaxTiles];
     const int t = (int)threadIdx.x, N = Q.N, n = Q.n;
     const int tiles = (N + kTile - 1) >> kTileShift;
@@ -140,51 +143,110 @@ __global__ __launch_bounds__(kThreads) void peer_resample_kernel(const PeerPlan 
     }
     __syncthreads();
     auto cdf_at = [&](int i) { return (tile_before[i >> kTileShift] + Q.cdf[i]) / total; };
-
-    // kSamples evenly spaced cdf values in LDS: a search narrows to one stretch of `stride` particles there, and
-    // only the last few probes go to memory (a probe is a dependent L2 read: eighteen of them were 12 us).
     __shared__ double sample[kSamples];
     const int stride = (N + kSamples - 1) / kSamples, stretches = (N + stride - 1) / stride;
     for (int j = t; j < stretches; j += kThreads) sample[j] = cdf_at(min(N, (j + 1) * stride) - 1);
+    __syncthreads();
+    const int k = (int)blockIdx.x * kThreads + t;
+    if (k >= n) return;
+    const double u = Q.uniforms[(size_t)Q.rank * n + k];
+    // cdf_at(i) <= u without the division where the answer is clear: the quotient's rounding (and the product's, u x
+    // total) moves either side by parts in 1e16, so outside a band of 1e-15 around u x total the sums decide
+    const bool weighable = total > 0.0 && total < INFINITY;   // (no particle weighs anything: every comparison takes the division)
+    const double ut = u * total;
+    const double ut_lo = weighable ? ut * (1.0 - 1e-15) : -INFINITY, ut_hi = weighable ? ut * (1.0 + 1e-15) : INFINITY;
+    int a = 0, b = stretches;
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (sample[mid] <= u) a = mid + 1; else b = mid;
+    }
+    int p = N;                                                   // first particle with cdf > u (N: none)
+    if (a < stretches) {
+        int lo = a * stride, hi = min(N, (a + 1) * stride) - 1;  // cdf(hi) > u, and cdf(lo - 1) <= u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const double x = tile_before[mid >> kTileShift] + Q.cdf[mid];
+            const bool le = x <= ut_lo ? true : x >= ut_hi ? false : x / total <= u;
+            if (le) lo = mid + 1; else hi = mid;
+        }
+        p = lo;
+    }
+    const int pc = min(p, N - 1);
+    Q.mine[k] = pc;
+    if (Q.parents_local) Q.parents_local[k] = pc;
+}
+
+// One block: the plan of this rank's children from their parents (peer_search_kernel).
+__global__ __launch_bounds__(kThreads) void peer_resample_kernel(const PeerPlan Q)
+{
+    __shared__ double shd[kThreads / 64];
+    __shared__ int shi[kThreads / 64];
+    const int t = (int)threadIdx.x, n = Q.n;
     // (the plan's two work arrays: in LDS when this rank's children fit)
     __shared__ int mine_s[kLdsChildren], aux_s[kLdsChildren];
     int* __restrict__ const mine = n <= kLdsChildren ? mine_s : Q.mine;
     int* __restrict__ const aux = n <= kLdsChildren ? aux_s : Q.aux;
-    __syncthreads();
-    auto upper_bound = [&](double u) {               // first particle with cdf > u (N: none)
-        int a = 0, b = stretches;
-        while (a < b) {
-            const int mid = (a + b) >> 1;
-            if (sample[mid] <= u) a = mid + 1; else b = mid;
-        }
-        if (a == stretches) return N;
-        int lo = a * stride, hi = min(N, (a + 1) * stride) - 1;     // cdf(hi) > u, and cdf(lo - 1) <= u
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf_at(mid) <= u) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-    };
-
-    // ---- this rank's children: parent = upper_bound(cdf, u), clamped (the last cdf value is 1 up to rounding).  The
-    // uniforms are ascending, so are the parents: a thread's chunk of consecutive children searches ONCE, then walks
-    // the cdf forwards, searching again only past sixteen steps (a long stretch of weightless particles).
+    if (n <= kLdsChildren)
+        for (int k = t; k < n; k += kThreads) mine_s[k] = Q.mine[k];
     const int Ln = (n + kThreads - 1) / kThreads;
     const int klo = min(n, t * Ln), khi = min(n, klo + Ln);
-    {
-        int p = 0;
-        for (int k = klo; k < khi; ++k) {
-            const double u = Q.uniforms[(size_t)Q.rank * n + k];
-            int steps = 0;
-            if (k != klo)
-                while (p < N && steps < 16 && cdf_at(p) <= u) { ++p; ++steps; }
-            if (k == klo || (steps == 16 && p < N && cdf_at(p) <= u)) p = upper_bound(u);
-            const int pc = min(p, N - 1);
-            mine[k] = pc;
-            if (Q.parents_local) Q.parents_local[k] = pc;
-        }
-    }
     __syncthreads();
+
+    // ---- min_share == 2 and more children than LDS holds: "at least two children share the parent" is a question to a
+    // child's two neighbours, so ONE forward sweep does the plan -- tiles of 4 x kThreads children, four consecutive ones
+    // per thread, everything read and written in order (the general plan below walks a thread's 25 scattered children
+    // four times: 200 us of 25 000 children, one CU reading 64 cache lines per wave load)
+    if (Q.min_share == 2 && n > kLdsChildren) {
+        long long c_remote = 0, c_shared = 0, c_start = 0, c_runs = 0;
+        int carry = 0, dummy;                            // windows staged before this tile
+        for (int base = 0; base < n; base += 4 * kThreads) {
+            const int k0 = base + 4 * t;
+            int pm[6];                                   // parents of children k0 - 1 ... k0 + 4 (-1 / -2: no such child)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int kk = k0 - 1 + j;
+                pm[j] = kk < 0 ? -1 : kk >= n ? -2 : Q.mine[kk];
+            }
+            int f[4], starts = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[j] = 0;
+                if (k0 + j >= n) continue;
+                const int p = pm[j + 1], owner = p / n;
+                const bool nw = p != pm[j], last = p != pm[j + 2], remote = owner != Q.rank;
+                const bool shared = remote && !(nw && last);
+                f[j] = shared ? (nw ? 2 : 1) : 0;       // 2: the run's first child (stages the window)
+                starts += f[j] == 2;
+                c_remote += remote; c_shared += shared; c_start += f[j] == 2; c_runs += nw;
+            }
+            int tile_total;
+            const int before = block_exscan(starts, 0, OpAdd(), shi, &tile_total);
+            int sidx = carry + before - 1;              // (a shared child whose run began earlier: the last start before it is its run's)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j;
+                if (k >= n) continue;
+                const int p = pm[j + 1], owner = p / n;
+                const int pg = owner * Q.cap + (p - owner * n);
+                if (f[j] == 2) ++sidx;
+                Q.parent_idx[k] = f[j] ? Q.rank * Q.cap + n + sidx : pg;
+                Q.stage_src[k] = f[j] == 2 ? pg : -1;
+                Q.stage_dst[k] = f[j] == 2 ? n + sidx : -1;
+            }
+            carry += tile_total;
+        }
+        (void)dummy;
+        long long tot;
+        (void)block_exscan(c_remote, 0ll, OpAdd(), reinterpret_cast<long long*>(shd), &tot);
+        if (t == 0) Q.counts[0] += tot;
+        (void)block_exscan(c_shared, 0ll, OpAdd(), reinterpret_cast<long long*>(shd), &tot);
+        if (t == 0) Q.counts[1] += tot;
+        (void)block_exscan(c_start, 0ll, OpAdd(), reinterpret_cast<long long*>(shd), &tot);
+        if (t == 0) Q.counts[2] += tot;
+        (void)block_exscan(c_runs, 0ll, OpAdd(), reinterpret_cast<long long*>(shd), &tot);
+        if (t == 0) Q.counts[3] += tot;
+        return;
+    }
 
     // ---- runs of equal parents: where each child's run starts ...
     int last_start = -1;

@@ -92,6 +92,8 @@ def test_ipc_attach_refuses_mismatched_handles(gpu_lib):
     (1, 64, 2, 1.0, 1.0),          # a single rank: nothing is remote
     (4, 3000, 2, 1.0, 6.0),        # some dozens of survivors, long weightless stretches between them
     (8, 25000, 2, 1.0, 2.0),       # BASELINE C3 over eight ranks
+    (2, 5000, 3, 1.0, 4.0),        # more children than the plan keeps in LDS, min_share 3: the general plan in memory
+    (4, 6250, 2, 1.0, 40.0),       # ... min_share 2: the one-sweep plan, few survivors
 ])
 def test_peer_resample_matches_tensor_arithmetic(gpu_lib, world, n, min_share, temp, spread):
     """rbs_peer_resample (one call) against dist.global_resample + dist.plan_shard (the same step as tensor
