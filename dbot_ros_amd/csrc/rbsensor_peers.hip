@@ -28,6 +28,7 @@ namespace rbp {
 constexpr int kThreads = 1024;
 constexpr int kTileShift = 11, kTile = 1 << kTileShift;   // particles per block of the two elementwise passes: two per thread
 constexpr int kMaxTiles = 1024;                            // (their totals sit in the plan kernel's LDS: N <= 2 M particles)
+constexpr int kOwnMaxTiles = 16;                           // up to here peer_weights_kernel's blocks find the maximum themselves
 constexpr int kSamples = 2048;                             // cdf values kept in LDS to start a search from
 constexpr int kLdsChildren = 4096;                         // a rank's children's parents stay in LDS up to this many
 
@@ -98,7 +99,11 @@ __global__ __launch_bounds__(kThreads) void peer_weights_kernel(const PeerPlan Q
     __shared__ double shd[kThreads / 64];
     const int t = (int)threadIdx.x, tiles = (int)gridDim.x;
     double m = -INFINITY;
-    for (int k = t; k < tiles; k += kThreads) m = fmax(m, Q.tile_max[k]);
+    if (tiles <= kOwnMaxTiles) {   // few tiles: every block finds the largest log-likelihood itself (a launch less: ~4.5 us)
+        for (int i = t; i < Q.N; i += kThreads) m = fmax(m, Q.ll_all[i]);
+    } else {
+        for (int k = t; k < tiles; k += kThreads) m = fmax(m, Q.tile_max[k]);
+    }
     {
         double tot;
         (void)block_exscan(m, -(double)INFINITY, OpMax(), shd, &tot);
@@ -182,21 +187,11 @@ __global__ __launch_bounds__(kThreads) void peer_resample_kernel(const PeerPlan 
     __shared__ double shd[kThreads / 64];
     __shared__ int shi[kThreads / 64];
     const int t = (int)threadIdx.x, n = Q.n;
-    // (the plan's two work arrays: in LDS when this rank's children fit)
-    __shared__ int mine_s[kLdsChildren], aux_s[kLdsChildren];
-    int* __restrict__ const mine = n <= kLdsChildren ? mine_s : Q.mine;
-    int* __restrict__ const aux = n <= kLdsChildren ? aux_s : Q.aux;
-    if (n <= kLdsChildren)
-        for (int k = t; k < n; k += kThreads) mine_s[k] = Q.mine[k];
-    const int Ln = (n + kThreads - 1) / kThreads;
-    const int klo = min(n, t * Ln), khi = min(n, klo + Ln);
-    __syncthreads();
-
-    // ---- min_share == 2 and more children than LDS holds: "at least two children share the parent" is a question to a
+    // ---- min_share == 2 (the default): "at least two children share the parent" is a question to a
     // child's two neighbours, so ONE forward sweep does the plan -- tiles of 4 x kThreads children, four consecutive ones
-    // per thread, everything read and written in order (the general plan below walks a thread's 25 scattered children
-    // four times: 200 us of 25 000 children, one CU reading 64 cache lines per wave load)
-    if (Q.min_share == 2 && n > kLdsChildren) {
+    // per thread, everything read and written in order (the general plan below, on more children than LDS holds, walks a
+    // thread's scattered children four times: 200 us of 25 000 children, one CU reading 64 cache lines per wave load)
+    if (Q.min_share == 2) {
         long long c_remote = 0, c_shared = 0, c_start = 0, c_runs = 0;
         int carry = 0, dummy;                            // windows staged before this tile
         for (int base = 0; base < n; base += 4 * kThreads) {
@@ -236,19 +231,26 @@ __global__ __launch_bounds__(kThreads) void peer_resample_kernel(const PeerPlan 
             carry += tile_total;
         }
         (void)dummy;
+        // (four counts, each at most n < 2^31, in two sums)
         long long tot;
-        (void)block_exscan(c_remote, 0ll, OpAdd(), reinterpret_cast<long long*>(shd), &tot);
-        if (t == 0) Q.counts[0] += tot;
-        (void)block_exscan(c_shared, 0ll, OpAdd(), reinterpret_cast<long long*>(shd), &tot);
-        if (t == 0) Q.counts[1] += tot;
-        (void)block_exscan(c_start, 0ll, OpAdd(), reinterpret_cast<long long*>(shd), &tot);
-        if (t == 0) Q.counts[2] += tot;
-        (void)block_exscan(c_runs, 0ll, OpAdd(), reinterpret_cast<long long*>(shd), &tot);
-        if (t == 0) Q.counts[3] += tot;
+        (void)block_exscan((c_remote << 32) | c_shared, 0ll, OpAdd(), reinterpret_cast<long long*>(shd), &tot);
+        if (t == 0) { Q.counts[0] += tot >> 32; Q.counts[1] += tot & 0xffffffffll; }
+        (void)block_exscan((c_start << 32) | c_runs, 0ll, OpAdd(), reinterpret_cast<long long*>(shd), &tot);
+        if (t == 0) { Q.counts[2] += tot >> 32; Q.counts[3] += tot & 0xffffffffll; }
         return;
     }
 
-    // ---- runs of equal parents: where each child's run starts ...
+    // ---- any other min_share: run lengths.  (The plan's two work arrays: in LDS when this rank's children fit.)
+    __shared__ int mine_s[kLdsChildren], aux_s[kLdsChildren];
+    int* __restrict__ const mine = n <= kLdsChildren ? mine_s : Q.mine;
+    int* __restrict__ const aux = n <= kLdsChildren ? aux_s : Q.aux;
+    if (n <= kLdsChildren)
+        for (int k = t; k < n; k += kThreads) mine_s[k] = Q.mine[k];
+    const int Ln = (n + kThreads - 1) / kThreads;
+    const int klo = min(n, t * Ln), khi = min(n, klo + Ln);
+    __syncthreads();
+
+    // runs of equal parents: where each child's run starts ...
     int last_start = -1;
     for (int k = klo; k < khi; ++k) {
         const bool nw = k == 0 || mine[k] != mine[k - 1];

@@ -333,7 +333,7 @@ int32_t rbs_ipc_attach(rbs_handle* h, int32_t rank, int32_t world, const void* b
  * the staged copy -- global slot rank * max_particles + d_dst_local[i] -- as the children's parent.
  * Both arrays in device memory.  Works on an unattached handle as well (src = local slots). */
 int32_t rbs_stage_windows(rbs_handle* h, const int32_t* d_src_global, const int32_t* d_dst_local, int32_t n, void* stream);
-/* The resampling half of the filter step across processes in one call: four launches on `stream` (three over
+/* The resampling half of the filter step across processes in one call: three or four launches on `stream` (two or three over
  * the chip for the cdf and the children's parents, one block for the plan), no host synchronisation after the first call, which
  * allocates scratch: what dbot_ros_amd/dist.py global_resample + plan_shard
  * compute with ~45 tensor kernels.  d_loglik_all [n_total = world * n_local]: the all-gathered
