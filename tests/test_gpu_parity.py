@@ -114,6 +114,28 @@ def test_sequence_matches_oracle(gpu_lib, meshes, cols, rows, n):
             assert np.abs(g.get_occlusion(slot) - lazy.get_occlusion(slot, now=True)).max() <= 2e-6
 
 
+@pytest.mark.parametrize("meshes,cols,rows,n,precision", [(("m1", "m2", "m3"), 640, 480, 12, "f64"), (("m4",), 1280, 960, 4, "f64"),
+                                                           (("m1_l2",), 322, 241, 16, "f32"), (("m1", "m4", "m2"), 640, 480, 6, "f32")])
+def test_both_sets_of_raster_kernels_agree_bit_for_bit(gpu_lib, monkeypatch, meshes, cols, rows, n, precision):
+    """The kernels with the cluster cull shared by a block's waves (picked for a body of more than 256 clusters) and the ones
+    where every wave culls for itself, forced either way (RBS_SHARED_CULL, read at create time) on the same scenes:
+    identical log-likelihoods and identical planes -- the cull only decides which clusters are looked at."""
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    nb = len(meshes)
+    eager = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    frames = sc.make_frames(eager, nb, 3, seed=5)
+    got = []
+    for forced in ("0", "1"):
+        monkeypatch.setenv("RBS_SHARED_CULL", forced)
+        with RbSensor(om, cam, P, max_particles=n, precision=precision) as g:
+            ll = sc.run_sequence(g, frames, n, n_bodies=nb)
+            got.append((ll, [g.get_occlusion(slot) for slot in range(n)]))
+    for a, b in zip(got[0][0], got[1][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(got[0][1], got[1][1]):
+        assert np.array_equal(a, b)
+
+
 def test_update_false_leaves_state_untouched(gpu_lib):
     """Non-final sampling blocks of a multi-object frame evaluate with update=false."""
     n = 16
