@@ -1,6 +1,8 @@
 // rbsensor_peers.hip -- the resampling half of the filter step across PROCESSES (one rank per GPU,
 // SURVEY 8(e); dbot_ros_amd/dist.py PeerShardedStep): everything between the all-gather of the
-// log-likelihoods and the next step's parent indices in four launches (three over the chip, one block for the plan).
+// log-likelihoods and the next step's parent indices in three or four launches: the largest log-likelihood per tile
+// (large jobs only), weights + cumulative sums per tile, the children's parents -- all over the chip -- and one block
+// for the plan.
 //
 // Every rank holds the gathered log-likelihoods of all N = world * n particles and the same N uniforms,
 // SORTED ascending (children are exchangeable: sorting the uniforms is sorting the children by parent,
@@ -30,7 +32,7 @@ constexpr int kTileShift = 11, kTile = 1 << kTileShift;   // particles per block
 constexpr int kMaxTiles = 1024;                            // (their totals sit in the plan kernel's LDS: N <= 2 M particles)
 constexpr int kOwnMaxTiles = 16;                           // up to here peer_weights_kernel's blocks find the maximum themselves
 constexpr int kSamples = 2048;                             // cdf values kept in LDS to start a search from
-constexpr int kLdsChildren = 4096;                         // a rank's children's parents stay in LDS up to this many
+constexpr int kLdsChildren = 4096;                         // the general plan (min_share != 2) keeps a rank's children's parents in LDS up to this many
 
 struct PeerPlan {
     const double* ll_all;     // [N] gathered log-likelihoods, rank-major
