@@ -110,7 +110,14 @@ struct rbs_handle {
     float background = 0.f;     // never-covered occlusion level of the current buffer
     int2* d_item_range = nullptr;   // [max_particles] work items of each particle
     int* d_item_particle = nullptr; // [partial_cap] owner of each work item
-    int* d_ctr = nullptr;           // [4] work-item counters of even / odd calls
+    int* d_ctr = nullptr;           // [4] work-item counters of even / odd calls (+ [2] the split launch's likelihood-kernel tickets)
+    // Split launch (round 5): geometry kernel -> depth tiles in memory -> likelihood kernel, each with its own occupancy
+    // (rbsensor_kernels.hip, rbs_depth_kernel / rbs_eval_kernel).  rbs_config has no field for it: RBS_SPLIT in the
+    // environment at rbs_create (tooling / A-B), otherwise the library's choice below.
+    bool split = false;
+    unsigned* d_depth = nullptr;    // [depth_items][kDepthTilePx]
+    size_t depth_items = 0;
+    int depth_blocks = 0, eval_blocks = 0;   // the two persistent grids
     int* d_done = nullptr;      // [max_particles] finished work items per particle
     double* d_partial = nullptr; // [partial_cap] per-item partial sums
     unsigned long long* d_phase = nullptr;  // RBS_PHASE_TIMING builds
@@ -414,6 +421,10 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     const bool f64 = h->precision == RBS_PRECISION_F64;   // (its math tables take a little of the LDS tile)
     P.tile_px = !h->windowed && h->raster_blocks <= 2 * h->cu_count ? (f64 ? rbs::kTilePxBigF64 : rbs::kTilePxBig)
                                                                      : (f64 ? rbs::kTilePxF64 : rbs::kTilePx);
+    // split launch: binary64 likelihood on windowed planes (the tile size is the handle's for its whole life, like the
+    // monolith's: the split of a rectangle into items decides the order in which a particle's partial sums are added)
+    const bool split = h->split && f64 && h->windowed;
+    if (split) P.tile_px = rbs::kDepthTilePx;
     P.tile_w = 256;
     P.tile_h = std::max(4, P.tile_px / 256 / std::max(1, h->smalln_target / std::max(1, n)));
     if (const char* m = h->tile_override) { P.tile_w = std::max(16, std::atoi(m) / 16 * 16); P.tile_h = std::max(1, std::atoi(m)); }
@@ -430,6 +441,25 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipMalloc(&h->d_partial, sizeof(double) * need));
         RBS_HIP(h, hipMalloc(&h->d_item_particle, sizeof(int) * need));
         h->partial_cap = need;
+    }
+    if (split) {
+        // the hand-over buffer: one tile per work item.  `need` is the worst case (every rectangle the whole frame);
+        // four items per particle (+ slack) is what is allocated -- C4's geometry has 8-12 per particle and asks for
+        // more through RBS_SPLIT_ITEMS_PER_PARTICLE; an item beyond the buffer is contained (NaN), never a wild write
+        static const int per = [] { const char* e = std::getenv("RBS_SPLIT_ITEMS_PER_PARTICLE"); return e ? std::max(1, std::atoi(e)) : 4; }();
+        const size_t want = std::min(need, (size_t)n * (size_t)per + 1024);
+        if (want > h->depth_items) {
+            RBS_HIP(h, hipStreamSynchronize(s));
+            (void)hipFree(h->d_depth);
+            h->d_depth = nullptr;
+            h->depth_items = 0;
+            RBS_HIP(h, hipMalloc(&h->d_depth, sizeof(unsigned) * (size_t)rbs::kDepthTilePx * want));
+            h->depth_items = want;
+        }
+        P.depth = h->d_depth;
+        P.depth_items = (int)std::min<size_t>(h->depth_items, 0x7fffffff);
+        P.ctrb_this = h->d_ctr + 4 + (int)(h->calls & 1);
+        P.ctrb_next = h->d_ctr + 4 + (int)((h->calls + 1) & 1);
     }
     int* const d_rects = h->d_rects[h->calls & 1];
     P.rects = d_rects;
@@ -519,10 +549,29 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     const int full_grid = h->balance && h->balance_blocks && h->windowed && update ? h->balance_blocks : h->raster_blocks;
     const dim3 rgrid((unsigned)(wide || mid ? std::min(h->raster_blocks, 2 * h->cu_count) : full_grid));
     // a host frame that is read where it was uploaded: only now does the stream wait for the upload
-    if (h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
+    // (split launch: the geometry kernel needs no frame -- the wait sits between the two kernels, and a host frame
+    // travels while the depth tiles are rasterized)
+    if (!split && h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
+    if (split) {
+        const bool two = wide || mid;   // (wide windows: fewer blocks, so that the streaming copy keeps its registers)
+        const dim3 dgrid((unsigned)(two ? std::min(h->depth_blocks, 2 * h->cu_count) : h->depth_blocks));
+        const dim3 egrid((unsigned)(two ? std::min(h->eval_blocks, 3 * h->cu_count) : h->eval_blocks));
+        const size_t dsm = rbs::smem_bytes_depth(P.tile_px, h->many_clusters), esm = rbs::smem_bytes(0, true);
+        if (h->many_clusters) hipLaunchKernelGGL((rbs::rbs_depth_kernel<true>), dgrid, block, dsm, s, P);
+        else hipLaunchKernelGGL((rbs::rbs_depth_kernel<false>), dgrid, block, dsm, s, P);
+        RBS_HIP(h, hipGetLastError());
+        if (h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
+        switch ((update ? 2 : 0) | (h->slab_px ? 1 : 0)) {
+            case 0: hipLaunchKernelGGL((rbs::rbs_eval_kernel<false, false>), egrid, block, esm, s, P); break;
+            case 1: hipLaunchKernelGGL((rbs::rbs_eval_kernel<false, true>), egrid, block, esm, s, P); break;
+            case 2: hipLaunchKernelGGL((rbs::rbs_eval_kernel<true, false>), egrid, block, esm, s, P); break;
+            default: hipLaunchKernelGGL((rbs::rbs_eval_kernel<true, true>), egrid, block, esm, s, P); break;
+        }
+        RBS_HIP(h, hipGetLastError());
+    }
     if (update) {
-        launch_raster(h, true, rgrid, block, rbs::smem_bytes(P.tile_px, f64, h->many_clusters), s, P);
+        if (!split) launch_raster(h, true, rgrid, block, rbs::smem_bytes(P.tile_px, f64, h->many_clusters), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
@@ -578,7 +627,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
         }
     } else {
-        launch_raster(h, false, rgrid, block, rbs::smem_bytes(P.tile_px, f64, h->many_clusters), s, P);
+        if (!split) launch_raster(h, false, rgrid, block, rbs::smem_bytes(P.tile_px, f64, h->many_clusters), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
     }
@@ -815,6 +864,7 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_item_range);
     (void)hipFree(h->d_item_particle);
     (void)hipFree(h->d_ctr);
+    (void)hipFree(h->d_depth);
     (void)hipFree(h->d_area);
     (void)hipFree(h->d_wide_flags);
     if (h->h_area) (void)hipHostFree(h->h_area);
@@ -956,14 +1006,27 @@ int32_t next_frame_staging(rbs_handle* h)
 // the launch of a call's kernels and the wait for its results, so the host's staging copy and the transfer pass
 // behind the raster kernel): staged into the other pinned image, sent on the upload stream, its model terms
 // (precision F64) computed behind it -- everything upload_frame does except making it the observation.
-int32_t prefetch_frame(rbs_handle* h, const float* depth)
+// What rbs_loglikes_prefetch needs, checked BEFORE the call's kernels are enqueued (a prefetch that failed
+// behind an updating call left the caller with a failed call whose planes had already flipped).
+int32_t prefetch_check(rbs_handle* h)
 {
     if (h->frame_ingest)   // (frames ingested on the launch stream: RBS_FRAME_INGEST tooling mode)
         return fail(h, RBS_ERR_UNSUPPORTED, "loglikes_prefetch: not with RBS_FRAME_INGEST");
+    if (h->prefetched_slot >= 0)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "loglikes_prefetch: the frame uploaded ahead by the previous rbs_loglikes_prefetch has not been "
+                                                 "installed yet (rbs_set_observation_prefetched)");
+    if ((h->frame_slot ^ 1) == h->cur_slot)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "loglikes_prefetch: the staging image the next frame would use is the current observation "
+                                                 "(the staging images did not alternate)");
+    return RBS_OK;
+}
+
+int32_t prefetch_frame(rbs_handle* h, const float* depth)
+{
+    if (int32_t rc = prefetch_check(h)) return rc;   // (before the staging image is switched: a refused call changes nothing)
     if (int32_t rc = next_frame_staging(h)) return rc;
     const int k = h->frame_slot;
     const size_t n = (size_t)h->npx;
-    if (k == h->cur_slot) return fail(h, RBS_ERR_HIP, "loglikes_prefetch: the staging images did not alternate");
     RBS_HIP(h, hipStreamWaitEvent(h->up_stream, h->ev_used[k], 0));   // d_fin[k]: its readers were enqueued two frames ago
     std::memcpy(h->h_frames[k], depth, n * sizeof(float));
     RBS_HIP(h, hipMemcpyAsync(h->d_fin[k], h->h_frames[k], n * sizeof(float), hipMemcpyHostToDevice, h->up_stream));
@@ -1006,10 +1069,14 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     // these the per-pixel arithmetic never meets a NaN of its own making: sigma > 0 for every finite o)
     if (!(cfg->model_sigma > 0.0) || !(cfg->sigma_factor >= 0.0) || !std::isfinite(cfg->model_sigma) || !std::isfinite(cfg->sigma_factor))
         return fail(h, RBS_ERR_INVALID_ARGUMENT, "need kinect.model_sigma > 0 and kinect.sigma_factor >= 0");
-    // tail_weight > 0: the library's erfc / exp are accurate in ABSOLUTE terms (1e-16), which is all the mixture can see
-    // next to tw / max_depth; with tw = 0 the far tails would be priced by that floor instead of the decaying value
-    if (!(cfg->tail_weight > 0.0) || !(cfg->tail_weight < 1.0))
-        return fail(h, RBS_ERR_INVALID_ARGUMENT, "need 0 < kinect.tail_weight < 1");
+    // tail_weight: the reference hands the ROS parameter through unchecked, 0 included, so 0 <= tw < 1 is
+    // accepted.  The library's erfc / exp are accurate in ABSOLUTE terms (1e-16), which is all the mixture can see next to
+    // tw / max_depth -- with tw = 0 the far tails would be priced by that floor instead of the decaying value --
+    // so a weight below kTailWeightFloor is EVALUATED as kTailWeightFloor (tw / max_depth = 1.7e-10: the tables' 1e-16 is
+    // then 6e-7 relative in the deepest tail, far inside the 1e-5 bar; a log-likelihood that the exact tw = 0 model
+    // drives to -inf becomes a large finite negative number instead).  Stated in the header and INTEGRATION.md.
+    if (!(cfg->tail_weight >= 0.0) || !(cfg->tail_weight < 1.0))
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, "need 0 <= kinect.tail_weight < 1");
     if (!(cfg->initial_occlusion_prob >= 0.0) || !(cfg->initial_occlusion_prob <= 1.0))
         return fail(h, RBS_ERR_INVALID_ARGUMENT, "need 0 <= occlusion.initial_occlusion_prob <= 1");
 
@@ -1055,9 +1122,9 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     B.rows = h->rows; B.cols = h->cols; B.npx = h->npx;
     B.n_bodies = h->n_bodies;
     B.fx = K[0]; B.fy = K[4]; B.cx = K[2]; B.cy = K[5];
-    B.tw = cfg->tail_weight; B.ms = cfg->model_sigma; B.sf = cfg->sigma_factor;
+    B.tw = std::max(cfg->tail_weight, RBS_TAIL_WEIGHT_FLOOR); B.ms = cfg->model_sigma; B.sf = cfg->sigma_factor;
     B.lambda = -std::log(0.5) / rbs::kHalfLifeDepth;
-    B.cv0 = (1.0 - cfg->tail_weight) / std::sqrt(M_PI);
+    B.cv0 = (1.0 - B.tw) / std::sqrt(M_PI);
     B.bands = copy_bands_for(h->rows, h->cols);
     B.band_rows = (h->rows + B.bands - 1) / B.bands;
 
@@ -1334,6 +1401,12 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         h->raster_blocks = 3 * h->cu_count;
         // tuning overrides (defaults are the measured best on MI355X)
         if (const char* m = std::getenv("RBS_RASTER_BLOCKS")) h->raster_blocks = std::max(1, std::atoi(m));
+        h->split = RBS_SPLIT_DEFAULT != 0;
+        if (const char* m = std::getenv("RBS_SPLIT")) h->split = std::atoi(m) != 0;
+        h->depth_blocks = RBS_DEPTH_MINWAVES * h->cu_count;
+        h->eval_blocks = RBS_EVAL_MINWAVES * h->cu_count;
+        if (const char* m = std::getenv("RBS_DEPTH_BLOCKS")) h->depth_blocks = std::max(1, std::atoi(m));
+        if (const char* m = std::getenv("RBS_EVAL_BLOCKS")) h->eval_blocks = std::max(1, std::atoi(m));
         h->tile_override = std::getenv("RBS_TILE");
         if (const char* m = std::getenv("RBS_COPY_ROWS")) h->copy_rows = std::atoi(m);
         if (const char* m = std::getenv("RBS_COPY_TPB")) h->copy_tpb = std::max(64, std::atoi(m) / 64 * 64);
@@ -1411,8 +1484,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     RBS_HIP(h, hipMalloc(&h->d_area, sizeof(unsigned long long)));
     RBS_HIP(h, hipHostMalloc(&h->h_area, sizeof(unsigned long long), hipHostMallocDefault));
     RBS_HIP(h, hipEventCreateWithFlags(&h->ev_area, hipEventDisableTiming));
-    RBS_HIP(h, hipMalloc(&h->d_ctr, sizeof(int) * 4));
-    RBS_HIP(h, hipMemset(h->d_ctr, 0, sizeof(int) * 4));
+    RBS_HIP(h, hipMalloc(&h->d_ctr, sizeof(int) * 8));
+    RBS_HIP(h, hipMemset(h->d_ctr, 0, sizeof(int) * 8));
     RBS_HIP(h, hipMalloc(&h->d_done, sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_cluster_sphere, sizeof(float) * cluster_sphere.size()));
     RBS_HIP(h, hipMemcpy(h->d_cluster_sphere, cluster_sphere.data(), sizeof(float) * cluster_sphere.size(),
@@ -1495,7 +1568,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
 
     {   // per-item partial sums: sized for the default tiling so no call ever allocates
         const size_t gmul = h->d_groups[0] ? rbs::kMaxGroups : 1;   // every group of bodies tiles its own rectangle
-        size_t need = gmul * (size_t)h->max_particles * tiles_upper_bound(h->cols, h->rows, 256, rbs::kTilePx);
+        size_t need = gmul * (size_t)h->max_particles * tiles_upper_bound(h->cols, h->rows, 256, h->split ? rbs::kDepthTilePx : rbs::kTilePx);
         for (int nn = 1; nn < std::min(h->max_particles, h->raster_blocks); nn *= 2) {
             const int th = std::max(4, rbs::kTilePx / 256 / std::max(1, std::max(h->smalln_target, h->raster_blocks) / nn));
             need = std::max(need, gmul * (size_t)std::min(2 * nn, h->max_particles) * tiles_upper_bound(h->cols, h->rows, 256, 256 * th));
@@ -1729,13 +1802,39 @@ void release_group(rbs_handle* g)
 // log-likelihoods straight into the pinned result buffer.  A separate H2D copy of 200 KB queued
 // behind the frame's upload on the same engine, and each copy <-> kernel hand-over costs ~10 us:
 // together 30 us of a 300 us step.  RBS_HOST_STAGED_COPIES=1 restores the copies.
-int32_t host_call(rbs_handle* h, const double* poses, const int32_t* indices, int n, bool update)
+// rbs_loglikes_deltas: state deltas + default poses instead of absolute poses (packed on the way into pinned memory,
+// composed on the device by rbt::compose_kernel).
+struct DeltaArgs { const double* deltas; const double* deflt; int stride; };
+
+int32_t host_call(rbs_handle* h, const double* poses, const int32_t* indices, int n, bool update, const DeltaArgs* da = nullptr)
 {
-    const bool copies = h->host_copies;
+    const bool copies = h->host_copies && !da;
     const size_t pose_bytes = sizeof(double) * 12 * h->n_bodies * (size_t)n;
     // slabs: the overflow flag as it stands BEFORE this call -- set, it belongs to an asynchronous call
     // that has not been reported yet
     if (h->slab_px) RBS_HIP(h, hipMemcpyAsync(h->h_err + 2, h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (da) {
+        // [n][bodies][6] deltas, then [bodies][6] default poses: half the bytes of the absolute poses they stand for
+        // (they fit the staging block sized for those: (n + 1) * 6 <= max_particles * 12)
+        const int B = h->n_bodies;
+        double* st = reinterpret_cast<double*>(h->h_in);
+        const size_t nb = (size_t)n * B;
+        if (da->stride == 6) std::memcpy(st, da->deltas, sizeof(double) * 6 * nb);
+        else for (size_t k = 0; k < nb; ++k) std::memcpy(st + 6 * k, da->deltas + (size_t)da->stride * k, sizeof(double) * 6);
+        for (int b = 0; b < B; ++b) std::memcpy(st + 6 * nb + 6 * b, da->deflt + (size_t)da->stride * b, sizeof(double) * 6);
+        std::memcpy(h->h_in + h->in_idx_off, indices, sizeof(int) * (size_t)n);
+        const double* dev = reinterpret_cast<const double*>(h->h_in_dev);
+        hipLaunchKernelGGL(rbt::compose_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, h->stream, dev, dev + 6 * nb,
+                           reinterpret_cast<double*>(h->d_in), n, B);
+        RBS_HIP(h, hipGetLastError());
+        if (int32_t rc = enqueue_loglikes(h, reinterpret_cast<const double*>(h->d_in),
+                                          reinterpret_cast<const int*>(h->h_in_dev + h->in_idx_off), n, update,
+                                          reinterpret_cast<double*>(h->h_out_dev), h->stream))
+            return rc;
+        if (h->slab_px) RBS_HIP(h, hipMemcpyAsync(h->h_err, h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        RBS_HIP(h, hipEventRecord(h->ev_out, h->stream));
+        return RBS_OK;
+    }
     std::memcpy(h->h_in, poses, pose_bytes);
     std::memcpy(h->h_in + h->in_idx_off, indices, sizeof(int) * (size_t)n);
     if (copies) {
@@ -1799,7 +1898,7 @@ int32_t group_grow_slabs(rbs_handle* g, const std::vector<CallState>* before)
 
 // rbs_loglikes on a group: particle i is evaluated by shard i / shard_cap and (update) written
 // to global slot i; `indices` are global parent slots.
-int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int32_t n, int32_t update, double* out)
+int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int32_t n, int32_t update, double* out, const DeltaArgs* da = nullptr)
 {
     const int nd = (int)g->shards.size();
     const int cap = g->shard_cap;
@@ -1828,7 +1927,10 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
                 return poison(g, gfail(g, h, fail(h, RBS_ERR_HIP, "injected fault (RBS_TEST_FAULT)")));
             }
 #endif
-            if (int32_t rc = host_call(h, poses + stride * (size_t)lo, indices + lo, cnt, update != 0)) return poison(g, gfail(g, h, rc));
+            DeltaArgs dk = {nullptr, nullptr, 0};
+            if (da) dk = DeltaArgs{da->deltas + (size_t)da->stride * g->n_bodies * (size_t)lo, da->deflt, da->stride};
+            if (int32_t rc = host_call(h, da ? nullptr : poses + stride * (size_t)lo, indices + lo, cnt, update != 0, da ? &dk : nullptr))
+                return poison(g, gfail(g, h, rc));
         }
         g->group_calls += 1;
         bool overflow = false;
@@ -2046,9 +2148,10 @@ int32_t rbs_reset(rbs_handle* h)
     if (int32_t rc = drain(h, true)) return rc;   // no copy kernel may still be writing planes
     // (a call that failed between its kernels may have left the work-item counters of either parity
     // in use: both pairs start from zero again)
-    RBS_HIP(h, hipMemsetAsync(h->d_ctr, 0, 4 * sizeof(int), h->stream));
+    RBS_HIP(h, hipMemsetAsync(h->d_ctr, 0, 8 * sizeof(int), h->stream));
     h->poisoned = false;
     h->frame_acquired = false;
+    h->prefetched_slot = -1;   // (a frame uploaded ahead belongs to the session that ended)
     h->cur = 0;
     h->pending_frames = 0;
     h->background = (float)h->init_occ;
@@ -2211,6 +2314,7 @@ int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* st
     // call comes on the same stream, and is launched on `s` by whatever needs the frame otherwise
     if (int32_t rc = flush_lazy_frame(h, s)) return rc;   // an earlier frame nobody evaluated
     if (int32_t rc = release_frame_slot(h)) return rc;
+    h->prefetched_slot = -1;   // (a frame uploaded ahead of its turn that another frame overtakes is abandoned: ADVICE r4)
     h->lazy_frame = d_depth;
     h->lazy_stream = s;
     h->pending_frames += 1;
@@ -2231,12 +2335,33 @@ int32_t rbs_get_observation(rbs_handle* h, float* out)
 }
 
 static int32_t loglikes_impl(rbs_handle* h, const double* poses, int32_t* indices, int32_t n, int32_t update, double* out_loglik,
-                             const float* next_depth);
+                             const float* next_depth, const DeltaArgs* da = nullptr);
 
 int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32_t n,
                      int32_t update, double* out_loglik)
 {
     return loglikes_impl(h, poses, indices, n, update, out_loglik, nullptr);
+}
+
+int32_t rbs_loglikes_deltas(rbs_handle* h, const double* deltas, const double* default_poses, int32_t body_stride,
+                            int32_t* indices, int32_t n, int32_t update, double* out_loglik)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (body_stride < 6) return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("loglikes_deltas: body_stride = %d, need >= 6 (position, rotation vector)", body_stride));
+    if (n > 0 && (!deltas || !default_poses)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "loglikes_deltas: null pointer");
+    const DeltaArgs da = {deltas, default_poses, body_stride};
+    return loglikes_impl(h, deltas, indices, n, update, out_loglik, nullptr, &da);
+}
+
+int32_t rbs_get_poses(rbs_handle* h, double* out, int32_t n)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty()) return fail(h, RBS_ERR_UNSUPPORTED, "get_poses: single-device handles");
+    if (!out || n < 0 || n > h->max_particles) return fail(h, RBS_ERR_INVALID_ARGUMENT, "get_poses: bad arguments");
+    RBS_HIP(h, hipSetDevice(h->device));
+    RBS_HIP(h, hipStreamSynchronize(h->stream));
+    RBS_HIP(h, hipMemcpy(out, h->d_in, sizeof(double) * 12 * h->n_bodies * (size_t)n, hipMemcpyDeviceToHost));
+    return RBS_OK;
 }
 
 int32_t rbs_loglikes_prefetch(rbs_handle* h, const double* poses, int32_t* indices, int32_t n, int32_t update, double* out_loglik,
@@ -2271,7 +2396,7 @@ int32_t rbs_set_observation_prefetched(rbs_handle* h)
 }
 
 static int32_t loglikes_impl(rbs_handle* h, const double* poses, int32_t* indices, int32_t n, int32_t update, double* out_loglik,
-                             const float* next_depth)
+                             const float* next_depth, const DeltaArgs* da)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
     RBS_REFUSE_POISONED(h);
@@ -2281,7 +2406,7 @@ static int32_t loglikes_impl(rbs_handle* h, const double* poses, int32_t* indice
     if (n == 0) return RBS_OK;
     if (!poses || !indices || !out_loglik)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, "loglikes: null pointer");
-    if (!h->shards.empty()) return group_loglikes(h, poses, indices, n, update, out_loglik);
+    if (!h->shards.empty()) return group_loglikes(h, poses, indices, n, update, out_loglik, da);
     const int32_t slots_total = h->peer_world > 1 ? h->peer_world * h->max_particles : h->max_particles;   // (attached: parents are global slots)
     for (int32_t i = 0; i < n; ++i)
         if (indices[i] < 0 || indices[i] >= slots_total)
@@ -2292,9 +2417,12 @@ static int32_t loglikes_impl(rbs_handle* h, const double* poses, int32_t* indice
     // the call waits for the log-likelihoods only -- the occlusion planes are finished by the second
     // stream and joined by the next call
     const CallState before = save_call_state(h);
-    if (int32_t rc = host_call(h, poses, indices, n, update != 0)) return rc;
-    if (next_depth)   // the next frame travels while this call's kernels run
-        if (int32_t rc = prefetch_frame(h, next_depth)) return rc;
+    if (next_depth)   // refused before anything is enqueued: the planes, the indices and the staging images stay as they are
+        if (int32_t rc = prefetch_check(h)) return rc;
+    if (int32_t rc = host_call(h, poses, indices, n, update != 0, da)) return rc;
+    // the next frame travels while this call's kernels run; should the upload itself fail (a runtime error), the
+    // likelihood call is still completed -- results copied, indices rewritten -- and the error reported after it
+    const int32_t prefetch_rc = next_depth ? prefetch_frame(h, next_depth) : RBS_OK;
     RBS_HIP(h, hipEventSynchronize(h->ev_out));
     const bool stale_overflow = h->slab_px && h->h_err[2] != 0;   // of an earlier asynchronous call: reported below, once
     if (h->slab_px && h->h_err[0]) {
@@ -2304,7 +2432,7 @@ static int32_t loglikes_impl(rbs_handle* h, const double* poses, int32_t* indice
         if (int32_t rc = drain(h, true)) return rc;
         restore_call_state(h, before);
         if (int32_t rc = slab_housekeeping(h)) return rc;
-        if (int32_t rc = host_call(h, poses, indices, n, update != 0)) return rc;
+        if (int32_t rc = host_call(h, poses, indices, n, update != 0, da)) return rc;
         RBS_HIP(h, hipEventSynchronize(h->ev_out));
         if (h->h_err[0]) return check_slab_error(h);   // (cannot happen: a region is never larger than the frame)
     }
@@ -2321,7 +2449,7 @@ static int32_t loglikes_impl(rbs_handle* h, const double* poses, int32_t* indice
         h->h_err[0] = 0;
         return rc;
     }
-    return RBS_OK;
+    return prefetch_rc;   // (its message is rbs_last_error's: nothing above overwrote it on the way here)
 }
 
 int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t* d_indices,
@@ -2580,8 +2708,19 @@ int32_t rbs_import_window(rbs_handle* h, int32_t slot, const int32_t rect[4], co
         return RBS_OK;
     }
     if (h->slab_px) {
-        if (!empty && (long)w * hh > (long)h->slab_px)
-            return fail(h, RBS_ERR_OUT_OF_MEMORY, fmt("import_window: a window of %d x %d values does not fit a slab of %d px (state_slab_px)", w, hh, h->slab_px));
+        if (!empty && (long)w * hh > (long)h->slab_px) {
+            // a window handed in from a handle whose slabs have already grown (every rank enlarges its slabs on its own
+            // schedule: ADVICE r4): the slabs grow here as they do behind rbs_import_plane / rbs_set_occlusion (slab_store)
+            // -- on a handle of its own; the shards of a group and attached ranks keep one size among them
+            if (h->group || h->peer_world > 1)
+                return fail(h, RBS_ERR_OUT_OF_MEMORY, fmt("import_window: a window of %d x %d values does not fit a slab of %d px (state_slab_px)", w, hh, h->slab_px));
+            if (int32_t rc = drain(h, true)) return rc;
+            RBS_HIP(h, hipStreamSynchronize(s));   // (earlier imports on the caller's stream wrote into the buffers about to be replaced)
+            if (int32_t rc = grow_slabs(h, slab_for(h, (int)std::min<long>((long)w * hh, h->npx)))) return rc;
+            if ((long)w * hh > (long)h->slab_px)
+                return fail(h, RBS_ERR_OUT_OF_MEMORY, fmt("import_window: a window of %d x %d values does not fit a slab of %d px (state_slab_px)", w, hh, h->slab_px));
+            dst = h->d_occ[h->cur] + (size_t)slot * h->plane_stride;
+        }
         if (!empty)   // the slot's stored region becomes the window itself, packed
             RBS_HIP(h, hipMemcpyAsync(dst, d_payload, sizeof(float) * (size_t)w * (size_t)hh, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_reg[h->cur] + slot, 1, r);

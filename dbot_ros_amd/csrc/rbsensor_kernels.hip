@@ -223,6 +223,12 @@ struct DevParams {
     int* ctr_next;                 // [2] ... and the next call's, zeroed by this call's raster kernel
     double* partial;               // [items] partial log-likelihood per work item
     int* done;                     // [n] finished work items per particle (the last one sums them)
+    // Split launch (rbs_depth_kernel -> rbs_eval_kernel, round 5): the depth tile of work item k, handed from the
+    // geometry kernel to the likelihood kernel through memory (L2 / MALL sized: ~23 KB per C1 item).
+    unsigned* depth;               // [depth_items][tile_px] order-preserving float bits, kInfBits = not covered
+    int depth_items;               // items the buffer holds (an item beyond it is contained: its particle's sum is NaN)
+    int* ctrb_this;                // [1] the likelihood kernel's ticket counter of this call ...
+    int* ctrb_next;                // ... and the next call's, zeroed by this call's geometry kernel
 #ifdef RBS_PHASE_TIMING
     unsigned long long* phase;     // [32] accumulated wave-0 cycles per phase and event counts (profiling builds only)
 #endif
@@ -1190,9 +1196,9 @@ __device__ inline Smem carve(unsigned char* smem, int kTilePx, bool math_tables)
 
 // One (particle, tile) work item: rasterize the tile window, evaluate its pixels, return the
 // block-reduced partial log-likelihood (valid in thread 0).
-template <bool UPDATE, int PREC, bool SLAB, bool MANY = false>
+template <bool UPDATE, int PREC, bool SLAB, bool MANY = false, int PHASE = 0>
 __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect r, int tile_id,
-                                          const Smem& m, unsigned body_mask, bool draw, int& ticket)
+                                          const Smem& m, unsigned body_mask, bool draw, int& ticket, const unsigned* gtile = nullptr)
 {
     const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
     const int ty = tile_id / tg.nx, tx = tile_id - ty * tg.nx;
@@ -1212,6 +1218,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
 
     RBS_TICK_DECL;
     // a rectangle that is a single tile was sized from the same spheres: nothing to cull
+    if (PHASE == 0)
     raster_window<MANY>(P, pose, wx0, wy0, wx1, wy1, !whole || (body_mask & (body_mask - 1u)) != 0u, m.tile, m.big, m.nbig,
                   m.evalq + (threadIdx.x >> 6) * kQPlanes * kEvalQueue, body_mask, m.cull);   // the eval queue is idle during the raster phase
     RBS_TICK(2);
@@ -1283,7 +1290,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
         const int qstep = kBlock / tq, rstep = kBlock - qstep * tq;
         int lr = (int)threadIdx.x / tq;
         int qc = (int)threadIdx.x - lr * tq;
-        const uint4* __restrict__ tile4 = reinterpret_cast<const uint4*>(m.tile);
+        const uint4* __restrict__ tile4 = reinterpret_cast<const uint4*>(PHASE == 2 ? gtile : m.tile);
         // kScanUnroll quads per lane per trip: all their loads (the parent's values come from HBM --
         // another call wrote them -- and a dependent load per trip left the phase latency bound:
         // 13 % of the kernel) are issued before the first is used
@@ -1353,7 +1360,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                 const int lr = p / tw;
                 const int gy = wy0 + lr, gx = wx0 + (p - lr * tw);
                 gi = gy * P.cols + gx;
-                dbits = m.tile[p];
+                dbits = PHASE == 2 ? gtile[p] : m.tile[p];
                 const bool stored = gx >= pw.x && gx < pw.z && gy >= pw.y && gy < pw.w;
                 if (stored && (UPDATE || dbits != kInfBits)) sv = src[gi];
                 if (dbits != kInfBits) ov = P.frame[gi];
@@ -1788,6 +1795,186 @@ template <bool UPDATE, bool SLAB>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_kernel_many_f64(const DevParams P)
 {
     raster_kernel_body<UPDATE, 0, SLAB, true>(P);
+}
+
+// ------------------------------------------------------------------ split launch (round 5)
+// The same work as rbs_raster_kernel_f64 in TWO kernels, each with a register budget and an occupancy of its own:
+//   rbs_depth_kernel   persistent; per work item cluster cull + triangle setup + sample loops into the LDS depth tile
+//                      (raster_window, unchanged: depth stays bit-exact), then the tile is written to P.depth.  Carries
+//                      neither the likelihood's registers nor its math tables nor the evaluation rings: four blocks
+//                      per CU (4 waves per SIMD) where the monolith has three.  Needs no frame: a host frame travels
+//                      while it runs.
+//   rbs_eval_kernel    per work item the pixel pass of raster_eval_tile with the tile read from P.depth (L2 / MALL):
+//                      occlusion process, compaction of covered + observed pixels, the binary64 likelihood 64 pixels
+//                      at a time, block reduce, plane write.  15 KB of LDS and a small register budget: 5-6 waves per
+//                      SIMD hide the 32-byte gather and the exp / erfc / log chains that three waves do not.
+#ifndef RBS_SPLIT_DEFAULT
+#define RBS_SPLIT_DEFAULT 0         // what a handle does when RBS_SPLIT is not in the environment
+#endif
+#ifndef RBS_DEPTH_TILE_PX
+#define RBS_DEPTH_TILE_PX 7680      // 30 KB + rings: what fits a CU four times (LDS is granted in 1 280-byte steps)
+#endif
+#ifndef RBS_DEPTH_MINWAVES
+#define RBS_DEPTH_MINWAVES 4
+#endif
+#ifndef RBS_DEPTH_VGPRS
+#define RBS_DEPTH_VGPRS 60          // 120 registers: four waves per SIMD and 32 left for one wave of the windowed copy kernel
+#endif
+#ifndef RBS_EVAL_MINWAVES
+#define RBS_EVAL_MINWAVES 5
+#endif
+constexpr int kDepthTilePx = RBS_DEPTH_TILE_PX;
+struct SmemDepth { unsigned* tile; int* big; int* nbig; int* item; int* tq; unsigned long long* cull; };
+__device__ inline SmemDepth carve_depth(unsigned char* smem, int tile_px)
+{
+    SmemDepth m;
+    m.tile = reinterpret_cast<unsigned*>(smem);
+    m.big = reinterpret_cast<int*>(smem + sizeof(unsigned) * tile_px);
+    m.nbig = m.big + kBigCap;
+    m.item = m.nbig + 1;
+    m.tq = m.nbig + 4;                                   // per wave: kTq triangle indices
+    m.cull = reinterpret_cast<unsigned long long*>(m.tq + kTq * (kBlock / 64));
+    return m;
+}
+constexpr size_t smem_bytes_depth(int tile_px, bool many)
+{
+    return sizeof(unsigned) * (size_t)tile_px + sizeof(int) * kBigCap + 16 + sizeof(int) * kTq * (kBlock / 64) + (many ? 16 * kCullSteps : 0);
+}
+static_assert(RBS_DEPTH_MINWAVES * ((smem_bytes_depth(kDepthTilePx, true) + 1279) / 1280 * 1280) <= 160 * 1024, "the geometry kernel's blocks per CU");
+
+template <bool MANY>
+__device__ __forceinline__ void depth_kernel_body(const DevParams& P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SmemDepth m = carve_depth(smem, P.tile_px);
+    const int total = P.ctr_this[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr_next[0] = 0; P.ctr_next[1] = 0; *P.ctrb_next = 0; }
+    const int grid = (int)gridDim.x;
+    int item = (int)blockIdx.x;   // the first round is dealt statically, the rest through the ticket counter (as in the monolith)
+    for (;;) {
+        if (item >= total) break;
+        const int particle = __builtin_amdgcn_readfirstlane(P.item_particle[item]);
+        const int first = P.item_range[particle].x;
+        Rect r;
+        unsigned body_mask = 0xffffffffu;
+        int tile_id = item - first;
+        bool have;
+        if (P.groups == nullptr) {
+            const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
+            r = Rect{q.x, q.y, q.z, q.w};
+            have = r.x1 > r.x0;
+        } else {
+            const Groups* G = P.groups + particle;
+            const int ng = __builtin_amdgcn_readfirstlane(G->n);
+            int g = 0;
+            for (int c = 1; c < ng; ++c) g += (tile_id >= __builtin_amdgcn_readfirstlane(G->first[c])) ? 1 : 0;
+            have = ng > 0;
+            r = Rect{0, 0, 0, 0};
+            if (have) {
+                const int4 gq = G->rect[g];
+                r = Rect{__builtin_amdgcn_readfirstlane(gq.x), __builtin_amdgcn_readfirstlane(gq.y),
+                         __builtin_amdgcn_readfirstlane(gq.z), __builtin_amdgcn_readfirstlane(gq.w)};
+                tile_id -= __builtin_amdgcn_readfirstlane(G->first[g]);
+                body_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)G->mask[g]);
+            }
+        }
+        const int parent = P.parents[particle];
+        if (have && (unsigned)parent < (unsigned)P.slots && item < P.depth_items) {
+            const TileGrid tg = tile_grid(r.x1 - r.x0, r.y1 - r.y0, P.tile_w, min(P.tile_w * P.tile_h, P.tile_px));
+            const int ty = tile_id / tg.nx, tx = tile_id - ty * tg.nx;
+            const int wx0 = r.x0 + tx * tg.tw, wy0 = r.y0 + ty * tg.th;
+            const int wx1 = min(r.x1, wx0 + tg.tw), wy1 = min(r.y1, wy0 + tg.th);
+            const int npx = (wx1 - wx0) * (wy1 - wy0);
+            const bool whole = (wx0 == r.x0 && wy0 == r.y0 && wx1 == r.x1 && wy1 == r.y1);
+            const double* pose = P.poses + (size_t)particle * 12 * P.n_bodies;
+            raster_window<MANY>(P, pose, wx0, wy0, wx1, wy1, !whole || (body_mask & (body_mask - 1u)) != 0u, m.tile, m.big, m.nbig,
+                                m.tq + (threadIdx.x >> 6) * kTq, body_mask, m.cull);
+            // the tile leaves through 16-byte stores (rectangles move in float4 columns whenever cols % 4 == 0)
+            unsigned* __restrict__ out = P.depth + (size_t)item * P.tile_px;
+            if ((npx & 3) == 0) {
+                const uint4* __restrict__ t4 = reinterpret_cast<const uint4*>(m.tile);
+                uint4* __restrict__ o4 = reinterpret_cast<uint4*>(out);
+                for (int k = threadIdx.x; k < (npx >> 2); k += kBlock) o4[k] = t4[k];
+            } else {
+                for (int k = threadIdx.x; k < npx; k += kBlock) out[k] = m.tile[k];
+            }
+        }
+        if (threadIdx.x == 0) *m.item = grid + atomicAdd(&P.ctr_this[1], 1);
+        __syncthreads();   // (also: the tile has been read before the next item clears it)
+        item = __builtin_amdgcn_readfirstlane(*m.item);
+        __syncthreads();   // (... and read by everybody before thread 0 writes the next one)
+    }
+}
+template <bool MANY>
+__global__ __launch_bounds__(kBlock, RBS_DEPTH_MINWAVES) __attribute__((amdgpu_num_vgpr(RBS_DEPTH_VGPRS)))
+void rbs_depth_kernel(const DevParams P)
+{
+    depth_kernel_body<MANY>(P);
+}
+
+// The likelihood half.  Block per work item (first round dealt statically, then tickets); the particle's sum as in
+// the monolith: its only item's, or the items' partial sums added in item order by whoever finishes last.
+template <bool UPDATE, bool SLAB>
+__global__ __launch_bounds__(kBlock, RBS_EVAL_MINWAVES) void rbs_eval_kernel(const DevParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Smem m = carve(smem, 0, true);
+    const int total = P.ctr_this[0];
+    {
+        constexpr int ne = rbsm::kErfcIntervals * rbsm::kErfcCoefs, nl = rbsm::kLogIntervals * 2;
+        for (int i = threadIdx.x; i < ne; i += kBlock) m.mtab[i] = rbsm::kErfcTab[i];
+        for (int i = threadIdx.x; i < nl; i += kBlock) m.mtab[ne + i] = rbsm::kLogTab[i];
+    }
+    __syncthreads();
+    const int grid = (int)gridDim.x;
+    int item = (int)blockIdx.x;
+    for (;;) {
+        if (item >= total) break;
+        const int particle = __builtin_amdgcn_readfirstlane(P.item_particle[item]);
+        const int2 range = P.item_range[particle];
+        const int first = range.x;
+        double part = 0.0;
+        int ticket = -1;
+        const unsigned* gtile = P.depth + (size_t)item * P.tile_px;
+        if (item >= P.depth_items) {
+            part = NAN;   // (the hand-over buffer was sized for fewer items: contained like a bad parent slot)
+        } else if (P.groups == nullptr) {
+            const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
+            const Rect r = {q.x, q.y, q.z, q.w};
+            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, 0, SLAB, false, 2>(P, particle, r, item - first, m, 0xffffffffu, false, ticket, gtile);
+        } else {
+            const Groups* G = P.groups + particle;
+            const int k = item - first, ng = __builtin_amdgcn_readfirstlane(G->n);
+            int g = 0;
+            for (int c = 1; c < ng; ++c) g += (k >= __builtin_amdgcn_readfirstlane(G->first[c])) ? 1 : 0;
+            if (ng > 0) {
+                const int4 gq = G->rect[g];
+                const Rect gr = {__builtin_amdgcn_readfirstlane(gq.x), __builtin_amdgcn_readfirstlane(gq.y),
+                                 __builtin_amdgcn_readfirstlane(gq.z), __builtin_amdgcn_readfirstlane(gq.w)};
+                part = raster_eval_tile<UPDATE, 0, SLAB, false, 2>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
+                                                                   (unsigned)__builtin_amdgcn_readfirstlane((int)G->mask[g]), false, ticket, gtile);
+            }
+        }
+        if (threadIdx.x == 0) {
+            const int cnt = range.y;
+            if (cnt == 1) {
+                P.out[particle] = part;
+            } else {   // (see raster_kernel_body: partial sums through device-scope atomics, added in item order)
+                unsigned long long* pp = reinterpret_cast<unsigned long long*>(P.partial);
+                const unsigned long long old = atomicExch(pp + item, (unsigned long long)__double_as_longlong(part));
+                const int bump = old == 0xfff8deadbeef0000ull ? 2 : 1;
+                if (atomicAdd(&P.done[particle], bump) == cnt - 1) {
+                    double sum = 0.0;
+                    for (int k = 0; k < cnt; ++k) sum += __longlong_as_double((long long)atomicOr(pp + first + k, 0ull));
+                    P.out[particle] = sum;
+                }
+            }
+            *m.item = grid + atomicAdd(P.ctrb_this, 1);
+        }
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(*m.item);
+        __syncthreads();
+    }
 }
 
 template <int VEC>

@@ -384,6 +384,13 @@ class PeerShardedStep:
         self.fused = fused
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.N = self.world * n
+        # ONE stream carries the whole step: the library calls (loglikes_device, stream_join, peer_resample,
+        # stage_windows) and torch's operations (the all-gather, global_resample / plan_shard) must be ordered among
+        # themselves -- the all-gather reads what the raster kernel writes, the next step reads the plan.  On a device
+        # the default is therefore torch's CURRENT stream (what torch's own operations are issued on), never the
+        # handle's private stream; a caller that passes a stream must run its torch operations under it.
+        if stream is None and device is not None and torch.device(device).type == "cuda":
+            stream = torch.cuda.current_stream(torch.device(device)).cuda_stream
         self.stream = stream
         self.d_out = torch.zeros(n, dtype=torch.float64, device=device)
         self.d_all = torch.zeros(self.N, dtype=torch.float64, device=device)

@@ -269,6 +269,29 @@ class RbSensor:
         poses = compose_with_default(deltas, self.integrated_poses, self.n_bodies)
         return self.loglikes_poses(poses, indices, update)
 
+    def loglikes_deltas(self, deltas, indices, update=False):
+        """The same call with the composition delta (+) default pose done by the LIBRARY on the device
+        (rbs_loglikes_deltas: what the dbot binding calls).  deltas: [n, n_bodies*12] as for loglikes()."""
+        d = np.ascontiguousarray(deltas, dtype=np.float64).reshape(-1, self.n_bodies * 12)
+        n = d.shape[0]
+        dflt = np.ascontiguousarray(self.integrated_poses, dtype=np.float64).reshape(self.n_bodies * 12)
+        if not (isinstance(indices, np.ndarray) and indices.dtype == np.int32
+                and indices.flags.c_contiguous and indices.size == n):
+            raise RbSensorError(_capi.RBS_ERR_INVALID_ARGUMENT,
+                                "indices must be a contiguous int32 array of length n")
+        out = np.empty(n, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.rbs_loglikes_deltas(
+            self._h, d.ctypes.data_as(dp), dflt.ctypes.data_as(dp), 12,
+            indices.ctypes.data_as(C.POINTER(C.c_int32)), n, int(bool(update)), out.ctypes.data_as(dp)))
+        return out
+
+    def get_poses(self, n):
+        """The absolute poses [n, n_bodies, 12] the last host-pointer likelihood call evaluated (test hook)."""
+        out = np.empty((n, self.n_bodies, 12), dtype=np.float64)
+        self._check(self._lib.rbs_get_poses(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), n))
+        return out
+
     def loglikes_poses(self, poses, indices, update=False):
         """poses: absolute R|t, [n, n_bodies, 12]."""
         poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, self.n_bodies * 12)

@@ -83,6 +83,13 @@ enum { RBS_STATE_DEFAULT = 0, RBS_STATE_WINDOWED = 1, RBS_STATE_DENSE = 2 };
 
 typedef struct rbs_handle rbs_handle;
 
+/* kinect.tail_weight = 0 is accepted, as the reference accepts it (it passes the ROS parameter through
+ * unchecked, R:source/dbot_ros/tracker/particle_tracker_node.cpp:183-184), but evaluated as this floor: the
+ * library's binary64 erfc / exp are accurate to 1e-16 ABSOLUTE, which is exact next to tw / max_depth for any
+ * tw >= 1e-9 and would not be in a mixture without a tail.  Observable difference: pixels the exact tw = 0
+ * model prices at log(0) = -inf contribute log(1.7e-10 / p_bg) ~ -22 each instead. */
+#define RBS_TAIL_WEIGHT_FLOOR 1e-9
+
 typedef struct rbs_config {
     int32_t abi_version;            /* RBS_ABI_VERSION                                        */
     int32_t device_id;              /* HIP device ordinal                                      */
@@ -101,7 +108,7 @@ typedef struct rbs_config {
     double p_occluded_visible;
     double p_occluded_occluded;
     double initial_occlusion_prob;
-    double tail_weight;
+    double tail_weight;             /* 0 <= tw < 1; below RBS_TAIL_WEIGHT_FLOOR it is evaluated AS the floor (see above) */
     double model_sigma;
     double sigma_factor;
     double delta_time;
@@ -224,6 +231,30 @@ int32_t rbs_set_observation_prefetched(rbs_handle* h);
 int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t* d_indices,
                             int32_t n, int32_t update, double* d_out_loglik, void* stream);
 
+/* RbSensor::loglikes(deltas, indices, update) WITH THE ARGUMENTS THE FILTER PASSES (round 5): the particles' state
+ * DELTAS around the sensor's default ("integrated") poses, not absolute poses -- what dbot's filter hands the
+ * sensor inside tracker_->track(image) (R:source/dbot_ros/object_tracker_ros.hpp:49; the State of
+ * R:source/dbot_ros/object_tracker_ros.h:40-41, read per body through component(i) as at .hpp:54-60).  The
+ * composition of SURVEY A.1,
+ *     R = R(delta rotation vector) R(default rotation vector),   t = t(delta) + t(default),
+ * rotation vector -> matrix through the unit quaternion, runs on the device in one small kernel in front of the
+ * rectangles kernel (the operations and their order are oracle/tracker_oracle.c's trk_compose_pose; sin / cos /
+ * sqrt are the device library's, so a composed entry may differ from a host libm composition in its last bit:
+ * rbs_get_poses returns exactly what was evaluated).  On the host it costs two sin / cos / sqrt and a 3x3 product
+ * per particle and body -- 0.25 ms at 2 000 particles, more than the device step.
+ *   deltas         [n][n_objects][body_stride] doubles; of each body's body_stride (>= 6) values the first six are
+ *                  read: position (3), rotation ("Euler") vector (3).  body_stride = 12 takes an array of dbot
+ *                  FreeFloatingRigidBodiesState storage as it is (position, rotation vector, velocities).
+ *   default_poses  [n_objects][body_stride], same layout: the sensor's integrated_poses().
+ * Everything else -- indices in / out, update, out_loglik, errors, slabs -- as rbs_loglikes.  Single-device handles
+ * and handles over several devices. */
+int32_t rbs_loglikes_deltas(rbs_handle* h, const double* deltas, const double* default_poses, int32_t body_stride,
+                            int32_t* indices, int32_t n, int32_t update, double* out_loglik);
+/* Test / inspection hook: the absolute poses ([n][n_objects][12] doubles: R row-major, t) the handle's LAST
+ * host-pointer likelihood call evaluated -- for rbs_loglikes the caller's own, for rbs_loglikes_deltas the
+ * device's compositions.  Synchronises.  Single-device handles. */
+int32_t rbs_get_poses(rbs_handle* h, double* out, int32_t n);
+
 /* Block until everything enqueued on the handle's own stream has finished. */
 int32_t rbs_synchronize(rbs_handle* h);
 
@@ -288,8 +319,11 @@ int32_t rbs_import_plane(rbs_handle* h, int32_t slot, const void* d_src, void* s
  * with nothing copied, rect_out still valid so the caller can size the buffer).  Waits for the
  * rectangle (one 16-byte read-back); the payload copy is enqueued on `stream`.
  * rbs_import_window: the slot's plane becomes "background everywhere, these values inside rect"
- * (x0 and x1 multiples of 4, inside the frame); a slab that is too small for rect fails with
- * RBS_ERR_OUT_OF_MEMORY like rbs_import_plane.  Both layouts, whole planes and slabs.
+ * (x0 and x1 multiples of 4, inside the frame); a slab that is too small for rect is ENLARGED first, as
+ * behind rbs_import_plane (one drain of the handle; every rank grows its slabs on its own schedule, so a
+ * window from a rank that has grown must not be refused by one that has not) -- only the shards of a
+ * multi-device handle and handles attached to other ranks (rbs_ipc_attach), whose slabs are addressed with
+ * a fixed stride from outside, fail with RBS_ERR_OUT_OF_MEMORY.  Both layouts, whole planes and slabs.
  * Used by dbot_ros_amd/dist.py (one process per GPU) to migrate a parent's plane to the rank its
  * surplus children were placed on: an RCCL send / recv of rect + payload. */
 int32_t rbs_export_window(rbs_handle* h, int32_t slot, int32_t rect_out[4], void* d_payload, size_t capacity_floats, void* stream);

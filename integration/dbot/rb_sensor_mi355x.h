@@ -1,9 +1,9 @@
-// rb_sensor_mi355x.hpp -- the dbot-side binding of librbsensor_mi355x.so: an RbSensor<State>
+// rb_sensor_mi355x.h -- the dbot-side binding of librbsensor_mi355x.so: an RbSensor<State>
 // subclass that forwards the sensor's virtuals to the C-ABI of include/rbsensor_mi355x.h.
 //
 // THIS FILE IS NOT BUILT IN THIS REPOSITORY: it needs dbot, fl and Eigen 3.2, which the build
 // image does not have.  It belongs in a dbot checkout as
-// dbot/model/rb_sensor_mi355x.hpp; include/dbot_amd/rb_sensor_builder.hpp is the same binding
+// dbot/model/rb_sensor_mi355x.h; include/dbot_amd/rb_sensor_builder.hpp is the same binding
 // over std::vector stand-ins and IS compiled and tested here (tests/cpp/shim_check.cpp), so the
 // two differ only in the container types and in how a State exposes its poses.
 //
@@ -23,9 +23,11 @@
 #include <string>
 #include <vector>
 
-#include <dbot/camera_data.hpp>
-#include <dbot/object_model.hpp>
-#include <dbot/model/rb_sensor.hpp>
+// (dbot's headers are .h: R:source/dbot_ros/tracker/particle_tracker_node.cpp:22-26 includes <dbot/camera_data.h>,
+// <dbot/builder/particle_tracker_builder.h>, <dbot/tracker/particle_tracker.h>)
+#include <dbot/camera_data.h>
+#include <dbot/object_model.h>
+#include <dbot/model/rb_sensor.h>
 
 #include <rbsensor_mi355x.h>
 
@@ -54,7 +56,7 @@ public:
                    double p_occluded_visible, double p_occluded_occluded, double initial_occlusion_prob,
                    double tail_weight, double model_sigma, double sigma_factor, double delta_time,
                    const Options& options = Options())
-        : Base(object_model->count_parts()), parts_(object_model->count_parts())
+        : Base(object_model->count_parts()), parts_(object_model->count_parts()), defaults_(static_cast<size_t>(6) * object_model->count_parts())
     {
         std::vector<double> vertices;
         std::vector<int32_t> triangles, vertex_counts, triangle_counts;
@@ -105,24 +107,32 @@ public:
         check(rbs_set_observation(handle_, image.data(), static_cast<size_t>(image.size())));
     }
 
+    // deltas: the particles' states around integrated_poses().  The composition
+    //   R = R(delta) R(default),  t = t(delta) + t(default)
+    // is the library's (rbs_loglikes_deltas: one small kernel in front of the rectangles kernel), so all the
+    // host does per particle is gather six numbers per body out of the particle's own Eigen vector -- composing
+    // on the host costs two sin / cos / sqrt and a 3x3 product per particle and body, 0.25 ms at 2 000 particles:
+    // more than the whole device step.
     RealArray loglikes(const StateArray& deltas, IntArray& indices, const bool& update = false) override
     {
         const int n = static_cast<int>(deltas.size());
-        poses_.resize(static_cast<size_t>(12) * n * parts_);
+        deltas_.resize(static_cast<size_t>(6) * n * parts_);
         for (int i = 0; i < n; ++i)
             for (int part = 0; part < parts_; ++part)
             {
-                // absolute pose = delta (+) default pose
-                double* out = &poses_[12 * (static_cast<size_t>(i) * parts_ + part)];
-                Eigen::Map<Eigen::Matrix<double, 3, 3, Eigen::RowMajor>> R(out);
-                R = deltas[i].component(part).orientation().rotation_matrix() *
-                    this->integrated_poses().component(part).orientation().rotation_matrix();
-                Eigen::Map<Eigen::Vector3d>(out + 9) =
-                    deltas[i].component(part).position() + this->integrated_poses().component(part).position();
+                double* out = &deltas_[6 * (static_cast<size_t>(i) * parts_ + part)];
+                const auto block = deltas[i].component(part);
+                for (int k = 0; k < 3; ++k) { out[k] = block.position()(k); out[3 + k] = block.orientation()(k); }
             }
+        for (int part = 0; part < parts_; ++part)
+        {
+            const auto block = this->integrated_poses().component(part);
+            for (int k = 0; k < 3; ++k) { defaults_[6 * part + k] = block.position()(k); defaults_[6 * part + 3 + k] = block.orientation()(k); }
+        }
         RealArray ll(n);
         static_assert(sizeof(int) == sizeof(int32_t), "IntArray holds 32-bit slots");
-        check(rbs_loglikes(handle_, poses_.data(), reinterpret_cast<int32_t*>(indices.data()), n, update ? 1 : 0, ll.data()));
+        check(rbs_loglikes_deltas(handle_, deltas_.data(), defaults_.data(), 6, reinterpret_cast<int32_t*>(indices.data()), n,
+                                  update ? 1 : 0, ll.data()));
         return ll;
     }
 
@@ -133,7 +143,7 @@ private:
     }
     rbs_handle* handle_ = nullptr;
     int parts_;
-    std::vector<double> poses_;
+    std::vector<double> deltas_, defaults_;
     std::vector<int32_t> devices_;
 };
 }  // namespace dbot

@@ -115,6 +115,8 @@ void orc_reset_mt(orc_sensor* s, int32_t n_threads);
 
 /* ---- tracker_oracle.c: transition + RBC filter step + tracker mean ---- */
 typedef struct orc_tracker orc_tracker;
+/* absolute poses from state deltas around default poses; see tracker_oracle.c */
+void orc_compose_poses(const double* deltas, const double* deflt, int32_t stride, int32_t n, int32_t parts, double* out);
 orc_tracker* orc_tracker_create(orc_sensor* s, int32_t parts, int32_t n, const double* sigma6,
                                 double velocity_factor, double max_kl_divergence);
 void orc_tracker_destroy(orc_tracker* t);

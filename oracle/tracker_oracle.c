@@ -70,6 +70,26 @@ static void matmul3(const double* A, const double* B, double* C)
             C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
 }
 
+/* The sensor's pose composition on its own: absolute pose = delta (+) default,
+ *   R = R(delta rotation vector) R(default rotation vector),  t = t(delta) + t(default),
+ * for n particles x parts bodies; deltas [n][parts][stride], deflt [parts][stride] (position, rotation vector first),
+ * out [n][parts][12] = R row-major, t.  What RbSensor::loglikes does with the deltas the filter hands it
+ * (R:source/dbot_ros/object_tracker_ros.hpp:49); the checker of rbs_loglikes_deltas' device composition. */
+void orc_compose_poses(const double* deltas, const double* deflt, int32_t stride, int32_t n, int32_t parts, double* out)
+{
+    for (int32_t i = 0; i < n; ++i)
+        for (int32_t b = 0; b < parts; ++b) {
+            const double* d = deltas + ((size_t)i * parts + b) * stride;
+            const double* d0 = deflt + (size_t)b * stride;
+            double Rd[9], R0[9];
+            double* o = out + ((size_t)i * parts + b) * 12;
+            rotvec_to_matrix(d + 3, Rd);
+            rotvec_to_matrix(d0 + 3, R0);
+            matmul3(Rd, R0, o);
+            for (int k = 0; k < 3; ++k) o[9 + k] = d[k] + d0[k];
+        }
+}
+
 orc_tracker* orc_tracker_create(orc_sensor* s, int32_t parts, int32_t n, const double* sigma6, double vf,
                                 double max_kl)
 {

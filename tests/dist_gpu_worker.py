@@ -1,4 +1,7 @@
-"""Spawned by tests/test_gpu_parity.py::test_two_rank_sharding_on_one_gpu."""
+"""Spawned by tests/test_gpu_parity.py::test_two_rank_sharding_on_one_gpu.
+argv: port [slab_px]: the ranks' handles store their planes in slabs of slab_px floats (0 = whole planes) -- small enough
+and every rank enlarges its slabs on its own schedule, so a migrating window may meet a receiver whose slabs are still
+smaller (rbs_import_window grows them: ADVICE r4)."""
 import os
 import sys
 
@@ -47,13 +50,13 @@ def single():
     return out
 
 
-def worker(rank, world, port, q):
+def worker(rank, world, port, q, slab_px=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         om, cam, P, frames, poses, uniforms = inputs()
         bounds = rdist.shard_bounds(N, world)
-        with RbSensor(om, cam, P, max_particles=2 * int(np.diff(bounds).max())) as s:
+        with RbSensor(om, cam, P, max_particles=2 * int(np.diff(bounds).max()), slab_px=slab_px) as s:
             ss = rdist.ShardedSensor(s, N)
             ss.reset()
             res, moves = [], 0
@@ -70,10 +73,11 @@ def worker(rank, world, port, q):
 
 if __name__ == "__main__":
     port = int(sys.argv[1])
+    slab_px = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     ref = single()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q, slab_px)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in procs]

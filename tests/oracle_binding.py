@@ -68,6 +68,8 @@ def load():
         lib.orc_background.argtypes = [H]
         lib.orc_eager_prior.restype = C.c_float
         lib.orc_eager_prior.argtypes = [C.c_float] * 4
+        lib.orc_compose_poses.restype = None
+        lib.orc_compose_poses.argtypes = [dp, dp, C.c_int32, C.c_int32, C.c_int32, dp]
         lib.orc_tracker_create.restype = H
         lib.orc_tracker_create.argtypes = [H, C.c_int32, C.c_int32, dp, C.c_double, C.c_double]
         lib.orc_tracker_destroy.argtypes = [H]
@@ -76,6 +78,17 @@ def load():
         lib.orc_tracker_get.argtypes = [H, dp, dp, ip]
         _lib = lib
     return _lib
+
+
+def compose_poses(deltas, default, parts):
+    """oracle/tracker_oracle.c orc_compose_poses: deltas [n, parts*12] around default [parts*12] -> [n, parts, 12] (R|t)."""
+    lib = load()
+    d = np.ascontiguousarray(deltas, dtype=np.float64).reshape(-1, parts * 12)
+    d0 = np.ascontiguousarray(default, dtype=np.float64).reshape(parts * 12)
+    out = np.empty((d.shape[0], parts, 12), dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    lib.orc_compose_poses(d.ctypes.data_as(dp), d0.ctypes.data_as(dp), 12, d.shape[0], parts, out.ctypes.data_as(dp))
+    return out
 
 
 class Oracle:

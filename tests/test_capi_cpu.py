@@ -82,9 +82,9 @@ def test_invalid_models_rejected():
         RbSensor(om, cam, P2, max_particles=4)
     assert e.value.code == _capi.RBS_ERR_INVALID_ARGUMENT
     for field, value in (("model_sigma", 0.0), ("model_sigma", float("nan")), ("sigma_factor", -1e-3), ("tail_weight", 1.0),
-                         ("tail_weight", -0.1), ("tail_weight", 0.0)):   # (0: the far tails would be priced by erfc's absolute floor)
+                         ("tail_weight", -0.1), ("tail_weight", float("nan"))):   # (0 is accepted, as the reference accepts it: test_gpu_parity)
         P3 = RbSensorBuilder.Parameters(sample_count=4)
-        setattr(P3.kinect, field, value)          # a density needs sigma > 0 and a mixture weight in (0, 1)
+        setattr(P3.kinect, field, value)          # a density needs sigma > 0 and a mixture weight in [0, 1)
         with pytest.raises(RbSensorError) as e:
             RbSensor(om, cam, P3, max_particles=4)
         assert e.value.code == _capi.RBS_ERR_INVALID_ARGUMENT, (field, value)

@@ -11,6 +11,7 @@ import scenarios as sc
 from dbot_ros_amd import CameraData, ObjectModel, RbSensorBuilder, pose, synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 BIN = os.path.join(HERE, "cpp", "shim_check")
 
 
@@ -68,6 +69,27 @@ def _scene(tmp_path):
             f.write(" ".join(repr(float(x)) for x in d) + "\n")
         f.write(" ".join("nan" if np.isnan(x) else repr(float(x)) for x in frame) + "\n")
     return path, o, default, deltas, frame, n
+
+
+def test_dbot_binding_compiles():
+    """integration/dbot/rb_sensor_mi355x.h -- the RbSensor<State> subclass a dbot maintainer adds -- type-checks against
+    STAND-IN dbot / fl / Eigen headers (tests/cpp/stubs/, labelled as such; the real ones are not in the build image), with
+    the include names the reference itself uses (<dbot/...>.h, R:source/dbot_ros/tracker/particle_tracker_node.cpp:22-26):
+    the file cannot rot unnoticed (VERDICT r4 #7).  Compile-only."""
+    import subprocess
+    root = ROOT
+    binding = os.path.join(root, "integration", "dbot", "rb_sensor_mi355x.h")
+    txt = open(binding).read()
+    assert "#include <dbot/camera_data.h>" in txt and "#include <dbot/object_model.h>" in txt and "#include <dbot/model/rb_sensor.h>" in txt
+    assert ".hpp>" not in txt
+    r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Wextra", "-I" + os.path.join(root, "tests", "cpp", "stubs"),
+                        "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "integration"),
+                        os.path.join(root, "tests", "cpp", "dbot_binding_check.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # INTEGRATION.md section 2 shows this very file (not a paraphrase that can drift)
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    body = txt[txt.index("#pragma once"):]
+    assert body.strip() in md, "INTEGRATION.md section 2 must quote integration/dbot/rb_sensor_mi355x.h verbatim (tools/sync_integration_md.py)"
 
 
 def test_cpp_shim_builds_and_fails_loudly_without_gpu(tmp_path):

@@ -378,16 +378,20 @@ def test_filter_resampling_indices_match_oracle(gpu_lib):
         assert n_resampled >= 2
 
 
-def test_two_rank_sharding_on_one_gpu(gpu_lib, tmp_path):
+@pytest.mark.parametrize("slab_px", [0, 256])
+def test_two_rank_sharding_on_one_gpu(gpu_lib, tmp_path, slab_px, state_layout):
     """dbot_ros_amd.dist.ShardedSensor over two processes (gloo rendezvous, both on cuda:0)
     with the PRODUCT sensor: log-likelihoods and parents equal the single-handle run, planes
-    migrate across ranks through rbs_get_occlusion / rbs_set_occlusion."""
+    migrate across ranks as windows (rbs_export_window / rbs_import_window).  slab_px = 256: the ranks'
+    handles start with slabs smaller than the object's region and enlarge them on their own schedules."""
     import subprocess
     import sys
     import os
+    if slab_px and state_layout == "dense":
+        pytest.skip("slabs are a windowed layout")
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_gpu_worker.py")
     port = 29700 + os.getpid() % 1000
-    r = subprocess.run([sys.executable, script, str(port)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, script, str(port), str(slab_px)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SHARDED_OK" in r.stdout
 

@@ -1,0 +1,253 @@
+"""Round 5: the plugin-surface call (deltas composed on the device), the split launch (geometry kernel ->
+depth tiles -> likelihood kernel), and the entry-point corners ADVICE r4 named."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scenarios as sc
+from dbot_ros_amd import RbSensor, RbSensorError, _capi, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_EAGER = 1e-9
+
+
+def rel_err(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+def _deltas(rng, n, parts, scale=1.0):
+    d = np.zeros((n, parts, 12))
+    d[:, :, 0:3] = rng.normal(0.0, 0.004 * scale, (n, parts, 3))
+    d[:, :, 3:6] = rng.normal(0.0, 0.03 * scale, (n, parts, 3))
+    d[:, :, 6:12] = rng.normal(0.0, 1.0, (n, parts, 6))    # velocities: must be ignored
+    d[0, :, 3:6] = 0.0                                       # the zero rotation (the series branch of sin(x)/x)
+    return d.reshape(n, parts * 12)
+
+
+@pytest.mark.parametrize("meshes,cols,rows", [(("m1",), 640, 480), (("m1_l2", "box12"), 320, 240)])
+def test_loglikes_deltas_composes_on_the_device(gpu_lib, meshes, cols, rows):
+    """rbs_loglikes_deltas = the filter's own arguments (state deltas + default poses,
+    R:source/dbot_ros/object_tracker_ros.hpp:49): the device's compositions agree with
+    oracle/tracker_oracle.c orc_compose_poses to the last bits (sin / cos / sqrt are the device library's),
+    and the log-likelihoods are those of the oracle fed with exactly the poses the device evaluated."""
+    parts, n = len(meshes), 48
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    o = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    frames = sc.make_frames(o, parts, 3, seed=3)
+    rng = np.random.default_rng(11)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64") as g:
+        g.reset(); o.reset()
+        ig, io = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for k, (truth, frame) in enumerate(frames):
+            # default pose = the truth as position + rotation vector (one body turned by almost pi: the large-angle branch)
+            from dbot_ros_amd import pose as ps
+            dflt = np.zeros((parts, 12))
+            for b in range(parts):
+                dflt[b, 0:3] = truth[b, 9:12]
+                dflt[b, 3:6] = ps.matrix_to_rotvec(truth[b, :9].reshape(3, 3))
+            g.integrated_poses = dflt.reshape(-1).copy()
+            d = _deltas(rng, n, parts, scale=1.0 + k)
+            g.set_observation(frame); o.set_observation(frame)
+            ll = g.loglikes_deltas(d, ig, update=True)
+            got = g.get_poses(n)
+            want = ob.compose_poses(d, dflt, parts)
+            assert np.abs(got - want).max() <= 4e-16 * max(1.0, np.abs(want).max()) * 4, np.abs(got - want).max()
+            ref = o.loglikes_poses(got, io, update=True)
+            assert rel_err(ll, ref).max() <= TOL_EAGER, rel_err(ll, ref).max()
+            # ... and next to the host composition the Python mirror performs: the same numbers to 1e-9
+            assert (ig == np.arange(n)).all()
+            w = np.exp(ll - ll.max())
+            ig = np.sort(rng.choice(n, size=n, p=w / w.sum())).astype(np.int32)
+            io = ig.copy()
+
+
+def test_loglikes_deltas_packed_stride_and_bad_arguments(gpu_lib):
+    n = 8
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    lib = _capi.load()
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    rng = np.random.default_rng(2)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64") as g:
+        truth = synth.truth_pose(1)
+        frame = synth.make_frame(g.render_depth(truth), 120, 160, rng)
+        from dbot_ros_amd import pose as ps
+        dflt12 = np.zeros(12); dflt12[0:3] = truth[0, 9:12]; dflt12[3:6] = ps.matrix_to_rotvec(truth[0, :9].reshape(3, 3))
+        g.integrated_poses = dflt12.copy()
+        d12 = _deltas(rng, n, 1)
+        g.reset(); g.set_observation(frame)
+        idx = np.zeros(n, np.int32)
+        a = g.loglikes_deltas(d12, idx.copy(), update=False)
+        # the same deltas packed six per body
+        d6 = np.ascontiguousarray(d12.reshape(n, 12)[:, :6]); f6 = np.ascontiguousarray(dflt12[:6])
+        out = np.empty(n)
+        rc = lib.rbs_loglikes_deltas(g._h, d6.ctypes.data_as(dp), f6.ctypes.data_as(dp), 6, idx.ctypes.data_as(ip), n, 0, out.ctypes.data_as(dp))
+        assert rc == 0 and np.array_equal(a, out)
+        rc = lib.rbs_loglikes_deltas(g._h, d6.ctypes.data_as(dp), f6.ctypes.data_as(dp), 5, idx.ctypes.data_as(ip), n, 0, out.ctypes.data_as(dp))
+        assert rc == _capi.RBS_ERR_INVALID_ARGUMENT
+        rc = lib.rbs_loglikes_deltas(g._h, None, f6.ctypes.data_as(dp), 6, idx.ctypes.data_as(ip), n, 0, out.ctypes.data_as(dp))
+        assert rc == _capi.RBS_ERR_INVALID_ARGUMENT
+        # a handle over several shards takes the same call
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", device_ids=[0, 0]) as grp:
+        grp.integrated_poses = dflt12.copy()
+        grp.reset(); grp.set_observation(frame)
+        b = grp.loglikes_deltas(d12, idx.copy(), update=False)
+        assert np.array_equal(a, b)
+
+
+def test_tail_weight_zero_is_accepted_and_evaluated_at_the_floor(gpu_lib):
+    """the reference hands kinect/tail_weight through unchecked, 0 included.  The library accepts 0 and
+    evaluates it as RBS_TAIL_WEIGHT_FLOOR = 1e-9 (include/rbsensor_mi355x.h says why)."""
+    n = 32
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    from dbot_ros_amd import RbSensorBuilder
+    P0 = RbSensorBuilder.Parameters(sample_count=n); P0.kinect.tail_weight = 0.0
+    Pf = RbSensorBuilder.Parameters(sample_count=n); Pf.kinect.tail_weight = 1e-9
+    o = ob.Oracle(om, cam, Pf, max_particles=n, mode=ob.EAGER)
+    frames = sc.make_frames(o, 1, 3, seed=4)
+    ref = sc.run_sequence(o, frames, n)
+    with RbSensor(om, cam, P0, max_particles=n, precision="f64") as g:
+        got = sc.run_sequence(g, frames, n)
+    for a, b in zip(got, ref):
+        assert np.isfinite(a).all()
+        assert rel_err(a, b).max() <= TOL_EAGER, rel_err(a, b).max()
+
+
+def test_prefetch_is_refused_before_anything_is_enqueued(gpu_lib):
+    """a second rbs_loglikes_prefetch before rbs_set_observation_prefetched used to fail AFTER the updating call's
+    kernels had been enqueued (planes flipped, indices stale).  It is refused up front: nothing changes."""
+    n = 16
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    o = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    frames = sc.make_frames(o, 1, 3, seed=9)
+    rng = np.random.default_rng(1)
+    poses = [synth.particle_poses(t, n, rng, scale=1.5) for t, _ in frames]
+    with RbSensor(om, cam, P, max_particles=n, precision="f64") as g, RbSensor(om, cam, P, max_particles=n, precision="f64") as plain:
+        for s in (g, plain):
+            s.reset(); s.set_observation(frames[0][1])
+        idx = np.zeros(n, np.int32)
+        a0 = g.loglikes_poses_prefetch(poses[0], idx, frames[1][1], update=True)
+        b0 = plain.loglikes_poses(poses[0], np.zeros(n, np.int32), update=True)
+        assert np.array_equal(a0, b0)
+        parents = np.sort(rng.integers(0, n, n)).astype(np.int32)
+        idx = parents.copy()
+        with pytest.raises(RbSensorError) as e:     # the frame uploaded ahead has not been installed
+            g.loglikes_poses_prefetch(poses[1], idx, frames[2][1], update=True)
+        assert e.value.code == _capi.RBS_ERR_INVALID_ARGUMENT
+        assert np.array_equal(idx, parents)          # nothing ran: the indices are the caller's
+        g.set_observation_prefetched()
+        a1 = g.loglikes_poses(poses[1], idx, update=True)
+        plain.set_observation(frames[1][1])
+        b1 = plain.loglikes_poses(poses[1], parents.copy(), update=True)
+        assert np.array_equal(a1, b1)               # ... and the planes are those of the first call
+
+
+def test_a_prefetched_frame_is_abandoned_by_set_observation_device(gpu_lib):
+    """rbs_set_observation_device (and rbs_reset) between a prefetch and its installation abandon the frame;
+    rbs_set_observation_prefetched then fails instead of re-installing a stale image."""
+    import torch
+    n = 8
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    rng = np.random.default_rng(1)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64") as g:
+        truth = synth.truth_pose(1)
+        f0 = synth.make_frame(g.render_depth(truth), 120, 160, rng)
+        f1 = synth.make_frame(g.render_depth(truth), 120, 160, rng)
+        poses = synth.particle_poses(truth, n, rng)
+        for breaker in ("device", "reset"):
+            g.reset(); g.set_observation(f0)
+            g.loglikes_poses_prefetch(poses, np.zeros(n, np.int32), f1, update=True)
+            if breaker == "device":
+                d = torch.from_numpy(f0).to("cuda:0")
+                torch.cuda.synchronize()
+                g.set_observation_device(d.data_ptr())
+            else:
+                g.reset()
+            with pytest.raises(RbSensorError) as e:
+                g.set_observation_prefetched()
+            assert e.value.code == _capi.RBS_ERR_INVALID_ARGUMENT
+            g.synchronize()
+
+
+def test_import_window_enlarges_the_slabs(gpu_lib):
+    """a window exported by a handle whose slabs have grown is imported by one whose slabs are still
+    at their initial size -- the receiver's slabs grow (as behind rbs_import_plane), the plane arrives whole."""
+    import torch
+    n = 8
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
+    rng = np.random.default_rng(3)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=16384) as src, \
+            RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=1024) as dst:
+        truth = synth.truth_pose(1, z=0.45)                     # a near object: regions of ~15 000 px
+        frame = synth.make_frame(src.render_depth(truth), 480, 640, rng)
+        src.reset(); src.set_observation(frame)
+        src.loglikes_poses(synth.particle_poses(truth, n, rng), np.zeros(n, np.int32), update=True)
+        win = src.get_window(2)
+        w, h = win[2] - win[0], win[3] - win[1]
+        assert w * h > 1024
+        buf = torch.empty(w * h, dtype=torch.float32, device="cuda:0")
+        rect = src.export_window(2, buf.data_ptr(), buf.numel())
+        torch.cuda.synchronize()
+        dst.reset(); dst.set_observation(frame)
+        dst.loglikes_poses(synth.particle_poses(truth, n, rng) + 0.0, np.zeros(n, np.int32), update=False)
+        dst.import_window(5, rect, buf.data_ptr())
+        dst.synchronize()
+        assert tuple(dst.get_window(5)) == tuple(win)
+        # same background level on both sides? no: src stepped once.  Compare inside the window only.
+        a, b = src.get_occlusion(2).reshape(480, 640), dst.get_occlusion(5).reshape(480, 640)
+        assert np.array_equal(a[win[1]:win[3], win[0]:win[2]], b[win[1]:win[3], win[0]:win[2]])
+
+
+# ---------------------------------------------------------------- split launch
+@pytest.mark.parametrize("meshes,cols,rows,n,slab", [(("m1",), 640, 480, 64, 0), (("m1",), 640, 480, 64, 38400),
+                                                     (("m1", "m2", "m3"), 640, 480, 24, 0), (("m4",), 1280, 960, 12, 0),
+                                                     (("m1_l2",), 322, 241, 40, 0)])
+def test_split_launch_matches_the_oracle(gpu_lib, monkeypatch, meshes, cols, rows, n, slab):
+    """RBS_SPLIT=1: geometry kernel -> depth tiles in memory -> likelihood kernel.  The same bars as the one-kernel launch:
+    log-likelihoods vs the device-rule oracle 1e-9, planes bit-exact but for 1-ulp posteriors, windows identical to the
+    one-kernel launch's, read-only calls included."""
+    nb = len(meshes)
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    o = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    frames = sc.make_frames(o, nb, 4, seed=5, z=0.5 if "m4" in meshes else 0.7)
+    ref = sc.run_sequence(o, frames, n, n_bodies=nb)
+    monkeypatch.setenv("RBS_SPLIT", "0")
+    with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=slab) as mono:
+        base = sc.run_sequence(mono, frames, n, n_bodies=nb)
+        monkeypatch.setenv("RBS_SPLIT", "1")
+        monkeypatch.setenv("RBS_SPLIT_ITEMS_PER_PARTICLE", "48")
+        with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=slab) as g:
+            got = sc.run_sequence(g, frames, n, n_bodies=nb)
+            for a, b, c in zip(got, ref, base):
+                assert rel_err(a, b).max() <= TOL_EAGER, rel_err(a, b).max()
+                assert rel_err(a, c).max() <= 1e-12          # (the tile size differs: items, hence the order of partial sums, may)
+            for slot in (0, n // 2, n - 1):
+                assert g.get_window(slot) == mono.get_window(slot)
+                pg, po = g.get_occlusion(slot), o.get_occlusion(slot)
+                diff = pg != po
+                assert diff.mean() <= 1e-4
+            rng = np.random.default_rng(8)
+            poses = synth.particle_poses(frames[-1][0], n, rng, scale=2.0)
+            idx = rng.integers(0, n, n).astype(np.int32)
+            ro = g.loglikes_poses(poses, idx.copy(), update=False)
+            assert rel_err(ro, mono.loglikes_poses(poses, idx.copy(), update=False)).max() <= 1e-12
+            assert rel_err(ro, o.loglikes_poses(poses, idx.copy(), update=False)).max() <= TOL_EAGER
+
+
+def test_split_launch_contains_items_beyond_its_buffer(gpu_lib, monkeypatch):
+    """The hand-over buffer holds RBS_SPLIT_ITEMS_PER_PARTICLE x n (+ 1 024) tiles; an item beyond it is contained
+    (its particle's log-likelihood is NaN), never a wild access."""
+    n = 2000
+    om, cam, P = sc.make_scene(("m1_l2",), 640, 480, max_particles=n)
+    monkeypatch.setenv("RBS_SPLIT", "1")
+    monkeypatch.setenv("RBS_SPLIT_ITEMS_PER_PARTICLE", "1")
+    rng = np.random.default_rng(0)
+    with RbSensor(om, cam, P, max_particles=n, precision="f64") as g:
+        truth = synth.truth_pose(1, z=0.12)          # fills the image: ~40 tiles per particle
+        frame = synth.make_frame(g.render_depth(truth), 480, 640, rng)
+        g.reset(); g.set_observation(frame)
+        ll = g.loglikes_poses(np.repeat(truth[None], n, 0), np.zeros(n, np.int32), update=True)
+        assert np.isnan(ll).any() and np.isfinite(ll).any()
+        g.synchronize()
