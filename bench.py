@@ -357,6 +357,132 @@ def setup_peer_run(a, om, cam, P, W, dev, stream, dist, backend, world):
     return sensor, run
 
 
+def multi_gpu_selfcheck(a, dev, stream, dist, backend, world, rank, n=256, steps=4, temperature=60.0):
+    """SURVEY 8(e)'s equality test on the job's OWN devices, before anything is timed (the first run on a
+    multi-GPU node must validate itself): `steps` steps of the multi-rank step -- loglikes(update) with GLOBAL parents,
+    the all-gather, the resampling over all ranks' particles, staging -- at n particles per rank, then ONE handle on
+    rank 0 holding all world * n particles replays the same poses, frames and uniforms.  Equal means: every rank's
+    gathered log-likelihood vector agrees with the single handle's to 1e-12 relative (the order of a particle's partial
+    sums depends on the call's particle count), and every rank's slice of the resampled parents is identical.  Never raises: a failure is reported in the line and the job goes on to its timed run."""
+    import copy
+    from dbot_ros_amd import RbSensor, synth
+    from dbot_ros_amd import dist as rdist
+    res = {"multi_gpu_check": f"{steps} steps x {n} particles per rank x {world} ranks against one handle holding {n * world} (rank 0), "
+                              f"resampling temperature {temperature:g}"}
+    b = copy.copy(a)
+    b.particles = n
+    om, cam, P, n_tri, nb = build_scene(b)
+    N = n * world
+    sensor = None
+    errs = []
+    try:
+        with RbSensor(om, cam, P, max_particles=1, device_id=dev.index, precision=a.precision) as r1:
+            rng = np.random.default_rng(0)
+            truths = [synth.truth_pose(nb, frame=k) for k in range(steps)]
+            frames = [synth.make_frame(r1.render_depth(t), cam.rows, cam.cols, rng) for t in truths]
+        rng = np.random.default_rng(12)
+        poses = [synth.particle_poses(t, N, rng, scale=2.0).reshape(N, -1) for t in truths]     # by global SLOT
+        gen = torch.Generator().manual_seed(5)
+        uniforms = [torch.rand(N, dtype=torch.float64, generator=gen).sort().values for _ in range(steps)]
+        sensor = RbSensor(om, cam, P, max_particles=2 * n, device_id=dev.index, precision=a.precision, state_layout=a.layout)
+        sensor.reset()
+    except Exception as e:   # noqa: BLE001
+        errs.append(f"setup: {e!r}")
+    attach_ok = False
+    if sensor is not None:
+        try:
+            if os.environ.get("RBS_BENCH_FAIL_ATTACH") == "1":
+                raise RuntimeError("attach_peers failed -- RBS_BENCH_FAIL_ATTACH=1")
+            rdist.attach_peers(sensor)     # (raises on EVERY rank when any rank fails, after all of them left the hand-shake)
+            attach_ok = True
+        except RuntimeError as e:
+            errs.append(str(e))
+    flags = [None] * world
+    dist.all_gather_object(flags, (sensor is not None, attach_ok))
+    res["ipc_attach_ok"] = [bool(f[1]) for f in flags]
+    mine_ll, mine_ps, counts, seen = [], [], [0, 0, 0, 0], 0
+    if all(f[0] and f[1] for f in flags):
+        def gather(out_t, inp_t):
+            if backend == "nccl":
+                dist.all_gather_into_tensor(out_t, inp_t)
+            else:
+                host = [torch.empty(inp_t.numel(), dtype=inp_t.dtype) for _ in range(world)]
+                dist.all_gather(host, inp_t.cpu())
+                out_t.copy_(torch.cat(host))
+        try:
+            # which ranks does the collective really reach?  every rank contributes its number
+            mark_in = torch.full((n,), float(rank), dtype=torch.float64, device=dev)
+            mark_out = torch.full((N,), -1.0, dtype=torch.float64, device=dev)
+            gather(mark_out, mark_in)
+            torch.cuda.synchronize()
+            seen = int(torch.unique(mark_out[mark_out >= 0]).numel())
+            pstep = rdist.PeerShardedStep(sensor, n, 2 * n, device=dev, min_share=2, stream=stream.cuda_stream, all_gather=gather,
+                                          temperature=temperature, fused=True)
+            for k in range(steps):
+                sensor.set_observation(frames[k])
+                d_poses = torch.from_numpy(poses[k][rank * n:(rank + 1) * n].copy()).to(dev)
+                ps = pstep.step(d_poses, uniforms[k].to(dev))
+                torch.cuda.synchronize()
+                mine_ll.append(pstep.d_all.cpu().numpy().copy())
+                mine_ps.append(ps.cpu().numpy().copy())
+            counts = [int(c) for c in pstep.counts.cpu().tolist()]
+        except Exception as e:   # noqa: BLE001
+            errs.append(f"rank {rank} step: {e!r}")
+        torch.cuda.synchronize()
+        dist.barrier()                 # nobody unmaps while a peer may still be reading
+    if sensor is not None:
+        sensor.close()
+    everyone = [None] * world
+    dist.all_gather_object(everyone, {"ll": mine_ll, "ps": mine_ps, "counts": counts, "seen": seen, "errs": errs})
+    if rank != 0:
+        return {}
+    res["rccl_ranks_seen"] = [e["seen"] for e in everyone]
+    res["multi_gpu_check_remote_children"] = [e["counts"][0] for e in everyone]
+    res["multi_gpu_check_planes_staged"] = [e["counts"][2] for e in everyone]
+    all_errs = [m for e in everyone for m in e["errs"]]
+    if all_errs or not all(len(e["ll"]) == steps for e in everyone):
+        res["multi_gpu_equals_single"] = False
+        res["peer_read_ok"] = [False] * world
+        res["multi_gpu_check_diagnosis"] = "the multi-rank step did not complete: " + ("; ".join(all_errs) or "a rank recorded fewer steps")
+        return res
+    try:
+        ref_ll, ref_ps = [], []
+        with RbSensor(om, cam, P, max_particles=N, device_id=dev.index, precision=a.precision, state_layout=a.layout) as one:
+            one.reset()
+            idx = np.zeros(N, np.int32)
+            for k in range(steps):
+                one.set_observation(frames[k])
+                ll = one.loglikes_poses(poses[k], idx, update=True)
+                ps = rdist.global_resample(torch.from_numpy(ll), uniforms[k], temperature).numpy()
+                ref_ll.append(ll.copy()); ref_ps.append(ps.copy())
+                idx = ps.astype(np.int32)
+        worst, bad_parents, read_ok = 0.0, 0, []
+        for r_, e in enumerate(everyone):
+            ok_r = True
+            for k in range(steps):
+                d = np.abs(e["ll"][k] - ref_ll[k])
+                # (not bit for bit: how a rectangle is cut into work items -- hence the order a particle's partial sums are
+                # added in -- depends on the number of particles in the call, n here and world * n there)
+                same = bool((d <= 1e-12 * np.maximum(1.0, np.abs(ref_ll[k]))).all())
+                worst = max(worst, float(np.nanmax(d)) if d.size else 0.0)
+                wrong = int((e["ps"][k] != ref_ps[k][r_ * n:(r_ + 1) * n]).sum())
+                bad_parents += wrong
+                ok_r = ok_r and same and wrong == 0
+            read_ok.append(bool(ok_r))
+        res["multi_gpu_equals_single"] = bool(all(read_ok))
+        res["peer_read_ok"] = read_ok
+        res["multi_gpu_check_max_abs_loglik_diff"] = worst
+        res["multi_gpu_check_parent_mismatches"] = bad_parents
+        if not all(read_ok):
+            res["multi_gpu_check_diagnosis"] = (f"ranks {[r_ for r_, o in enumerate(read_ok) if not o]} disagree with the single handle: max |d loglik| "
+                                                f"{worst:.3e}, {bad_parents} parents differ; remote children per rank {res['multi_gpu_check_remote_children']} "
+                                                "(a rank whose children never had a remote parent did not exercise the peer reads)")
+    except Exception as e:   # noqa: BLE001
+        res["multi_gpu_equals_single"] = False
+        res["multi_gpu_check_diagnosis"] = f"the single-handle replay failed: {e!r}"
+    return res
+
+
 def peer_configs_leg(a, dev, stream, dist, backend, world, rank, names=("c3_slice", "c4_slice")):
     """BASELINE C3 / C4 at their real per-GPU sizes (25 000 / 6 250 particles per rank) through the same multi-rank
     step: whole-job particle-likelihoods/s (MAX over ranks of the elapsed time) and where the parents were."""
@@ -714,6 +840,24 @@ def native_host_leg(a, om, cam, P, W, steps):
             t2 = line2.split()
             res.update({"host_api_native_prefetch_value": float(t2[2]), "host_api_native_prefetch_ms_per_step": float(t2[4]),
                         "host_api_native_prefetch_checksum_equal": t2[6] == tok[6] if len(t2) > 6 and len(tok) > 6 else None})
+        # ... and THROUGH THE PLUGIN SURFACE the reference drives: dbot_amd::RbSensor::set_observation(image of
+        # DOUBLES) + loglikes(state deltas, one heap vector per particle; indices; update), synchronous, no look-ahead
+        for tag, mode in (("plugin_api", "--plugin"), ("plugin_api_copying", "--plugin-copy")):
+            r3 = subprocess.run([exe, mode, path, str(steps), "10"], capture_output=True, text=True, timeout=300, env=env)
+            line3 = next((l for l in r3.stdout.splitlines() if l.startswith("host_bench ")), None)
+            if line3:
+                t3 = line3.split()
+                res.update({tag + "_value": float(t3[2]), tag + "_ms_per_step": float(t3[4])})
+                if len(t3) > 6 and len(tok) > 6:
+                    res[tag + "_checksum_rel_diff"] = abs(float(t3[6]) - float(tok[6])) / max(1.0, abs(float(tok[6])))
+            else:
+                res[tag + "_note"] = "host_bench --plugin did not run: " + (r3.stdout + r3.stderr)[-200:]
+        res["plugin_api_note"] = ("through the plugin surface, from C++ (tests/cpp/host_bench.cpp --plugin): dbot_amd::RbSensorBuilder(...).build(), then per step "
+                                  "set_observation(rows*cols doubles) + loglikes(deltas: one State per particle, indices, update) -- the frame's double -> float "
+                                  "staging, the gather of the deltas and the pose composition (on the device: rbs_loglikes_deltas) inside the clock; synchronous, "
+                                  "no look-ahead.  plugin_api_*: the image is BORROWED until loglikes returns, as the dbot binding does (it outlives the pair inside "
+                                  "tracker_->track(image)): loglikes stages it while its geometry kernel runs (rbs_set_observation_borrowed, two-kernel launch).  "
+                                  "plugin_api_copying_*: set_observation copies at once, as dbot's own sensors do (one-kernel launch)")
         return res
     except Exception as e:   # noqa: BLE001 -- a benchmark leg must not take the headline down
         return {"host_api_native_note": "host_bench failed: %r" % (e,)}
@@ -915,6 +1059,32 @@ def sharded_tracker_child(a):
     ids = [int(x) for x in a.device_ids.split(",")]
     dev = torch.device("cuda", ids[0])
     torch.cuda.set_device(dev)
+    # first the equality test of the in-handle form (one handle over the devices: peer reads between its shards, ncclCommInitAll
+    # communicators for the tracker): 256 particles per device, three resampled steps, against a handle on the first device alone
+    try:
+        from dbot_ros_amd import RbSensor, synth
+        n = 256 * len(ids)
+        with RbSensor(om, cam, P, max_particles=1, device_id=ids[0], precision=a.precision) as r1:
+            rng = np.random.default_rng(3)
+            truths = [synth.truth_pose(nb, frame=k) for k in range(3)]
+            frames = [synth.make_frame(r1.render_depth(t), cam.rows, cam.cols, rng) for t in truths]
+        poses = [synth.particle_poses(t, n, rng, scale=2.0) for t in truths]
+        parents = [np.sort(rng.integers(0, n, n)).astype(np.int32) for _ in truths]
+        got = []
+        for kw in ({"device_ids": ids}, {"device_id": ids[0]}):
+            with RbSensor(om, cam, P, max_particles=n, precision=a.precision, **kw) as g:
+                g.reset()
+                idx, lls = np.zeros(n, np.int32), []
+                for k in range(3):
+                    g.set_observation(frames[k])
+                    lls.append(g.loglikes_poses(poses[k], idx, update=True).copy())
+                    idx = parents[k].copy()
+                got.append(np.stack(lls))
+        d = float(np.abs(got[0] - got[1]).max())
+        print("IN_HANDLE_CHECK " + json.dumps({"in_handle_equals_single": bool(d <= 1e-12 * max(1.0, float(np.abs(got[1]).max()))),
+                                               "in_handle_max_abs_loglik_diff": d, "in_handle_devices": ids}), flush=True)
+    except Exception as e:   # noqa: BLE001
+        print("IN_HANDLE_CHECK " + json.dumps({"in_handle_equals_single": False, "in_handle_check_diagnosis": repr(e)}), flush=True)
     fps = tracker_fps(om, cam, dev, precision=a.precision, device_ids=ids)
     fps.pop("_native", None)
     print("SHARDED_TRACKER " + json.dumps({str(k): {"fps": v["fps"], "fps_pipelined": v["fps_pipelined"]} for k, v in fps.items()}), flush=True)
@@ -929,11 +1099,16 @@ def sharded_tracker_leg(a, ids, timeout=420):
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     except subprocess.TimeoutExpired:
-        return {"tracker_fps_sharded_note": f"sharded tracker leg did not finish within {timeout} s (stopped)"}
+        return {"in_handle_rccl_ok": False, "tracker_fps_sharded_note": f"sharded tracker leg did not finish within {timeout} s (stopped)"}
+    chk = {}
+    for line in r.stdout.splitlines():
+        if line.startswith("IN_HANDLE_CHECK "):
+            chk = json.loads(line[len("IN_HANDLE_CHECK "):])
     for line in r.stdout.splitlines():
         if line.startswith("SHARDED_TRACKER "):
             d = json.loads(line[len("SHARDED_TRACKER "):])
-            out = {}
+            out = dict(chk)
+            out["in_handle_rccl_ok"] = True      # (the tracker's per-block all-gather ran on the handle's own communicators)
             for k_, v_ in d.items():
                 out[f"tracker_fps_sharded_{k_}"] = v_["fps"]
                 out[f"tracker_fps_sharded_pipelined_{k_}"] = v_["fps_pipelined"]
@@ -942,7 +1117,7 @@ def sharded_tracker_leg(a, ids, timeout=420):
                                                "block; frame uploaded from host memory every frame; a process of its own started by rank 0 while "
                                                "the ranks wait")
             return out
-    return {"tracker_fps_sharded_note": "sharded tracker leg failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+    return dict(chk, in_handle_rccl_ok=False, tracker_fps_sharded_note="sharded tracker leg failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
 
 
 def main():
@@ -994,7 +1169,12 @@ def main():
     torch.cuda.synchronize()
 
     peer_ok, peer_msg = world > 1, None
+    selfcheck = {}
     if world > 1:
+        try:
+            selfcheck = multi_gpu_selfcheck(a, dev, stream, dist, backend, world, rank)
+        except Exception as e:   # noqa: BLE001 -- the check must not take the headline down
+            selfcheck = {"multi_gpu_equals_single": False, "multi_gpu_check_diagnosis": f"self-check raised {e!r}"} if rank == 0 else {}
         try:
             sensor, run = setup_peer_run(a, om, cam, P, W, dev, stream, dist, backend, world)
             d_out, d_all = run.step.d_out, run.step.d_all
@@ -1134,6 +1314,7 @@ def main():
             out["config"]["workload"] = (f"C1 per GPU: {n} particles/GPU ({n * world} in all) x [loglikes(update=true), parents on the rank's own GPU + "
                                          f"RCCL all-gather of the log-likelihoods] -- the ranks' handles could not be attached to each other, see peer_step")
             out["config"]["sharding"] = f"particles/{world}: one process per GPU, local parents, one RCCL all-gather per step"
+        out.update(selfcheck)
         out.update(peer_stats)
         out.update(peer_legs)
     single = world == 1

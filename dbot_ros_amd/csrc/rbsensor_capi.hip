@@ -15,6 +15,7 @@
 #include "../../include/rbsensor_mi355x.h"
 
 #include <dlfcn.h>
+#include <immintrin.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -189,6 +190,8 @@ struct rbs_handle {
     std::string err;
     bool frame_acquired = false;       // rbs_acquire_frame_buffer without its rbs_commit_frame_buffer yet
     int prefetched_slot = -1;          // staging slot holding a frame uploaded ahead of its turn (rbs_loglikes_prefetch), -1: none
+    const double* borrowed = nullptr;  // rbs_set_observation_borrowed: the caller's frame, staged by the next host-pointer likelihood call
+                                       // while that call's geometry kernel runs (or by whatever else needs the observation first)
     // A call that failed half-way through a fan-out (some shards enqueued, others not) or between a
     // tracker's buffer swaps leaves the handle's double buffers out of step: every later call is
     // refused with this message until rbs_reset (rbs_tracker_initialize) re-establishes a known state.
@@ -347,10 +350,16 @@ void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size
     }
 }
 
+int32_t stage_borrowed(rbs_handle* h);
+
 int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indices, int n,
                          bool update, double* d_out, hipStream_t s, const double* host_poses = nullptr)
 {
     h->quiet = false;
+    // a borrowed frame (rbs_set_observation_borrowed) is staged BETWEEN the two kernels of the split launch, while the
+    // geometry kernel -- which needs no frame -- runs; a handle that cannot launch that way stages it here and now
+    if (h->borrowed && !(h->precision == RBS_PRECISION_F64 && h->windowed && s == h->stream))
+        if (int32_t rc = stage_borrowed(h)) return rc;
     DevParams P = h->base;
     occlusion_coeffs(h, h->pending_frames, &P.alpha, &P.beta);
     P.bg_old = h->background;
@@ -423,8 +432,8 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
                                                                      : (f64 ? rbs::kTilePxF64 : rbs::kTilePx);
     // split launch: binary64 likelihood on windowed planes (the tile size is the handle's for its whole life, like the
     // monolith's: the split of a rectangle into items decides the order in which a particle's partial sums are added)
-    const bool split = h->split && f64 && h->windowed;
-    if (split) P.tile_px = rbs::kDepthTilePx;
+    bool split = (h->split || h->borrowed != nullptr) && f64 && h->windowed;   // (the same tile, the same items, the same bits either way)
+    if (split && !(!h->windowed && h->raster_blocks <= 2 * h->cu_count)) P.tile_px = rbs::kDepthTilePx;   // (= kTilePxF64 already)
     P.tile_w = 256;
     P.tile_h = std::max(4, P.tile_px / 256 / std::max(1, h->smalln_target / std::max(1, n)));
     if (const char* m = h->tile_override) { P.tile_w = std::max(16, std::atoi(m) / 16 * 16); P.tile_h = std::max(1, std::atoi(m)); }
@@ -443,12 +452,22 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         h->partial_cap = need;
     }
     if (split) {
-        // the hand-over buffer: one tile per work item.  `need` is the worst case (every rectangle the whole frame);
-        // four items per particle (+ slack) is what is allocated -- C4's geometry has 8-12 per particle and asks for
-        // more through RBS_SPLIT_ITEMS_PER_PARTICLE; an item beyond the buffer is contained (NaN), never a wild write
-        static const int per = [] { const char* e = std::getenv("RBS_SPLIT_ITEMS_PER_PARTICLE"); return e ? std::max(1, std::atoi(e)) : 4; }();
-        const size_t want = std::min(need, (size_t)n * (size_t)per + 1024);
-        if (want > h->depth_items) {
+        // the hand-over buffer: one tile per work item, sized for the WORST case (every rectangle the whole frame: 36 tiles per
+        // particle at 640x480) so that no item can ever lie beyond it -- 2.7 GB at 2 000 particles.  Where that exceeds
+        // kDepthBudget (20 000 particles) the call is launched as ONE kernel instead (a borrowed frame is staged first).
+        // RBS_SPLIT_ITEMS_PER_PARTICLE (tooling / tests): a buffer of n x that many tiles (+ 1 024); an item beyond it is
+        // contained (its particle's log-likelihood is NaN), never a wild access.
+        constexpr size_t kDepthBudget = (size_t)8 << 30;
+        const char* pe = std::getenv("RBS_SPLIT_ITEMS_PER_PARTICLE");
+        const size_t want = pe ? std::min(need, (size_t)n * (size_t)std::max(1, std::atoi(pe)) + 1024) : need;
+        if (want > h->depth_items && sizeof(unsigned) * (size_t)rbs::kDepthTilePx * want > kDepthBudget) {
+            split = false;
+            if (h->borrowed) {
+                if (int32_t rc = stage_borrowed(h)) return rc;
+                P.frame = h->cur_frame;
+                P.aux = h->cur_aux;
+            }
+        } else if (want > h->depth_items) {
             RBS_HIP(h, hipStreamSynchronize(s));
             (void)hipFree(h->d_depth);
             h->d_depth = nullptr;
@@ -456,6 +475,8 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             RBS_HIP(h, hipMalloc(&h->d_depth, sizeof(unsigned) * (size_t)rbs::kDepthTilePx * want));
             h->depth_items = want;
         }
+    }
+    if (split) {
         P.depth = h->d_depth;
         P.depth_items = (int)std::min<size_t>(h->depth_items, 0x7fffffff);
         P.ctrb_this = h->d_ctr + 4 + (int)(h->calls & 1);
@@ -561,6 +582,11 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         if (h->many_clusters) hipLaunchKernelGGL((rbs::rbs_depth_kernel<true>), dgrid, block, dsm, s, P);
         else hipLaunchKernelGGL((rbs::rbs_depth_kernel<false>), dgrid, block, dsm, s, P);
         RBS_HIP(h, hipGetLastError());
+        if (h->borrowed) {   // the host converts and sends the caller's frame while the depth tiles are rasterized
+            if (int32_t rc = stage_borrowed(h)) return rc;
+            P.frame = h->cur_frame;
+            P.aux = h->cur_aux;
+        }
         if (h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
         switch ((update ? 2 : 0) | (h->slab_px ? 1 : 0)) {
             case 0: hipLaunchKernelGGL((rbs::rbs_eval_kernel<false, false>), egrid, block, esm, s, P); break;
@@ -928,11 +954,31 @@ int32_t release_frame_slot(rbs_handle* h)
 // `pageable`: the caller's own frame, still to be staged into `src` (= h->h_frame) -- staged and sent
 // in h->upload_chunks pieces, so that the copy engine carries one piece while the host copies the next
 // (a 640x480 frame: 41 us of memcpy + 29 us of transfer one after the other, ~20 us less interleaved).
+// dbot hands the image over as a vector of DOUBLES (R:source/dbot_ros/util/ros_interface.h:152-168): double -> float while
+// staging.  The scalar loop converts 2 values per instruction on a baseline x86-64 build; AVX2 (every host this library
+// meets; checked at run time) does 4 per instruction and halves the time of a 640x480 frame.
+__attribute__((target("avx2"))) static void convert_f64_f32_avx2(float* __restrict__ dst, const double* __restrict__ src, size_t n)
+{
+    size_t p = 0;
+    for (; p + 8 <= n; p += 8) {
+        const __m128 a = _mm256_cvtpd_ps(_mm256_loadu_pd(src + p)), b = _mm256_cvtpd_ps(_mm256_loadu_pd(src + p + 4));
+        _mm256_storeu_ps(dst + p, _mm256_set_m128(b, a));
+    }
+    for (; p < n; ++p) dst[p] = (float)src[p];
+}
+static void convert_f64_f32(float* __restrict__ dst, const double* __restrict__ src, size_t n)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return convert_f64_f32_avx2(dst, src, n);
+    for (size_t p = 0; p < n; ++p) dst[p] = (float)src[p];
+}
+
 int32_t upload_frame(rbs_handle* h, const float* src, const float* pageable = nullptr, const double* pageable_f64 = nullptr)
 {
     const int k = h->frame_slot;
     const size_t n = (size_t)h->npx;
     h->prefetched_slot = -1;   // (a frame uploaded ahead of its turn that another frame overtakes is abandoned)
+    h->borrowed = nullptr;     // (... and so is a borrowed frame nobody evaluated)
     // (the two staging images alternate, so k is never the image that serves as the observation --
     // should it be, its readers are recorded first: the wait below must not be on a stale event)
     if (k == h->cur_slot)
@@ -953,7 +999,7 @@ int32_t upload_frame(rbs_handle* h, const float* src, const float* pageable = nu
         for (size_t off = 0; off < n; off += per) {
             const size_t len = std::min(per, n - off);
             if (pageable) std::memcpy(stage + off, pageable + off, len * sizeof(float));
-            else for (size_t p = off; p < off + len; ++p) stage[p] = (float)pageable_f64[p];   // dbot hands a vector of doubles
+            else convert_f64_f32(stage + off, pageable_f64 + off, len);   // dbot hands a vector of doubles
             if (!pull) RBS_HIP(h, hipMemcpyAsync(h->d_fin[k] + off, stage + off, len * sizeof(float), hipMemcpyHostToDevice, h->up_stream));
         }
     } else if (!pull) {
@@ -1000,6 +1046,16 @@ int32_t next_frame_staging(rbs_handle* h)
     h->h_frame = h->h_frames[h->frame_slot];
     RBS_HIP(h, hipEventSynchronize(h->ev_frame[h->frame_slot]));
     return RBS_OK;
+}
+
+// rbs_set_observation_borrowed's frame becomes the observation now: staged (double -> float) into pinned memory and sent.
+int32_t stage_borrowed(rbs_handle* h)
+{
+    if (!h->borrowed) return RBS_OK;
+    const double* d = h->borrowed;
+    h->borrowed = nullptr;
+    if (int32_t rc = next_frame_staging(h)) return rc;
+    return upload_frame(h, h->h_frame, nullptr, d);
 }
 
 // The NEXT frame, uploaded while the current one is still the observation (rbs_loglikes_prefetch: called between
@@ -2152,6 +2208,7 @@ int32_t rbs_reset(rbs_handle* h)
     h->poisoned = false;
     h->frame_acquired = false;
     h->prefetched_slot = -1;   // (a frame uploaded ahead belongs to the session that ended)
+    h->borrowed = nullptr;
     h->cur = 0;
     h->pending_frames = 0;
     h->background = (float)h->init_occ;
@@ -2194,6 +2251,24 @@ int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n)
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     if (int32_t rc = next_frame_staging(h)) return rc;
     if (int32_t rc = upload_frame(h, h->h_frame, nullptr, depth)) return rc;   // (converted and sent piece by piece)
+    h->pending_frames += 1;
+    return RBS_OK;
+}
+
+int32_t rbs_set_observation_borrowed(rbs_handle* h, const double* depth, size_t n)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    // handles that cannot stage between two kernels (several devices; float32 likelihood; whole planes) copy at once
+    if (!h->shards.empty() || h->group || h->precision != RBS_PRECISION_F64 || !h->windowed || h->frame_ingest)
+        return rbs_set_observation(h, depth, n);
+    RBS_REFUSE_POISONED(h);
+    h->frame_acquired = false;
+    if (!depth || n != (size_t)h->npx)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("set_observation_borrowed: expected %d pixels, got %zu", h->npx, n));
+    RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
+    h->prefetched_slot = -1;
+    h->borrowed = depth;          // (a borrowed frame nobody evaluated is simply replaced)
     h->pending_frames += 1;
     return RBS_OK;
 }
@@ -2315,6 +2390,7 @@ int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* st
     if (int32_t rc = flush_lazy_frame(h, s)) return rc;   // an earlier frame nobody evaluated
     if (int32_t rc = release_frame_slot(h)) return rc;
     h->prefetched_slot = -1;   // (a frame uploaded ahead of its turn that another frame overtakes is abandoned: ADVICE r4)
+    h->borrowed = nullptr;
     h->lazy_frame = d_depth;
     h->lazy_stream = s;
     h->pending_frames += 1;
@@ -2327,6 +2403,7 @@ int32_t rbs_get_observation(rbs_handle* h, float* out)
     RBS_GROUP_FIRST(h, rbs_get_observation(sh_, out));
     if (!out) return fail(h, RBS_ERR_INVALID_ARGUMENT, "get_observation: null pointer");
     RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = stage_borrowed(h)) return rc;
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     RBS_HIP(h, hipStreamSynchronize(h->stream));
     if (h->frame_wait >= 0) RBS_HIP(h, hipEventSynchronize(h->ev_frame[h->frame_wait]));
@@ -2417,8 +2494,10 @@ static int32_t loglikes_impl(rbs_handle* h, const double* poses, int32_t* indice
     // the call waits for the log-likelihoods only -- the occlusion planes are finished by the second
     // stream and joined by the next call
     const CallState before = save_call_state(h);
-    if (next_depth)   // refused before anything is enqueued: the planes, the indices and the staging images stay as they are
+    if (next_depth) {   // refused before anything is enqueued: the planes, the indices and the staging images stay as they are
+        if (int32_t rc = stage_borrowed(h)) return rc;   // (a borrowed frame and a look-ahead frame: the borrowed one is staged first)
         if (int32_t rc = prefetch_check(h)) return rc;
+    }
     if (int32_t rc = host_call(h, poses, indices, n, update != 0, da)) return rc;
     // the next frame travels while this call's kernels run; should the upload itself fail (a runtime error), the
     // likelihood call is still completed -- results copied, indices rewritten -- and the error reported after it
@@ -2466,6 +2545,7 @@ int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t*
     if (!h->shards.empty()) return group_loglikes_device(h, d_poses, d_indices, n, update, d_out_loglik, static_cast<hipStream_t>(stream));
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    if (int32_t rc = stage_borrowed(h)) return rc;   // (only the host-pointer calls stage a borrowed frame behind their own kernels)
     if (h->slab_auto && !h->slab_probed && update && h->peer_world <= 1) {
         // slabs the LIBRARY chose (state_slab_px = 0, more than 8 192 particles): an asynchronous call cannot be taken
         // back, so the first one is preceded by a look at the regions it will store -- one small kernel and ONE host
@@ -2505,6 +2585,7 @@ int32_t rbs_synchronize(rbs_handle* h)
         return first;
     }
     RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = stage_borrowed(h)) return rc;   // (the caller's frame is released when this returns)
     if (int32_t rc = drain(h, true)) return rc;
     if (h->slab_px) RBS_HIP(h, hipMemcpy(h->h_err, h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost));
     // an asynchronous call whose region did not fit is reported here, ONCE; the slabs are enlarged

@@ -1296,7 +1296,10 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
         // 13 % of the kernel) are issued before the first is used
         // (binary64 likelihood: two quads per trip as well since it fits the budget without spilling in the loops:
         // raster kernel 0.179 -> 0.175 ms)
-        constexpr int kScanUnroll = PREC ? RBS_SCAN_UNROLL : RBS_SCAN_UNROLL_F64;
+#ifndef RBS_SCAN_UNROLL_EVAL
+#define RBS_SCAN_UNROLL_EVAL 2   // (the likelihood kernel of the split launch: its tile reads are global loads)
+#endif
+        constexpr int kScanUnroll = PHASE == 2 ? RBS_SCAN_UNROLL_EVAL : PREC ? RBS_SCAN_UNROLL : RBS_SCAN_UNROLL_F64;
         for (int q0 = wave * 64; q0 < nq; q0 += kBlock * kScanUnroll) {
             uint4 d4[kScanUnroll];
             floatx4 s4[kScanUnroll], o4[kScanUnroll];
@@ -1801,9 +1804,8 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET voi
 // The same work as rbs_raster_kernel_f64 in TWO kernels, each with a register budget and an occupancy of its own:
 //   rbs_depth_kernel   persistent; per work item cluster cull + triangle setup + sample loops into the LDS depth tile
 //                      (raster_window, unchanged: depth stays bit-exact), then the tile is written to P.depth.  Carries
-//                      neither the likelihood's registers nor its math tables nor the evaluation rings: four blocks
-//                      per CU (4 waves per SIMD) where the monolith has three.  Needs no frame: a host frame travels
-//                      while it runs.
+//                      neither the likelihood's registers nor its math tables nor the evaluation rings.  Needs no
+//                      frame: a host frame is staged and travels while it runs.
 //   rbs_eval_kernel    per work item the pixel pass of raster_eval_tile with the tile read from P.depth (L2 / MALL):
 //                      occlusion process, compaction of covered + observed pixels, the binary64 likelihood 64 pixels
 //                      at a time, block reduce, plane write.  15 KB of LDS and a small register budget: 5-6 waves per
@@ -1811,19 +1813,24 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET voi
 #ifndef RBS_SPLIT_DEFAULT
 #define RBS_SPLIT_DEFAULT 0         // what a handle does when RBS_SPLIT is not in the environment
 #endif
+// Measured (round 5, profiles/r05_split_*): four geometry blocks per CU need a 7 680-px tile and a 120-register budget that
+// spills 55 registers -- 126 us; three blocks per CU at the one-kernel launch's own tile and budget: 105 us.  The tile of the
+// one-kernel launch also makes the two launches interchangeable call by call: the same work items, the same summation order,
+// the same bits.
 #ifndef RBS_DEPTH_TILE_PX
-#define RBS_DEPTH_TILE_PX 7680      // 30 KB + rings: what fits a CU four times (LDS is granted in 1 280-byte steps)
+#define RBS_DEPTH_TILE_PX kTilePxF64
 #endif
 #ifndef RBS_DEPTH_MINWAVES
-#define RBS_DEPTH_MINWAVES 4
+#define RBS_DEPTH_MINWAVES 3
 #endif
 #ifndef RBS_DEPTH_VGPRS
-#define RBS_DEPTH_VGPRS 60          // 120 registers: four waves per SIMD and 32 left for one wave of the windowed copy kernel
+#define RBS_DEPTH_VGPRS 80          // 160 registers: three waves per SIMD and 32 left for one wave of the windowed copy kernel
 #endif
 #ifndef RBS_EVAL_MINWAVES
 #define RBS_EVAL_MINWAVES 5
 #endif
 constexpr int kDepthTilePx = RBS_DEPTH_TILE_PX;
+static_assert(kDepthTilePx == kTilePxF64 || RBS_DEPTH_MINWAVES != 3, "the split launch shares the one-kernel launch's tile");
 struct SmemDepth { unsigned* tile; int* big; int* nbig; int* item; int* tq; unsigned long long* cull; };
 __device__ inline SmemDepth carve_depth(unsigned char* smem, int tile_px)
 {

@@ -237,6 +237,13 @@ class RbSensor:
             self._check(self._lib.rbs_set_observation(
                 self._h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size))
 
+    def set_observation_borrowed(self, image):
+        """rbs_set_observation_borrowed: `image` (float64, contiguous) is NOT copied now -- keep it alive and unchanged until
+        the next loglikes* / synchronize has returned (this object holds a reference until then)."""
+        img = np.ascontiguousarray(image, dtype=np.float64).ravel()
+        self._borrowed = img
+        self._check(self._lib.rbs_set_observation_borrowed(self._h, img.ctypes.data_as(C.POINTER(C.c_double)), img.size))
+
     def frame_buffer(self):
         """The handle's pinned staging buffer for the NEXT frame as a numpy float32 view
         [rows*cols]: write the frame into it, then commit_frame() -- rbs_set_observation_f32

@@ -243,9 +243,14 @@ public:
 
     void reset() { check(rbs_reset(handle_)); }
 
+    /// borrow_observations(true): set_observation(image) does not copy -- `image` must stay alive and unchanged until the
+    /// next loglikes() has returned, as it does inside dbot's tracker_->track(image) -- and that loglikes() converts and sends
+    /// the frame while its geometry kernel runs (rbs_set_observation_borrowed).  Off by default: dbot's own sensors copy.
+    void borrow_observations(bool on) { borrow_ = on; }
     void set_observation(const Observation& image)
     {
-        check(rbs_set_observation(handle_, image.data(), image.size()));
+        if (borrow_) check(rbs_set_observation_borrowed(handle_, image.data(), image.size()));
+        else check(rbs_set_observation(handle_, image.data(), image.size()));
     }
 
     /// The driver's float pixels directly (no double round trip), or a frame that already lives
@@ -297,14 +302,20 @@ private:
         // takes absolute poses.
         RealArray ll(n);
         if (!next_depth) {
-            const size_t D = static_cast<size_t>(n_bodies_) * State::BODY_SIZE;
-            deltas_.resize(n * D);
+            // (position + rotation vector of every body, six numbers: the velocities stay where they are)
+            const size_t B = static_cast<size_t>(n_bodies_), D = B * State::BODY_SIZE;
+            deltas_.resize(n * B * 6);
+            defaults_.resize(B * 6);
+            Real* out = deltas_.data();
             for (size_t i = 0; i < n; ++i) {
-                if (deltas[i].data().size() != D) throw std::runtime_error("RbSensor::loglikes: a state of the wrong size");
-                std::copy(deltas[i].data().begin(), deltas[i].data().end(), deltas_.begin() + static_cast<std::ptrdiff_t>(i * D));
+                const std::vector<Real>& d = deltas[i].data();
+                if (d.size() != D) throw std::runtime_error("RbSensor::loglikes: a state of the wrong size");
+                for (size_t b = 0; b < B; ++b, out += 6) std::copy(d.begin() + static_cast<std::ptrdiff_t>(b * State::BODY_SIZE),
+                                                                   d.begin() + static_cast<std::ptrdiff_t>(b * State::BODY_SIZE + 6), out);
             }
-            check(rbs_loglikes_deltas(handle_, deltas_.data(), integrated_poses_.data().data(), State::BODY_SIZE, indices.data(),
-                                      static_cast<int32_t>(n), update ? 1 : 0, ll.data()));
+            for (size_t b = 0; b < B; ++b)
+                std::copy(integrated_poses_.component(static_cast<int>(b)), integrated_poses_.component(static_cast<int>(b)) + 6, defaults_.begin() + static_cast<std::ptrdiff_t>(6 * b));
+            check(rbs_loglikes_deltas(handle_, deltas_.data(), defaults_.data(), 6, indices.data(), static_cast<int32_t>(n), update ? 1 : 0, ll.data()));
             return ll;
         }
         poses_.resize(n * static_cast<size_t>(n_bodies_) * 12);
@@ -333,7 +344,8 @@ private:
     rbs_handle* handle_ = nullptr;
     int n_bodies_;
     State integrated_poses_;
-    std::vector<Real> poses_, deltas_;
+    std::vector<Real> poses_, deltas_, defaults_;
+    bool borrow_ = false;
 };
 
 /// dbot::ObjectTransitionBuilder<State>: parameters of the velocity random walk

@@ -167,6 +167,17 @@ int32_t rbs_reset(rbs_handle* h);
 int32_t rbs_set_observation(rbs_handle* h, const double* depth, size_t n);
 /* Same, from the float32 pixels the camera driver delivers (skips the double round trip). */
 int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n);
+/* rbs_set_observation WITHOUT the copy at call time (round 5): the library BORROWS `depth` -- it must stay valid and
+ * unchanged until the next rbs_loglikes / rbs_loglikes_deltas / rbs_loglikes_prefetch or rbs_synchronize on the handle has
+ * RETURNED (any other entry point that needs the observation stages it first as well; a later rbs_set_observation* or
+ * rbs_reset simply drops it).  That next likelihood call launches its rectangles kernel and its GEOMETRY kernel -- which
+ * need no frame -- first, converts (double -> float) and sends the frame while they run, and only then launches the
+ * likelihood kernel: the two-kernel form of the raster launch (same work items, same summation order, same bits as the
+ * one-kernel launch), so the frame's journey, 60-100 us of a synchronous 300 us step, hides behind the geometry.
+ * This is what the dbot binding calls: inside tracker_->track(image) (R:source/dbot_ros/object_tracker_ros.hpp:49) the
+ * image outlives the filter's set_observation / loglikes pair.  The occlusion clock advances at this call, as for
+ * rbs_set_observation.  Handles over several devices, precision F32 and whole-plane handles copy at once (= rbs_set_observation). */
+int32_t rbs_set_observation_borrowed(rbs_handle* h, const double* depth, size_t n);
 
 /* Frame ingest straight from the camera driver: `native` is the full-resolution
  * float32 image (width x height, metres, NaN = no reading); the evaluated image is its

@@ -102,9 +102,12 @@ public:
 
     // image: rows*cols depths, row-major, metres, NaN = no reading (ri::to_eigen_vector,
     // R:source/dbot_ros/util/ros_interface.h:152-168)
+    // The image is BORROWED until the filter's next loglikes() has returned: inside tracker_->track(image) it outlives the
+    // set_observation / loglikes pair, and that loglikes() converts and sends it while its geometry kernel runs (the frame's
+    // 60-100 us hide behind the kernel).  A caller that cannot promise this uses rbs_set_observation (copies at once).
     void set_observation(const Observation& image) override
     {
-        check(rbs_set_observation(handle_, image.data(), static_cast<size_t>(image.size())));
+        check(rbs_set_observation_borrowed(handle_, image.data(), static_cast<size_t>(image.size())));
     }
 
     // deltas: the particles' states around integrated_poses().  The composition

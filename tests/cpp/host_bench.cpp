@@ -10,6 +10,14 @@
 //   float frames[F][rows*cols]; double poses[F][n][n_objects][12]; int32 parents[n];
 //   double tracker_init[n_objects][12] (position, rotation vector, velocities: the model-frame state the
 //   device tracker starts from)
+//   host_bench --plugin <workload.bin> <steps> [warmup]
+// the same steps THROUGH THE PLUGIN SURFACE the reference drives: dbot_amd::RbSensorBuilder<State>(object_model,
+// camera_data, parameters).build() (R:source/dbot_ros/tracker/particle_tracker_node.cpp:164-203), then per step
+// sensor->set_observation(image) with the image as the reference hands it over -- a vector of rows*cols DOUBLES
+// (R:source/dbot_ros/util/ros_interface.h:152-168, R:source/dbot_ros/object_tracker_ros.hpp:44-49) -- and
+// sensor->loglikes(deltas, indices, update) with the particles' state DELTAS, one State (a heap vector of its own) per
+// particle, around integrated_poses(); synchronous, the frame inside the clock, no look-ahead.  The image is borrowed until
+// loglikes returns, as in the dbot binding (integration/dbot/rb_sensor_mi355x.h); --plugin-copy: copied at set_observation.
 //   host_bench --tracker <workload.bin> <particles>
 // the device tracker (rbs_tracker_*: transition, loglikes, weights, KL test, resampling, mean; device
 // RNG) over the workload's frames, frame by frame (rbs_tracker_track: one host synchronisation per
@@ -17,6 +25,7 @@
 // rbs_tracker_result) -- what the reference's C++ node would see, no interpreter between the frames.
 // Prints one line: "host_bench particle-likelihoods/s <v> ms/step <t> checksum <sum of finite log-likelihoods of the last step>".
 #include <rbsensor_mi355x.h>
+#include <dbot_amd/rb_sensor_builder.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -33,7 +42,9 @@ int main(int argc, char** argv)
 {
     const bool tracker_mode = argc > 1 && !std::strcmp(argv[1], "--tracker");
     const bool prefetch_mode = argc > 1 && !std::strcmp(argv[1], "--prefetch");   // the next frame travels behind each call's kernels
-    if (tracker_mode || prefetch_mode) { --argc; ++argv; }
+    const bool plugin_copy = argc > 1 && !std::strcmp(argv[1], "--plugin-copy");  // ... set_observation copying at once, as dbot's own sensors do
+    const bool plugin_mode = plugin_copy || (argc > 1 && !std::strcmp(argv[1], "--plugin"));   // through dbot_amd::RbSensor (double frame, state deltas)
+    if (tracker_mode || prefetch_mode || plugin_mode) { --argc; ++argv; }
     if (argc < 3) { std::fprintf(stderr, "usage: host_bench workload.bin steps [warmup] | host_bench --tracker workload.bin particles\n"); return 2; }
     std::FILE* f = std::fopen(argv[1], "rb");
     if (!f) { std::perror(argv[1]); return 2; }
@@ -61,6 +72,81 @@ int main(int argc, char** argv)
     const bool have_init = rd(f, init.data(), init.size());
     std::fclose(f);
     if (tracker_mode && !have_init) { std::fprintf(stderr, "host_bench --tracker: the workload holds no initial state\n"); return 2; }
+
+    if (plugin_mode) {
+        using namespace dbot_amd;
+        typedef FreeFloatingRigidBodiesState State;
+        // construction in the node's order (particle_tracker_node.cpp:89-121, 164-203); the meshes are taken as they are
+        // (center = false: the workload's poses are poses of these vertices)
+        std::vector<std::vector<Real>> vs(nobj);
+        std::vector<std::vector<int32_t>> ts(nobj);
+        size_t vo = 0, to = 0;
+        for (int b = 0; b < nobj; ++b) {
+            vs[b].assign(verts.begin() + vo, verts.begin() + vo + 3 * (size_t)vcnt[b]); vo += 3 * (size_t)vcnt[b];
+            ts[b].assign(tris.begin() + to, tris.begin() + to + 3 * (size_t)tcnt[b]); to += 3 * (size_t)tcnt[b];
+        }
+        auto om = std::make_shared<ObjectModel>(vs, ts, false);
+        auto cam = std::make_shared<CameraData>();
+        for (int i = 0; i < 9; ++i) cam->camera_matrix[i] = K[i];
+        cam->resolution.width = cols; cam->resolution.height = rows;
+        RbSensorBuilder<State>::Parameters p;
+        p.use_gpu = true; p.sample_count = n;
+        p.occlusion.p_occluded_visible = prm[0]; p.occlusion.p_occluded_occluded = prm[1]; p.occlusion.initial_occlusion_prob = prm[2];
+        p.kinect.tail_weight = prm[3]; p.kinect.model_sigma = prm[4]; p.kinect.sigma_factor = prm[5]; p.delta_time = prm[6];
+        std::shared_ptr<RbSensor<State>> sensor;
+        try { sensor = RbSensorBuilder<State>(om, cam, p).build(); }
+        catch (const std::exception& e) { std::printf("NO_DEVICE %s\n", e.what()); return 0; }
+        sensor->borrow_observations(!plugin_copy);   // (--plugin: as the dbot binding does -- the image outlives the set_observation / loglikes pair)
+        // the images as the reference's tracker receives them: doubles
+        std::vector<std::vector<double>> images(F, std::vector<double>(npx));
+        for (int k = 0; k < F; ++k) for (size_t q = 0; q < npx; ++q) images[k][q] = (double)frames[npx * k + q];
+        // deltas around the default pose = body b's pose of particle 0 in frame 0 (what a tracker's integrated_poses() would be
+        // near); delta = pose (-) default:  R(delta) = R R0^T,  t(delta) = t - t0
+        auto to_rotvec = [](const double* R, double* rv) {   // atan2 form (oracle/tracker_oracle.c matrix_to_rotvec, small angles)
+            const double sx = 0.5 * (R[7] - R[5]), sy = 0.5 * (R[2] - R[6]), sz = 0.5 * (R[3] - R[1]);
+            const double sn = std::sqrt(sx * sx + sy * sy + sz * sz), cs = 0.5 * ((R[0] + R[4] + R[8]) - 1.0);
+            const double k = sn > 1e-12 ? std::atan2(sn, cs) / sn : 1.0;
+            rv[0] = sx * k; rv[1] = sy * k; rv[2] = sz * k;
+        };
+        State& dflt = sensor->integrated_poses();
+        for (int b = 0; b < nobj; ++b) {
+            const double* P0 = poses.data() + 12 * (size_t)b;
+            for (int k = 0; k < 3; ++k) dflt.position(b)[k] = P0[9 + k];
+            to_rotvec(P0, dflt.euler_vector(b));
+        }
+        std::vector<std::vector<State>> deltas(F, std::vector<State>(n, State(nobj)));
+        double R0[9];
+        for (int k = 0; k < F; ++k)
+            for (int i = 0; i < n; ++i)
+                for (int b = 0; b < nobj; ++b) {
+                    const double* Pp = poses.data() + stride * k + 12 * ((size_t)i * nobj + b);
+                    State::rotation_matrix(dflt.euler_vector(b), R0);
+                    double Rd[9];
+                    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+                        Rd[3 * r + c] = Pp[3 * r] * R0[3 * c] + Pp[3 * r + 1] * R0[3 * c + 1] + Pp[3 * r + 2] * R0[3 * c + 2];   // R R0^T
+                    State& d = deltas[k][i];
+                    to_rotvec(Rd, d.euler_vector(b));
+                    for (int q = 0; q < 3; ++q) d.position(b)[q] = Pp[9 + q] - dflt.position(b)[q];
+                }
+        RbSensor<State>::IntArray indices(n);
+        RbSensor<State>::RealArray ll;
+        auto pstep = [&](int i) {
+            const int k = i % F;
+            sensor->set_observation(images[k]);
+            indices.assign(parents.begin(), parents.end());
+            ll = sensor->loglikes(deltas[k], indices, update != 0);
+        };
+        try {
+            for (int i = 0; i < warmup; ++i) pstep(i);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < steps; ++i) pstep(warmup + i);
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            double sum = 0.0;
+            for (double v : ll) if (std::isfinite(v)) sum += v;
+            std::printf("host_bench particle-likelihoods/s %.1f ms/step %.5f checksum %.10g\n", (double)n * steps / dt, dt / steps * 1e3, sum);
+        } catch (const std::exception& e) { std::printf("ERROR %s\n", e.what()); return 1; }
+        return 0;
+    }
 
     rbs_config cfg;
     std::memset(&cfg, 0, sizeof cfg);

@@ -301,6 +301,11 @@ def test_bench_line_of_two_ranks_on_one_gpu(gpu_lib):
     # the step resamples over BOTH ranks' particles: some children inherit from the other rank
     assert 0.0 < line["remote_parent_frac"] < 1.0 and line["distinct_parents_per_step"] > 4
     assert "global" in line["config"]["workload"].lower() and "IPC" in line["config"]["sharding"]
+    # the job validated itself before it timed anything (SURVEY 8e's equality test)
+    assert line["multi_gpu_equals_single"] is True, line.get("multi_gpu_check_diagnosis")
+    assert line["ipc_attach_ok"] == [True, True] and line["peer_read_ok"] == [True, True] and line["rccl_ranks_seen"] == [2, 2]
+    assert line["multi_gpu_check_parent_mismatches"] == 0 and line["multi_gpu_check_max_abs_loglik_diff"] <= 1e-9
+    assert min(line["multi_gpu_check_remote_children"]) > 0      # both ranks really read planes of the other
 
 
 def test_bench_line_when_the_ranks_cannot_attach(gpu_lib):
@@ -323,3 +328,6 @@ def test_bench_line_when_the_ranks_cannot_attach(gpu_lib):
     assert "could not be attached" in line["config"]["workload"] and "local parents" in line["config"]["sharding"]
     assert line["value"] > 0 and "roofline" in line
     assert abs(line["value"] - 2 * 256 * 5 / (line["ms_per_step"] * 5e-3)) <= 1e-6 * line["value"]
+    # ... and the self-check says the same, with a diagnosis, instead of stopping the job
+    assert line["multi_gpu_equals_single"] is False and line["ipc_attach_ok"] == [False, False]
+    assert "RBS_BENCH_FAIL_ATTACH" in line["multi_gpu_check_diagnosis"]

@@ -7,7 +7,7 @@ import pytest
 
 import oracle_binding as ob
 import scenarios as sc
-from dbot_ros_amd import RbSensor, RbSensorError, _capi, synth
+from dbot_ros_amd import RbSensor, RbSensorError, _capi, synth  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -217,7 +217,7 @@ def test_split_launch_matches_the_oracle(gpu_lib, monkeypatch, meshes, cols, row
     with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=slab) as mono:
         base = sc.run_sequence(mono, frames, n, n_bodies=nb)
         monkeypatch.setenv("RBS_SPLIT", "1")
-        monkeypatch.setenv("RBS_SPLIT_ITEMS_PER_PARTICLE", "48")
+        monkeypatch.setenv("RBS_SPLIT_ITEMS_PER_PARTICLE", "400")   # (few particles: a rectangle is cut into many row bands)
         with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=slab) as g:
             got = sc.run_sequence(g, frames, n, n_bodies=nb)
             for a, b, c in zip(got, ref, base):
@@ -251,3 +251,56 @@ def test_split_launch_contains_items_beyond_its_buffer(gpu_lib, monkeypatch):
         ll = g.loglikes_poses(np.repeat(truth[None], n, 0), np.zeros(n, np.int32), update=True)
         assert np.isnan(ll).any() and np.isfinite(ll).any()
         g.synchronize()
+
+
+def test_borrowed_frame_gives_the_same_bits(gpu_lib):
+    """rbs_set_observation_borrowed: the frame is staged by the next likelihood call between its geometry and its likelihood
+    kernel (two-kernel launch) -- log-likelihoods and planes are bit for bit those of rbs_set_observation + the one-kernel
+    launch, on a resampled sequence; a borrowed frame that another frame overtakes is dropped, one that rbs_synchronize or
+    a device-pointer call meets is staged there."""
+    import torch
+    n = 96
+    om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
+    o = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    frames = sc.make_frames(o, 1, 4, seed=21)
+    rng = np.random.default_rng(4)
+    poses = [synth.particle_poses(t, n, rng, scale=1.5) for t, _ in frames]
+    parents = [np.sort(rng.integers(0, n, n)).astype(np.int32) for _ in frames]
+    with RbSensor(om, cam, P, max_particles=n, precision="f64") as a, RbSensor(om, cam, P, max_particles=n, precision="f64") as b:
+        a.reset(); b.reset()
+        ia, ib = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for k, (_, frame) in enumerate(frames):
+            f64 = frame.astype(np.float64)
+            a.set_observation(f64)
+            if k == 2:      # overtaken: dropped, but its clock tick stays -- the same on both sides
+                a.set_observation(f64)
+                b.set_observation_borrowed(np.full_like(f64, 0.3))
+            b.set_observation_borrowed(f64)
+            la = a.loglikes_poses(poses[k], ia, update=True)
+            lb = b.loglikes_poses(poses[k], ib, update=True)
+            assert np.array_equal(la, lb), np.abs(la - lb).max()
+            ia, ib = parents[k].copy(), parents[k].copy()
+        for slot in (0, n // 3, n - 1):
+            assert a.get_window(slot) == b.get_window(slot)
+            assert np.array_equal(a.get_occlusion(slot), b.get_occlusion(slot))
+        # staged by whatever needs the observation first
+        f64 = frames[0][1].astype(np.float64)
+        b.set_observation_borrowed(f64)
+        assert np.array_equal(b.get_observation(), frames[0][1], equal_nan=True)
+        b.set_observation_borrowed(f64)
+        b.synchronize()
+        a.set_observation(f64); a.set_observation(f64)
+        d_poses = torch.from_numpy(poses[0].reshape(n, -1)).cuda()
+        d_idx = torch.from_numpy(parents[0]).cuda()
+        outs = []
+        for s_ in (a, b):
+            if s_ is b:
+                b.set_observation_borrowed(f64)
+            else:
+                a.set_observation(f64)
+            d_out = torch.empty(n, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            s_.loglikes_device(d_poses.data_ptr(), d_idx.data_ptr(), n, False, d_out.data_ptr())
+            s_.synchronize()
+            outs.append(d_out.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])

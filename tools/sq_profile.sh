@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/sq_profile.sh TAG [ENV=...]: SQ counters of the raster kernel on the default bench step
-# (run on the GPU box).  One rocprofv3 pass per counter group; raw csv under gpurun_out/sq_TAG.
+# (run on the GPU box; SQ_KERNELS="name1 name2": kernels to summarise, default the raster kernel).  One rocprofv3 pass per counter group; raw csv under gpurun_out/sq_TAG.
 tag=${1:-sq}; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/sq_$tag; rm -rf $out; mkdir -p $out
@@ -14,4 +14,4 @@ for grp in \
   i=$((i+1))
   env "$@" rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/p$i -o p -- $BENCH > $out/p$i.log 2>&1
 done
-python tools/sq_summary.py $out
+python tools/sq_summary.py $out $SQ_KERNELS

@@ -99,9 +99,10 @@ if os.path.exists(sq_path):
         g = lambda c: sq.get((k, c), 0.0)
         # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves
         summary = {"precision": os.environ.get("RBS_PROFILE_PRECISION", "f64"), "state_layout": layout, "kernel": k, "workload": WORKLOAD,
+                   # (only what this pass collected: a counter that was not in the --pmc list is omitted, not reported as 0)
                    "per_dispatch": {c: g(c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
                                                       "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
-                                                      "SQ_BUSY_CYCLES", "SQ_INSTS_SALU")},
+                                                      "SQ_BUSY_CYCLES", "SQ_INSTS_SALU") if (k, c) in sq},
                    "valu_instructions_per_particle": g("SQ_INSTS_VALU") / float(N_PART),
                    "cycles_per_valu_instruction": 4.0 * g("SQ_ACTIVE_INST_VALU") / max(g("SQ_INSTS_VALU"), 1.0),
                    "fraction_of_wave_time_issuing_valu": g("SQ_ACTIVE_INST_VALU") / max(g("SQ_WAVE_CYCLES"), 1.0),
