@@ -117,6 +117,8 @@ def parse():
     ap.add_argument("--no-host-leg", action="store_true")
     ap.add_argument("--no-tracker-fps", action="store_true")
     ap.add_argument("--no-configs-leg", action="store_true", help="skip the C2 / C3-slice / C4-slice / read-only / 80x60 runs")
+    ap.add_argument("--no-sweep-leg", action="store_true", help="skip the moving-object / window-fraction legs")
+    ap.add_argument("--sweep-only", action="store_true", help="only the moving-object / window-fraction legs (prints their keys)")
     ap.add_argument("--no-pmc", action="store_true", help="no live rocprofv3 counter passes (roofline falls back to profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -132,7 +134,7 @@ def parse():
     for k, v in PRESETS.get(a.config, {}).items():
         setattr(a, k, v)
     if a.quick or a.config not in (None, "c1"):
-        a.no_dense_leg = a.no_f32_leg = a.no_host_leg = a.no_tracker_fps = a.no_cpu_baseline = a.no_configs_leg = True
+        a.no_dense_leg = a.no_f32_leg = a.no_host_leg = a.no_tracker_fps = a.no_cpu_baseline = a.no_configs_leg = a.no_sweep_leg = True
         a.no_pmc = a.no_pmc or a.quick
     return a
 
@@ -569,6 +571,106 @@ def configs_leg(a, dev, stream, names=("c1_readonly", "c2", "c3_slice", "c4_slic
                            "loglikes(update=false); c2 = 6 666 particles x (M1, M2, M3), particle-likelihoods/s (x3 = body renders/s); "
                            "c3_slice = 25 000 particles (1/8 of C3); c4_slice = 6 250 particles, mesh M4 (50 880 triangles), 1280x960 "
                            "(1/8 of C4); default_res = C1 at 80x60 (downsampling_factor 8)")
+    return res
+
+
+def sweep_leg(a, dev, stream, n_frames=1000, tail=200, table=(0.03, 0.10, 0.25, 0.50)):
+    """What the windowed state layout sustains when the object MOVES ACROSS THE IMAGE: a pixel stays in a
+    particle's window until its occlusion value has relaxed to within 2^-18 of the background, ~730 frames (24 s) after the
+    object left it, and a window is ONE bounding box of everything an ancestor touched in that time.  C1 (2 000 particles, M1,
+    640x480, update=true, permutation parents) with the object travelling along the image diagonal and back at 2 mm per frame
+    for n_frames frames; `sweep_value` = the rate over the LAST `tail` frames (every window then holds a 24 s trail),
+    `sweep_window_fraction` = the mean stored fraction of a plane at the end.  And a table: the same C1 step with every plane's
+    window pre-filled to a given fraction of the frame (window_fraction_table: fraction -> particle-likelihoods/s)."""
+    import copy
+    from dbot_ros_amd import RbSensor, synth
+    b = copy.copy(a)
+    for k, v in PRESETS["c1"].items():
+        setattr(b, k, v)
+    om, cam, P, n_tri, nb = build_scene(b)
+    n = b.particles
+    res = {}
+    rng = np.random.default_rng(7)
+    prng = np.random.default_rng(8)
+    # the diagonal of the visible volume at 0.7 m (fx = 570: +-0.39 m x +-0.29 m), a margin of the object's size kept
+    p0, p1 = np.array([-0.30, -0.21, 0.7]), np.array([0.30, 0.21, 0.7])
+    length = float(np.linalg.norm(p1 - p0))
+    truths = []
+    for k in range(n_frames):
+        s_ = (0.002 * k) % (2.0 * length)
+        s_ = s_ if s_ <= length else 2.0 * length - s_           # there and back
+        t = synth.truth_pose(1, frame=k % 360).copy()
+        t[0, 9:12] = p0 + (p1 - p0) * (s_ / length)
+        truths.append(t)
+    with RbSensor(om, cam, P, device_id=dev.index, max_particles=1) as r:
+        frames = np.stack([synth.make_frame(r.render_depth(t), b.rows, b.cols, rng) for t in truths]).astype(np.float32)
+    # the particles of a tracker that follows the object: a cloud around the truth, one fixed set of offsets (the transition's spread)
+    base = synth.particle_poses(truths[0], n, prng).reshape(n, -1)
+    off = base[:, 9:12] - truths[0][0, 9:12]
+    d_frames = torch.from_numpy(frames).to(dev)
+    poses = np.repeat(base[None], 2, axis=0)         # two staging copies, rewritten on the device per frame
+    d_base = torch.from_numpy(base).to(dev)
+    d_pose = d_base.clone()
+    d_off = torch.from_numpy(off).to(dev)
+    d_t = torch.from_numpy(np.stack([t[0, 9:12] for t in truths])).to(dev)
+    d_idx = torch.from_numpy(synth.resample_like_indices(n, prng)).to(dev)
+    d_out = torch.empty(n, dtype=torch.float64, device=dev)
+    del poses
+    frame_bytes = d_frames[0].numel() * 4
+    with make_sensor(b, om, cam, P, dev) as s:
+        s.reset()
+        s.set_observation(frames[0])
+        s.synchronize()
+
+        def step(k):
+            d_pose[:, 9:12] = d_t[k] + d_off         # (two tiny torch kernels on the same stream: inside the clock)
+            s.set_observation_device(d_frames.data_ptr() + k * frame_bytes, stream.cuda_stream)
+            s.loglikes_device(d_pose.data_ptr(), d_idx.data_ptr(), n, True, d_out.data_ptr(), stream.cuda_stream)
+
+        marks = {}
+        for k in range(n_frames - tail):
+            step(k)
+            if k in (30, 100, 300):
+                torch.cuda.synchronize()
+                w = np.array([s.get_window(q) for q in range(0, n, max(1, n // 32))])
+                marks[k] = float(np.mean(np.maximum(0, w[:, 2] - w[:, 0]) * np.maximum(0, w[:, 3] - w[:, 1]))) / (b.rows * b.cols)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_frames - tail, n_frames):
+            step(k)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ok = bool(np.isfinite(d_out.cpu().numpy()).all())
+        w = np.array([s.get_window(q) for q in range(0, n, max(1, n // 64))])
+        frac = float(np.mean(np.maximum(0, w[:, 2] - w[:, 0]) * np.maximum(0, w[:, 3] - w[:, 1]))) / (b.rows * b.cols)
+    res.update({"sweep_value": n * tail / el if ok else None, "sweep_ms_per_step": el / tail * 1e3, "sweep_window_fraction": frac,
+                "sweep_window_fraction_after_frames": {str(k): v for k, v in marks.items()},
+                "sweep_note": (f"C1 with the object travelling along the image diagonal and back at 2 mm/frame, {n_frames} frames, particles following it; "
+                               f"rate over the last {tail} frames (windows hold the ~730-frame trail the 2^-18 snap leaves), stored fraction of a plane "
+                               "at the end; inputs resident in HBM.  The headline's object oscillates over 6 cm (window 3 % of the plane)")})
+    del d_frames
+    torch.cuda.empty_cache()
+    # ---- window fraction -> rate: the headline's own step with every plane's window pre-filled
+    tab = {}
+    for f in table:
+        c = copy.copy(b)
+        c.fill_planes, c.fill_fraction = 0.9, f
+        W = Workload(c, om, cam, P, nb, dev, 0)
+        s = make_sensor(c, om, cam, P, dev)
+        prime(s, c, W)
+        run = ResidentRun(c, W, s, stream, d_out)
+        run.timed(48, 0)                      # the handle samples the stored area every 8th call and picks its launch shape from it
+        el = run.timed(100, 0)
+        w = np.array([s.get_window(q) for q in range(0, n, max(1, n // 64))])
+        got = float(np.mean(np.maximum(0, w[:, 2] - w[:, 0]) * np.maximum(0, w[:, 3] - w[:, 1]))) / (b.rows * b.cols)
+        s.close()
+        tab[f"{f:.2f}"] = {"value": n * 100 / el, "ms_per_step": el / 100 * 1e3, "stored_fraction_measured": got}
+        del W
+        torch.cuda.empty_cache()
+    res["window_fraction_table"] = tab
+    res["window_fraction_table_note"] = ("C1's step with every plane's window pre-filled to that fraction of the frame (a centred block of values "
+                                         "that differ from the background): above 15 % the raster kernel runs two blocks per CU, above 50 % the call "
+                                         "takes the whole-plane machinery")
     return res
 
 
@@ -1168,6 +1270,9 @@ def main():
     d_out.zero_()                  # first submission creates the stream's hardware queue: setup, not a step
     torch.cuda.synchronize()
 
+    if a.sweep_only:
+        print(json.dumps(sweep_leg(a, dev, stream), indent=1), flush=True)
+        return
     peer_ok, peer_msg = world > 1, None
     selfcheck = {}
     if world > 1:
@@ -1371,6 +1476,11 @@ def main():
                                "reference semantics only for well-conditioned sums, parent indices not reproduced at large particle counts")
     if single and not a.no_configs_leg and a.config in (None, "c1"):
         out.update(configs_leg(a, dev, stream))
+    if single and not a.no_sweep_leg and a.config in (None, "c1") and a.layout == "window":
+        try:
+            out.update(sweep_leg(a, dev, stream))
+        except Exception as e:   # noqa: BLE001 -- a leg must not take the headline down
+            out["sweep_note"] = f"sweep leg failed: {e!r}"
     # ---- host-pointer API: frame upload + pose upload + log-likelihood download inside the clock
     if single and not a.no_host_leg:
         hs = make_sensor(a, om, cam, P, dev)

@@ -17,6 +17,29 @@
 #include <omp.h>
 #endif
 
+/* EXPOSURE VARIANTS (round 5).  The restatement is unpinned: where SURVEY Appendix A left a rule open, this
+ * file chose one (divergence ledger).  These compile-time switches build the oracle with the rule
+ * upstream MIGHT have chosen instead, so that tests/test_oracle_variants.py can print how far log-likelihoods and resampled
+ * parents would move -- the size of the exposure, not a pin.  0 everywhere = the rule of record (what the device matches).
+ *   ORC_VARIANT_COVERAGE   ledger L1: 0 closed triangle at integer sample points, either winding;
+ *                                      1 top-left fill rule (a sample exactly ON an edge belongs to one of the two triangles);
+ *                                      2 scan-line spans (per row the columns between the edges' intersections, inclusive:
+ *                                        SURVEY A.2's own wording);
+ *                                      3 sample points at pixel CENTRES (col + 0.5, row + 0.5): the GL convention (A.7)
+ *   ORC_VARIANT_ROUNDING   ledger L6: 0 float temporaries (prior, a, b, p_bg, their sum and ratios);
+ *                                      1 binary64 throughout, only the stored posterior rounded to float
+ *   ORC_VARIANT_NONFINITE  ledger L4: 0 a pixel whose observation is not finite (NaN or +-inf) is skipped;
+ *                                      1 only NaN is skipped, +-inf is evaluated like any other reading */
+#ifndef ORC_VARIANT_COVERAGE
+#define ORC_VARIANT_COVERAGE 0
+#endif
+#ifndef ORC_VARIANT_ROUNDING
+#define ORC_VARIANT_ROUNDING 0
+#endif
+#ifndef ORC_VARIANT_NONFINITE
+#define ORC_VARIANT_NONFINITE 0
+#endif
+
 #define ORC_MAX_DEPTH 6.0       /* hard-coded max_depth        */
 #define ORC_HALF_LIFE_DEPTH 1.0 /* hard-coded half_life_depth  */
 
@@ -156,20 +179,63 @@ static void raster_triangle(const orc_sensor* s, const double* tri, const double
 
     const double umin = fmin(fmin(u[0], u[1]), u[2]), umax = fmax(fmax(u[0], u[1]), u[2]);
     const double vmin = fmin(fmin(v[0], v[1]), v[2]), vmax = fmax(fmax(v[0], v[1]), v[2]);
-    const double xlo_d = fmax(ceil(umin), 0.0), xhi_d = fmin(floor(umax), (double)(s->cfg.cols - 1));
-    const double ylo_d = fmax(ceil(vmin), 0.0), yhi_d = fmin(floor(vmax), (double)(s->cfg.rows - 1));
+#if ORC_VARIANT_COVERAGE == 3
+    const double smp = 0.5;   /* (pixel centres: the candidate samples of the bounding box move with the grid) */
+#else
+    const double smp = 0.0;
+#endif
+    const double xlo_d = fmax(ceil(umin - smp), 0.0), xhi_d = fmin(floor(umax - smp), (double)(s->cfg.cols - 1));
+    const double ylo_d = fmax(ceil(vmin - smp), 0.0), yhi_d = fmin(floor(vmax - smp), (double)(s->cfg.rows - 1));
     if (!(xlo_d <= xhi_d) || !(ylo_d <= yhi_d)) return;
     const int xlo = (int)xlo_d, xhi = (int)xhi_d, ylo = (int)ylo_d, yhi = (int)yhi_d;
 
-    for (int row = ylo; row <= yhi; ++row) {
-        const double py = (double)row;
-        for (int col = xlo; col <= xhi; ++col) {
-            const double px = (double)col;
+    const double shift = smp;   /* the sample of pixel (col, row) sits at (col + shift, row + shift) */
+#define ORC_XLO xlo
+#define ORC_XHI xhi
+#define ORC_YLO ylo
+#define ORC_YHI yhi
+    (void)xlo; (void)xhi; (void)ylo; (void)yhi; (void)e12u; (void)e12v; (void)e20u; (void)e20v;   /* (not every variant uses all of them) */
+    for (int row = ORC_YLO; row <= ORC_YHI; ++row) {
+        const double py = (double)row + shift;
+#if ORC_VARIANT_COVERAGE == 2
+        /* scan line: the span of this row between the edges' intersections, both ends inclusive */
+        double xl = INFINITY, xr = -INFINITY;
+        for (int k = 0; k < 3; ++k) {
+            const int a = k, b = (k + 1) % 3;
+            if (v[a] == v[b]) {
+                if (v[a] == py) { xl = fmin(xl, fmin(u[a], u[b])); xr = fmax(xr, fmax(u[a], u[b])); }
+                continue;
+            }
+            if (py >= fmin(v[a], v[b]) && py <= fmax(v[a], v[b])) {
+                const double x = u[a] + (py - v[a]) * ((u[b] - u[a]) / (v[b] - v[a]));
+                xl = fmin(xl, x); xr = fmax(xr, x);
+            }
+        }
+#endif
+        for (int col = ORC_XLO; col <= ORC_XHI; ++col) {
+            const double px = (double)col + shift;
+#if ORC_VARIANT_COVERAGE == 2
+            const int in = px >= xl && px <= xr;
+#else
             const double E0 = e01u * (py - v[0]) - e01v * (px - u[0]);
             const double E1 = e12u * (py - v[1]) - e12v * (px - u[1]);
             const double E2 = e20u * (py - v[2]) - e20v * (px - u[2]);
+#if ORC_VARIANT_COVERAGE == 1
+            /* top-left: inside = strictly on the interior side of every edge, or exactly on an edge that owns its samples
+             * (one fixed half of the edge directions, so that a sample on a shared edge belongs to exactly one triangle) */
+            const double sg = area2 > 0.0 ? 1.0 : -1.0;
+            const double F[3] = {sg * E0, sg * E1, sg * E2};
+            const double du[3] = {sg * e01u, sg * e12u, sg * e20u}, dv[3] = {sg * e01v, sg * e12v, sg * e20v};
+            int in = 1;
+            for (int k = 0; k < 3; ++k) {
+                const int owns = dv[k] > 0.0 || (dv[k] == 0.0 && du[k] < 0.0);
+                if (!(F[k] > 0.0 || (F[k] == 0.0 && owns))) in = 0;
+            }
+#else
             const int in = (E0 >= 0.0 && E1 >= 0.0 && E2 >= 0.0) ||
                            (E0 <= 0.0 && E1 <= 0.0 && E2 <= 0.0);
+#endif
+#endif
             if (!in) continue;
             const double den = (pa * px + pb * py) + pc;
             const float zf = (float)(nv0 / den);
@@ -316,8 +382,22 @@ void orc_set_observation(orc_sensor* s, const double* depth)
  * log-likelihood and its posterior occlusion b / (a + b).  Rounding points: a = p_vis (1 - occ),
  * b = p_occ occ and p_bg -> float ("float temporaries upstream"); a + b and both ratios in float;
  * log in double. */
+#if ORC_VARIANT_ROUNDING == 1
+/* binary64 throughout (the prior included): only the stored posterior is rounded to float */
+static double pixel_term_f64(const orc_sensor* s, float o, float r, double occ, float* posterior)
+{
+    const double a = orc_prob_visible(s, (double)o, (double)r) * (1.0 - occ);
+    const double b = orc_prob_occluded(s, (double)o, (double)r) * occ;
+    const double pbg = orc_prob_occluded(s, (double)o, INFINITY);
+    *posterior = (float)(b / (a + b));
+    return log((a + b) / pbg);
+}
+#endif
 double orc_pixel_term(const orc_sensor* s, float o, float r, float occ, float* posterior)
 {
+#if ORC_VARIANT_ROUNDING == 1
+    return pixel_term_f64(s, o, r, (double)occ, posterior);
+#endif
     const float a = (float)(orc_prob_visible(s, (double)o, (double)r) * (1.0 - (double)occ));
     const float b = (float)(orc_prob_occluded(s, (double)o, (double)r) * (double)occ);
     const float pbg = (float)orc_prob_occluded(s, (double)o, INFINITY);
@@ -365,16 +445,29 @@ static double loglik_one(orc_sensor* s, const double* pose, int32_t parent, int3
         const float r = depth[p];
         depth[p] = INFINITY; /* leave the scratch buffer clean for the next particle */
         const float o = s->frame[p];
+#if ORC_VARIANT_NONFINITE == 1
+        if (isnan(o)) continue;
+#else
         if (!isfinite(o)) continue;
+#endif
         float occ;
+        float post;
+#if ORC_VARIANT_ROUNDING == 1
+        double occ_d;
+        if (lazy) occ_d = orc_propagate(s, (double)pocc[p], (double)(s->clock - pstamp[p]) * s->cfg.delta_time);
+        else occ_d = (double)orc_eager_prior(alpha, beta, pocc[p], bg_now);
+        occ = (float)occ_d;
+        (void)occ;
+        const double term = pixel_term_f64(s, o, r, occ_d, &post);
+#else
         if (lazy) {
             const double dt = (double)(s->clock - pstamp[p]) * s->cfg.delta_time;
             occ = (float)orc_propagate(s, (double)pocc[p], dt);
         } else {
             occ = orc_eager_prior(alpha, beta, pocc[p], bg_now);
         }
-        float post;
         const double term = orc_pixel_term(s, o, r, occ, &post);
+#endif
         ll += term;
         abs_ll += fabs(term);
         if (update) {

@@ -39,11 +39,28 @@ def build():
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
 
-def load():
+VARIANTS = ("cov_topleft", "cov_scanline", "cov_centres", "round_f64", "inf_evaluated")
+_variant_libs = {}
+
+
+def load(variant=None):
+    """The oracle of record, or (variant = one of VARIANTS) the same source rebuilt with ONE ledger rule changed
+    (oracle/rbsensor_oracle.c "EXPOSURE VARIANTS", oracle/Makefile `variants`): tests/test_oracle_variants.py."""
     global _lib
+    if variant is not None:
+        if variant not in _variant_libs:
+            assert variant in VARIANTS, variant
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", f"librbsensor_oracle_{variant}.so"])
+            _variant_libs[variant] = _bind(C.CDLL(os.path.join(ORACLE_DIR, f"librbsensor_oracle_{variant}.so")))
+        return _variant_libs[variant]
     if _lib is None:
         build()
-        lib = C.CDLL(ORACLE_LIB)
+        _lib = _bind(C.CDLL(ORACLE_LIB))
+    return _lib
+
+
+def _bind(lib):
+    if True:
         H, dp, fp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
         lib.orc_create.restype = H
         lib.orc_create.argtypes = [C.POINTER(OrcConfig)]
@@ -76,8 +93,7 @@ def load():
         lib.orc_tracker_initialize.argtypes = [H, dp]
         lib.orc_tracker_track.argtypes = [H, dp, dp, dp, dp, ip]
         lib.orc_tracker_get.argtypes = [H, dp, dp, ip]
-        _lib = lib
-    return _lib
+    return lib
 
 
 def compose_poses(deltas, default, parts):
@@ -94,8 +110,8 @@ def compose_poses(deltas, default, parts):
 class Oracle:
     """Same constructor arguments as dbot_ros_amd.RbSensor so parity tests read symmetrically."""
 
-    def __init__(self, object_model, camera_data, params, max_particles=None, mode=LAZY):
-        self._lib = load()
+    def __init__(self, object_model, camera_data, params, max_particles=None, mode=LAZY, variant=None):
+        self._lib = load(variant)
         self.n_bodies = object_model.count_parts
         self.rows, self.cols = int(camera_data.rows), int(camera_data.cols)
         K = np.asarray(camera_data.camera_matrix, dtype=np.float64)

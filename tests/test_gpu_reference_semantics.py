@@ -20,7 +20,8 @@ device to north_star's bar against the LAZY one, at the sizes BASELINE.json name
     oracle can follow 20 000 particles);
   * the device's occlusion planes after the 30 frames against orc_get_occlusion_now (LAZY);
   * C1 (all 2 000) and C2 (a random 1 000 of 6 666 x 3 bodies) in the two-frame full-size harness of
-    test_gpu_fullsize.py with the LAZY oracle as the checker;
+    test_gpu_fullsize.py with the LAZY oracle as the checker; C4's geometry (M4 at 1280x960, 256 particles) likewise;
+  * C2's structure as a 30-frame sequence: three bodies, three sampling blocks per frame, resampling after any block;
   * rbs_tracker_* at 20 000 particles against oracle/tracker_oracle.c over the LAZY sensor.
 """
 import numpy as np
@@ -43,24 +44,30 @@ def rel_err(a, b):
 
 
 def _poses_around(truth, dl, da):
-    """Particles at R = R(da) R_truth, t = t_truth + dl (one body)."""
+    """Particles at R_b = R(da_b) R_truth_b, t_b = t_truth_b + dl_b for every body b (dl, da: [n, 3] for one body or [n, bodies, 3])."""
     truth = np.asarray(truth).reshape(-1, 12)
-    R0 = truth[:, :9].reshape(1, 3, 3)
-    return pack_Rt(rotvec_to_matrix(da[:, None, :]) @ R0[None], truth[None, :, 9:12] + dl[:, None, :])
+    nb = truth.shape[0]
+    dl = np.asarray(dl).reshape(len(dl), nb, 3)
+    da = np.asarray(da).reshape(len(da), nb, 3)
+    R0 = truth[:, :9].reshape(1, nb, 3, 3)
+    return pack_Rt(rotvec_to_matrix(da) @ R0, truth[None, :, 9:12] + dl)
 
 
 def _lockstep(meshes, cols, rows, n, n_frames, seed, plane_slots):
     """The filter step (log-weights, KL test, multinomial resampling from host-supplied uniforms:
     dbot_ros_amd/filter.py) driven twice on identical inputs: once from the device's
     log-likelihoods, once from the LAZY oracle's.  Particles are a random walk around the moving
-    ground truth and are inherited by the children.  Returns per-resampling mismatch counts, the worst
-    log-likelihood error and the worst plane difference."""
+    ground truth and are inherited by the children.  Several bodies: one SAMPLING BLOCK per body and frame
+     -- block b moves body b only, the blocks before the last are read-only calls, the last one
+    updates; weights, KL test and resampling after every block, the parent indices carried from block to
+    block.  Returns per-resampling mismatch counts, the worst log-likelihood error and the worst plane difference."""
+    nb = len(meshes)
     om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
     lazy = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
     threads = sc.usable_threads()
     rng = np.random.default_rng(seed)
-    dl = rng.normal(0.0, 0.0025, size=(n, 3))
-    da = rng.normal(0.0, 0.02, size=(n, 3))
+    dl = rng.normal(0.0, 0.0025, size=(n, nb, 3))
+    da = rng.normal(0.0, 0.02, size=(n, nb, 3))
     idx_g, idx_o = np.zeros(n, np.int32), np.zeros(n, np.int32)
     logw = [np.zeros(n), np.zeros(n)]     # device, oracle
     ll_prev = [np.zeros(n), np.zeros(n)]
@@ -69,45 +76,50 @@ def _lockstep(meshes, cols, rows, n, n_frames, seed, plane_slots):
         g.reset()
         lazy.reset(threads=threads)
         for k in range(n_frames):
-            truth = synth.truth_pose(1, frame=k)
+            truth = synth.truth_pose(nb, frame=k)
             frame = synth.make_frame(lazy.render_depth(truth), rows, cols, rng)
-            poses = _poses_around(truth, dl, da)
             g.set_observation(frame)
             lazy.set_observation(frame)
-            ll = [g.loglikes_poses(poses, idx_g, update=True),
-                  lazy.loglikes_poses(poses, idx_o, update=True, threads=threads)]
-            e = rel_err(ll[0], ll[1])
-            assert e.max() <= TOL_LAZY, (k, int(e.argmax()), float(e.max()))      # EVERY particle
-            worst_ll = max(worst_ll, float(e.max()))
-            w, kl = [], []
-            for s in range(2):
-                logw[s] += ll[s] - ll_prev[s]
-                ll_prev[s] = ll[s]
-                w.append(flt.normalized_weights(logw[s]))
-                kl.append(flt.kl_to_uniform(w[s]))
-            assert (kl[0] > 2.0) == (kl[1] > 2.0), (k, kl)
-            if kl[1] > 2.0:
-                u = rng.random(n)
-                pg, po = flt.multinomial_resample(w[0], u), flt.multinomial_resample(w[1], u)
-                bad = np.nonzero(pg != po)[0]
-                mismatches.append(len(bad))
-                n_children += n
-                if len(bad):
-                    # each one drew a uniform within CDF_DELTA of the cumulative weights of EVERY parent between
-                    # the two answers (neighbours, or neighbours but for parents of weight ~0 between them)
-                    c = np.cumsum(w[1])
-                    c /= c[-1]
-                    a, b = np.minimum(pg[bad], po[bad]), np.maximum(pg[bad], po[bad])
-                    worst = np.maximum(np.abs(u[bad] - c[a]), np.abs(u[bad] - c[b - 1]))
-                    assert (worst <= CDF_DELTA).all(), (k, pg[bad], po[bad], worst)
-                # both sides continue with the REFERENCE-semantics parents: identical histories
-                dl, da = dl[po], da[po]
-                idx_g, idx_o = po.copy(), po.copy()
+            for blk in range(nb):
+                # block blk's transition: body blk moves (AR(1) around the truth), the bodies of later blocks keep last frame's delta
+                dl[:, blk] = 0.8 * dl[:, blk] + rng.normal(0.0, 0.0025, size=(n, 3))
+                da[:, blk] = 0.8 * da[:, blk] + rng.normal(0.0, 0.02, size=(n, 3))
+                poses = _poses_around(truth, dl, da)
+                upd = blk == nb - 1
+                ll = [g.loglikes_poses(poses, idx_g, update=upd),
+                      lazy.loglikes_poses(poses, idx_o, update=upd, threads=threads)]
+                e = rel_err(ll[0], ll[1])
+                assert e.max() <= TOL_LAZY, (k, blk, int(e.argmax()), float(e.max()))      # EVERY particle
+                worst_ll = max(worst_ll, float(e.max()))
+                w, kl = [], []
                 for s in range(2):
-                    ll_prev[s] = ll_prev[s][po]
-                    logw[s] = np.zeros(n)
-            dl = 0.8 * dl + rng.normal(0.0, 0.0025, size=(n, 3))
-            da = 0.8 * da + rng.normal(0.0, 0.02, size=(n, 3))
+                    logw[s] += ll[s] - ll_prev[s]
+                    ll_prev[s] = ll[s]
+                    w.append(flt.normalized_weights(logw[s]))
+                    kl.append(flt.kl_to_uniform(w[s]))
+                assert (kl[0] > 2.0) == (kl[1] > 2.0), (k, blk, kl)
+                if kl[1] > 2.0:
+                    u = rng.random(n)
+                    pg, po = flt.multinomial_resample(w[0], u), flt.multinomial_resample(w[1], u)
+                    bad = np.nonzero(pg != po)[0]
+                    mismatches.append(len(bad))
+                    n_children += n
+                    if len(bad):
+                        # each one drew a uniform within CDF_DELTA of the cumulative weights of EVERY parent between
+                        # the two answers (neighbours, or neighbours but for parents of weight ~0 between them)
+                        c = np.cumsum(w[1])
+                        c /= c[-1]
+                        a, b = np.minimum(pg[bad], po[bad]), np.maximum(pg[bad], po[bad])
+                        worst = np.maximum(np.abs(u[bad] - c[a]), np.abs(u[bad] - c[b - 1]))
+                        assert (worst <= CDF_DELTA).all(), (k, pg[bad], po[bad], worst)
+                    # both sides continue with the REFERENCE-semantics parents: identical histories
+                    dl, da = dl[po], da[po]
+                    # (the occlusion slot a child inherits: its parent's -- after an updating call that is the parent's own
+                    # index, after a read-only one whatever slot the parent itself was still pointing at)
+                    idx_g, idx_o = idx_g[po].copy(), idx_o[po].copy()
+                    for s in range(2):
+                        ll_prev[s] = ll_prev[s][po]
+                        logw[s] = np.zeros(n)
         # the planes the next frame would start from: device (stored, eager) against LAZY "as of now"
         worst_plane, n_diff = 0.0, 0
         for slot in rng.choice(n, size=min(plane_slots, n), replace=False):
@@ -142,13 +154,13 @@ def test_20000_particles_parents_vs_lazy_oracle(gpu_lib):
     assert worst_plane <= PLANE_TOL, worst_plane
 
 
-def _two_frames(meshes, cols, rows, n, k_oracle, blocks_readonly, chunk):
+def _two_frames(meshes, cols, rows, n, k_oracle, blocks_readonly, chunk, z=0.7):
     """test_gpu_fullsize._full_size_case's two-frame run with the LAZY oracle as the checker."""
     nb = len(meshes)
     om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
     render = ob.Oracle(om, cam, P, max_particles=1, mode=ob.LAZY)
     rng = np.random.default_rng(21)
-    truth = synth.truth_pose(nb)
+    truth = synth.truth_pose(nb, z=z)
     frame = synth.make_frame(render.render_depth(truth), rows, cols, rng)
     render.close()
     poses = synth.particle_poses(truth, n, rng, scale=2.0)
@@ -192,6 +204,27 @@ def test_c2_full_size_random_1000_vs_lazy_oracle(gpu_lib):
     two read-only blocks and the updating one per frame; a random 1 000 against the LAZY oracle."""
     worst = _two_frames(("m1", "m2", "m3"), 640, 480, 6666, 1000, 2, 500)
     print(f"\nC2, a random 1 000 particles vs LAZY oracle: {worst:.3e}")
+
+
+def test_c4_geometry_vs_lazy_oracle(gpu_lib):
+    """BASELINE C4's geometry -- M4 (50 880 triangles) at 1280x960, the object at 0.5 m (8 work items per particle,
+    the shared cluster cull of the many-cluster kernels) -- 256 particles, two frames, against the LAZY oracle (VERDICT r4 #4a)."""
+    worst = _two_frames(("m4",), 1280, 960, 256, 256, 0, 128, z=0.5)
+    print(f"\nC4 geometry (M4, 1280x960), 256 particles vs LAZY oracle: {worst:.3e}")
+
+
+def test_c2_sequence_three_bodies_three_blocks_vs_lazy_oracle(gpu_lib):
+    """BASELINE C2's structure as a tracked sequence (VERDICT r4 #4b): meshes [M1, M2, M3] (R:config/object.yaml:3-5 lists several),
+    three sampling blocks per frame -- two read-only calls and the updating one -- 30 frames, KL-triggered multinomial resampling
+    after every block, EVERY particle on every block against the LAZY oracle, the parents of every resampling compared.
+    1 200 particles (the CPU oracle renders 1 200 x 3 bodies x 90 calls)."""
+    mism, children, worst_ll, worst_plane, n_diff = _lockstep(("m1", "m2", "m3"), 640, 480, 1200, 30, seed=47, plane_slots=60)
+    print(f"\nC2 sequence (3 bodies, 3 blocks per frame, 1 200 particles) vs LAZY oracle: worst |d ll| / max(1,|ll|) = {worst_ll:.3e}; "
+          f"{len(mism)} resamplings, parent mismatches per resampling {mism} = {sum(mism)} of {children} children; "
+          f"planes: worst |d| = {worst_plane:.3e}, {n_diff} pixels above 1e-6 in 60 planes")
+    assert len(mism) >= 5
+    assert max(mism) <= 2 and sum(mism) <= max(2, children // 10000), mism
+    assert worst_plane <= PLANE_TOL, worst_plane
 
 
 def test_device_tracker_20000_particles_vs_lazy_oracle_tracker(gpu_lib):
