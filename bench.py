@@ -648,10 +648,55 @@ def sweep_leg(a, dev, stream, n_frames=1000, tail=200, table=(0.03, 0.10, 0.25, 
                 "sweep_note": (f"C1 with the object travelling along the image diagonal and back at 2 mm/frame, {n_frames} frames, particles following it; "
                                f"rate over the last {tail} frames (windows hold the ~730-frame trail the 2^-18 snap leaves), stored fraction of a plane "
                                "at the end; inputs resident in HBM.  The headline's object oscillates over 6 cm (window 3 % of the plane)")})
+    # ---- the same sweep under the DEVICE TRACKER (rbs_tracker_*: transition, KL-triggered multinomial resampling, mean): the
+    # filter's own genealogy -- children share parents, so the trail is common to the particles -- with the shared background
+    # plane (the library's default once windows have grown) and without it (RBS_SHARED_TRAIL=0)
+    try:
+        from dbot_ros_amd import pose
+        from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
+        init = np.zeros(12)
+        Rt = truths[0][0]
+        init[3:6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+        init[0:3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0]
+        for tag, env in (("sweep_tracker", "1"), ("sweep_tracker_scalar_background", "0")):
+            old_env = os.environ.get("RBS_SHARED_TRAIL")
+            os.environ["RBS_SHARED_TRAIL"] = env
+            try:
+                with make_sensor(b, om, cam, P, dev) as s:
+                    trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=1)).build()
+                    tr = DeviceParticleTracker(trans, s, om, ParticleTrackerBuilder.Parameters(evaluation_count=n), device_rng=True, seed=3)
+                    tr.initialize([init])
+                    errs = []
+                    for k in range(1, n_frames - tail):
+                        tr.track(frames[k])
+                    t0 = time.perf_counter()
+                    for k in range(n_frames - tail, n_frames):
+                        est = tr.track(frames[k])
+                        errs.append(float(np.linalg.norm(est[0:3] - (truths[k][0, 9:12] - truths[k][0, :9].reshape(3, 3) @ om.centers[0]))))
+                    el = time.perf_counter() - t0
+                    w = np.array([s.get_window(q) for q in range(0, n, max(1, n // 64))])
+                    fr = float(np.mean(np.maximum(0, w[:, 2] - w[:, 0]) * np.maximum(0, w[:, 3] - w[:, 1]))) / (b.rows * b.cols)
+                    active, rebases = s.shared_trail_state()
+                    tr.close()
+                res.update({tag + "_fps": tail / el, tag + "_value": n * tail / el, tag + "_window_fraction": fr,
+                            tag + "_position_error_max_m": max(errs), tag + "_rebasings": rebases})
+            finally:
+                if old_env is None:
+                    os.environ.pop("RBS_SHARED_TRAIL", None)
+                else:
+                    os.environ["RBS_SHARED_TRAIL"] = old_env
+        res["sweep_tracker_note"] = ("the same travelling object followed by the device tracker (2 000 particles, frame by frame from host memory, "
+                                     "its own KL-triggered resampling): frames/s and particle-likelihoods/s over the last %d of %d frames, stored window "
+                                     "fraction at the end; sweep_tracker_*: planes stored against the shared background plane once windows have grown "
+                                     "(the default), sweep_tracker_scalar_background_*: RBS_SHARED_TRAIL=0" % (tail, n_frames))
+    except Exception as e:   # noqa: BLE001
+        res["sweep_tracker_note"] = f"tracker sweep failed: {e!r}"
     del d_frames
     torch.cuda.empty_cache()
     # ---- window fraction -> rate: the headline's own step with every plane's window pre-filled
     tab = {}
+    old_env = os.environ.get("RBS_SHARED_TRAIL")
+    os.environ["RBS_SHARED_TRAIL"] = "0"      # (identical pre-filled blocks are a trail every particle shares: the shared plane would store them once)
     for f in table:
         c = copy.copy(b)
         c.fill_planes, c.fill_fraction = 0.9, f
@@ -667,10 +712,15 @@ def sweep_leg(a, dev, stream, n_frames=1000, tail=200, table=(0.03, 0.10, 0.25, 
         tab[f"{f:.2f}"] = {"value": n * 100 / el, "ms_per_step": el / 100 * 1e3, "stored_fraction_measured": got}
         del W
         torch.cuda.empty_cache()
+    if old_env is None:
+        os.environ.pop("RBS_SHARED_TRAIL", None)
+    else:
+        os.environ["RBS_SHARED_TRAIL"] = old_env
     res["window_fraction_table"] = tab
-    res["window_fraction_table_note"] = ("C1's step with every plane's window pre-filled to that fraction of the frame (a centred block of values "
-                                         "that differ from the background): above 15 % the raster kernel runs two blocks per CU, above 50 % the call "
-                                         "takes the whole-plane machinery")
+    res["window_fraction_table_note"] = ("what a stored window of that size COSTS (scalar background, RBS_SHARED_TRAIL=0): C1's step with every plane's window "
+                                         "pre-filled to that fraction of the frame (a centred block of values that differ from the background): above 15 % "
+                                         "the raster kernel runs two blocks per CU, above 50 % the call takes the whole-plane machinery.  With the shared "
+                                         "background plane (the default) identical blocks are stored once and every row of this table is the headline's rate")
     return res
 
 

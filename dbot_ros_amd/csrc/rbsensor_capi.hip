@@ -115,6 +115,23 @@ struct rbs_handle {
     // Split launch (round 5): geometry kernel -> depth tiles in memory -> likelihood kernel, each with its own occupancy
     // (rbsensor_kernels.hip, rbs_depth_kernel / rbs_eval_kernel).  rbs_config has no field for it: RBS_SPLIT in the
     // environment at rbs_create (tooling / A-B), otherwise the library's choice below.
+    // Shared trail (round 5): a plane equals a handle-wide background PLANE outside its window instead of a scalar level.  A
+    // pixel stays in a window ~730 frames after the object left it, and every child inherits that trail from its parent: with
+    // resampling the particles soon share it from a common ancestor, and it was stored, read and stepped once per PARTICLE per
+    // frame (a sweeping object: windows of 85 % of the frame, 2.2 M particle-likelihoods/s where the headline has 10.5).  Once
+    // the sampled window area exceeds stp_enter the handle switches: the shared plane starts as the scalar background everywhere
+    // and is RE-BASED on one particle's plane (inside that plane's window its values), every child of that call is re-measured
+    // against it (its window shrinks to where it really differs), and so again every stp_every updating calls while windows
+    // are large.  Values are unchanged bit for bit (the plane steps with the same float operations as any stored value); only
+    // what is stored changes.  Single-device handles, whole planes, binary64 likelihood; RBS_SHARED_TRAIL=0 disables.
+    bool stp = false, stp_allowed = true;
+    float* d_bgp[2] = {nullptr, nullptr};   // [npx] the shared plane of either buffer (indexed like d_occ: by `cur`)
+    double stp_enter = 0.10;
+    int stp_every = 32;
+    long stp_last_rebase = -1000000;
+    long stp_rebases = 0;
+    long stp_block_until = 0;               // re-basing did not shrink the windows (particles that share no ancestor): not again before this call
+    int4* d_bgp_box = nullptr;              // [1] bounding box of the shared plane's values that differ from the scalar background
     bool split = false;
     unsigned* d_depth = nullptr;    // [depth_items][kDepthTilePx]
     size_t depth_items = 0;
@@ -329,6 +346,15 @@ int32_t flush_lazy_frame(rbs_handle* h, hipStream_t then)
 // whole planes or slabs, and the same eight again for object models with a body of many clusters.
 void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size_t smem, hipStream_t s, const DevParams& P)
 {
+    if (P.bgp_src) {   // the shared background plane (binary64, whole planes)
+        switch ((update ? 2 : 0) | (h->many_clusters ? 1 : 0)) {
+            case 0: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<false, false>), grid, block, smem, s, P); break;
+            case 1: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<false, true>), grid, block, smem, s, P); break;
+            case 2: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<true, false>), grid, block, smem, s, P); break;
+            default: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<true, true>), grid, block, smem, s, P); break;
+        }
+        return;
+    }
     const int key = (h->many_clusters ? 8 : 0) | (update ? 4 : 0) | (h->precision == RBS_PRECISION_F32 ? 2 : 0) | (h->slab_px ? 1 : 0);
     switch (key) {
         case 0: hipLaunchKernelGGL((rbs::rbs_raster_kernel_f64<false, false>), grid, block, smem, s, P); break;
@@ -422,6 +448,43 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         else if (frac < h->wide_leave) h->wide = false;
         h->area_pending = false;
     }
+    // shared trail: enter once the windows have grown, re-base while they stay large (see rbs_handle::stp)
+    int rebase = -1;          // >= 0: re-base on that slot's plane; -2: back to the scalar background
+    bool stp_leaving = false;
+    P.bgp_src = nullptr; P.bgp_dst = nullptr; P.rebase_box = nullptr;
+    if (h->windowed && !h->slab_px && !h->group && h->peer_world <= 1 && h->precision == RBS_PRECISION_F64 && h->stp_allowed) {
+        const long since = h->calls - h->stp_last_rebase;
+        if (update && h->stp && h->area_frac > h->wide_enter && since >= 16 && since < h->stp_every) {
+            // re-basing did not help: the windows are still most of the frame a sample or two later -- the particles share no
+            // ancestor (a synthetic permutation of parents; a filter that never resamples).  Back to the scalar background and
+            // the whole-plane machinery that serves such windows best: this call re-measures every child against the scalar
+            // level over the bounding box of the shared plane's own values.
+            hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_bgp_box, 1, make_int4(h->cols, h->rows, 0, 0));
+            hipLaunchKernelGGL(rbs::rbs_bbox_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, h->d_bgp[h->cur], h->rows, h->cols,
+                               h->background, reinterpret_cast<int*>(h->d_bgp_box));
+            RBS_HIP(h, hipGetLastError());
+            rebase = -2;
+            stp_leaving = true;
+        } else if (update && !h->stp && h->area_frac > h->stp_enter && h->calls > 0 && h->calls >= h->stp_block_until) {
+            for (int k = 0; k < 2; ++k)
+                if (!h->d_bgp[k]) RBS_HIP(h, hipMalloc(&h->d_bgp[k], sizeof(float) * (size_t)h->npx));
+            if (!h->d_bgp_box) RBS_HIP(h, hipMalloc(&h->d_bgp_box, sizeof(int4)));
+            hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(256), dim3(256), 0, s, h->d_bgp[h->cur], (size_t)h->npx, h->background);
+            RBS_HIP(h, hipGetLastError());
+            h->stp = true;
+            h->wide = false;
+            rebase = 0;
+        } else if (update && h->stp && h->area_frac > h->stp_enter && h->calls - h->stp_last_rebase >= h->stp_every) {
+            rebase = 0;
+        }
+        if (h->stp) {
+            P.bgp_src = h->d_bgp[h->cur];
+            P.bgp_dst = h->d_bgp[1 - h->cur];
+            P.rebase_box = rebase >= 0 ? P.win_src + rebase : rebase == -2 ? h->d_bgp_box : nullptr;
+            h->wide = false;   // (the whole-plane machinery knows the scalar background only)
+            if (rebase >= 0) { h->stp_last_rebase = h->calls; h->stp_rebases += 1; h->area_frac = 0.0; }   // (judged again from the next sample)
+        }
+    }
     // the whole-plane layout always runs two raster blocks per CU and can afford the larger LDS
     // tile (fewer rectangles split into two work items).  Windowed planes keep ONE tile size
     // whatever the number of blocks of a call: the split decides the order in which a
@@ -470,6 +533,9 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         } else if (want > h->depth_items) {
             RBS_HIP(h, hipStreamSynchronize(s));
             (void)hipFree(h->d_depth);
+    (void)hipFree(h->d_bgp[0]);
+    (void)hipFree(h->d_bgp[1]);
+    (void)hipFree(h->d_bgp_box);
             h->d_depth = nullptr;
             h->depth_items = 0;
             RBS_HIP(h, hipMalloc(&h->d_depth, sizeof(unsigned) * (size_t)rbs::kDepthTilePx * want));
@@ -505,6 +571,11 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     if (h->windowed && h->join_pending >= 0) {
         RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
         h->join_pending = -1;
+    }
+    if (P.bgp_src && update) {   // the shared plane's own step (and re-basing): reads the current planes, complete after the join above
+        hipLaunchKernelGGL(rbs::rbs_bgp_step_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, P.bgp_src, h->d_bgp[1 - h->cur],
+                           P.occ_src, P.win_src, P.plane_stride, rebase, h->rows, h->cols, P.alpha, P.beta, P.bg_new);
+        RBS_HIP(h, hipGetLastError());
     }
     bool sample_area = false;
     if (h->windowed && update) {
@@ -588,6 +659,10 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             P.aux = h->cur_aux;
         }
         if (h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
+        if (P.bgp_src) {
+            if (update) hipLaunchKernelGGL((rbs::rbs_eval_kernel<true, false, true>), egrid, block, esm, s, P);
+            else hipLaunchKernelGGL((rbs::rbs_eval_kernel<false, false, true>), egrid, block, esm, s, P);
+        } else
         switch ((update ? 2 : 0) | (h->slab_px ? 1 : 0)) {
             case 0: hipLaunchKernelGGL((rbs::rbs_eval_kernel<false, false>), egrid, block, esm, s, P); break;
             case 1: hipLaunchKernelGGL((rbs::rbs_eval_kernel<false, true>), egrid, block, esm, s, P); break;
@@ -608,7 +683,10 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             const int ny = std::min(n, 32768);
             const dim3 wg((unsigned)(P.groups || !RBS_COPY_STRIPS ? h->win_chunks : h->win_chunks_single), (unsigned)ny, (unsigned)((n + ny - 1) / ny));
             const bool strips = RBS_COPY_STRIPS && !P.groups;
-            if (h->slab_px) {
+            if (P.bgp_src) {
+                if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, true, true>), wg, dim3(64), 0, h->copy_stream, P);
+                else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, false, true>), wg, dim3(64), 0, h->copy_stream, P);
+            } else if (h->slab_px) {
                 if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, true>), wg, dim3(64), 0, h->copy_stream, P);
                 else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, false>), wg, dim3(64), 0, h->copy_stream, P);
             } else {
@@ -663,6 +741,12 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipEventRecord(h->ev_reader, s));
         RBS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_reader, 0));
     }
+    if (stp_leaving) {   // from the next call on the planes are measured against the scalar background again
+        h->stp = false;
+        h->stp_block_until = h->calls + 4000;
+        h->area_frac = 1.0;   // (what the last sample said: the next calls take the whole-plane machinery at once)
+        h->wide = !h->slab_px;
+    }
     if (update) h->join_pending = slot;   // joined lazily: by the next call, or by drain()
     if (h->group) {
         // other shards read this shard's planes: one event that covers both streams of this call
@@ -689,7 +773,7 @@ int32_t materialize(rbs_handle* h, int slot, hipStream_t s)
     if (h->slab_px) return fail(h, RBS_ERR_UNSUPPORTED, "a slab cannot be made dense in place (state_slab_px)");
     hipLaunchKernelGGL(rbs::rbs_materialize_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s,
                        h->d_occ[h->cur] + (size_t)slot * h->plane_stride, h->d_win[h->cur] + slot, h->rows, h->cols,
-                       h->background);
+                       h->background, h->stp ? (const float*)h->d_bgp[h->cur] : (const float*)nullptr);
     RBS_HIP(h, hipGetLastError());
     hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_win[h->cur] + slot, 1,
                        make_int4(0, 0, h->cols, h->rows));
@@ -1457,6 +1541,9 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         h->raster_blocks = 3 * h->cu_count;
         // tuning overrides (defaults are the measured best on MI355X)
         if (const char* m = std::getenv("RBS_RASTER_BLOCKS")) h->raster_blocks = std::max(1, std::atoi(m));
+        if (const char* m = std::getenv("RBS_SHARED_TRAIL")) h->stp_allowed = std::atoi(m) != 0;
+        if (const char* m = std::getenv("RBS_STP_ENTER")) h->stp_enter = std::atof(m);
+        if (const char* m = std::getenv("RBS_STP_EVERY")) h->stp_every = std::max(1, std::atoi(m));
         h->split = RBS_SPLIT_DEFAULT != 0;
         if (const char* m = std::getenv("RBS_SPLIT")) h->split = std::atoi(m) != 0;
         h->depth_blocks = RBS_DEPTH_MINWAVES * h->cu_count;
@@ -2209,6 +2296,10 @@ int32_t rbs_reset(rbs_handle* h)
     h->frame_acquired = false;
     h->prefetched_slot = -1;   // (a frame uploaded ahead belongs to the session that ended)
     h->borrowed = nullptr;
+    h->stp = false;            // (every plane is all background again: the scalar says it all)
+    h->stp_last_rebase = -1000000;
+    h->stp_block_until = 0;
+    h->area_frac = 0.0;
     h->cur = 0;
     h->pending_frames = 0;
     h->background = (float)h->init_occ;
@@ -2739,6 +2830,9 @@ int32_t rbs_export_window(rbs_handle* h, int32_t slot, int32_t rect_out[4], void
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    // (shared trail: outside its window the plane is the handle's background PLANE, which the receiver does not have -- the
+    // slot is made dense first and travels whole)
+    if (h->stp) if (int32_t rc = materialize(h, slot, s)) return rc;
     int box[4];
     if (int32_t rc = window_of(h, slot, s, box)) return rc;
     for (int k = 0; k < 4; ++k) rect_out[k] = box[k];
@@ -2779,13 +2873,18 @@ int32_t rbs_import_window(rbs_handle* h, int32_t slot, const int32_t rect[4], co
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("import_window: bad rectangle (%d, %d, %d, %d)", rect[0], rect[1], rect[2], rect[3]));
     const int w = r.z - r.x, hh = r.w - r.y;
     float* dst = h->d_occ[h->cur] + (size_t)slot * h->plane_stride;
-    if (!h->windowed) {
-        // whole planes without windows: the background has to be written out
+    if (!h->windowed || h->stp) {
+        // whole planes without windows (or a handle whose implicit background is a plane of its own): the sender's scalar
+        // background has to be written out
         hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(256), dim3(256), 0, s, dst, (size_t)h->npx, h->background);
         RBS_HIP(h, hipGetLastError());
         if (!empty)
             RBS_HIP(h, hipMemcpy2DAsync(dst + (size_t)r.y * h->cols + r.x, sizeof(float) * (size_t)h->cols, d_payload, sizeof(float) * (size_t)w,
                                         sizeof(float) * (size_t)w, (size_t)hh, hipMemcpyDeviceToDevice, s));
+        if (h->stp) {
+            hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_win[h->cur] + slot, 1, make_int4(0, 0, h->cols, h->rows));
+            RBS_HIP(h, hipGetLastError());
+        }
         return RBS_OK;
     }
     if (h->slab_px) {
@@ -2831,6 +2930,9 @@ int32_t rbs_ipc_export(rbs_handle* h, void* blob_out)
     if (!h || !blob_out) return RBS_ERR_INVALID_ARGUMENT;
     if (!h->shards.empty()) return fail(h, RBS_ERR_UNSUPPORTED, "ipc_export: a handle over several devices already shares its planes in-process");
     RBS_HIP(h, hipSetDevice(h->device));
+    if (h->stp) return fail(h, RBS_ERR_UNSUPPORTED, "ipc_export: the handle already stores its planes against a shared background plane of its own "
+                                                    "(windows grew past the shared-trail threshold): rbs_reset first, then export");
+    h->stp_allowed = false;   // (other ranks read these planes in place: the implicit background must be the scalar they all have)
     if (int32_t rc = drain(h, true)) return rc;
     std::memset(blob_out, 0, RBS_IPC_BLOB_BYTES);
     IpcBlob b{};
@@ -3098,6 +3200,15 @@ int32_t rbs_get_window(rbs_handle* h, int32_t slot, int32_t out[4])
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;
     RBS_HIP(h, hipMemcpy(out, h->d_win[h->cur] + slot, sizeof(int32_t) * 4, hipMemcpyDeviceToHost));
+    return RBS_OK;
+}
+
+int32_t rbs_shared_trail_state(rbs_handle* h, int32_t* active, int32_t* rebases)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    RBS_GROUP_FIRST(h, rbs_shared_trail_state(sh_, active, rebases));
+    if (active) *active = h->stp ? 1 : 0;
+    if (rebases) *rebases = (int32_t)h->stp_rebases;
     return RBS_OK;
 }
 

@@ -225,6 +225,15 @@ struct DevParams {
     int* done;                     // [n] finished work items per particle (the last one sums them)
     // Split launch (rbs_depth_kernel -> rbs_eval_kernel, round 5): the depth tile of work item k, handed from the
     // geometry kernel to the likelihood kernel through memory (L2 / MALL sized: ~23 KB per C1 item).
+    // Shared background PLANE (round 5; handles whose windows have grown, see rbsensor_capi.hip "shared trail"): outside its
+    // window a plane equals bgp_src[pixel] instead of the scalar bg_old -- the trail every particle inherited from a common
+    // ancestor is stored ONCE.  bgp_dst = the same plane after this call's step (what the children's windows are measured
+    // against).  Null: the scalar background.
+    const float* bgp_src;
+    const float* bgp_dst;
+    const int4* rebase_box;        // null, or the rectangle every child's region additionally covers in this call: the window of the
+                                   // plane the shared plane is re-based on -- or, when the handle goes back to the scalar background,
+                                   // the bounding box of the shared plane's own values
     unsigned* depth;               // [depth_items][tile_px] order-preserving float bits, kInfBits = not covered
     int depth_items;               // items the buffer holds (an item beyond it is contained: its particle's sum is NaN)
     int* ctrb_this;                // [1] the likelihood kernel's ticket counter of this call ...
@@ -1196,7 +1205,7 @@ __device__ inline Smem carve(unsigned char* smem, int kTilePx, bool math_tables)
 
 // One (particle, tile) work item: rasterize the tile window, evaluate its pixels, return the
 // block-reduced partial log-likelihood (valid in thread 0).
-template <bool UPDATE, int PREC, bool SLAB, bool MANY = false, int PHASE = 0>
+template <bool UPDATE, int PREC, bool SLAB, bool MANY = false, int PHASE = 0, bool STP = false>
 __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect r, int tile_id,
                                           const Smem& m, unsigned body_mask, bool draw, int& ticket, const unsigned* gtile = nullptr)
 {
@@ -1324,6 +1333,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                     const bool stored = gx >= pw.x && gx < pw.z && gy >= pw.y && gy < pw.w;
 #ifndef RBS_EXP_NO_SRCLOAD
                     if (stored && (UPDATE || ac[u])) s4[u] = *reinterpret_cast<const floatx4*>(src + sb[u]);
+                    else if (STP && (UPDATE || ac[u])) s4[u] = *reinterpret_cast<const floatx4*>(P.bgp_src + gb[u]);   // the shared plane's value
 #endif
                     if (ac[u]) o4[u] = *reinterpret_cast<const floatx4*>(P.frame + gb[u]);
                 }
@@ -1366,6 +1376,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                 dbits = PHASE == 2 ? gtile[p] : m.tile[p];
                 const bool stored = gx >= pw.x && gx < pw.z && gy >= pw.y && gy < pw.w;
                 if (stored && (UPDATE || dbits != kInfBits)) sv = src[gi];
+                else if (STP && (UPDATE || dbits != kInfBits)) sv = P.bgp_src[gi];
                 if (dbits != kInfBits) ov = P.frame[gi];
             }
             const float prior = occ_step(P.alpha, P.beta, sv, P.bg_new);
@@ -1599,6 +1610,10 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
         int4 pw = make_int4(P.cols, P.rows, 0, 0);
         if ((unsigned)parent < (unsigned)P.slots) pw = parent_window(P, parent);
         int4 u = make_int4(min(pw.x, rw.x), min(pw.y, rw.y), max(pw.z, rw.z), max(pw.w, rw.w));
+        if (P.rebase_box) {   // the shared plane is re-based: every child is re-measured over the rectangle in which it changes
+            const int4 bw = *P.rebase_box;
+            u = make_int4(min(u.x, bw.x), min(u.y, bw.y), max(u.z, bw.z), max(u.w, bw.w));
+        }
         int4 seed = rw;
         if (P.slab_px) {
             // the child's slab stores exactly the region this call writes
@@ -1660,7 +1675,7 @@ __global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_frame_prep_kernel(cons
 // Persistent: a fixed number of raster blocks per CU keeps its LDS/VGPR share for the whole
 // launch (never starved by the many small copy blocks) and pulls (particle, tile) items from
 // an atomic queue.
-template <bool UPDATE, int PREC, bool SLAB, bool MANY = false>
+template <bool UPDATE, int PREC, bool SLAB, bool MANY = false, bool STP = false>
 __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1703,7 +1718,7 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
         RBS_TICK(15);   // the item's descriptor
 #endif
         if (P.groups == nullptr) {
-            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC, SLAB, MANY>(P, particle, r, item - first, m, 0xffffffffu, draw, ticket);
+            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC, SLAB, MANY, 0, STP>(P, particle, r, item - first, m, 0xffffffffu, draw, ticket);
         } else {   // several bodies: the item belongs to one group of bodies with its own rectangle
             const Groups* G = P.groups + particle;
             const int k = item - first, ng = __builtin_amdgcn_readfirstlane(G->n);
@@ -1713,7 +1728,7 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
                 const int4 gq = G->rect[g];
                 const Rect gr = {__builtin_amdgcn_readfirstlane(gq.x), __builtin_amdgcn_readfirstlane(gq.y),
                                  __builtin_amdgcn_readfirstlane(gq.z), __builtin_amdgcn_readfirstlane(gq.w)};
-                part = raster_eval_tile<UPDATE, PREC, SLAB, MANY>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
+                part = raster_eval_tile<UPDATE, PREC, SLAB, MANY, 0, STP>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
                                                       (unsigned)__builtin_amdgcn_readfirstlane((int)G->mask[g]), draw, ticket);
             }
         }
@@ -1786,6 +1801,12 @@ template <bool UPDATE, bool SLAB>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_kernel_f64(const DevParams P)
 {
     raster_kernel_body<UPDATE, 0, SLAB>(P);
+}
+// ... with the shared background plane (STP: binary64, whole planes), kernels of their own so that the others stay as they are
+template <bool UPDATE, bool MANY>
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_kernel_stp_f64(const DevParams P)
+{
+    raster_kernel_body<UPDATE, 0, false, MANY, true>(P);
 }
 // ... and the same two for object models with a body of more than 256 clusters (MANY: the shared cluster cull).
 template <bool UPDATE, bool SLAB>
@@ -1921,7 +1942,7 @@ void rbs_depth_kernel(const DevParams P)
 
 // The likelihood half.  Block per work item (first round dealt statically, then tickets); the particle's sum as in
 // the monolith: its only item's, or the items' partial sums added in item order by whoever finishes last.
-template <bool UPDATE, bool SLAB>
+template <bool UPDATE, bool SLAB, bool STP = false>
 __global__ __launch_bounds__(kBlock, RBS_EVAL_MINWAVES) void rbs_eval_kernel(const DevParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1948,7 +1969,7 @@ __global__ __launch_bounds__(kBlock, RBS_EVAL_MINWAVES) void rbs_eval_kernel(con
         } else if (P.groups == nullptr) {
             const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
             const Rect r = {q.x, q.y, q.z, q.w};
-            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, 0, SLAB, false, 2>(P, particle, r, item - first, m, 0xffffffffu, false, ticket, gtile);
+            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, 0, SLAB, false, 2, STP>(P, particle, r, item - first, m, 0xffffffffu, false, ticket, gtile);
         } else {
             const Groups* G = P.groups + particle;
             const int k = item - first, ng = __builtin_amdgcn_readfirstlane(G->n);
@@ -1958,7 +1979,7 @@ __global__ __launch_bounds__(kBlock, RBS_EVAL_MINWAVES) void rbs_eval_kernel(con
                 const int4 gq = G->rect[g];
                 const Rect gr = {__builtin_amdgcn_readfirstlane(gq.x), __builtin_amdgcn_readfirstlane(gq.y),
                                  __builtin_amdgcn_readfirstlane(gq.z), __builtin_amdgcn_readfirstlane(gq.w)};
-                part = raster_eval_tile<UPDATE, 0, SLAB, false, 2>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
+                part = raster_eval_tile<UPDATE, 0, SLAB, false, 2, STP>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
                                                                    (unsigned)__builtin_amdgcn_readfirstlane((int)G->mask[g]), false, ticket, gtile);
             }
         }
@@ -2107,9 +2128,15 @@ __global__ __launch_bounds__(64) void rbs_wide_window_kernel(const DevParams P, 
 constexpr int kWinUnroll = RBS_WIN_UNROLL;
 // STRIPS: one rectangle per particle (P.groups == nullptr) -- only the cells outside it are enumerated; otherwise the
 // whole window is walked and the cells the raster kernel writes are skipped (several bodies: up to kMaxGroups rectangles).
-template <bool SLAB, bool STRIPS>
+// STP: the shared background PLANE (DevParams.bgp_src / bgp_dst) stands where the scalar background stands -- a cell outside the
+// parent's window holds bgp_src there, and the child's window grows over the cells that differ from bgp_dst.  One cell in flight
+// per lane (its shared-plane values take the registers of the second).
+template <bool SLAB, bool STRIPS, bool STP = false>
 __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
 {
+    constexpr int kU = STP ? 1 : kWinUnroll;
+    const floatx4* __restrict__ bc4 = reinterpret_cast<const floatx4*>(P.bgp_src);
+    const floatx4* __restrict__ bn4 = reinterpret_cast<const floatx4*>(P.bgp_dst);
     const int particle = (int)blockIdx.y + (int)blockIdx.z * (int)gridDim.y;
     if (particle >= P.n) return;
     const int parent = P.parents[particle];
@@ -2148,11 +2175,11 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
         const int n_top = (ty1 - u.y) * w4, n_mid = (tby0 - ty1) * m, L = n_top + n_mid + (u.w - tby0) * w4;
         const int per = (L + (int)gridDim.x - 1) / (int)gridDim.x;
         const int lo = (int)blockIdx.x * per, hi = min(L, lo + per);
-        for (int base = lo; base < hi; base += 64 * kWinUnroll) {
-            floatx4 v[kWinUnroll];
-            int pk[kWinUnroll];    // state << 28 | row << 14 | float4 column (rows and columns <= 8 192: create refuses more)
+        for (int base = lo; base < hi; base += 64 * kU) {
+            floatx4 v[kU], bn[kU];
+            int pk[kU];    // state << 28 | row << 14 | float4 column (rows and columns <= 8 192: create refuses more)
 #pragma unroll
-            for (int k = 0; k < kWinUnroll; ++k) {
+            for (int k = 0; k < kU; ++k) {
                 const int idx = base + k * 64 + lane;
                 const bool live = idx < hi;
                 int row, c4;
@@ -2165,13 +2192,15 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
                 const bool stored = live && col >= pw.x && col < pw.z && row >= pw.y && row < pw.w;
                 pk[k] = ((live ? (stored ? 2 : 1) : 0) << 28) | (row << 14) | (ux4 + c4);
                 if (stored) v[k] = __builtin_nontemporal_load(&s4[(row - sy0) * ss4 + (ux4 + c4 - sx4)]);
+                else if (STP && live) v[k] = bc4[row * W4 + (ux4 + c4)];
+                if (STP && live) bn[k] = bn4[row * W4 + (ux4 + c4)];
             }
 #pragma unroll
-            for (int k = 0; k < kWinUnroll; ++k) {
+            for (int k = 0; k < kU; ++k) {
                 const int st_ = pk[k] >> 28, row_ = (pk[k] >> 14) & 0x3fff, at_ = pk[k] & 0x3fff;
                 if (!st_) continue;
                 floatx4 w;
-                if (st_ == 2) {
+                if (st_ == 2 || STP) {
                     w.x = occ_step(alpha, beta, v[k].x, bg_new);
                     w.y = occ_step(alpha, beta, v[k].y, bg_new);
                     w.z = occ_step(alpha, beta, v[k].z, bg_new);
@@ -2180,7 +2209,8 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
                     w.x = w.y = w.z = w.w = bg_new;
                 }
                 __builtin_nontemporal_store(w, &d4[(row_ - dy0) * ds4 + (at_ - dx4)]);
-                if (w.x != bg_new || w.y != bg_new || w.z != bg_new || w.w != bg_new) {
+                if (STP ? (w.x != bn[k].x || w.y != bn[k].y || w.z != bn[k].z || w.w != bn[k].w)
+                        : (w.x != bg_new || w.y != bg_new || w.z != bg_new || w.w != bg_new)) {
                     const int col = at_ << 2;
                     bx0 = min(bx0, col); bx1 = max(bx1, col + 4);
                     by0 = min(by0, row_); by1 = max(by1, row_ + 1);
@@ -2191,11 +2221,11 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
     const int qstep = 64 / w4, rstep = 64 - qstep * w4;
     int row = ry0 + lane / w4;
     int c4 = lane - (lane / w4) * w4;
-    for (int base = 0; base < n4; base += 64 * kWinUnroll) {
-        floatx4 v[kWinUnroll];
-        int st[kWinUnroll], at[kWinUnroll], rr[kWinUnroll];
+    for (int base = 0; base < n4; base += 64 * kU) {
+        floatx4 v[kU], bn[kU];
+        int st[kU], at[kU], rr[kU];
 #pragma unroll
-        for (int k = 0; k < kWinUnroll; ++k) {
+        for (int k = 0; k < kU; ++k) {
             const int idx = base + k * 64 + lane;
             const int col = (ux4 + c4) << 2;
             const bool live = idx < n4 && !raster_writes(P, particle, q, row, col);
@@ -2204,14 +2234,16 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
             at[k] = ux4 + c4;
             rr[k] = row;
             if (stored) v[k] = __builtin_nontemporal_load(&s4[(row - sy0) * ss4 + (at[k] - sx4)]);
+            else if (STP && live) v[k] = bc4[row * W4 + at[k]];
+            if (STP && live) bn[k] = bn4[row * W4 + at[k]];
             c4 += rstep; row += qstep;
             if (c4 >= w4) { c4 -= w4; ++row; }
         }
 #pragma unroll
-        for (int k = 0; k < kWinUnroll; ++k) {
+        for (int k = 0; k < kU; ++k) {
             if (!st[k]) continue;
             floatx4 w;
-            if (st[k] == 2) {
+            if (st[k] == 2 || STP) {
                 w.x = occ_step(alpha, beta, v[k].x, bg_new);
                 w.y = occ_step(alpha, beta, v[k].y, bg_new);
                 w.z = occ_step(alpha, beta, v[k].z, bg_new);
@@ -2220,7 +2252,8 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
                 w.x = w.y = w.z = w.w = bg_new;
             }
             __builtin_nontemporal_store(w, &d4[(rr[k] - dy0) * ds4 + (at[k] - dx4)]);
-            if (w.x != bg_new || w.y != bg_new || w.z != bg_new || w.w != bg_new) {
+            if (STP ? (w.x != bn[k].x || w.y != bn[k].y || w.z != bn[k].z || w.w != bn[k].w)
+                    : (w.x != bg_new || w.y != bg_new || w.z != bg_new || w.w != bg_new)) {
                 const int col = at[k] << 2;
                 bx0 = min(bx0, col); bx1 = max(bx1, col + 4);
                 by0 = min(by0, rr[k]); by1 = max(by1, rr[k] + 1);
@@ -2294,16 +2327,36 @@ __global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_region_probe_kernel(co
     if (u.z > u.x && u.w > u.y) atomicMax(out_max, (u.z - u.x) * (u.w - u.y));
 }
 
+// The shared background plane's step: bgp_dst = occ_step(bgp_src) -- the same float operations as on any stored value, so a
+// pixel outside a parent's window and the same pixel of the shared plane stay bit-identical.  rebase >= 0: the plane is
+// RE-BASED on the plane of that slot first (inside its window the slot's stored values, outside the old shared plane);
+// rebase == -2: the new plane is the scalar background everywhere (the handle leaves the shared-plane representation).
+__global__ void rbs_bgp_step_kernel(const float* __restrict__ bgp_src, float* __restrict__ bgp_dst, const float* __restrict__ occ_src,
+                                    const int4* __restrict__ win_src, int plane_stride, int rebase, int rows, int cols,
+                                    float alpha, float beta, float bg_new)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    if (rebase == -2) { bgp_dst[i] = bg_new; return; }   // back to the scalar background: the plane that IS it
+    float v = bgp_src[i];
+    if (rebase >= 0) {
+        const int4 w = win_src[rebase];
+        const int y = i / cols, x = i - y * cols;
+        if (x >= w.x && x < w.z && y >= w.y && y < w.w) v = occ_src[(size_t)rebase * plane_stride + i];
+    }
+    bgp_dst[i] = occ_step(alpha, beta, v, bg_new);
+}
+
 // Make one windowed plane dense in place: pixels outside its window become the background.
 // (The caller then marks the window full with rbs_set_window_kernel.)
 __global__ void rbs_materialize_kernel(float* __restrict__ plane, const int4* __restrict__ win,
-                                       int rows, int cols, float bg)
+                                       int rows, int cols, float bg, const float* __restrict__ bgp = nullptr)
 {
     const int4 w = *win;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols) return;
     const int y = i / cols, x = i - y * cols;
-    if (!(x >= w.x && x < w.z && y >= w.y && y < w.w)) plane[i] = bg;
+    if (!(x >= w.x && x < w.z && y >= w.y && y < w.w)) plane[i] = bgp ? bgp[i] : bg;   // (bgp: the handle's shared background plane)
 }
 
 // Slabs: a slot's slab -> a whole plane (the background outside its window), a whole plane -> a

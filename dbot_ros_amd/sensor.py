@@ -361,6 +361,12 @@ class RbSensor:
         self._check(self._lib.rbs_get_window(self._h, int(slot), w))
         return tuple(int(x) for x in w)
 
+    def shared_trail_state(self):
+        """(active, rebases): has the handle switched to a shared background plane, how often has it re-based (rbsensor_mi355x.h)."""
+        a, r = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.rbs_shared_trail_state(self._h, C.byref(a), C.byref(r)))
+        return bool(a.value), int(r.value)
+
     def get_background(self):
         v = C.c_float()
         self._check(self._lib.rbs_get_background(self._h, C.byref(v)))

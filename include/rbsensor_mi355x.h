@@ -307,6 +307,17 @@ int32_t rbs_synchronize(rbs_handle* h);
  * background); (0, 0, cols, rows) always with state_layout dense. */
 int32_t rbs_get_window(rbs_handle* h, int32_t slot, int32_t out[4]);
 /* Never-covered occlusion level of the current planes. */
+/* Shared trail (round 5).  With a scalar background a pixel stays in a window until its value has relaxed to within 2^-18 of
+ * that level, ~730 frames after the object left it, and every child inherits the whole trail from its parent: an object that
+ * moves across the image leaves windows of most of the frame, stored, read and stepped once per particle per frame.  Once the
+ * sampled window area exceeds a tenth of the frame, a single-device handle on whole planes (binary64 likelihood) stores its
+ * planes against a handle-wide background PLANE instead: the plane is re-based on one particle's plane and every child is
+ * re-measured against it, so that what the particles share from a common ancestor is stored once (after a resampling that is
+ * nearly all of it).  Stored VALUES do not change by a bit -- the shared plane steps with the float operations of any stored
+ * value -- and every entry point sees whole planes as before (rbs_get_occlusion, rbs_export_window: the slot is made dense first).
+ * RBS_SHARED_TRAIL=0 in the environment disables it; handles whose planes other ranks read in place (rbs_ipc_export) never use it.
+ * Inspection: *active = the handle has switched, *rebases = how often it re-based so far. */
+int32_t rbs_shared_trail_state(rbs_handle* h, int32_t* active, int32_t* rebases);
 int32_t rbs_get_background(rbs_handle* h, float* out);
 /* Stored occlusion plane of a slot -> host float[rows*cols]. */
 int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out);

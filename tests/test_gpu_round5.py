@@ -304,3 +304,94 @@ def test_borrowed_frame_gives_the_same_bits(gpu_lib):
             s_.synchronize()
             outs.append(d_out.cpu().numpy())
         assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("meshes,cols,rows,n", [(("m1",), 640, 480, 128), (("m1_l2", "box12"), 320, 240, 96)])
+def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols, rows, n):
+    """The shared background plane (rbsensor_mi355x.h "shared trail") changes what is STORED, not a bit of what is computed: a
+    handle forced into it (RBS_STP_ENTER=0: at the first sampled window area; re-based every 3rd updating call) against a handle
+    that never uses it, on a tracked sequence whose object travels across the image with resampling (children share parents):
+    log-likelihoods and whole planes bit for bit, read-only calls included -- and the windows really are smaller."""
+    nb = len(meshes)
+    om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
+    o = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER)
+    rng = np.random.default_rng(31)
+    frames = []
+    for k in range(26):
+        t = synth.truth_pose(nb, frame=k)
+        t[:, 9] += -0.12 + 0.01 * k            # 1 cm per frame across the image: a long trail
+        t[:, 10] += -0.06 + 0.005 * k
+        frames.append((t, synth.make_frame(o.render_depth(t), rows, cols, rng)))
+    poses = [synth.particle_poses(t, n, rng, scale=1.0) for t, _ in frames]
+    parents = [np.sort(rng.choice(n, size=n, p=(lambda w: w / w.sum())(rng.random(n) ** 8))).astype(np.int32) for _ in frames]   # few survivors
+    monkeypatch.setenv("RBS_SHARED_TRAIL", "0")
+    with RbSensor(om, cam, P, max_particles=n, precision="f64") as plain:
+        monkeypatch.setenv("RBS_SHARED_TRAIL", "1")
+        monkeypatch.setenv("RBS_STP_ENTER", "0.0")
+        monkeypatch.setenv("RBS_STP_EVERY", "3")
+        with RbSensor(om, cam, P, max_particles=n, precision="f64") as g:
+            g.set_timing_every(1); plain.set_timing_every(1)      # (the window area is sampled on timed calls)
+            for s_ in (g, plain):
+                s_.reset()
+            o.reset()
+            ig, ip, io = (np.zeros(n, np.int32) for _ in range(3))
+            for k, (_, frame) in enumerate(frames):
+                for s_ in (g, plain, o):
+                    s_.set_observation(frame)
+                if k % 5 == 4:      # a read-only block in front of the updating one
+                    ra, rb = g.loglikes_poses(poses[k - 1], ig.copy(), update=False), plain.loglikes_poses(poses[k - 1], ip.copy(), update=False)
+                    assert np.array_equal(ra, rb), (k, np.abs(ra - rb).max())
+                la, lb = g.loglikes_poses(poses[k], ig, update=True), plain.loglikes_poses(poses[k], ip, update=True)
+                lo = o.loglikes_poses(poses[k], io, update=True)
+                assert np.array_equal(la, lb), (k, np.abs(la - lb).max())
+                assert rel_err(la, lo).max() <= TOL_EAGER
+                ig, ip, io = parents[k].copy(), parents[k].copy(), parents[k].copy()
+            active, rebases = g.shared_trail_state()
+            assert active and rebases >= 3, (active, rebases)
+            assert plain.shared_trail_state() == (False, 0)
+            area = lambda w: max(0, w[2] - w[0]) * max(0, w[3] - w[1])
+            slots = list(range(0, n, max(1, n // 16)))
+            a_g, a_p = np.mean([area(g.get_window(q)) for q in slots]), np.mean([area(plain.get_window(q)) for q in slots])
+            print(f"\nmean window: shared trail {a_g:.0f} px, scalar background {a_p:.0f} px ({rebases} re-basings)")
+            assert a_g < 0.75 * a_p
+            for q in slots:
+                assert np.array_equal(g.get_occlusion(q), plain.get_occlusion(q)), q
+                assert np.array_equal(g.get_occlusion(q), o.get_occlusion(q)) or (g.get_occlusion(q) != o.get_occlusion(q)).mean() <= 1e-4
+
+
+def test_shared_trail_is_left_when_the_particles_share_nothing(gpu_lib, monkeypatch):
+    """Particles that never resample (every child its own parent's only child) share no ancestor: re-basing the shared plane
+    on one of them shrinks nobody else's window.  The handle notices -- windows still most of the frame 16 calls after a
+    re-basing -- and goes back to the scalar background (and the whole-plane machinery such windows are served best by).
+    Bit-identical planes and log-likelihoods all the way, through entering, re-basing and leaving."""
+    n, cols, rows = 24, 160, 120
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    o = ob.Oracle(om, cam, P, max_particles=1, mode=ob.EAGER)
+    rng = np.random.default_rng(17)
+    frames = []
+    for k in range(110):
+        t = synth.truth_pose(1, frame=0)
+        s_ = min(k, 70) / 70.0
+        t[0, 9], t[0, 10] = -0.32 + 0.64 * s_, -0.23 + 0.46 * s_       # corner to corner in 70 frames, then rest: a window of most of the frame
+        frames.append((t, synth.make_frame(o.render_depth(t), rows, cols, rng)))
+    poses = [synth.particle_poses(t, n, rng, scale=1.0) for t, _ in frames]
+    monkeypatch.setenv("RBS_SHARED_TRAIL", "0")
+    with RbSensor(om, cam, P, max_particles=n, precision="f64") as plain:
+        monkeypatch.setenv("RBS_SHARED_TRAIL", "1")
+        monkeypatch.setenv("RBS_STP_ENTER", "0.05")
+        with RbSensor(om, cam, P, max_particles=n, precision="f64") as g:
+            g.set_timing_every(1); plain.set_timing_every(1)
+            g.reset(); plain.reset()
+            ig, ip = np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32)
+            states = []
+            for k, (_, frame) in enumerate(frames):
+                g.set_observation(frame); plain.set_observation(frame)
+                la, lb = g.loglikes_poses(poses[k], ig, update=True), plain.loglikes_poses(poses[k], ip, update=True)
+                assert np.array_equal(la, lb), (k, np.abs(la - lb).max())
+                states.append(g.shared_trail_state())
+            entered = next(k for k, st in enumerate(states) if st[0])
+            left = next(k for k in range(entered, len(states)) if not states[k][0])
+            print(f"\nshared trail entered at call {entered}, re-based {states[left][1]}x, left at call {left}")
+            assert states[-1][0] is False and states[-1][1] >= 1
+            for q in range(0, n, 5):
+                assert np.array_equal(g.get_occlusion(q), plain.get_occlusion(q)), q
