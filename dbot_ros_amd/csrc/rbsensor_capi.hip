@@ -379,7 +379,7 @@ void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size
 int32_t stage_borrowed(rbs_handle* h);
 
 int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indices, int n,
-                         bool update, double* d_out, hipStream_t s, const double* host_poses = nullptr)
+                         bool update, double* d_out, hipStream_t s, const double* host_poses = nullptr, const double* host_deltas = nullptr)
 {
     h->quiet = false;
     // a borrowed frame (rbs_set_observation_borrowed) is staged BETWEEN the two kernels of the split launch, while the
@@ -402,6 +402,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     P.occ_dst = h->d_occ[1 - h->cur];
     P.poses = d_poses;
     P.poses_src = host_poses;   // pinned host memory the rectangles kernel pulls the poses from (into d_poses)
+    P.deltas_src = host_deltas; // ... or composes them from (rbs_loglikes_deltas)
     P.indices = d_indices;
     P.slots = h->max_particles;
     P.n_dev = 1;
@@ -594,7 +595,8 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         if (h->lazy_slot >= 0) { RBS_HIP(h, hipEventRecord(h->ev_used[h->lazy_slot], s)); h->lazy_slot = -1; }
     } else {
         if (int32_t rc = flush_lazy_frame(h, s)) return rc;
-        hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(64 * rbs::kPrepPerBlock), 0, s, P, d_rects, update ? 1 : 0);
+        if (host_deltas) hipLaunchKernelGGL(rbs::rbs_prep_deltas_kernel, pgrid, dim3(64 * rbs::kPrepPerBlock), 0, s, P, d_rects, update ? 1 : 0);
+        else hipLaunchKernelGGL(rbs::rbs_prep_kernel, pgrid, dim3(64 * rbs::kPrepPerBlock), 0, s, P, d_rects, update ? 1 : 0);
     }
     RBS_HIP(h, hipGetLastError());
     if (sample_area) {
@@ -1946,7 +1948,7 @@ void release_group(rbs_handle* g)
 // behind the frame's upload on the same engine, and each copy <-> kernel hand-over costs ~10 us:
 // together 30 us of a 300 us step.  RBS_HOST_STAGED_COPIES=1 restores the copies.
 // rbs_loglikes_deltas: state deltas + default poses instead of absolute poses (packed on the way into pinned memory,
-// composed on the device by rbt::compose_kernel).
+// composed on the device by the rectangles kernel, rbs_prep_deltas_kernel).
 struct DeltaArgs { const double* deltas; const double* deflt; int stride; };
 
 int32_t host_call(rbs_handle* h, const double* poses, const int32_t* indices, int n, bool update, const DeltaArgs* da = nullptr)
@@ -1966,13 +1968,12 @@ int32_t host_call(rbs_handle* h, const double* poses, const int32_t* indices, in
         else for (size_t k = 0; k < nb; ++k) std::memcpy(st + 6 * k, da->deltas + (size_t)da->stride * k, sizeof(double) * 6);
         for (int b = 0; b < B; ++b) std::memcpy(st + 6 * nb + 6 * b, da->deflt + (size_t)da->stride * b, sizeof(double) * 6);
         std::memcpy(h->h_in + h->in_idx_off, indices, sizeof(int) * (size_t)n);
-        const double* dev = reinterpret_cast<const double*>(h->h_in_dev);
-        hipLaunchKernelGGL(rbt::compose_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, h->stream, dev, dev + 6 * nb,
-                           reinterpret_cast<double*>(h->d_in), n, B);
-        RBS_HIP(h, hipGetLastError());
+        // (the rectangles kernel composes: the wave that owns a particle reads its 48 bytes per body from here)
+        if (h->lazy_frame) if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;   // (a pending device frame: its ingest has no deltas variant)
         if (int32_t rc = enqueue_loglikes(h, reinterpret_cast<const double*>(h->d_in),
                                           reinterpret_cast<const int*>(h->h_in_dev + h->in_idx_off), n, update,
-                                          reinterpret_cast<double*>(h->h_out_dev), h->stream))
+                                          reinterpret_cast<double*>(h->h_out_dev), h->stream, nullptr,
+                                          reinterpret_cast<const double*>(h->h_in_dev)))
             return rc;
         if (h->slab_px) RBS_HIP(h, hipMemcpyAsync(h->h_err, h->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         RBS_HIP(h, hipEventRecord(h->ev_out, h->stream));

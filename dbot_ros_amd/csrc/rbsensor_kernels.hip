@@ -207,6 +207,8 @@ struct DevParams {
     float* occ_dst;                // [slots][npx]
     const double* poses;           // [n][n_bodies][12]
     const double* poses_src;       // host-pointer calls: pinned host memory the rectangles kernel copies the poses from (into `poses`)
+    const double* deltas_src;      // rbs_loglikes_deltas: pinned [n][bodies][6] state deltas followed by [bodies][6] default poses (position,
+                                   //   rotation vector) -- the rectangles kernel COMPOSES the absolute poses from them (into `poses`)
     const int* indices;            // [n] parent slot as the caller passed it: read by the rectangles kernel ONLY,
                                    //   in the caller's stream order (the caller may rewrite it right after the call)
     int* parents;                  // [n] the rectangles kernel's snapshot of `indices`, double-buffered across calls
@@ -1488,10 +1490,39 @@ __device__ inline void copy_band(const DevParams& P, int particle, int band, Rec
 // background).  An empty window is (cols, rows, 0, 0), so unions are plain min/max.
 constexpr int kPrepPerBlock = 8;   // particles (= waves) per block of the rectangles kernel
 
+// Absolute pose of one body from a state delta and the body's default pose:
+//   R = R(delta rotation vector) R(default rotation vector),  t = t(delta) + t(default),
+// rotation vector -> matrix through the unit quaternion.  The operations and their order are those of
+// oracle/tracker_oracle.c orc_compose_poses (and of rbsensor_tracker.hip propagate_body); sin / cos / sqrt are the device library's.
+__device__ inline void rotvec_to_matrix_(const double* rv, double* R)
+{
+    const double angle = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    const double half = 0.5 * angle;
+    const double k = angle < 1e-9 ? 0.5 - angle * angle / 48.0 : sin(half) / angle;
+    const double w = cos(half), x = rv[0] * k, y = rv[1] * k, z = rv[2] * k;
+    R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - w * z); R[2] = 2.0 * (x * z + w * y);
+    R[3] = 2.0 * (x * y + w * z); R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - w * x);
+    R[6] = 2.0 * (x * z - w * y); R[7] = 2.0 * (y * z + w * x); R[8] = 1.0 - 2.0 * (x * x + y * y);
+}
+__device__ inline void compose_pose(const double* __restrict__ d, const double* __restrict__ d0, double* __restrict__ out)
+{
+    double Rd[9], R0[9];
+    rotvec_to_matrix_(d + 3, Rd);
+    rotvec_to_matrix_(d0 + 3, R0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            out[3 * r + c] = Rd[3 * r] * R0[c] + Rd[3 * r + 1] * R0[3 + c] + Rd[3 * r + 2] * R0[6 + c];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[9 + k] = d[k] + d0[k];
+}
+
 // One wave per particle, kPrepPerBlock particles per block.  The work items of the block's
 // particles are allotted with ONE atomicAdd per block (any free range will do: a particle's
 // items are summed in their own order, so no scan kernel is needed -- but two thousand blocks
 // bumping one counter serialise at 11-13 ns each, 26 us at 2 000 particles).
+template <bool DELTAS = false>
 __device__ inline void prep_particles(const DevParams& P, int block, int* __restrict__ rects, int update)
 {
     __shared__ int cnts[kPrepPerBlock + 1];
@@ -1511,7 +1542,21 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
     Groups& G = G_s[w];
     if (lane == 0) G.n = 0;
     const int cap_px = min(P.tile_w * P.tile_h, P.tile_px);
-    if (P.poses_src && live) {
+    if (DELTAS && live) {
+        // rbs_loglikes_deltas: lane b composes body b's absolute pose from its delta (48 bytes read from pinned host memory) and the
+        // body's default pose, into the device array everything else reads -- this wave included, once its own stores have landed
+        const int B = P.n_bodies;
+        double* dstp = const_cast<double*>(P.poses) + (size_t)i * 12 * B;
+        for (int b = lane; b < B; b += 64) {
+            double d[6], d0[6], out[12];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { d[k] = P.deltas_src[((size_t)i * B + b) * 6 + k]; d0[k] = P.deltas_src[((size_t)P.n * B + b) * 6 + k]; }
+            compose_pose(d, d0, out);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) dstp[12 * b + k] = out[k];
+        }
+        __threadfence_block();
+    } else if (P.poses_src && live) {
         // a host-pointer call: the particle's pose is pulled from pinned host memory (one PCIe read of
         // 96 B per body instead of a copy-engine transfer ahead of this kernel) into the device
         // array everything else reads -- this wave included, once its own stores have landed
@@ -1646,6 +1691,12 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
 __global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_prep_kernel(const DevParams P, int* __restrict__ rects, int update)
 {
     prep_particles(P, (int)blockIdx.x, rects, update);
+}
+// ... composing the poses from state deltas first (rbs_loglikes_deltas): a kernel of its own, so that the sin / cos it carries
+// cost the other calls' rectangles kernel neither registers nor occupancy
+__global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_prep_deltas_kernel(const DevParams P, int* __restrict__ rects, int update)
+{
+    prep_particles<true>(P, (int)blockIdx.x, rects, update);
 }
 
 // A frame handed over right before this call: its per-pixel terms (aux_blocks blocks) and the
@@ -1848,7 +1899,7 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET voi
 #define RBS_DEPTH_VGPRS 80          // 160 registers: three waves per SIMD and 32 left for one wave of the windowed copy kernel
 #endif
 #ifndef RBS_EVAL_MINWAVES
-#define RBS_EVAL_MINWAVES 5
+#define RBS_EVAL_MINWAVES 4         // (5 and 6 waves per SIMD run it no faster -- it waits for memory, section 4 of DESIGN.md -- and 128 registers leave the compiler room)
 #endif
 constexpr int kDepthTilePx = RBS_DEPTH_TILE_PX;
 static_assert(kDepthTilePx == kTilePxF64 || RBS_DEPTH_MINWAVES != 3, "the split launch shares the one-kernel launch's tile");

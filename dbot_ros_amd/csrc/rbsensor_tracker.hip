@@ -94,30 +94,6 @@ __device__ inline void matmul3(const double* A, const double* B, double* C)
             C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
 }
 
-// rbs_loglikes_deltas (the sensor's plugin-surface call): absolute poses from state deltas around the default poses,
-//   R = R(delta) R(default),  t = t(delta) + t(default)      (checker: oracle/tracker_oracle.c orc_compose_poses)
-// -- propagate_body's last lines on their own.  One thread per (particle, body); deltas6 / deflt6 are packed
-// [.][6] = position, rotation vector (pinned host memory: read in place over PCIe, 48 B per body).
-__global__ __launch_bounds__(256) void compose_kernel(const double* __restrict__ deltas6, const double* __restrict__ deflt6,
-                                                      double* __restrict__ poses, int n, int parts)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n * parts) return;
-    const int b = k % parts;
-    double d[6], d0[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) { d[j] = deltas6[(size_t)k * 6 + j]; d0[j] = deflt6[b * 6 + j]; }
-    double Rd[9], R0[9], R[9];
-    rotvec_to_matrix(d + 3, Rd);
-    rotvec_to_matrix(d0 + 3, R0);
-    matmul3(Rd, R0, R);
-    double* out = poses + (size_t)k * 12;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) out[j] = R[j];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) out[9 + j] = d[j] + d0[j];
-}
-
 // ------------------------------------------------------------------ random numbers
 // Philox4x32-10 counter-based generator: (seed, frame, stream, index) -> 4 x 32 random bits.
 __device__ inline uint4 philox(unsigned long long seed, unsigned long long ctr_hi, unsigned long long ctr_lo)

@@ -248,8 +248,8 @@ int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t*
  * R:source/dbot_ros/object_tracker_ros.h:40-41, read per body through component(i) as at .hpp:54-60).  The
  * composition of SURVEY A.1,
  *     R = R(delta rotation vector) R(default rotation vector),   t = t(delta) + t(default),
- * rotation vector -> matrix through the unit quaternion, runs on the device in one small kernel in front of the
- * rectangles kernel (the operations and their order are oracle/tracker_oracle.c's trk_compose_pose; sin / cos /
+ * rotation vector -> matrix through the unit quaternion, runs on the device inside the rectangles kernel (the wave that owns a
+ * particle composes its poses first; the operations and their order are oracle/tracker_oracle.c's orc_compose_poses; sin / cos /
  * sqrt are the device library's, so a composed entry may differ from a host libm composition in its last bit:
  * rbs_get_poses returns exactly what was evaluated).  On the host it costs two sin / cos / sqrt and a 3x3 product
  * per particle and body -- 0.25 ms at 2 000 particles, more than the device step.

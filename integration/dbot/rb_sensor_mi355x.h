@@ -112,7 +112,7 @@ public:
 
     // deltas: the particles' states around integrated_poses().  The composition
     //   R = R(delta) R(default),  t = t(delta) + t(default)
-    // is the library's (rbs_loglikes_deltas: one small kernel in front of the rectangles kernel), so all the
+    // is the library's (rbs_loglikes_deltas: the rectangles kernel composes each particle's poses first), so all the
     // host does per particle is gather six numbers per body out of the particle's own Eigen vector -- composing
     // on the host costs two sin / cos / sqrt and a 3x3 product per particle and body, 0.25 ms at 2 000 particles:
     // more than the whole device step.
