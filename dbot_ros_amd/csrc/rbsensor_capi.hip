@@ -123,7 +123,7 @@ struct rbs_handle {
     // and is RE-BASED on one particle's plane (inside that plane's window its values), every child of that call is re-measured
     // against it (its window shrinks to where it really differs), and so again every stp_every updating calls while windows
     // are large.  Values are unchanged bit for bit (the plane steps with the same float operations as any stored value); only
-    // what is stored changes.  Single-device handles, whole planes, binary64 likelihood; RBS_SHARED_TRAIL=0 disables.
+    // what is stored changes.  Single-device handles (whole planes or slabs), binary64 likelihood; RBS_SHARED_TRAIL=0 disables.
     bool stp = false, stp_allowed = true;
     float* d_bgp[2] = {nullptr, nullptr};   // [npx] the shared plane of either buffer (indexed like d_occ: by `cur`)
     double stp_enter = 0.10;
@@ -346,12 +346,16 @@ int32_t flush_lazy_frame(rbs_handle* h, hipStream_t then)
 // whole planes or slabs, and the same eight again for object models with a body of many clusters.
 void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size_t smem, hipStream_t s, const DevParams& P)
 {
-    if (P.bgp_src) {   // the shared background plane (binary64, whole planes)
-        switch ((update ? 2 : 0) | (h->many_clusters ? 1 : 0)) {
-            case 0: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<false, false>), grid, block, smem, s, P); break;
-            case 1: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<false, true>), grid, block, smem, s, P); break;
-            case 2: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<true, false>), grid, block, smem, s, P); break;
-            default: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<true, true>), grid, block, smem, s, P); break;
+    if (P.bgp_src) {   // the shared background plane (binary64)
+        switch ((update ? 4 : 0) | (h->slab_px ? 2 : 0) | (h->many_clusters ? 1 : 0)) {
+            case 0: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<false, false, false>), grid, block, smem, s, P); break;
+            case 1: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<false, false, true>), grid, block, smem, s, P); break;
+            case 2: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<false, true, false>), grid, block, smem, s, P); break;
+            case 3: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<false, true, true>), grid, block, smem, s, P); break;
+            case 4: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<true, false, false>), grid, block, smem, s, P); break;
+            case 5: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<true, false, true>), grid, block, smem, s, P); break;
+            case 6: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<true, true, false>), grid, block, smem, s, P); break;
+            default: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<true, true, true>), grid, block, smem, s, P); break;
         }
         return;
     }
@@ -453,7 +457,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     int rebase = -1;          // >= 0: re-base on that slot's plane; -2: back to the scalar background
     bool stp_leaving = false;
     P.bgp_src = nullptr; P.bgp_dst = nullptr; P.rebase_box = nullptr;
-    if (h->windowed && !h->slab_px && !h->group && h->peer_world <= 1 && h->precision == RBS_PRECISION_F64 && h->stp_allowed) {
+    if (h->windowed && !h->group && h->peer_world <= 1 && h->precision == RBS_PRECISION_F64 && h->stp_allowed) {
         const long since = h->calls - h->stp_last_rebase;
         if (update && h->stp && h->area_frac > h->wide_enter && since >= 16 && since < h->stp_every) {
             // re-basing did not help: the windows are still most of the frame a sample or two later -- the particles share no
@@ -575,7 +579,8 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     }
     if (P.bgp_src && update) {   // the shared plane's own step (and re-basing): reads the current planes, complete after the join above
         hipLaunchKernelGGL(rbs::rbs_bgp_step_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, P.bgp_src, h->d_bgp[1 - h->cur],
-                           P.occ_src, P.win_src, P.plane_stride, rebase, h->rows, h->cols, P.alpha, P.beta, P.bg_new);
+                           P.occ_src, P.win_src, h->slab_px ? P.reg_src : (const int4*)nullptr, P.plane_stride, rebase, h->rows, h->cols,
+                           P.alpha, P.beta, P.bg_new);
         RBS_HIP(h, hipGetLastError());
     }
     bool sample_area = false;
@@ -656,14 +661,24 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         else hipLaunchKernelGGL((rbs::rbs_depth_kernel<false>), dgrid, block, dsm, s, P);
         RBS_HIP(h, hipGetLastError());
         if (h->borrowed) {   // the host converts and sends the caller's frame while the depth tiles are rasterized
-            if (int32_t rc = stage_borrowed(h)) return rc;
+            if (int32_t rc = stage_borrowed(h)) {
+                // half a call is enqueued (rectangles + geometry kernel: the work-item counters of this parity are spent, no plane
+                // has been written): every later call is refused until rbs_reset re-establishes a known state
+                h->poisoned = true;
+                h->poison_msg = h->err;
+                return rc;
+            }
             P.frame = h->cur_frame;
             P.aux = h->cur_aux;
         }
         if (h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
         if (P.bgp_src) {
-            if (update) hipLaunchKernelGGL((rbs::rbs_eval_kernel<true, false, true>), egrid, block, esm, s, P);
-            else hipLaunchKernelGGL((rbs::rbs_eval_kernel<false, false, true>), egrid, block, esm, s, P);
+            switch ((update ? 2 : 0) | (h->slab_px ? 1 : 0)) {
+                case 0: hipLaunchKernelGGL((rbs::rbs_eval_kernel<false, false, true>), egrid, block, esm, s, P); break;
+                case 1: hipLaunchKernelGGL((rbs::rbs_eval_kernel<false, true, true>), egrid, block, esm, s, P); break;
+                case 2: hipLaunchKernelGGL((rbs::rbs_eval_kernel<true, false, true>), egrid, block, esm, s, P); break;
+                default: hipLaunchKernelGGL((rbs::rbs_eval_kernel<true, true, true>), egrid, block, esm, s, P); break;
+            }
         } else
         switch ((update ? 2 : 0) | (h->slab_px ? 1 : 0)) {
             case 0: hipLaunchKernelGGL((rbs::rbs_eval_kernel<false, false>), egrid, block, esm, s, P); break;
@@ -685,7 +700,10 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             const int ny = std::min(n, 32768);
             const dim3 wg((unsigned)(P.groups || !RBS_COPY_STRIPS ? h->win_chunks : h->win_chunks_single), (unsigned)ny, (unsigned)((n + ny - 1) / ny));
             const bool strips = RBS_COPY_STRIPS && !P.groups;
-            if (P.bgp_src) {
+            if (P.bgp_src && h->slab_px) {
+                if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, true, true>), wg, dim3(64), 0, h->copy_stream, P);
+                else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, false, true>), wg, dim3(64), 0, h->copy_stream, P);
+            } else if (P.bgp_src) {
                 if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, true, true>), wg, dim3(64), 0, h->copy_stream, P);
                 else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, false, true>), wg, dim3(64), 0, h->copy_stream, P);
             } else if (h->slab_px) {
@@ -788,7 +806,7 @@ int32_t slab_expand(rbs_handle* h, int slot, float* d_full, hipStream_t s)
 {
     hipLaunchKernelGGL(rbs::rbs_expand_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s,
                        h->d_occ[h->cur] + (size_t)slot * h->plane_stride, h->d_reg[h->cur] + slot, h->d_win[h->cur] + slot,
-                       h->rows, h->cols, h->background, d_full);
+                       h->rows, h->cols, h->background, d_full, h->stp ? (const float*)h->d_bgp[h->cur] : (const float*)nullptr);
     RBS_HIP(h, hipGetLastError());
     return RBS_OK;
 }
@@ -804,7 +822,7 @@ int32_t slab_store(rbs_handle* h, int slot, const float* d_full, hipStream_t s)
     const int init[4] = {h->cols, h->rows, 0, 0};
     RBS_HIP(h, hipMemcpyAsync(h->d_bbox, init, sizeof(init), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(rbs::rbs_bbox_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, d_full, h->rows,
-                       h->cols, h->background, h->d_bbox);
+                       h->cols, h->background, h->d_bbox, h->stp ? (const float*)h->d_bgp[h->cur] : (const float*)nullptr);
     RBS_HIP(h, hipGetLastError());
     int box[4];
     RBS_HIP(h, hipMemcpyAsync(box, h->d_bbox, sizeof(box), hipMemcpyDeviceToHost, s));
@@ -2833,6 +2851,12 @@ int32_t rbs_export_window(rbs_handle* h, int32_t slot, int32_t rect_out[4], void
     if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
     // (shared trail: outside its window the plane is the handle's background PLANE, which the receiver does not have -- the
     // slot is made dense first and travels whole)
+    if (h->stp && h->slab_px) {   // (a slab cannot be made dense in place: the whole plane is assembled beside it and travels from there)
+        for (int k = 0; k < 4; ++k) rect_out[k] = k < 2 ? 0 : (k == 2 ? h->cols : h->rows);
+        if ((size_t)h->npx > capacity_floats || !d_payload)
+            return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("export_window: the plane of slot %d travels whole (%d values), the buffer holds %zu", slot, h->npx, capacity_floats));
+        return slab_expand(h, slot, static_cast<float*>(d_payload), s);
+    }
     if (h->stp) if (int32_t rc = materialize(h, slot, s)) return rc;
     int box[4];
     if (int32_t rc = window_of(h, slot, s, box)) return rc;
@@ -2874,6 +2898,15 @@ int32_t rbs_import_window(rbs_handle* h, int32_t slot, const int32_t rect[4], co
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("import_window: bad rectangle (%d, %d, %d, %d)", rect[0], rect[1], rect[2], rect[3]));
     const int w = r.z - r.x, hh = r.w - r.y;
     float* dst = h->d_occ[h->cur] + (size_t)slot * h->plane_stride;
+    if (h->stp && h->slab_px) {
+        // the sender's plane = its scalar background outside rect: assembled whole beside the slabs, stored like any plane handed in
+        hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(256), dim3(256), 0, s, h->d_render, (size_t)h->npx, h->background);
+        RBS_HIP(h, hipGetLastError());
+        if (!empty)
+            RBS_HIP(h, hipMemcpy2DAsync(h->d_render + (size_t)r.y * h->cols + r.x, sizeof(float) * (size_t)h->cols, d_payload, sizeof(float) * (size_t)w,
+                                        sizeof(float) * (size_t)w, (size_t)hh, hipMemcpyDeviceToDevice, s));
+        return slab_store(h, slot, h->d_render, s);
+    }
     if (!h->windowed || h->stp) {
         // whole planes without windows (or a handle whose implicit background is a plane of its own): the sender's scalar
         // background has to be written out

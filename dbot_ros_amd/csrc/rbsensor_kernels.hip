@@ -1853,11 +1853,12 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET voi
 {
     raster_kernel_body<UPDATE, 0, SLAB>(P);
 }
-// ... with the shared background plane (STP: binary64, whole planes), kernels of their own so that the others stay as they are
-template <bool UPDATE, bool MANY>
+// ... with the shared background plane (STP: binary64; whole planes or slabs -- the shared plane itself is always a whole plane,
+// addressed by frame offsets), kernels of their own so that the others stay as they are
+template <bool UPDATE, bool SLAB, bool MANY>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_kernel_stp_f64(const DevParams P)
 {
-    raster_kernel_body<UPDATE, 0, false, MANY, true>(P);
+    raster_kernel_body<UPDATE, 0, SLAB, MANY, true>(P);
 }
 // ... and the same two for object models with a body of more than 256 clusters (MANY: the shared cluster cull).
 template <bool UPDATE, bool SLAB>
@@ -2383,8 +2384,8 @@ __global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_region_probe_kernel(co
 // RE-BASED on the plane of that slot first (inside its window the slot's stored values, outside the old shared plane);
 // rebase == -2: the new plane is the scalar background everywhere (the handle leaves the shared-plane representation).
 __global__ void rbs_bgp_step_kernel(const float* __restrict__ bgp_src, float* __restrict__ bgp_dst, const float* __restrict__ occ_src,
-                                    const int4* __restrict__ win_src, int plane_stride, int rebase, int rows, int cols,
-                                    float alpha, float beta, float bg_new)
+                                    const int4* __restrict__ win_src, const int4* __restrict__ reg_src, int plane_stride, int rebase,
+                                    int rows, int cols, float alpha, float beta, float bg_new)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols) return;
@@ -2393,7 +2394,14 @@ __global__ void rbs_bgp_step_kernel(const float* __restrict__ bgp_src, float* __
     if (rebase >= 0) {
         const int4 w = win_src[rebase];
         const int y = i / cols, x = i - y * cols;
-        if (x >= w.x && x < w.z && y >= w.y && y < w.w) v = occ_src[(size_t)rebase * plane_stride + i];
+        if (x >= w.x && x < w.z && y >= w.y && y < w.w) {
+            if (reg_src) {   // slabs: the slot stores its region row-major from its first float
+                const int4 g = reg_src[rebase];
+                v = occ_src[(size_t)rebase * plane_stride + (size_t)(y - g.y) * (g.z - g.x) + (x - g.x)];
+            } else {
+                v = occ_src[(size_t)rebase * plane_stride + i];
+            }
+        }
     }
     bgp_dst[i] = occ_step(alpha, beta, v, bg_new);
 }
@@ -2414,14 +2422,15 @@ __global__ void rbs_materialize_kernel(float* __restrict__ plane, const int4* __
 // slab with stored region r, and the float4-aligned bounding box of the values of a whole plane
 // that differ from the background (out4 starts as (cols, rows, 0, 0)).
 __global__ void rbs_expand_kernel(const float* __restrict__ slab, const int4* __restrict__ reg,
-                                  const int4* __restrict__ win, int rows, int cols, float bg, float* __restrict__ out)
+                                  const int4* __restrict__ win, int rows, int cols, float bg, float* __restrict__ out,
+                                  const float* __restrict__ bgp = nullptr)
 {
     const int4 r = *reg, w = *win;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols) return;
     const int y = i / cols, x = i - y * cols;
     const bool in = x >= w.x && x < w.z && y >= w.y && y < w.w;
-    out[i] = in ? slab[(size_t)(y - r.y) * (r.z - r.x) + (x - r.x)] : bg;
+    out[i] = in ? slab[(size_t)(y - r.y) * (r.z - r.x) + (x - r.x)] : (bgp ? bgp[i] : bg);   // (bgp: the handle's shared background plane)
 }
 __global__ void rbs_pack_kernel(const float* __restrict__ full, int4 r, int cols, float* __restrict__ slab)
 {
@@ -2431,11 +2440,12 @@ __global__ void rbs_pack_kernel(const float* __restrict__ full, int4 r, int cols
     const int ly = i / w, lx = i - ly * w;
     slab[i] = full[(size_t)(r.y + ly) * cols + r.x + lx];
 }
-__global__ void rbs_bbox_kernel(const float* __restrict__ full, int rows, int cols, float bg, int* __restrict__ out4)
+__global__ void rbs_bbox_kernel(const float* __restrict__ full, int rows, int cols, float bg, int* __restrict__ out4,
+                                const float* __restrict__ bgp = nullptr)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols) return;
-    if (full[i] == bg) return;
+    if (full[i] == (bgp ? bgp[i] : bg)) return;
     const int y = i / cols, x = i - y * cols;
     atomicMin(out4 + 0, x & ~3); atomicMin(out4 + 1, y);
     atomicMax(out4 + 2, (x & ~3) + 4); atomicMax(out4 + 3, y + 1);

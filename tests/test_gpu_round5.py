@@ -306,8 +306,8 @@ def test_borrowed_frame_gives_the_same_bits(gpu_lib):
         assert np.array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("meshes,cols,rows,n", [(("m1",), 640, 480, 128), (("m1_l2", "box12"), 320, 240, 96)])
-def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols, rows, n):
+@pytest.mark.parametrize("meshes,cols,rows,n,slab", [(("m1",), 640, 480, 128, 0), (("m1_l2", "box12"), 320, 240, 96, 0), (("m1",), 640, 480, 96, 16384)])
+def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols, rows, n, slab):
     """The shared background plane (rbsensor_mi355x.h "shared trail") changes what is STORED, not a bit of what is computed: a
     handle forced into it (RBS_STP_ENTER=0: at the first sampled window area; re-based every 3rd updating call) against a handle
     that never uses it, on a tracked sequence whose object travels across the image with resampling (children share parents):
@@ -325,11 +325,11 @@ def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols,
     poses = [synth.particle_poses(t, n, rng, scale=1.0) for t, _ in frames]
     parents = [np.sort(rng.choice(n, size=n, p=(lambda w: w / w.sum())(rng.random(n) ** 8))).astype(np.int32) for _ in frames]   # few survivors
     monkeypatch.setenv("RBS_SHARED_TRAIL", "0")
-    with RbSensor(om, cam, P, max_particles=n, precision="f64") as plain:
+    with RbSensor(om, cam, P, max_particles=n, precision="f64") as plain:      # (whole planes, scalar background: the reference run)
         monkeypatch.setenv("RBS_SHARED_TRAIL", "1")
         monkeypatch.setenv("RBS_STP_ENTER", "0.0")
         monkeypatch.setenv("RBS_STP_EVERY", "3")
-        with RbSensor(om, cam, P, max_particles=n, precision="f64") as g:
+        with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=slab) as g:      # (slab > 0: window-sized slabs, which grow on the way)
             g.set_timing_every(1); plain.set_timing_every(1)      # (the window area is sampled on timed calls)
             for s_ in (g, plain):
                 s_.reset()
@@ -354,6 +354,14 @@ def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols,
             a_g, a_p = np.mean([area(g.get_window(q)) for q in slots]), np.mean([area(plain.get_window(q)) for q in slots])
             print(f"\nmean window: shared trail {a_g:.0f} px, scalar background {a_p:.0f} px ({rebases} re-basings)")
             assert a_g < 0.75 * a_p
+            if slab:     # window transport on slabs against a shared plane: the plane travels whole, and comes back the same
+                import torch
+                buf = torch.empty(cols * rows, dtype=torch.float32, device="cuda:0")
+                rect = g.export_window(slots[1], buf.data_ptr(), buf.numel())
+                assert rect == (0, 0, cols, rows)
+                g.import_window(n - 1, rect, buf.data_ptr())
+                g.synchronize()
+                assert np.array_equal(g.get_occlusion(n - 1), g.get_occlusion(slots[1]))
             for q in slots:
                 assert np.array_equal(g.get_occlusion(q), plain.get_occlusion(q)), q
                 assert np.array_equal(g.get_occlusion(q), o.get_occlusion(q)) or (g.get_occlusion(q) != o.get_occlusion(q)).mean() <= 1e-4

@@ -28,7 +28,10 @@ def test_slabs_hold_the_same_planes_as_whole_planes(gpu_lib, precision, meshes, 
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
         for slot in range(n):
-            assert whole.get_window(slot) == slabs.get_window(slot)       # (before get_occlusion makes whole planes dense)
+            # (before get_occlusion makes whole planes dense; handles that store against a shared background plane -- forced runs of
+            # the suite, RBS_STP_ENTER=0 -- re-base on their own schedules, a slab handle's repeated calls included: same planes, other windows)
+            if not (whole.shared_trail_state()[0] or slabs.shared_trail_state()[0]):
+                assert whole.get_window(slot) == slabs.get_window(slot)
         for slot in range(n):
             assert np.array_equal(whole.get_occlusion(slot), slabs.get_occlusion(slot))
         # read-only calls with resampled parents
