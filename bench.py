@@ -685,10 +685,10 @@ def sweep_leg(a, dev, stream, n_frames=1000, tail=200, table=(0.03, 0.10, 0.25, 
                     os.environ.pop("RBS_SHARED_TRAIL", None)
                 else:
                     os.environ["RBS_SHARED_TRAIL"] = old_env
-        res["sweep_tracker_note"] = ("the same travelling object followed by the device tracker (2 000 particles, frame by frame from host memory, "
+        res["sweep_tracker_note"] = ("the same travelling object followed by the device tracker (%d particles, frame by frame from host memory, "
                                      "its own KL-triggered resampling): frames/s and particle-likelihoods/s over the last %d of %d frames, stored window "
                                      "fraction at the end; sweep_tracker_*: planes stored against the shared background plane once windows have grown "
-                                     "(the default), sweep_tracker_scalar_background_*: RBS_SHARED_TRAIL=0" % (tail, n_frames))
+                                     "(the default), sweep_tracker_scalar_background_*: RBS_SHARED_TRAIL=0" % (n, tail, n_frames))
     except Exception as e:   # noqa: BLE001
         res["sweep_tracker_note"] = f"tracker sweep failed: {e!r}"
     del d_frames
