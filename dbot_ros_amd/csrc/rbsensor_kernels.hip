@@ -1337,6 +1337,8 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                     if (stored && (UPDATE || ac[u])) s4[u] = *reinterpret_cast<const floatx4*>(src + sb[u]);
                     else if (STP && (UPDATE || ac[u])) s4[u] = *reinterpret_cast<const floatx4*>(P.bgp_src + gb[u]);   // the shared plane's value
 #endif
+                    // (the split launch's likelihood kernel, whose tile read is a memory round trip: requesting the frame's quad WITH it
+                    // instead of behind it was measured -- 0.1945 ms either way)
                     if (ac[u]) o4[u] = *reinterpret_cast<const floatx4*>(P.frame + gb[u]);
                 }
                 qc += rstep; lr += qstep;
