@@ -496,6 +496,8 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     // particle's partial sums are added, and the switch between the modes depends on when an
     // asynchronous read-back lands -- results must not.
     const bool f64 = h->precision == RBS_PRECISION_F64;   // (its math tables take a little of the LDS tile)
+    // (round 5, C4 slice: the 16 384-px tile with two blocks per CU -- 6 work items per particle instead of 10 -- 7.62 ms against 6.32 with
+    // three blocks and the small tile; two blocks with the small tile 8.16: the larger tile is worth 7 %, the third wave per SIMD 25 %)
     P.tile_px = !h->windowed && h->raster_blocks <= 2 * h->cu_count ? (f64 ? rbs::kTilePxBigF64 : rbs::kTilePxBig)
                                                                      : (f64 ? rbs::kTilePxF64 : rbs::kTilePx);
     // split launch: binary64 likelihood on windowed planes (the tile size is the handle's for its whole life, like the

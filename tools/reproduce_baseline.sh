@@ -27,3 +27,7 @@ for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); print('tracker C2 %-6s filter %6d evaluations x %d objects  %8.0f frames/s' % (d['filter'], d['evaluation_count'], d['objects'], d['value']))
 "
+# BASELINE.md section 3a (round 5): the host legs from C++ (host-pointer step, look-ahead, through the plugin surface) and the moving-object legs
+python tools/host_legs.py --config c1 2>/dev/null | grep -E '_value|_ms_per_step'
+python bench.py --sweep-only 2>/dev/null | grep -E 'sweep_value|sweep_window_fraction\"|tracker(_scalar_background)?_(fps|value|window_fraction)|\"value\"|stored_fraction'
+python bench.py --sweep-only --particles 20000 2>/dev/null | grep -E 'tracker(_scalar_background)?_(fps|window_fraction)'
