@@ -207,6 +207,7 @@ struct rbs_handle {
     std::string err;
     bool frame_acquired = false;       // rbs_acquire_frame_buffer without its rbs_commit_frame_buffer yet
     int prefetched_slot = -1;          // staging slot holding a frame uploaded ahead of its turn (rbs_loglikes_prefetch), -1: none
+    const float* borrowed_f32 = nullptr;   // ... the same for a float frame (the device tracker's frames at small particle counts)
     const double* borrowed = nullptr;  // rbs_set_observation_borrowed: the caller's frame, staged by the next host-pointer likelihood call
                                        // while that call's geometry kernel runs (or by whatever else needs the observation first)
     // A call that failed half-way through a fan-out (some shards enqueued, others not) or between a
@@ -388,7 +389,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     h->quiet = false;
     // a borrowed frame (rbs_set_observation_borrowed) is staged BETWEEN the two kernels of the split launch, while the
     // geometry kernel -- which needs no frame -- runs; a handle that cannot launch that way stages it here and now
-    if (h->borrowed && !(h->precision == RBS_PRECISION_F64 && h->windowed && s == h->stream))
+    if ((h->borrowed || h->borrowed_f32) && !(h->precision == RBS_PRECISION_F64 && h->windowed && s == h->stream))
         if (int32_t rc = stage_borrowed(h)) return rc;
     DevParams P = h->base;
     occlusion_coeffs(h, h->pending_frames, &P.alpha, &P.beta);
@@ -502,7 +503,8 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
                                                                      : (f64 ? rbs::kTilePxF64 : rbs::kTilePx);
     // split launch: binary64 likelihood on windowed planes (the tile size is the handle's for its whole life, like the
     // monolith's: the split of a rectangle into items decides the order in which a particle's partial sums are added)
-    bool split = (h->split || h->borrowed != nullptr) && f64 && h->windowed;   // (the same tile, the same items, the same bits either way)
+    const bool have_borrowed = h->borrowed != nullptr || h->borrowed_f32 != nullptr;
+    bool split = (h->split || have_borrowed) && f64 && h->windowed;   // (the same tile, the same items, the same bits either way)
     if (split && !(!h->windowed && h->raster_blocks <= 2 * h->cu_count)) P.tile_px = rbs::kDepthTilePx;   // (= kTilePxF64 already)
     P.tile_w = 256;
     P.tile_h = std::max(4, P.tile_px / 256 / std::max(1, h->smalln_target / std::max(1, n)));
@@ -532,7 +534,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         const size_t want = pe ? std::min(need, (size_t)n * (size_t)std::max(1, std::atoi(pe)) + 1024) : need;
         if (want > h->depth_items && sizeof(unsigned) * (size_t)rbs::kDepthTilePx * want > kDepthBudget) {
             split = false;
-            if (h->borrowed) {
+            if (have_borrowed) {
                 if (int32_t rc = stage_borrowed(h)) return rc;
                 P.frame = h->cur_frame;
                 P.aux = h->cur_aux;
@@ -662,7 +664,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         if (h->many_clusters) hipLaunchKernelGGL((rbs::rbs_depth_kernel<true>), dgrid, block, dsm, s, P);
         else hipLaunchKernelGGL((rbs::rbs_depth_kernel<false>), dgrid, block, dsm, s, P);
         RBS_HIP(h, hipGetLastError());
-        if (h->borrowed) {   // the host converts and sends the caller's frame while the depth tiles are rasterized
+        if (have_borrowed) {   // the host converts and sends the caller's frame while the depth tiles are rasterized
             if (int32_t rc = stage_borrowed(h)) {
                 // half a call is enqueued (rectangles + geometry kernel: the work-item counters of this parity are spent, no plane
                 // has been written): every later call is refused until rbs_reset re-establishes a known state
@@ -1085,6 +1087,7 @@ int32_t upload_frame(rbs_handle* h, const float* src, const float* pageable = nu
     const size_t n = (size_t)h->npx;
     h->prefetched_slot = -1;   // (a frame uploaded ahead of its turn that another frame overtakes is abandoned)
     h->borrowed = nullptr;     // (... and so is a borrowed frame nobody evaluated)
+    h->borrowed_f32 = nullptr;
     // (the two staging images alternate, so k is never the image that serves as the observation --
     // should it be, its readers are recorded first: the wait below must not be on a stale event)
     if (k == h->cur_slot)
@@ -1157,11 +1160,13 @@ int32_t next_frame_staging(rbs_handle* h)
 // rbs_set_observation_borrowed's frame becomes the observation now: staged (double -> float) into pinned memory and sent.
 int32_t stage_borrowed(rbs_handle* h)
 {
-    if (!h->borrowed) return RBS_OK;
+    if (!h->borrowed && !h->borrowed_f32) return RBS_OK;
     const double* d = h->borrowed;
+    const float* f = h->borrowed_f32;
     h->borrowed = nullptr;
+    h->borrowed_f32 = nullptr;
     if (int32_t rc = next_frame_staging(h)) return rc;
-    return upload_frame(h, h->h_frame, nullptr, d);
+    return d ? upload_frame(h, h->h_frame, nullptr, d) : upload_frame(h, h->h_frame, f);
 }
 
 // The NEXT frame, uploaded while the current one is still the observation (rbs_loglikes_prefetch: called between
@@ -1970,6 +1975,9 @@ void release_group(rbs_handle* g)
 // rbs_loglikes_deltas: state deltas + default poses instead of absolute poses (packed on the way into pinned memory,
 // composed on the device by the rectangles kernel, rbs_prep_deltas_kernel).
 struct DeltaArgs { const double* deltas; const double* deflt; int stride; };
+#ifndef RBS_TRACKER_SPLIT_MAX_DEFAULT
+#define RBS_TRACKER_SPLIT_MAX_DEFAULT 5000   // (measured, tests/cpp/host_bench --tracker: frame by frame +12-16 % at 1 000-2 000 particles, +6-10 % at 4 000, nothing from 6 000 up)
+#endif
 
 int32_t host_call(rbs_handle* h, const double* poses, const int32_t* indices, int n, bool update, const DeltaArgs* da = nullptr)
 {
@@ -2317,6 +2325,7 @@ int32_t rbs_reset(rbs_handle* h)
     h->frame_acquired = false;
     h->prefetched_slot = -1;   // (a frame uploaded ahead belongs to the session that ended)
     h->borrowed = nullptr;
+    h->borrowed_f32 = nullptr;
     h->stp = false;            // (every plane is all background again: the scalar says it all)
     h->stp_last_rebase = -1000000;
     h->stp_block_until = 0;
@@ -2503,6 +2512,7 @@ int32_t rbs_set_observation_device(rbs_handle* h, const float* d_depth, void* st
     if (int32_t rc = release_frame_slot(h)) return rc;
     h->prefetched_slot = -1;   // (a frame uploaded ahead of its turn that another frame overtakes is abandoned: ADVICE r4)
     h->borrowed = nullptr;
+    h->borrowed_f32 = nullptr;
     h->lazy_frame = d_depth;
     h->lazy_stream = s;
     h->pending_frames += 1;
@@ -3700,8 +3710,23 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
         // the frame is handed over AFTER the first transition launch: the transition (and the
         // sensor's rectangles kernel behind it) do not depend on it, and run while the host copies
         // the frame into pinned memory and the copy engine uploads it
-        if (b == 0 && frame)
-            if (int32_t rc = rbs_set_observation_f32(h, frame, (size_t)h->npx)) return rc;
+        if (b == 0 && frame) {
+            // Few particles: the frame's own journey (staging copy, transfer, model terms: ~80 us) is most of a frame, and the sensor's
+            // GEOMETRY kernel does not need it -- the frame is handed to the sensor as a borrowed one and staged by enqueue_loglikes
+            // between the two kernels of the split launch (inside this call: the caller's buffer is free on return as before).  Above
+            // kTrackerSplitMax evaluations the one-kernel launch's shorter kernel time wins (RBS_TRACKER_SPLIT_MAX, 0: never).
+            static const int split_max = [] { const char* e = std::getenv("RBS_TRACKER_SPLIT_MAX"); return e ? std::atoi(e) : RBS_TRACKER_SPLIT_MAX_DEFAULT; }();
+            const bool idle = t->submitted == t->collected;   // (a frame already in flight -- look-ahead -- hides the journey by itself, and the one-kernel launch is the shorter)
+            if (idle && T.n * T.parts <= split_max && h->precision == RBS_PRECISION_F64 && h->windowed && !h->frame_ingest && !h->group) {
+                RBS_REFUSE_POISONED(h);
+                h->frame_acquired = false;
+                if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
+                h->prefetched_slot = -1;
+                h->borrowed = nullptr;
+                h->borrowed_f32 = frame;
+                h->pending_frames += 1;
+            } else if (int32_t rc = rbs_set_observation_f32(h, frame, (size_t)h->npx)) return rc;
+        }
         if (int32_t rc = enqueue_loglikes(h, T.poses, T.idx, T.n, last, T.ll_new, s)) return rc;
         if (fused) {
             hipLaunchKernelGGL(rbt::filter_step_kernel, dim3(1), dim3(1024), 0, s, T, b, last ? 1 : 0, last ? 1 : 0);
