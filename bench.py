@@ -1032,6 +1032,15 @@ def native_tracker_leg(om, cam, P, frames, init, counts, precision):
     out = {}
     try:
         env = dict(os.environ, RBS_PRECISION=precision)
+        for n in counts:      # ... and through the mirror of the reference's builders, the images as doubles (plugin_tracker_fps_*)
+            rp = subprocess.run([exe, "--tracker-plugin", path, str(n)], capture_output=True, text=True, timeout=300, env=env)
+            lp = next((l for l in rp.stdout.splitlines() if l.startswith("tracker_bench ")), None)
+            if lp:
+                tk = lp.split()
+                out[f"plugin_tracker_fps_{n}"] = float(tk[4])
+                out[f"plugin_tracker_fps_pipelined_{n}"] = float(tk[6])
+        out["plugin_tracker_fps_note"] = ("the device tracker through dbot_amd::ParticleTrackerBuilder(...).build(): tracker->track(image of rows*cols DOUBLES) frame by "
+                                          "frame / submit + result with one frame of look-ahead (tests/cpp/host_bench.cpp --tracker-plugin)")
         for n in counts:
             r = subprocess.run([exe, "--tracker", path, str(n)], capture_output=True, text=True, timeout=300, env=env)
             line = next((l for l in r.stdout.splitlines() if l.startswith("tracker_bench ")), None)

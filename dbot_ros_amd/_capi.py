@@ -38,7 +38,7 @@ EXPORTS = (
     "rbs_render_depth",
     "rbs_last_kernel_ms", "rbs_timing_summary",
     "rbs_tracker_create", "rbs_tracker_destroy", "rbs_tracker_initialize", "rbs_tracker_track",
-    "rbs_tracker_submit", "rbs_tracker_result",
+    "rbs_tracker_submit", "rbs_tracker_result", "rbs_tracker_track_f64", "rbs_tracker_submit_f64",
     "rbs_tracker_get",
 )
 
@@ -200,6 +200,10 @@ def load():
     lib.rbs_tracker_initialize.argtypes = [H, dp]
     lib.rbs_tracker_track.restype = C.c_int32
     lib.rbs_tracker_track.argtypes = [H, fp, dp, dp, C.c_uint64, dp, ip]
+    lib.rbs_tracker_track_f64.restype = C.c_int32
+    lib.rbs_tracker_track_f64.argtypes = [H, dp, dp, dp, C.c_uint64, dp, ip]
+    lib.rbs_tracker_submit_f64.restype = C.c_int32
+    lib.rbs_tracker_submit_f64.argtypes = [H, dp, dp, dp, C.c_uint64]
     lib.rbs_tracker_submit.restype = C.c_int32
     lib.rbs_tracker_submit.argtypes = [H, fp, dp, dp, C.c_uint64]
     lib.rbs_tracker_result.restype = C.c_int32

@@ -3277,6 +3277,8 @@ int32_t rbs_get_background(rbs_handle* h, float* out)
 }  // extern "C"
 
 struct rbs_tracker {
+    const double* frame64 = nullptr;   // rbs_tracker_submit_f64: this submit's frame as doubles (tracker_submit_impl reads it instead of `frame`)
+    std::vector<float> frame_tmp;      // ... converted here where a float frame is needed (a sensor over several devices)
     rbs_handle* s = nullptr;
     rbt::TrackerDev T{};
     std::vector<void*> allocs;
@@ -3667,6 +3669,14 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
     if (t->submitted - t->collected >= 2)
         return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_submit: two frames are in flight already (call rbs_tracker_result)");
     const int slot = (int)(t->submitted & 1);
+    const double* frame64 = t->frame64;
+    t->frame64 = nullptr;
+    if (frame64 && !t->reps.empty()) {   // (the sharded form uploads float frames: converted once here)
+        t->frame_tmp.resize((size_t)t->reps[0]->s->npx);
+        convert_f64_f32(t->frame_tmp.data(), frame64, t->frame_tmp.size());
+        frame = t->frame_tmp.data();
+        frame64 = nullptr;
+    }
     if (!t->reps.empty()) {   // several devices: the frame runs to completion here, its result waits in the slot
         rbs_tracker* r0 = t->reps[0];
         t->res_rc[slot] = group_tracker_track(t, frame, normals, uniforms, seed, r0->h_state[slot], &r0->h_flags[slot][1]);
@@ -3676,7 +3686,7 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
     rbt::TrackerDev& T = t->T;
     rbs_handle* h = t->s;
     RBT_HIP(t, hipSetDevice(h->device));
-    if (frame && h->npx <= 0) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_submit: bad sensor");
+    if ((frame || frame64) && h->npx <= 0) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_submit: bad sensor");
     hipStream_t s = h->stream;
     const size_t n = (size_t)T.n;
     T.normals = nullptr;
@@ -3710,7 +3720,7 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
         // the frame is handed over AFTER the first transition launch: the transition (and the
         // sensor's rectangles kernel behind it) do not depend on it, and run while the host copies
         // the frame into pinned memory and the copy engine uploads it
-        if (b == 0 && frame) {
+        if (b == 0 && (frame || frame64)) {
             // Few particles: the frame's own journey (staging copy, transfer, model terms: ~80 us) is most of a frame, and the sensor's
             // GEOMETRY kernel does not need it -- the frame is handed to the sensor as a borrowed one and staged by enqueue_loglikes
             // between the two kernels of the split launch (inside this call: the caller's buffer is free on return as before).  Above
@@ -3722,10 +3732,10 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
                 h->frame_acquired = false;
                 if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
                 h->prefetched_slot = -1;
-                h->borrowed = nullptr;
-                h->borrowed_f32 = frame;
+                h->borrowed = frame64;          // (doubles, as dbot hands images over: converted while they are staged)
+                h->borrowed_f32 = frame64 ? nullptr : frame;
                 h->pending_frames += 1;
-            } else if (int32_t rc = rbs_set_observation_f32(h, frame, (size_t)h->npx)) return rc;
+            } else if (int32_t rc = frame64 ? rbs_set_observation(h, frame64, (size_t)h->npx) : rbs_set_observation_f32(h, frame, (size_t)h->npx)) return rc;
         }
         if (int32_t rc = enqueue_loglikes(h, T.poses, T.idx, T.n, last, T.ll_new, s)) return rc;
         if (fused) {
@@ -3820,6 +3830,25 @@ int32_t rbs_tracker_result(rbs_tracker* t, double* out_state, int32_t* out_resam
         return rc;
     }
     return RBS_OK;
+}
+
+int32_t rbs_tracker_submit_f64(rbs_tracker* t, const double* frame, const double* normals, const double* uniforms, uint64_t seed)
+{
+    if (!t) return RBS_ERR_INVALID_ARGUMENT;
+    t->frame64 = frame;
+    const int32_t rc = rbs_tracker_submit(t, nullptr, normals, uniforms, seed);
+    t->frame64 = nullptr;
+    return rc;
+}
+
+int32_t rbs_tracker_track_f64(rbs_tracker* t, const double* frame, const double* normals, const double* uniforms, uint64_t seed,
+                              double* out_state, int32_t* out_resamplings)
+{
+    if (!t) return RBS_ERR_INVALID_ARGUMENT;
+    t->frame64 = frame;
+    const int32_t rc = rbs_tracker_track(t, nullptr, normals, uniforms, seed, out_state, out_resamplings);
+    t->frame64 = nullptr;
+    return rc;
 }
 
 int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* normals,

@@ -403,18 +403,17 @@ public:
     /// R:source/dbot_ros/object_tracker_ros.hpp:49  current_state_ = tracker_->track(image)
     State track(const Obsrv& image)
     {
-        to_frame(image);
+        // (the image goes in as the doubles it is: converted while it is staged, behind the sensor's geometry kernel -- rbs_tracker_track_f64)
         State model(parts_);
         int32_t nres = 0;
-        check(rbs_tracker_track(t_, frame_.data(), nullptr, nullptr, seed_, model.data().data(), &nres));
+        check(rbs_tracker_track_f64(t_, image.data(), nullptr, nullptr, seed_, model.data().data(), &nres));
         return averaged(model, nres);
     }
     /// The same frame in two halves (rbs_tracker_submit / rbs_tracker_result): a caller that has
     /// the next image before it needs this estimate keeps up to two frames in flight.
     void submit(const Obsrv& image)
     {
-        to_frame(image);
-        check(rbs_tracker_submit(t_, frame_.data(), nullptr, nullptr, seed_));
+        check(rbs_tracker_submit_f64(t_, image.data(), nullptr, nullptr, seed_));
     }
     State result()
     {
@@ -429,11 +428,6 @@ private:
     void check(int32_t rc) const
     {
         if (rc != RBS_OK) throw std::runtime_error(std::string("ParticleTracker: ") + rbs_last_error(sensor_->handle()));
-    }
-    void to_frame(const Obsrv& image)
-    {
-        frame_.resize(image.size());
-        for (size_t i = 0; i < image.size(); ++i) frame_[i] = static_cast<float>(image[i]);
     }
     State averaged(const State& model, int32_t nres)
     {
@@ -467,7 +461,6 @@ private:
     uint64_t seed_;
     int parts_;
     rbs_tracker* t_ = nullptr;
-    std::vector<float> frame_;
     State average_{1};
     bool have_average_ = false;
     int resamplings_ = 0;

@@ -482,6 +482,12 @@ int32_t rbs_tracker_track(rbs_tracker* t, const float* frame, const double* norm
 int32_t rbs_tracker_submit(rbs_tracker* t, const float* frame, const double* normals,
                            const double* uniforms, uint64_t seed);
 int32_t rbs_tracker_result(rbs_tracker* t, double* out_state, int32_t* out_resamplings);
+/* The same two with the image as dbot's tracker receives it -- rows*cols DOUBLES (Obsrv of R:source/dbot_ros/object_tracker_ros.h:40-41,
+ * filled by ri::to_eigen_vector, R:source/dbot_ros/util/ros_interface.h:152-168): converted to float while it is staged (AVX2), and, frame
+ * by frame with at most 5 000 evaluations, staged BEHIND the sensor's geometry kernel like any borrowed frame (the buffer is free on return). */
+int32_t rbs_tracker_track_f64(rbs_tracker* t, const double* frame, const double* normals, const double* uniforms, uint64_t seed,
+                              double* out_state, int32_t* out_resamplings);
+int32_t rbs_tracker_submit_f64(rbs_tracker* t, const double* frame, const double* normals, const double* uniforms, uint64_t seed);
 /* Inspection: particle deltas [n][n_objects*12], log-weights [n], occlusion slot map [n]
  * (any pointer may be NULL). */
 int32_t rbs_tracker_get(rbs_tracker* t, double* particles, double* log_weights, int32_t* indices);

@@ -18,6 +18,9 @@
 // sensor->loglikes(deltas, indices, update) with the particles' state DELTAS, one State (a heap vector of its own) per
 // particle, around integrated_poses(); synchronous, the frame inside the clock, no look-ahead.  The image is borrowed until
 // loglikes returns, as in the dbot binding (integration/dbot/rb_sensor_mi355x.h); --plugin-copy: copied at set_observation.
+//   host_bench --tracker-plugin <workload.bin> <particles>
+// the device tracker THROUGH THE MIRROR of the reference's builders (dbot_amd::ParticleTrackerBuilder(...).build(), tracker->initialize,
+// tracker->track(image of doubles) / submit + result): what dbot_ros's node would see.
 //   host_bench --tracker <workload.bin> <particles>
 // the device tracker (rbs_tracker_*: transition, loglikes, weights, KL test, resampling, mean; device
 // RNG) over the workload's frames, frame by frame (rbs_tracker_track: one host synchronisation per
@@ -40,7 +43,8 @@ static bool rd(std::FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n
 
 int main(int argc, char** argv)
 {
-    const bool tracker_mode = argc > 1 && !std::strcmp(argv[1], "--tracker");
+    const bool tracker_plugin = argc > 1 && !std::strcmp(argv[1], "--tracker-plugin");   // the tracker through dbot_amd::ParticleTrackerBuilder, images of doubles
+    const bool tracker_mode = tracker_plugin || (argc > 1 && !std::strcmp(argv[1], "--tracker"));
     const bool prefetch_mode = argc > 1 && !std::strcmp(argv[1], "--prefetch");   // the next frame travels behind each call's kernels
     const bool plugin_copy = argc > 1 && !std::strcmp(argv[1], "--plugin-copy");  // ... set_observation copying at once, as dbot's own sensors do
     const bool plugin_mode = plugin_copy || (argc > 1 && !std::strcmp(argv[1], "--plugin"));   // through dbot_amd::RbSensor (double frame, state deltas)
@@ -72,6 +76,66 @@ int main(int argc, char** argv)
     const bool have_init = rd(f, init.data(), init.size());
     std::fclose(f);
     if (tracker_mode && !have_init) { std::fprintf(stderr, "host_bench --tracker: the workload holds no initial state\n"); return 2; }
+
+    if (tracker_plugin) {
+        // dbot_ros's own construction order (R:source/dbot_ros/tracker/particle_tracker_node.cpp:138-218): transition builder, sensor builder,
+        // tracker builder -> build(); then tracker->initialize({state}) (:252) and, per frame, tracker->track(image) with the image a vector of
+        // DOUBLES (R:source/dbot_ros/object_tracker_ros.hpp:44-49).  Frame by frame and with one frame of look-ahead (submit / result).
+        using namespace dbot_amd;
+        typedef FreeFloatingRigidBodiesState State;
+        const int track_n = std::max(1, steps / nobj);
+        std::vector<std::vector<Real>> vs(nobj);
+        std::vector<std::vector<int32_t>> ts(nobj);
+        size_t vo = 0, to = 0;
+        for (int b = 0; b < nobj; ++b) {
+            vs[b].assign(verts.begin() + vo, verts.begin() + vo + 3 * (size_t)vcnt[b]); vo += 3 * (size_t)vcnt[b];
+            ts[b].assign(tris.begin() + to, tris.begin() + to + 3 * (size_t)tcnt[b]); to += 3 * (size_t)tcnt[b];
+        }
+        auto om = std::make_shared<ObjectModel>(vs, ts, false);
+        auto cam = std::make_shared<CameraData>();
+        for (int i = 0; i < 9; ++i) cam->camera_matrix[i] = K[i];
+        cam->resolution.width = cols; cam->resolution.height = rows;
+        RbSensorBuilder<State>::Parameters sp;
+        sp.use_gpu = true; sp.sample_count = track_n;
+        sp.occlusion.p_occluded_visible = prm[0]; sp.occlusion.p_occluded_occluded = prm[1]; sp.occlusion.initial_occlusion_prob = prm[2];
+        sp.kinect.tail_weight = prm[3]; sp.kinect.model_sigma = prm[4]; sp.kinect.sigma_factor = prm[5]; sp.delta_time = prm[6];
+        ObjectTransitionBuilder<State>::Parameters tpar;
+        tpar.part_count = nobj;
+        ParticleTrackerBuilder<ParticleTracker>::Parameters pp;
+        pp.evaluation_count = track_n * nobj; pp.center_object_frame = false; pp.seed = 1;
+        std::shared_ptr<ParticleTracker> tracker;
+        try {
+            tracker = ParticleTrackerBuilder<ParticleTracker>(std::make_shared<ObjectTransitionBuilder<State>>(tpar),
+                                                              std::make_shared<RbSensorBuilder<State>>(om, cam, sp), om, pp).build();
+        } catch (const std::exception& e) { std::printf("NO_DEVICE %s\n", e.what()); return 0; }
+        std::vector<std::vector<double>> images(F, std::vector<double>(npx));
+        for (int k = 0; k < F; ++k) for (size_t q = 0; q < npx; ++q) images[k][q] = (double)frames[npx * k + q];
+        State st(nobj);
+        st.data().assign(init.begin(), init.end());
+        try {
+            double dts[3], dts2[3];
+            State est(nobj), est2(nobj);
+            for (int rep = 0; rep < 3; ++rep) {
+                tracker->initialize(std::vector<State>(1, st));
+                tracker->track(images[0]);
+                auto t0 = std::chrono::steady_clock::now();
+                for (int k = 1; k < F; ++k) est = tracker->track(images[k]);
+                dts[rep] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                tracker->initialize(std::vector<State>(1, st));
+                tracker->track(images[0]);
+                t0 = std::chrono::steady_clock::now();
+                tracker->submit(images[1]);
+                for (int k = 2; k < F; ++k) { tracker->submit(images[k]); est2 = tracker->result(); }
+                est2 = tracker->result();
+                dts2[rep] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+            std::sort(dts, dts + 3); std::sort(dts2, dts2 + 3);
+            const bool same = est.data() == est2.data();
+            std::printf("tracker_bench particles %d fps %.1f fps_pipelined %.1f resamplings %d identical %d state %.9g %.9g %.9g\n", track_n,
+                        (F - 1) / dts[1], (F - 1) / dts2[1], tracker->resamplings(), same ? 1 : 0, est.data()[0], est.data()[1], est.data()[2]);
+        } catch (const std::exception& e) { std::printf("ERROR %s\n", e.what()); return 1; }
+        return 0;
+    }
 
     if (plugin_mode) {
         using namespace dbot_amd;
