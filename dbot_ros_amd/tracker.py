@@ -263,7 +263,9 @@ class DeviceParticleTracker(ParticleTracker):
         dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
         if not self.device_rng and (normals is None or uniforms is None):
             normals, uniforms = self.draw_randomness()
-        img = np.ascontiguousarray(image, dtype=np.float32).ravel()
+        # a float64 image (what dbot's tracker receives) goes in as it is: rbs_tracker_track_f64 / _submit_f64 convert while staging
+        f64 = isinstance(image, np.ndarray) and image.dtype == np.float64
+        img = np.ascontiguousarray(image, dtype=np.float64 if f64 else np.float32).ravel()
         nptr = uptr = None
         if normals is not None:
             normals = np.ascontiguousarray(normals, dtype=np.float64)
@@ -271,7 +273,8 @@ class DeviceParticleTracker(ParticleTracker):
         if uniforms is not None:
             uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
             uptr = uniforms.ctypes.data_as(dp)
-        return (img, normals, uniforms), (img.ctypes.data_as(fp), nptr, uptr, C.c_uint64(self.seed))
+        self._f64 = f64
+        return (img, normals, uniforms), (img.ctypes.data_as(dp if f64 else fp), nptr, uptr, C.c_uint64(self.seed))
 
     def _estimate(self, out, nres):
         self.default = out
@@ -286,15 +289,15 @@ class DeviceParticleTracker(ParticleTracker):
         _keep, args = self._frame_args(image, normals, uniforms)
         out = np.empty(self.parts * BODY)
         nres = C.c_int32()
-        self.sensor._check(self._lib.rbs_tracker_track(self._t, *args, out.ctypes.data_as(C.POINTER(C.c_double)),
-                                                       C.byref(nres)))
+        fn = self._lib.rbs_tracker_track_f64 if self._f64 else self._lib.rbs_tracker_track
+        self.sensor._check(fn(self._t, *args, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nres)))
         return self._estimate(out, nres)
 
     def submit(self, image, normals=None, uniforms=None):
         """Enqueue one frame (rbs_tracker_submit) and return at once; at most two frames may be in
         flight.  result() hands out the estimates in submission order."""
         _keep, args = self._frame_args(image, normals, uniforms)
-        self.sensor._check(self._lib.rbs_tracker_submit(self._t, *args))
+        self.sensor._check((self._lib.rbs_tracker_submit_f64 if self._f64 else self._lib.rbs_tracker_submit)(self._t, *args))
 
     def result(self):
         """The moving-average estimate of the oldest submitted frame (rbs_tracker_result)."""

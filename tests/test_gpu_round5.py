@@ -403,3 +403,42 @@ def test_shared_trail_is_left_when_the_particles_share_nothing(gpu_lib, monkeypa
             assert states[-1][0] is False and states[-1][1] >= 1
             for q in range(0, n, 5):
                 assert np.array_equal(g.get_occlusion(q), plain.get_occlusion(q)), q
+
+
+@pytest.mark.parametrize("n", [300, 9000])
+def test_tracker_takes_double_frames_and_stages_them_behind_the_geometry_kernel(gpu_lib, monkeypatch, n):
+    """rbs_tracker_track_f64 / _submit_f64 (the image as dbot's tracker receives it: doubles) against the float entry points, frame by
+    frame and with look-ahead; n = 300: the frame is staged between the two kernels of the split launch (RBS_TRACKER_SPLIT_MAX), n = 9 000:
+    it is copied first and the one-kernel launch runs -- the estimates are the same bits every way (device RNG, same seed)."""
+    from dbot_ros_amd import pose
+    from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
+    cols, rows = (320, 240)
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    rng = np.random.default_rng(3)
+    init = np.zeros(12)
+    Rt = synth.truth_pose(1, frame=0)[0]
+    init[3:6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+    init[0:3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0]
+    runs = {}
+    for tag, env, dtype, ahead in (("f32", "5000", np.float32, False), ("f64", "5000", np.float64, False), ("f64_mono", "0", np.float64, False),
+                                   ("f64_ahead", "5000", np.float64, True)):
+        monkeypatch.setenv("RBS_TRACKER_SPLIT_MAX", env)
+        with RbSensor(om, cam, P, max_particles=n, precision="f64") as s:
+            if tag == "f32":
+                frames = [synth.make_frame(s.render_depth(synth.truth_pose(1, frame=k)), rows, cols, rng, occluder=False) for k in range(8)]
+            trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters()).build()
+            tr = DeviceParticleTracker(trans, s, om, ParticleTrackerBuilder.Parameters(evaluation_count=n), device_rng=True, seed=9)
+            tr.initialize([init])
+            ests = []
+            if ahead:
+                tr.submit(frames[0].astype(dtype))
+                for k in range(1, 8):
+                    tr.submit(frames[k].astype(dtype))
+                    ests.append(tr.result())
+                ests.append(tr.result())
+            else:
+                ests = [tr.track(f.astype(dtype)) for f in frames]
+            runs[tag] = np.stack(ests)
+            tr.close()
+    for tag in ("f64", "f64_mono", "f64_ahead"):
+        assert np.array_equal(runs[tag], runs["f32"]), (tag, np.abs(runs[tag] - runs["f32"]).max())
