@@ -1992,7 +1992,8 @@ int32_t host_call(rbs_handle* h, const double* poses, const int32_t* indices, in
         const int B = h->n_bodies;
         double* st = reinterpret_cast<double*>(h->h_in);
         const size_t nb = (size_t)n * B;
-        if (da->stride == 6) std::memcpy(st, da->deltas, sizeof(double) * 6 * nb);
+        if (da->deltas == st) {}   // (rbs_deltas_buffer: the caller gathered straight into the staging block)
+        else if (da->stride == 6) std::memcpy(st, da->deltas, sizeof(double) * 6 * nb);
         else for (size_t k = 0; k < nb; ++k) std::memcpy(st + 6 * k, da->deltas + (size_t)da->stride * k, sizeof(double) * 6);
         for (int b = 0; b < B; ++b) std::memcpy(st + 6 * nb + 6 * b, da->deflt + (size_t)da->stride * b, sizeof(double) * 6);
         std::memcpy(h->h_in + h->in_idx_off, indices, sizeof(int) * (size_t)n);
@@ -2550,6 +2551,14 @@ int32_t rbs_loglikes_deltas(rbs_handle* h, const double* deltas, const double* d
     if (n > 0 && (!deltas || !default_poses)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "loglikes_deltas: null pointer");
     const DeltaArgs da = {deltas, default_poses, body_stride};
     return loglikes_impl(h, deltas, indices, n, update, out_loglik, nullptr, &da);
+}
+
+int32_t rbs_deltas_buffer(rbs_handle* h, double** buf)
+{
+    if (!h || !buf) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty()) return fail(h, RBS_ERR_UNSUPPORTED, "deltas_buffer: single-device handles");
+    *buf = reinterpret_cast<double*>(h->h_in);
+    return RBS_OK;
 }
 
 int32_t rbs_get_poses(rbs_handle* h, double* out, int32_t n)

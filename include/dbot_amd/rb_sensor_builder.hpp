@@ -304,9 +304,12 @@ private:
         if (!next_depth) {
             // (position + rotation vector of every body, six numbers: the velocities stay where they are)
             const size_t B = static_cast<size_t>(n_bodies_), D = B * State::BODY_SIZE;
-            deltas_.resize(n * B * 6);
             defaults_.resize(B * 6);
-            Real* out = deltas_.data();
+            // (gathered straight into the library's pinned staging block where there is one -- rbs_deltas_buffer: a handle on one
+            // device --, so that the call has nothing left to copy)
+            Real* staging = nullptr;
+            if (rbs_deltas_buffer(handle_, &staging) != RBS_OK) { deltas_.resize(n * B * 6); staging = deltas_.data(); }
+            Real* out = staging;
             for (size_t i = 0; i < n; ++i) {
                 const std::vector<Real>& d = deltas[i].data();
                 if (d.size() != D) throw std::runtime_error("RbSensor::loglikes: a state of the wrong size");
@@ -315,7 +318,7 @@ private:
             }
             for (size_t b = 0; b < B; ++b)
                 std::copy(integrated_poses_.component(static_cast<int>(b)), integrated_poses_.component(static_cast<int>(b)) + 6, defaults_.begin() + static_cast<std::ptrdiff_t>(6 * b));
-            check(rbs_loglikes_deltas(handle_, deltas_.data(), defaults_.data(), 6, indices.data(), static_cast<int32_t>(n), update ? 1 : 0, ll.data()));
+            check(rbs_loglikes_deltas(handle_, staging, defaults_.data(), 6, indices.data(), static_cast<int32_t>(n), update ? 1 : 0, ll.data()));
             return ll;
         }
         poses_.resize(n * static_cast<size_t>(n_bodies_) * 12);

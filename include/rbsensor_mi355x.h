@@ -261,6 +261,12 @@ int32_t rbs_loglikes_device(rbs_handle* h, const double* d_poses, const int32_t*
  * and handles over several devices. */
 int32_t rbs_loglikes_deltas(rbs_handle* h, const double* deltas, const double* default_poses, int32_t body_stride,
                             int32_t* indices, int32_t n, int32_t update, double* out_loglik);
+/* The pinned staging block rbs_loglikes_deltas reads the deltas from, for callers whose particles are separate vectors (dbot's
+ * StateArray: one Eigen vector per particle) and who must gather them anyway: gather position + rotation vector of every body, six
+ * doubles each, particle-major ([n][n_objects][6], n <= max_particles) straight into *buf and pass *buf itself as `deltas` with
+ * body_stride = 6 -- rbs_loglikes_deltas then skips its own staging copy.  The block is the handle's; valid until rbs_destroy; its
+ * contents are consumed by the call.  Single-device handles. */
+int32_t rbs_deltas_buffer(rbs_handle* h, double** buf);
 /* Test / inspection hook: the absolute poses ([n][n_objects][12] doubles: R row-major, t) the handle's LAST
  * host-pointer likelihood call evaluated -- for rbs_loglikes the caller's own, for rbs_loglikes_deltas the
  * device's compositions.  Synchronises.  Single-device handles. */

@@ -119,11 +119,12 @@ public:
     RealArray loglikes(const StateArray& deltas, IntArray& indices, const bool& update = false) override
     {
         const int n = static_cast<int>(deltas.size());
-        deltas_.resize(static_cast<size_t>(6) * n * parts_);
+        double* staging = nullptr;                     // the library's pinned staging block (a handle on one device), else our own
+        if (rbs_deltas_buffer(handle_, &staging) != RBS_OK) { deltas_.resize(static_cast<size_t>(6) * n * parts_); staging = deltas_.data(); }
         for (int i = 0; i < n; ++i)
             for (int part = 0; part < parts_; ++part)
             {
-                double* out = &deltas_[6 * (static_cast<size_t>(i) * parts_ + part)];
+                double* out = staging + 6 * (static_cast<size_t>(i) * parts_ + part);
                 const auto block = deltas[i].component(part);
                 for (int k = 0; k < 3; ++k) { out[k] = block.position()(k); out[3 + k] = block.orientation()(k); }
             }
@@ -134,7 +135,7 @@ public:
         }
         RealArray ll(n);
         static_assert(sizeof(int) == sizeof(int32_t), "IntArray holds 32-bit slots");
-        check(rbs_loglikes_deltas(handle_, deltas_.data(), defaults_.data(), 6, reinterpret_cast<int32_t*>(indices.data()), n,
+        check(rbs_loglikes_deltas(handle_, staging, defaults_.data(), 6, reinterpret_cast<int32_t*>(indices.data()), n,
                                   update ? 1 : 0, ll.data()));
         return ll;
     }
