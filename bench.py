@@ -986,6 +986,14 @@ def native_host_leg(a, om, cam, P, W, steps):
         res = {"host_api_native_value": float(tok[2]), "host_api_native_ms_per_step": float(tok[4]),
                "host_api_native_note": "the host-pointer step (rbs_set_observation_f32 + rbs_loglikes, synchronous) called from C++ "
                                        "(tests/cpp/host_bench.cpp), frames cycling forwards through the sequence"}
+        rb = subprocess.run([exe, "--borrowed", path, str(steps), "10"], capture_output=True, text=True, timeout=300, env=env)
+        lineb = next((l for l in rb.stdout.splitlines() if l.startswith("host_bench ")), None)
+        if lineb:
+            tb = lineb.split()
+            res.update({"host_api_native_borrowed_value": float(tb[2]), "host_api_native_borrowed_ms_per_step": float(tb[4]),
+                        "host_api_native_borrowed_checksum_equal": tb[6] == tok[6] if len(tb) > 6 and len(tok) > 6 else None,
+                        "host_api_native_borrowed_note": "the same synchronous step with the frame BORROWED until rbs_loglikes returns (rbs_set_observation_borrowed_f32): "
+                                                         "staged behind the geometry kernel of the two-kernel launch"})
         r2 = subprocess.run([exe, "--prefetch", path, str(steps), "10"], capture_output=True, text=True, timeout=300, env=env)
         line2 = next((l for l in r2.stdout.splitlines() if l.startswith("host_bench ")), None)
         if line2:

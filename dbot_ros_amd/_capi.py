@@ -30,7 +30,7 @@ EXPORTS = (
     "rbs_reset", "rbs_set_observation", "rbs_set_observation_f32",
     "rbs_set_observation_native_f32", "rbs_set_observation_device", "rbs_get_observation", "rbs_loglikes",
     "rbs_acquire_frame_buffer", "rbs_commit_frame_buffer", "rbs_loglikes_prefetch", "rbs_set_observation_prefetched",
-    "rbs_loglikes_deltas", "rbs_get_poses", "rbs_deltas_buffer", "rbs_set_observation_borrowed", "rbs_shared_trail_state",
+    "rbs_loglikes_deltas", "rbs_get_poses", "rbs_deltas_buffer", "rbs_set_observation_borrowed", "rbs_set_observation_borrowed_f32", "rbs_shared_trail_state",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_export_plane", "rbs_import_plane",
     "rbs_export_window", "rbs_import_window", "rbs_stream_join", "rbs_ipc_export", "rbs_ipc_attach", "rbs_stage_windows", "rbs_peer_resample",
@@ -120,6 +120,8 @@ def load():
     lib.rbs_set_observation.argtypes = [H, dp, C.c_size_t]
     lib.rbs_set_observation_borrowed.restype = C.c_int32
     lib.rbs_set_observation_borrowed.argtypes = [H, dp, C.c_size_t]
+    lib.rbs_set_observation_borrowed_f32.restype = C.c_int32
+    lib.rbs_set_observation_borrowed_f32.argtypes = [H, fp, C.c_size_t]
     lib.rbs_set_observation_f32.restype = C.c_int32
     lib.rbs_set_observation_f32.argtypes = [H, fp, C.c_size_t]
     lib.rbs_set_observation_native_f32.restype = C.c_int32

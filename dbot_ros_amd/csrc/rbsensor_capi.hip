@@ -2390,7 +2390,26 @@ int32_t rbs_set_observation_borrowed(rbs_handle* h, const double* depth, size_t 
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
     h->prefetched_slot = -1;
+    h->borrowed_f32 = nullptr;
     h->borrowed = depth;          // (a borrowed frame nobody evaluated is simply replaced)
+    h->pending_frames += 1;
+    return RBS_OK;
+}
+
+int32_t rbs_set_observation_borrowed_f32(rbs_handle* h, const float* depth, size_t n)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty() || h->group || h->precision != RBS_PRECISION_F64 || !h->windowed || h->frame_ingest)
+        return rbs_set_observation_f32(h, depth, n);
+    RBS_REFUSE_POISONED(h);
+    h->frame_acquired = false;
+    if (!depth || n != (size_t)h->npx)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("set_observation_borrowed_f32: expected %d pixels, got %zu", h->npx, n));
+    RBS_HIP(h, hipSetDevice(h->device));
+    if (int32_t rc = flush_lazy_frame(h, h->stream)) return rc;
+    h->prefetched_slot = -1;
+    h->borrowed = nullptr;
+    h->borrowed_f32 = depth;
     h->pending_frames += 1;
     return RBS_OK;
 }

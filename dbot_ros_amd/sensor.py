@@ -240,6 +240,11 @@ class RbSensor:
     def set_observation_borrowed(self, image):
         """rbs_set_observation_borrowed: `image` (float64, contiguous) is NOT copied now -- keep it alive and unchanged until
         the next loglikes* / synchronize has returned (this object holds a reference until then)."""
+        if isinstance(image, np.ndarray) and image.dtype == np.float32:
+            img = np.ascontiguousarray(image).ravel()
+            self._borrowed = img
+            self._check(self._lib.rbs_set_observation_borrowed_f32(self._h, img.ctypes.data_as(C.POINTER(C.c_float)), img.size))
+            return
         img = np.ascontiguousarray(image, dtype=np.float64).ravel()
         self._borrowed = img
         self._check(self._lib.rbs_set_observation_borrowed(self._h, img.ctypes.data_as(C.POINTER(C.c_double)), img.size))

@@ -178,6 +178,7 @@ int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n);
  * image outlives the filter's set_observation / loglikes pair.  The occlusion clock advances at this call, as for
  * rbs_set_observation.  Handles over several devices, precision F32 and whole-plane handles copy at once (= rbs_set_observation). */
 int32_t rbs_set_observation_borrowed(rbs_handle* h, const double* depth, size_t n);
+int32_t rbs_set_observation_borrowed_f32(rbs_handle* h, const float* depth, size_t n);   /* the same for the driver's float pixels */
 
 /* Frame ingest straight from the camera driver: `native` is the full-resolution
  * float32 image (width x height, metres, NaN = no reading); the evaluated image is its

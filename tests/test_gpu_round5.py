@@ -283,6 +283,10 @@ def test_borrowed_frame_gives_the_same_bits(gpu_lib):
         for slot in (0, n // 3, n - 1):
             assert a.get_window(slot) == b.get_window(slot)
             assert np.array_equal(a.get_occlusion(slot), b.get_occlusion(slot))
+        # the driver's float pixels, borrowed the same way (rbs_set_observation_borrowed_f32)
+        a.set_observation(frames[1][1]); b.set_observation_borrowed(frames[1][1].astype(np.float32))
+        la, lb = a.loglikes_poses(poses[1], ia, update=True), b.loglikes_poses(poses[1], ib, update=True)
+        assert np.array_equal(la, lb)
         # staged by whatever needs the observation first
         f64 = frames[0][1].astype(np.float64)
         b.set_observation_borrowed(f64)
