@@ -1308,7 +1308,10 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
         // (binary64 likelihood: two quads per trip as well since it fits the budget without spilling in the loops:
         // raster kernel 0.179 -> 0.175 ms)
 #ifndef RBS_SCAN_UNROLL_EVAL
-#define RBS_SCAN_UNROLL_EVAL 2   // (the likelihood kernel of the split launch: its tile reads are global loads)
+#define RBS_SCAN_UNROLL_EVAL 4   // (the likelihood kernel of the split launch: its tile reads are memory round trips, and it has the registers --
+                                 //  four quads' loads in flight per lane: 0.1945 -> 0.1873 ms for both kernels on C1; six: 0.1880; eight waves per
+                                 //  SIMD at one quad, 64 registers, every item resident at once: 0.1933.  The order in which a wave queues its
+                                 //  pixels does not depend on it: same bits)
 #endif
         constexpr int kScanUnroll = PHASE == 2 ? RBS_SCAN_UNROLL_EVAL : PREC ? RBS_SCAN_UNROLL : RBS_SCAN_UNROLL_F64;
         for (int q0 = wave * 64; q0 < nq; q0 += kBlock * kScanUnroll) {
