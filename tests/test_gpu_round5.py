@@ -409,6 +409,56 @@ def test_shared_trail_is_left_when_the_particles_share_nothing(gpu_lib, monkeypa
                 assert np.array_equal(g.get_occlusion(q), plain.get_occlusion(q)), q
 
 
+def test_shared_trail_survives_the_first_borrowed_frame(gpu_lib, monkeypatch):
+    """The hand-over buffer of the two-kernel launch is allocated at the first call that needs it -- here a borrowed frame arriving
+    AFTER the handle entered the shared trail on one-kernel launches.  (Round 5: that allocation used to free the shared planes
+    it had nothing to do with and went on using them -- harmless only as long as nobody else was handed that memory, which is
+    why this sequence passed then too; it is kept as the sequence, with foreign allocations of a plane's size in between.)  Same
+    bits as a handle that never shares, before and after."""
+    n, cols, rows = 48, 320, 240
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    o = ob.Oracle(om, cam, P, max_particles=1, mode=ob.EAGER)
+    rng = np.random.default_rng(5)
+    frames = []
+    for k in range(16):
+        t = synth.truth_pose(1, frame=k)
+        t[:, 9] += -0.08 + 0.01 * k
+        frames.append((t, synth.make_frame(o.render_depth(t), rows, cols, rng)))
+    poses = [synth.particle_poses(t, n, rng, scale=1.0) for t, _ in frames]
+    parents = [np.sort(rng.choice(n, size=n, p=(lambda w: w / w.sum())(rng.random(n) ** 8))).astype(np.int32) for _ in frames]
+    monkeypatch.setenv("RBS_SPLIT", "0")
+    monkeypatch.setenv("RBS_SHARED_TRAIL", "0")
+    with RbSensor(om, cam, P, max_particles=n, precision="f64") as plain:
+        monkeypatch.setenv("RBS_SHARED_TRAIL", "1")
+        monkeypatch.setenv("RBS_STP_ENTER", "0.0")
+        monkeypatch.setenv("RBS_STP_EVERY", "3")
+        with RbSensor(om, cam, P, max_particles=n, precision="f64") as g:
+            g.set_timing_every(1); plain.set_timing_every(1)
+            g.reset(); plain.reset()
+            ig, ip = np.zeros(n, np.int32), np.zeros(n, np.int32)
+            for k, (_, frame) in enumerate(frames):
+                plain.set_observation(frame)
+                if k >= 8:
+                    assert g.shared_trail_state()[0]
+                    g.set_observation_borrowed(np.ascontiguousarray(frame, dtype=np.float64))   # two-kernel launch: its buffer appears at k == 8
+                else:
+                    g.set_observation(frame)
+                la, lb = g.loglikes_poses(poses[k], ig, update=True), plain.loglikes_poses(poses[k], ip, update=True)
+                assert np.array_equal(la, lb), (k, np.abs(la - lb).max())
+                ig, ip = parents[k].copy(), parents[k].copy()
+                if k == 8:      # somebody else's allocations of a plane's size, written: freed planes would be handed out again here
+                    import torch
+                    junk = [torch.full((cols * rows,), float("nan"), dtype=torch.float32, device="cuda:0") for _ in range(8)]
+                    with RbSensor(om, cam, P, max_particles=n, precision="f64") as other:
+                        other.reset()
+                        other.set_observation(np.full_like(frame, 0.3))
+                        other.loglikes_poses(poses[k], np.zeros(n, np.int32), update=True)
+                    torch.cuda.synchronize()
+            del junk
+            for q in range(0, n, 6):
+                assert np.array_equal(g.get_occlusion(q), plain.get_occlusion(q)), q
+
+
 @pytest.mark.parametrize("n", [300, 9000])
 def test_tracker_takes_double_frames_and_stages_them_behind_the_geometry_kernel(gpu_lib, monkeypatch, n):
     """rbs_tracker_track_f64 / _submit_f64 (the image as dbot's tracker receives it: doubles) against the float entry points, frame by
