@@ -911,9 +911,20 @@ int32_t grow_slabs(rbs_handle* h, int new_slab)
 
 // What a call must put back to be run again: an updating call only flips the buffers and moves the
 // background level on -- the planes it read are intact.
-struct CallState { int cur; int pending_frames; float background; };
-CallState save_call_state(const rbs_handle* h) { return {h->cur, h->pending_frames, h->background}; }
-void restore_call_state(rbs_handle* h, const CallState& c) { h->cur = c.cur; h->pending_frames = c.pending_frames; h->background = c.background; }
+// What a call that is taken back (a region did not fit its slab) must find as it was.  The shared trail's mode belongs to it:
+// the planes the repeated call reads are measured against whatever background -- shared plane or scalar -- the FIRST attempt
+// found, and an attempt that left the shared trail (or entered it, or re-based) has already switched the handle's view.
+struct CallState { int cur; int pending_frames; float background; bool stp; long stp_last_rebase, stp_rebases, stp_block_until; double area_frac; bool wide; };
+CallState save_call_state(const rbs_handle* h)
+{
+    return {h->cur, h->pending_frames, h->background, h->stp, h->stp_last_rebase, h->stp_rebases, h->stp_block_until, h->area_frac, h->wide};
+}
+void restore_call_state(rbs_handle* h, const CallState& c)
+{
+    h->cur = c.cur; h->pending_frames = c.pending_frames; h->background = c.background;
+    h->stp = c.stp; h->stp_last_rebase = c.stp_last_rebase; h->stp_rebases = c.stp_rebases; h->stp_block_until = c.stp_block_until;
+    h->area_frac = c.area_frac; h->wide = c.wide;
+}
 
 // Slab size that holds a region of `need` px with room to move.
 // (1.5 x: a slab enlarged for `need` is at most two thirds full, below the three quarters that trigger the next
@@ -1183,6 +1194,24 @@ int32_t stage_borrowed(rbs_handle* h)
     if (int32_t rc = next_frame_staging(h)) return rc;
     return d ? upload_frame(h, h->h_frame, nullptr, d) : upload_frame(h, h->h_frame, f);
 }
+
+// A borrowed frame is the caller's memory until the likelihood call behind it RETURNS -- however it returns.  A call that is
+// refused or fails before its kernels staged the frame must not leave the pointer behind for a later call to read: on the way
+// out the frame is copied after all (it becomes the observation, as rbs_set_observation would have made it), or dropped where
+// the handle takes no more work.
+struct BorrowedFrameGuard {
+    rbs_handle* h;
+    ~BorrowedFrameGuard()
+    {
+        if (!h->borrowed && !h->borrowed_f32) return;
+        if (h->poisoned || hipSetDevice(h->device) != hipSuccess) { h->borrowed = nullptr; h->borrowed_f32 = nullptr; return; }
+        const std::string keep = h->err;      // (the message of the failure that brought us here stays rbs_last_error's)
+        const int32_t rc = stage_borrowed(h);
+        h->borrowed = nullptr;
+        h->borrowed_f32 = nullptr;
+        if (rc == RBS_OK) h->err = keep;
+    }
+};
 
 // The NEXT frame, uploaded while the current one is still the observation (rbs_loglikes_prefetch: called between
 // the launch of a call's kernels and the wait for its results, so the host's staging copy and the transfer pass
@@ -2641,6 +2670,7 @@ static int32_t loglikes_impl(rbs_handle* h, const double* poses, int32_t* indice
                              const float* next_depth, const DeltaArgs* da)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    const BorrowedFrameGuard borrowed_guard{h};   // (a frame borrowed for this call is not the library's any longer once it returns)
     RBS_REFUSE_POISONED(h);
     if (n < 0 || n > h->max_particles)
         return fail(h, RBS_ERR_INVALID_ARGUMENT,
@@ -3728,6 +3758,7 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
     }
     rbt::TrackerDev& T = t->T;
     rbs_handle* h = t->s;
+    const BorrowedFrameGuard borrowed_guard{h};   // (the caller's frame is the caller's again when this returns, whatever happened)
     RBT_HIP(t, hipSetDevice(h->device));
     if ((frame || frame64) && h->npx <= 0) return tfail(t, RBS_ERR_INVALID_ARGUMENT, "tracker_submit: bad sensor");
     hipStream_t s = h->stream;

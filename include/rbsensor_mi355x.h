@@ -176,7 +176,9 @@ int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n);
  * one-kernel launch), so the frame's journey, 60-100 us of a synchronous 300 us step, hides behind the geometry.
  * This is what the dbot binding calls: inside tracker_->track(image) (R:source/dbot_ros/object_tracker_ros.hpp:49) the
  * image outlives the filter's set_observation / loglikes pair.  The occlusion clock advances at this call, as for
- * rbs_set_observation.  Handles over several devices, precision F32 and whole-plane handles copy at once (= rbs_set_observation). */
+ * rbs_set_observation.  Handles over several devices, precision F32 and whole-plane handles copy at once (= rbs_set_observation).
+ * "Returned" includes returned with an error: a likelihood call that is refused (bad indices, ...) or fails before it staged
+ * the frame copies it on its way out -- the frame is the observation from then on, the buffer the caller's again. */
 int32_t rbs_set_observation_borrowed(rbs_handle* h, const double* depth, size_t n);
 int32_t rbs_set_observation_borrowed_f32(rbs_handle* h, const float* depth, size_t n);   /* the same for the driver's float pixels */
 

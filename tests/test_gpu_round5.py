@@ -308,6 +308,19 @@ def test_borrowed_frame_gives_the_same_bits(gpu_lib):
             s_.synchronize()
             outs.append(d_out.cpu().numpy())
         assert np.array_equal(outs[0], outs[1])
+        # a likelihood call that is REFUSED gives the frame back all the same: it is copied on the way out (the observation it
+        # would have been), and what the caller does to the buffer afterwards is the caller's business
+        g64 = frames[2][1].astype(np.float64)
+        a.set_observation(g64)
+        mine = g64.copy()
+        b.set_observation_borrowed(mine)
+        bad = parents[2].copy(); bad[3] = n + 5
+        with pytest.raises(Exception):
+            b.loglikes_poses(poses[2], bad, update=True)
+        mine[:] = 0.123
+        ia, ib = parents[1].copy(), parents[1].copy()
+        la, lb = a.loglikes_poses(poses[2], ia, update=True), b.loglikes_poses(poses[2], ib, update=True)
+        assert np.array_equal(la, lb)
 
 
 @pytest.mark.parametrize("meshes,cols,rows,n,slab", [(("m1",), 640, 480, 128, 0), (("m1_l2", "box12"), 320, 240, 96, 0), (("m1",), 640, 480, 96, 16384)])
@@ -371,7 +384,8 @@ def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols,
                 assert np.array_equal(g.get_occlusion(q), o.get_occlusion(q)) or (g.get_occlusion(q) != o.get_occlusion(q)).mean() <= 1e-4
 
 
-def test_shared_trail_is_left_when_the_particles_share_nothing(gpu_lib, monkeypatch):
+@pytest.mark.parametrize("slab", [0, 2048])
+def test_shared_trail_is_left_when_the_particles_share_nothing(gpu_lib, monkeypatch, slab):
     """Particles that never resample (every child its own parent's only child) share no ancestor: re-basing the shared plane
     on one of them shrinks nobody else's window.  The handle notices -- windows still most of the frame 16 calls after a
     re-basing -- and goes back to the scalar background (and the whole-plane machinery such windows are served best by).
@@ -391,9 +405,9 @@ def test_shared_trail_is_left_when_the_particles_share_nothing(gpu_lib, monkeypa
     with RbSensor(om, cam, P, max_particles=n, precision="f64") as plain:
         monkeypatch.setenv("RBS_SHARED_TRAIL", "1")
         monkeypatch.setenv("RBS_STP_ENTER", "0.05")
-        with RbSensor(om, cam, P, max_particles=n, precision="f64") as g:
-            g.set_timing_every(1); plain.set_timing_every(1)
-            g.reset(); plain.reset()
+        with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=slab) as g:      # (slabs: the call that leaves re-measures every
+            g.set_timing_every(1); plain.set_timing_every(1)                                # child against the scalar level -- regions that no
+            g.reset(); plain.reset()                                                        # longer fit, a call taken back and repeated)
             ig, ip = np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32)
             states = []
             for k, (_, frame) in enumerate(frames):
