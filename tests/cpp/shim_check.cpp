@@ -89,6 +89,15 @@ int main(int argc, char** argv)
     std::printf("\nLL2");
     for (double v : ll2) std::printf(" %.17g", v);
     std::printf("\n");
+    // ... and with the image BORROWED until loglikes returns, as the dbot binding does (integration/dbot/rb_sensor_mi355x.h):
+    // staged between the geometry and the likelihood kernel of that call
+    sensor->borrow_observations(true);
+    sensor->set_observation(frame);
+    auto ll3 = sensor->loglikes(deltas, indices, true);
+    sensor->borrow_observations(false);
+    std::printf("LL3");
+    for (double v : ll3) std::printf(" %.17g", v);
+    std::printf("\n");
     // ---- the tracker, built exactly as R:source/dbot_ros/tracker/particle_tracker_node.cpp:138-252 ----
     {
         typedef dbot_amd::ParticleTracker Tracker;

@@ -152,7 +152,10 @@ def test_cpp_shim_matches_oracle(tmp_path, gpu_lib, monkeypatch, precision):
     r1 = o.loglikes_poses(poses, idx, update=True)
     o.set_observation(frame)
     r2 = o.loglikes_poses(poses, np.arange(n - 1, -1, -1, dtype=np.int32), update=False)
-    for got, ref in ((ll1, r1), (ll2, r2)):
+    o.set_observation(frame)
+    r3 = o.loglikes_poses(poses, np.arange(n - 1, -1, -1, dtype=np.int32), update=True)
+    ll3 = np.array(lines["LL3"], dtype=np.float64)      # (the image borrowed: rbs_set_observation_borrowed, two-kernel launch)
+    for got, ref in ((ll1, r1), (ll2, r2), (ll3, r3)):
         # F32: north_star's tolerance (these sums are well conditioned)
         assert (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max() <= (1e-9 if precision == "f64" else 1e-5)
     # the C++ tracker mirror against the Python device tracker: same device RNG key -> same states
