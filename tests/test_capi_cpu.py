@@ -151,7 +151,11 @@ def test_register_budgets_the_kernels_overlap_depends_on():
     for name in ("rbs_raster_kernel_many_f64ILb1ELb0EE", "rbs_raster_kernel_many_f64ILb1ELb1EE", "rbs_raster_kernel_many_f32ILb1ELb0EE",
                  "rbs_raster_kernel_many_f32ILb1ELb1EE"):
         vgprs, spills = usage(name)        # object models with a body of more than 256 clusters: the shared cluster cull
-        assert vgprs <= 160 and spills <= 6, (name, vgprs, spills)   # (kernel-lifetime values again: nothing spilled in the loops)
+        # (kernel-lifetime values again: nothing spilled in the loops.  The bound is what the GPU suite has validated, not a
+        # taste: round 5 compiled a second cull path into these kernels, the float32 ones came out with 7-10 spilled VGPRs
+        # next to ~75 SGPRs spilled to lanes -- and returned NaN for most particles of C4 (tools/dbg/f32_many.py), while
+        # the same source at a 168-register budget was correct.  More spills than this need the GPU suite again.)
+        assert vgprs <= 160 and spills <= (5 if "f32" in name else 4), (name, vgprs, spills)
 
 
 def test_create_survives_arbitrary_configs():
