@@ -323,7 +323,8 @@ def test_borrowed_frame_gives_the_same_bits(gpu_lib):
         assert np.array_equal(la, lb)
 
 
-@pytest.mark.parametrize("meshes,cols,rows,n,slab", [(("m1",), 640, 480, 128, 0), (("m1_l2", "box12"), 320, 240, 96, 0), (("m1",), 640, 480, 96, 16384)])
+@pytest.mark.parametrize("meshes,cols,rows,n,slab", [(("m1",), 640, 480, 128, 0), (("m1_l2", "box12"), 320, 240, 96, 0), (("m1",), 640, 480, 96, 16384),
+                                                       (("m4",), 640, 480, 32, 0), (("m4",), 640, 480, 32, 16384)])   # (m4: the many-cluster kernels)
 def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols, rows, n, slab):
     """The shared background plane (rbsensor_mi355x.h "shared trail") changes what is STORED, not a bit of what is computed: a
     handle forced into it (RBS_STP_ENTER=0: at the first sampled window area; re-based every 3rd updating call) against a handle
