@@ -296,6 +296,36 @@ class PeerRun(ResidentRun):
                 "distinct_parents_per_step": c[3] / steps / (1 if self.step.fused else world)}
 
 
+def single_rank_filter_step_leg(a, om, cam, P, W, dev, stream, steps=300):
+    """N = 1 only: the step the multi-rank lines time -- loglikes(update) with the parents the previous step's resampling chose,
+    the (here trivial) exchange of the log-likelihoods, multinomial resampling + plan in one library call (rbs_peer_resample),
+    staging -- on ONE rank.  The headline times rbs_loglikes alone (BASELINE's metric); `--gpus N` times this step, so its
+    values are to be set against THIS figure, not against the headline."""
+    from dbot_ros_amd import dist as rdist
+    n = a.particles
+    sensor = make_sensor(a, om, cam, P, dev, n=2 * n)
+    try:
+        prime(sensor, a, W)
+        pstep = rdist.PeerShardedStep(sensor, n, 2 * n, device=dev, min_share=2, stream=stream.cuda_stream,
+                                      temperature=a.resample_temperature, fused=True, world=1, rank=0)
+        gen = torch.Generator().manual_seed(1234)
+        uniforms = [torch.rand(n, dtype=torch.float64, generator=gen).sort().values.to(dev) for _ in range(16)]
+        run = PeerRun(a, W, sensor, stream, pstep, uniforms)
+        el = run.timed(steps, a.warmup)
+        st = run.stats()
+        ll = pstep.d_out.cpu().numpy()
+        return {"filter_step_value": n * steps / el, "filter_step_ms_per_step": el / steps * 1e3,
+                "filter_step_finite": bool(np.isfinite(ll).all()),
+                "filter_step_distinct_parents_per_step": st["distinct_parents_per_step"],
+                "filter_step_note": "ONE rank doing what every rank of `--gpus N` does per step: loglikes(update) with the parents the previous step's "
+                                    "resampling chose + exchange of the log-likelihoods (a copy here) + multinomial resampling and plan (rbs_peer_resample) + "
+                                    "staging, all on one stream.  The multi-rank `value`s are to be compared with N x THIS figure (the headline times "
+                                    "rbs_loglikes alone, on permutation parents: every particle its own plane -- after a resampling the children of one "
+                                    "parent share its lines)"}
+    finally:
+        sensor.close()
+
+
 class LocalShardRun(ResidentRun):
     """The multi-rank step WITHOUT cross-rank parents (every rank's children inherit from its own slots) + the
     all-gather of the log-likelihoods: what bench.py --gpus N falls back to when the ranks' handles cannot be
@@ -1548,6 +1578,12 @@ def main():
             out.update(sweep_leg(a, dev, stream))
         except Exception as e:   # noqa: BLE001 -- a leg must not take the headline down
             out["sweep_note"] = f"sweep leg failed: {e!r}"
+    # ---- the step `--gpus N` times, on this one rank: the like-for-like reference of the multi-rank values
+    if single and not a.no_configs_leg and a.config in (None, "c1") and a.layout == "window" and a.update:
+        try:
+            out.update(single_rank_filter_step_leg(a, om, cam, P, W, dev, stream))
+        except Exception as e:   # noqa: BLE001 -- a leg must not take the headline down
+            out["filter_step_note"] = f"single-rank filter-step leg failed: {e!r}"
     # ---- host-pointer API: frame upload + pose upload + log-likelihood download inside the clock
     if single and not a.no_host_leg:
         hs = make_sensor(a, om, cam, P, dev)

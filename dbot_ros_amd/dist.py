@@ -378,11 +378,13 @@ class PeerShardedStep:
     sorted either way, and they are the same parents), step() returns this rank's slice of the sorted parents."""
 
     def __init__(self, sensor, n, cap, group=None, device=None, min_share=2, stream=None, evaluate=None, stage=None, all_gather=None,
-                 temperature=1.0, fused=False):
+                 temperature=1.0, fused=False, world=None, rank=None):
         self.sensor, self.n, self.cap, self.group, self.device, self.min_share = sensor, n, cap, group, device, min_share
         self.temperature = temperature
         self.fused = fused
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        # (world / rank given: no process group is consulted -- world = 1 is the same step on ONE rank, its "all-gather" a copy:
+        # what bench.py's single-GPU line times beside the headline so that the multi-rank values have a like-for-like reference)
+        self.world, self.rank = (world, rank or 0) if world is not None else (dist.get_world_size(group), dist.get_rank(group))
         self.N = self.world * n
         # ONE stream carries the whole step: the library calls (loglikes_device, stream_join, peer_resample,
         # stage_windows) and torch's operations (the all-gather, global_resample / plan_shard) must be ordered among
@@ -399,7 +401,8 @@ class PeerShardedStep:
         self.children = 0
         self._evaluate = evaluate or self._evaluate_device
         self._stage = stage or (lambda src, dst: sensor.stage_windows(src.data_ptr(), dst.data_ptr(), n, self.stream))
-        self._all_gather = all_gather or (lambda out, inp: dist.all_gather_into_tensor(out, inp, group=group))
+        self._all_gather = all_gather or ((lambda out, inp: out.copy_(inp)) if self.world == 1 and world is not None
+                                          else (lambda out, inp: dist.all_gather_into_tensor(out, inp, group=group)))
         self._keep = None
         if fused:   # two sets of plan buffers: a step's plan is read by kernels enqueued behind the next step's
             self._plans = [tuple(torch.full((n,), -1, dtype=torch.int32, device=device) for _ in range(4)) for _ in range(2)]
