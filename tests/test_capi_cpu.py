@@ -154,7 +154,10 @@ def test_register_budgets_the_kernels_overlap_depends_on():
         # (kernel-lifetime values again: nothing spilled in the loops.  The bound is what the GPU suite has validated, not a
         # taste: round 5 compiled a second cull path into these kernels, the float32 ones came out with 7-10 spilled VGPRs
         # next to ~75 SGPRs spilled to lanes -- and returned NaN for most particles of C4 (tools/dbg/f32_many.py), while
-        # the same source at a 168-register budget was correct.  More spills than this need the GPU suite again.)
+        # the same source at a 168-register budget was correct, and so was the same source at the same budget with
+        # `-mllvm -amdgpu-spill-sgpr-to-vgpr=false` (scalar spills to memory instead of to lanes): the compiler's lane spills,
+        # not the source.  A 152-register build with 16-18 spilled VGPRs was correct too -- it is not the count as such, so
+        # any change of these numbers needs the GPU suite again.)
         assert vgprs <= 160 and spills <= (5 if "f32" in name else 4), (name, vgprs, spills)
 
 
