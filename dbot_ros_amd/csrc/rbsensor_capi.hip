@@ -652,6 +652,35 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     // (split launch: the geometry kernel needs no frame -- the wait sits between the two kernels, and a host frame
     // travels while the depth tiles are rasterized)
     if (!split && h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
+    // the windowed copy kernel (one-wave blocks beside the persistent kernels, on the handle's second stream).  A call that stages a
+    // borrowed frame between its two kernels launches it BEFORE the staging: it then runs beside the geometry kernel instead of
+    // beside the likelihood kernel the caller is waiting for (plugin step +0.7 %, tests/cpp/host_bench --plugin)
+    bool window_copy_launched = false;
+    auto launch_window_copy = [&]() -> int32_t {
+        RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
+        if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
+        const int ny = std::min(n, 32768);
+        const dim3 wg((unsigned)(P.groups || !RBS_COPY_STRIPS ? h->win_chunks : h->win_chunks_single), (unsigned)ny, (unsigned)((n + ny - 1) / ny));
+        const bool strips = RBS_COPY_STRIPS && !P.groups;
+        if (P.bgp_src && h->slab_px) {
+            if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, true, true>), wg, dim3(64), 0, h->copy_stream, P);
+            else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, false, true>), wg, dim3(64), 0, h->copy_stream, P);
+        } else if (P.bgp_src) {
+            if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, true, true>), wg, dim3(64), 0, h->copy_stream, P);
+            else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, false, true>), wg, dim3(64), 0, h->copy_stream, P);
+        } else if (h->slab_px) {
+            if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, true>), wg, dim3(64), 0, h->copy_stream, P);
+            else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, false>), wg, dim3(64), 0, h->copy_stream, P);
+        } else {
+            if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, true>), wg, dim3(64), 0, h->copy_stream, P);
+            else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, false>), wg, dim3(64), 0, h->copy_stream, P);
+        }
+        RBS_HIP(h, hipGetLastError());
+        if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_stop[tslot], h->copy_stream));
+        RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
+        window_copy_launched = true;
+        return RBS_OK;
+    };
     if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_start[tslot], s));
     if (split) {
         const bool two = wide || mid;   // (wide windows: fewer blocks, so that the streaming copy keeps its registers)
@@ -661,6 +690,9 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         if (h->many_clusters) hipLaunchKernelGGL((rbs::rbs_depth_kernel<true>), dgrid, block, dsm, s, P);
         else hipLaunchKernelGGL((rbs::rbs_depth_kernel<false>), dgrid, block, dsm, s, P);
         RBS_HIP(h, hipGetLastError());
+        static const bool copy_first = [] { const char* e = std::getenv("RBS_SPLIT_COPY_FIRST"); return e ? std::atoi(e) != 0 : true; }();
+        if (copy_first && have_borrowed && update && h->windowed && !wide)
+            if (int32_t rc = launch_window_copy()) return rc;
         if (have_borrowed) {   // the host converts and sends the caller's frame while the depth tiles are rasterized
             if (int32_t rc = stage_borrowed(h)) {
                 // half a call is enqueued (rectangles + geometry kernel: the work-item counters of this parity are spent, no plane
@@ -696,27 +728,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
         if (timed && (!h->windowed || wide)) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
         if (h->windowed && !wide) {
-            RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
-            if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
-            const int ny = std::min(n, 32768);
-            const dim3 wg((unsigned)(P.groups || !RBS_COPY_STRIPS ? h->win_chunks : h->win_chunks_single), (unsigned)ny, (unsigned)((n + ny - 1) / ny));
-            const bool strips = RBS_COPY_STRIPS && !P.groups;
-            if (P.bgp_src && h->slab_px) {
-                if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, true, true>), wg, dim3(64), 0, h->copy_stream, P);
-                else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, false, true>), wg, dim3(64), 0, h->copy_stream, P);
-            } else if (P.bgp_src) {
-                if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, true, true>), wg, dim3(64), 0, h->copy_stream, P);
-                else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, false, true>), wg, dim3(64), 0, h->copy_stream, P);
-            } else if (h->slab_px) {
-                if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, true>), wg, dim3(64), 0, h->copy_stream, P);
-                else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, false>), wg, dim3(64), 0, h->copy_stream, P);
-            } else {
-                if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, true>), wg, dim3(64), 0, h->copy_stream, P);
-                else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, false>), wg, dim3(64), 0, h->copy_stream, P);
-            }
-            RBS_HIP(h, hipGetLastError());
-            if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_stop[tslot], h->copy_stream));
-            RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
+            if (!window_copy_launched) if (int32_t rc = launch_window_copy()) return rc;
         } else if (wide) {
             const int W4 = P.cols >> 2;
             const int nseg = (W4 + 63) / 64;

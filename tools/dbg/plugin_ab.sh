@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 python tools/dbg/write_workload.py /tmp/wl.bin > gpurun_out/pt_wl.log 2>&1
 MODES=${MODES:---plugin}
-for rep in 1 2 3 4 5 6; do
+for rep in 1 2 3 4 5 6 7 8; do
 for cfg in "$@"; do
   for mode in $MODES; do
     echo -n "[$cfg] ${mode}: "
