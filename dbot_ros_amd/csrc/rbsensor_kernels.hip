@@ -1534,6 +1534,9 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = block * kPrepPerBlock + w;
     const bool live = i < P.n;
+    // (the parent slot is needed last but asked for first: a host-pointer call's indices sit in pinned HOST memory, a PCIe round
+    // trip of ~2 us that would otherwise follow the rectangle's arithmetic instead of passing beneath it)
+    const int parent_early = live ? P.indices[i] : -1;
     Rect r = {0, 0, 0, 0};
     int cnt = 0;
     // (the per-body rectangles and the particle's groups live in LDS, one set per wave: indexed at run time, arrays of the
@@ -1650,7 +1653,7 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
         for (int g = 0; g < G.n; ++g) { out->rect[g] = G.rect[g]; out->first[g] = G.first[g]; out->mask[g] = G.mask[g]; }
     }
     P.done[i] = 0;
-    const int parent = P.indices[i];
+    const int parent = parent_early;
     P.parents[i] = parent;
     const int first = cnts[kPrepPerBlock] + cnts[w];
     P.item_range[i] = make_int2(first, cnt);
