@@ -23,6 +23,8 @@ RBS_PRECISION_DEFAULT, RBS_PRECISION_F64, RBS_PRECISION_F32 = 0, 1, 2
 RBS_STATE_DEFAULT, RBS_STATE_WINDOWED, RBS_STATE_DENSE = 0, 1, 2
 PRECISIONS = {None: 0, "default": 0, "f64": 1, "f32": 2}
 LAYOUTS = {None: 0, "default": 0, "window": 1, "windowed": 1, "dense": 2}
+RBS_OCC_DEFAULT, RBS_OCC_DEVICE_RULE, RBS_OCC_REFERENCE = 0, 1, 2
+OCC_MODES = {None: 0, "default": 0, "device": 1, "eager": 1, "reference": 2, "lazy": 2, "exact": 2}
 
 # every symbol include/rbsensor_mi355x.h declares
 EXPORTS = (
@@ -78,7 +80,7 @@ class RbsConfig(C.Structure):
         ("n_devices", C.c_int32),
         ("device_ids", C.POINTER(C.c_int32)),
         ("state_slab_px", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("occlusion_mode", C.c_int32),
     ]
 
 

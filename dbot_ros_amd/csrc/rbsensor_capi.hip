@@ -148,6 +148,14 @@ struct rbs_handle {
     float* d_vtx = nullptr;         // [sum of vertex counts][4] float32 vertices (screen rectangles)
     float* d_tri_plane = nullptr;   // [n_tri][4] model-space plane of each triangle (float32 pre-cull)
     int precision = RBS_PRECISION_F64;
+    // Stamped planes (rbs_config.occlusion_mode = RBS_OCC_REFERENCE; DevParams::exact): a slot is plane_px floats + plane_px
+    // 16-bit ages, plane_stride floats in all.
+    bool exact = false;
+    int age_max = 0;            // ages beyond it are background
+    double* d_ptab = nullptr;   // [age_max + 1][2] the propagation table
+    std::vector<double> ptab;   // ... its host copy
+    long update_clock = 0;      // frames between rbs_reset and the last updating call: the planes' epoch
+    float* d_tmp_plane = nullptr;   // [npx] scratch of the plane hooks (the shared plane's effective values)
     float* d_render = nullptr;
     // pinned staging of the host-pointer API: poses | indices in one block (one H2D copy), the
     // log-likelihoods in another, and the event the caller waits on (the out copy alone -- the
@@ -299,6 +307,23 @@ void occlusion_coeffs(const rbs_handle* h, int n_frames, float* alpha, float* be
     *beta = (float)((1.0 - a) - g);
 }
 
+// OcclusionModel propagate as the oracle evaluates it (oracle orc_propagate): the same expressions, the same libm.
+double host_propagate(const rbs_handle* h, double occ, double dt)
+{
+    const double c = h->p_oo - h->p_ov;
+    const double pow_c = std::exp(dt * std::log(c));
+    const double new_visible = pow_c * (1.0 - occ) + (1.0 - h->p_oo) * (pow_c - 1.0) / (c - 1.0);
+    return 1.0 - new_visible;
+}
+// Stamped planes: the prior of a never-covered pixel `frames` frames after rbs_reset (the oracle's slot of initial values, stamp 0).
+float exact_background(const rbs_handle* h, long frames)
+{
+    return (float)host_propagate(h, (double)(float)h->init_occ, (double)frames * h->delta_time);
+}
+// Floats per slot of `px` pixels: the values, then the ages (two per float), rounded to whole float4s.
+size_t exact_stride(size_t px) { return (px + (px + 1) / 2 + 3) & ~(size_t)3; }
+constexpr double kExactTau = 0x1p-40;   // c^(age_max dt) <= this: what a pixel declared background can still differ by
+
 int copy_bands_for(int rows, int cols)
 {
     // ~3840 float4 (60 KB) per copy block; an EVEN band count keeps 1+bands odd so raster
@@ -347,6 +372,21 @@ int32_t flush_lazy_frame(rbs_handle* h, hipStream_t then)
 // whole planes or slabs, and the same eight again for object models with a body of many clusters.
 void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size_t smem, hipStream_t s, const DevParams& P)
 {
+    if (h->exact) {   // stamped planes (binary64): updating or not, whole planes or slabs, many clusters, shared background plane
+#define RBS_X(U, S, M, T) hipLaunchKernelGGL((rbs::rbs_raster_kernel_exact_f64<U, S, M, T>), grid, block, smem, s, P); break
+        switch ((update ? 8 : 0) | (h->slab_px ? 4 : 0) | (h->many_clusters ? 2 : 0) | (P.bgp_src ? 1 : 0)) {
+            case 0: RBS_X(false, false, false, false);  case 1: RBS_X(false, false, false, true);
+            case 2: RBS_X(false, false, true, false);   case 3: RBS_X(false, false, true, true);
+            case 4: RBS_X(false, true, false, false);   case 5: RBS_X(false, true, false, true);
+            case 6: RBS_X(false, true, true, false);    case 7: RBS_X(false, true, true, true);
+            case 8: RBS_X(true, false, false, false);   case 9: RBS_X(true, false, false, true);
+            case 10: RBS_X(true, false, true, false);   case 11: RBS_X(true, false, true, true);
+            case 12: RBS_X(true, true, false, false);   case 13: RBS_X(true, true, false, true);
+            case 14: RBS_X(true, true, true, false);    default: RBS_X(true, true, true, true);
+        }
+#undef RBS_X
+        return;
+    }
     if (P.bgp_src) {   // the shared background plane (binary64)
         switch ((update ? 4 : 0) | (h->slab_px ? 2 : 0) | (h->many_clusters ? 1 : 0)) {
             case 0: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<false, false, false>), grid, block, smem, s, P); break;
@@ -395,6 +435,16 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     occlusion_coeffs(h, h->pending_frames, &P.alpha, &P.beta);
     P.bg_old = h->background;
     P.bg_new = std::fmaf(P.alpha, h->background, P.beta);
+    P.exact = h->exact ? 1 : 0;
+    P.plane_px = h->slab_px ? h->slab_px : h->npx;
+    if (h->exact) {   // stamped planes: nothing is stepped; a never-covered pixel's prior comes from the model clock
+        const unsigned e = (unsigned)std::min(h->pending_frames, 0xffff);
+        P.elapsed2 = e | (e << 16);
+        P.age_max = h->age_max;
+        P.ptab = h->d_ptab;
+        P.bg_new = exact_background(h, h->update_clock + h->pending_frames);
+        P.bg_old = P.bg_new;
+    }
     P.windowed = h->windowed ? 1 : 0;
     P.rect_align = h->windowed ? h->rect_align : rbs::kRectAlign;
     P.win_src = h->d_win[h->cur];
@@ -450,7 +500,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     if (h->windowed && update && h->area_pending && hipEventQuery(h->ev_area) == hipSuccess) {
         const double frac = (double)*h->h_area / ((double)h->area_n * (double)h->npx);   // sampled a few calls ago
         h->area_frac = frac;
-        if (frac > h->wide_enter && !h->slab_px) h->wide = true;   // (slabs: regions that large do not fit anyway)
+        if (frac > h->wide_enter && !h->slab_px && !h->exact) h->wide = true;   // (slabs: regions that large do not fit anyway; stamped planes: the windowed copy serves every size)
         else if (frac < h->wide_leave) h->wide = false;
         h->area_pending = false;
     }
@@ -466,6 +516,10 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             // the whole-plane machinery that serves such windows best: this call re-measures every child against the scalar
             // level over the bounding box of the shared plane's own values.
             hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_bgp_box, 1, make_int4(h->cols, h->rows, 0, 0));
+            if (h->exact)
+                hipLaunchKernelGGL(rbs::rbs_bbox_age_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, h->d_bgp[h->cur], h->rows, h->cols,
+                                   (unsigned)h->age_max, reinterpret_cast<int*>(h->d_bgp_box));
+            else
             hipLaunchKernelGGL(rbs::rbs_bbox_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, h->d_bgp[h->cur], h->rows, h->cols,
                                h->background, reinterpret_cast<int*>(h->d_bgp_box));
             RBS_HIP(h, hipGetLastError());
@@ -473,10 +527,12 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             stp_leaving = true;
         } else if (update && !h->stp && h->area_frac > h->stp_enter && h->calls > 0 && h->calls >= h->stp_block_until) {
             for (int k = 0; k < 2; ++k)
-                if (!h->d_bgp[k]) RBS_HIP(h, hipMalloc(&h->d_bgp[k], sizeof(float) * (size_t)h->npx));
+                if (!h->d_bgp[k]) RBS_HIP(h, hipMalloc(&h->d_bgp[k], sizeof(float) * (h->exact ? exact_stride((size_t)h->npx) : (size_t)h->npx)));
             if (!h->d_bgp_box) RBS_HIP(h, hipMalloc(&h->d_bgp_box, sizeof(int4)));
             hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(256), dim3(256), 0, s, h->d_bgp[h->cur], (size_t)h->npx, h->background);
             RBS_HIP(h, hipGetLastError());
+            if (h->exact)   // (every pixel background: ages 0xffff)
+                RBS_HIP(h, hipMemsetAsync(h->d_bgp[h->cur] + h->npx, 0xff, sizeof(unsigned short) * (size_t)h->npx, s));
             h->stp = true;
             h->wide = false;
             rebase = 0;
@@ -500,12 +556,12 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     // (round 5, C4 slice: the 16 384-px tile with two blocks per CU -- 6 work items per particle instead of 10 -- 7.62 ms against 6.32 with
     // three blocks and the small tile; two blocks with the small tile 8.16: the larger tile is worth 7 %, the third wave per SIMD 25 %)
     P.tile_px = !h->windowed && h->raster_blocks <= 2 * h->cu_count ? (f64 ? rbs::kTilePxBigF64 : rbs::kTilePxBig)
-                                                                     : (f64 ? rbs::kTilePxF64 : rbs::kTilePx);
+                                                                     : (h->exact ? rbs::kTilePxExact : f64 ? rbs::kTilePxF64 : rbs::kTilePx);
     // split launch: binary64 likelihood on windowed planes (the tile size is the handle's for its whole life, like the
     // monolith's: the split of a rectangle into items decides the order in which a particle's partial sums are added)
     const bool have_borrowed = h->borrowed != nullptr || h->borrowed_f32 != nullptr;
     bool split = (h->split || have_borrowed) && f64 && h->windowed;   // (the same tile, the same items, the same bits either way)
-    if (split && !(!h->windowed && h->raster_blocks <= 2 * h->cu_count)) P.tile_px = rbs::kDepthTilePx;   // (= kTilePxF64 already)
+    if (split && !h->exact && !(!h->windowed && h->raster_blocks <= 2 * h->cu_count)) P.tile_px = rbs::kDepthTilePx;   // (= kTilePxF64 already; stamped planes: their own, smaller)
     P.tile_w = 256;
     P.tile_h = std::max(4, P.tile_px / 256 / std::max(1, h->smalln_target / std::max(1, n)));
     if (const char* m = h->tile_override) { P.tile_w = std::max(16, std::atoi(m) / 16 * 16); P.tile_h = std::max(1, std::atoi(m)); }
@@ -578,6 +634,12 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
         h->join_pending = -1;
     }
+    if (P.bgp_src && update && h->exact) {
+        hipLaunchKernelGGL(rbs::rbs_bgp_step_exact_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, P.bgp_src, h->d_bgp[1 - h->cur],
+                           P.occ_src, P.win_src, h->slab_px ? P.reg_src : (const int4*)nullptr, P.plane_stride, P.plane_px, rebase, h->rows, h->cols,
+                           P.elapsed2, P.bg_new);
+        RBS_HIP(h, hipGetLastError());
+    } else
     if (P.bgp_src && update) {   // the shared plane's own step (and re-basing): reads the current planes, complete after the join above
         hipLaunchKernelGGL(rbs::rbs_bgp_step_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, P.bgp_src, h->d_bgp[1 - h->cur],
                            P.occ_src, P.win_src, h->slab_px ? P.reg_src : (const int4*)nullptr, P.plane_stride, rebase, h->rows, h->cols,
@@ -662,6 +724,16 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         const int ny = std::min(n, 32768);
         const dim3 wg((unsigned)(P.groups || !RBS_COPY_STRIPS ? h->win_chunks : h->win_chunks_single), (unsigned)ny, (unsigned)((n + ny - 1) / ny));
         const bool strips = RBS_COPY_STRIPS && !P.groups;
+        if (h->exact) {
+#define RBS_X(S, T, B) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<S, T, B, true>), wg, dim3(64), 0, h->copy_stream, P); break
+            switch ((h->slab_px ? 4 : 0) | (strips ? 2 : 0) | (P.bgp_src ? 1 : 0)) {
+                case 0: RBS_X(false, false, false);  case 1: RBS_X(false, false, true);
+                case 2: RBS_X(false, true, false);   case 3: RBS_X(false, true, true);
+                case 4: RBS_X(true, false, false);   case 5: RBS_X(true, false, true);
+                case 6: RBS_X(true, true, false);    default: RBS_X(true, true, true);
+            }
+#undef RBS_X
+        } else
         if (P.bgp_src && h->slab_px) {
             if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, true, true>), wg, dim3(64), 0, h->copy_stream, P);
             else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, false, true>), wg, dim3(64), 0, h->copy_stream, P);
@@ -686,7 +758,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         const bool two = wide || mid;   // (wide windows: fewer blocks, so that the streaming copy keeps its registers)
         const dim3 dgrid((unsigned)(two ? std::min(h->depth_blocks, 2 * h->cu_count) : h->depth_blocks));
         const dim3 egrid((unsigned)(two ? std::min(h->eval_blocks, 3 * h->cu_count) : h->eval_blocks));
-        const size_t dsm = rbs::smem_bytes_depth(P.tile_px, h->many_clusters), esm = rbs::smem_bytes(0, true);
+        const size_t dsm = rbs::smem_bytes_depth(P.tile_px, h->many_clusters), esm = rbs::smem_bytes(0, true, false, h->exact);
         if (h->many_clusters) hipLaunchKernelGGL((rbs::rbs_depth_kernel<true>), dgrid, block, dsm, s, P);
         else hipLaunchKernelGGL((rbs::rbs_depth_kernel<false>), dgrid, block, dsm, s, P);
         RBS_HIP(h, hipGetLastError());
@@ -705,6 +777,16 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             P.aux = h->cur_aux;
         }
         if (h->frame_wait >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_frame[h->frame_wait], 0));
+        if (h->exact) {
+#define RBS_X(U, S, T) hipLaunchKernelGGL((rbs::rbs_eval_kernel<U, S, T, true>), egrid, block, esm, s, P); break
+            switch ((update ? 4 : 0) | (h->slab_px ? 2 : 0) | (P.bgp_src ? 1 : 0)) {
+                case 0: RBS_X(false, false, false);  case 1: RBS_X(false, false, true);
+                case 2: RBS_X(false, true, false);   case 3: RBS_X(false, true, true);
+                case 4: RBS_X(true, false, false);   case 5: RBS_X(true, false, true);
+                case 6: RBS_X(true, true, false);    default: RBS_X(true, true, true);
+            }
+#undef RBS_X
+        } else
         if (P.bgp_src) {
             switch ((update ? 2 : 0) | (h->slab_px ? 1 : 0)) {
                 case 0: hipLaunchKernelGGL((rbs::rbs_eval_kernel<false, false, true>), egrid, block, esm, s, P); break;
@@ -722,7 +804,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipGetLastError());
     }
     if (update) {
-        if (!split) launch_raster(h, true, rgrid, block, rbs::smem_bytes(P.tile_px, f64, h->many_clusters), s, P);
+        if (!split) launch_raster(h, true, rgrid, block, rbs::smem_bytes(P.tile_px, f64, h->many_clusters, h->exact), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
         const dim3 cgrid((unsigned)std::min<long>((long)h->copy_blocks, (long)n * P.bands));
@@ -764,7 +846,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
             RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
         }
     } else {
-        if (!split) launch_raster(h, false, rgrid, block, rbs::smem_bytes(P.tile_px, f64, h->many_clusters), s, P);
+        if (!split) launch_raster(h, false, rgrid, block, rbs::smem_bytes(P.tile_px, f64, h->many_clusters, h->exact), s, P);
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_raster_stop[tslot], s));
     }
@@ -778,7 +860,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         h->stp = false;
         h->stp_block_until = h->calls + 4000;
         h->area_frac = 1.0;   // (what the last sample said: the next calls take the whole-plane machinery at once)
-        h->wide = !h->slab_px;
+        h->wide = !h->slab_px && !h->exact;
     }
     if (update) h->join_pending = slot;   // joined lazily: by the next call, or by drain()
     if (h->group) {
@@ -792,6 +874,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     h->calls += 1;
     if (update) {
         h->cur = 1 - h->cur;
+        h->update_clock += h->pending_frames;
         h->pending_frames = 0;
         h->background = P.bg_new;
     }
@@ -803,6 +886,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
 int32_t materialize(rbs_handle* h, int slot, hipStream_t s)
 {
     if (!h->windowed) return RBS_OK;
+    if (h->exact) return fail(h, RBS_ERR_UNSUPPORTED, "a slot of stamped planes (occlusion_mode REFERENCE) is not a float plane: use rbs_export_plane / rbs_get_occlusion");
     if (h->slab_px) return fail(h, RBS_ERR_UNSUPPORTED, "a slab cannot be made dense in place (state_slab_px)");
     hipLaunchKernelGGL(rbs::rbs_materialize_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s,
                        h->d_occ[h->cur] + (size_t)slot * h->plane_stride, h->d_win[h->cur] + slot, h->rows, h->cols,
@@ -867,6 +951,63 @@ int32_t slab_store(rbs_handle* h, int slot, const float* d_full, hipStream_t s)
 
 int32_t drain(rbs_handle* h, bool host_sync);
 
+// Stamped planes (occlusion_mode REFERENCE): the hooks' two conversions.  A slot -> its plane of EFFECTIVE values as of the
+// epoch (device, npx floats); slot < 0: the shared background plane itself.
+int32_t exact_expand(rbs_handle* h, int slot, float* d_full, hipStream_t s)
+{
+    DevParams P = h->base;
+    P.ptab = h->d_ptab;
+    P.age_max = h->age_max;
+    const float* base = slot >= 0 ? h->d_occ[h->cur] + (size_t)slot * h->plane_stride : nullptr;
+    hipLaunchKernelGGL(rbs::rbs_expand_exact_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, base, h->slab_px ? h->slab_px : h->npx,
+                       slot >= 0 && h->slab_px ? (const int4*)(h->d_reg[h->cur] + slot) : (const int4*)nullptr,
+                       slot >= 0 ? (const int4*)(h->d_win[h->cur] + slot) : (const int4*)nullptr, h->rows, h->cols, h->background,
+                       h->stp ? (const float*)h->d_bgp[h->cur] : (const float*)nullptr, P, d_full);
+    RBS_HIP(h, hipGetLastError());
+    return RBS_OK;
+}
+// A plane of effective values handed in from outside -> a slot: the values as given with age 0 ("as of now", the rule of the
+// oracle's set_occlusion), stored over the bounding box of what differs from the background (the scalar level, or the shared
+// plane's effective values).  Synchronises (the box is needed on the host: slabs must fit it).
+int32_t exact_store(rbs_handle* h, int slot, const float* d_full, hipStream_t s)
+{
+    const float* bgref = nullptr;
+    if (h->stp) {
+        if (int32_t rc = exact_expand(h, -1, h->d_tmp_plane, s)) return rc;
+        bgref = h->d_tmp_plane;
+    }
+    const int init[4] = {h->cols, h->rows, 0, 0};
+    RBS_HIP(h, hipMemcpyAsync(h->d_bbox, init, sizeof(init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(rbs::rbs_bbox_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, d_full, h->rows, h->cols, h->background, h->d_bbox, bgref);
+    RBS_HIP(h, hipGetLastError());
+    int box[4];
+    RBS_HIP(h, hipMemcpyAsync(box, h->d_bbox, sizeof(box), hipMemcpyDeviceToHost, s));
+    RBS_HIP(h, hipStreamSynchronize(s));
+    int4 r = make_int4(box[0], box[1], std::min(box[2], h->cols), box[3]);
+    if (r.z <= r.x || r.w <= r.y) r = make_int4(h->cols, h->rows, 0, 0);   // all background
+    const long area = r.z > r.x ? (long)(r.z - r.x) * (r.w - r.y) : 0;
+    if (h->slab_px && area > (long)h->slab_px) {
+        if (h->group || h->peer_world > 1)
+            return fail(h, RBS_ERR_OUT_OF_MEMORY,
+                        fmt("a plane whose values differ from the background over %ld px does not fit a slab of %d px (state_slab_px)", area, h->slab_px));
+        if (int32_t rc = drain(h, true)) return rc;
+        if (int32_t rc = grow_slabs(h, slab_for(h, (int)std::min<long>(area, h->npx)))) return rc;
+        if (area > (long)h->slab_px)
+            return fail(h, RBS_ERR_OUT_OF_MEMORY, fmt("a plane of %ld px does not fit a slab of %d px (state_slab_px)", area, h->slab_px));
+    }
+    if (area > 0) {
+        hipLaunchKernelGGL(rbs::rbs_pack_exact_kernel, dim3((unsigned)((area + 255) / 256)), dim3(256), 0, s, d_full, bgref, h->background, r, h->cols,
+                           h->slab_px ? r.x : 0, h->slab_px ? r.y : 0, h->slab_px ? r.z - r.x : h->cols,
+                           h->d_occ[h->cur] + (size_t)slot * h->plane_stride, h->slab_px ? h->slab_px : h->npx);
+        RBS_HIP(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_win[h->cur] + slot, 1, r);
+    if (h->slab_px) hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_reg[h->cur] + slot, 1, r);
+    RBS_HIP(h, hipGetLastError());
+    RBS_HIP(h, hipStreamSynchronize(s));
+    return RBS_OK;
+}
+
 // "A region did not fit its slab" (h_err[0], fetched by the synchronising entry points): the message
 // of the calls that cannot repair it themselves (asynchronous calls, the device tracker).
 int32_t check_slab_error(rbs_handle* h)
@@ -902,22 +1043,26 @@ int32_t grow_slabs(rbs_handle* h, int new_slab)
                                       h->h_err[1], h->slab_px))
                            : RBS_OK;
     float* nb[2] = {nullptr, nullptr};
-    const size_t bytes = sizeof(float) * (size_t)new_slab * h->max_particles;
+    const size_t new_stride = h->exact ? exact_stride((size_t)new_slab) : (size_t)new_slab;
+    const size_t bytes = sizeof(float) * new_stride * h->max_particles;
     for (int k = 0; k < 2; ++k)
         if (hipMalloc(&nb[k], occ_alloc_bytes(bytes)) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(nb[0]);
             return fail(h, RBS_ERR_OUT_OF_MEMORY, fmt("enlarging the occlusion slabs from %d to %d px per slot needs 2 x %zu bytes more", h->slab_px, new_slab, bytes));
         }
-    RBS_HIP(h, hipMemcpy2DAsync(nb[h->cur], sizeof(float) * (size_t)new_slab, h->d_occ[h->cur], sizeof(float) * (size_t)h->slab_px,
+    RBS_HIP(h, hipMemcpy2DAsync(nb[h->cur], sizeof(float) * new_stride, h->d_occ[h->cur], sizeof(float) * h->plane_stride,
                                 sizeof(float) * (size_t)h->slab_px, (size_t)h->max_particles, hipMemcpyDeviceToDevice, h->stream));
+    if (h->exact)   // ... and the slots' ages, which follow the values of a slot
+        RBS_HIP(h, hipMemcpy2DAsync(nb[h->cur] + new_slab, sizeof(float) * new_stride, h->d_occ[h->cur] + h->slab_px, sizeof(float) * h->plane_stride,
+                                    sizeof(unsigned short) * (size_t)h->slab_px, (size_t)h->max_particles, hipMemcpyDeviceToDevice, h->stream));
     RBS_HIP(h, hipStreamSynchronize(h->stream));
     (void)hipFree(h->d_occ[0]);
     (void)hipFree(h->d_occ[1]);
     h->d_occ[0] = nb[0];
     h->d_occ[1] = nb[1];
     h->slab_px = new_slab;
-    h->plane_stride = (size_t)new_slab;
+    h->plane_stride = new_stride;
     return RBS_OK;
 }
 
@@ -926,14 +1071,14 @@ int32_t grow_slabs(rbs_handle* h, int new_slab)
 // What a call that is taken back (a region did not fit its slab) must find as it was.  The shared trail's mode belongs to it:
 // the planes the repeated call reads are measured against whatever background -- shared plane or scalar -- the FIRST attempt
 // found, and an attempt that left the shared trail (or entered it, or re-based) has already switched the handle's view.
-struct CallState { int cur; int pending_frames; float background; bool stp; long stp_last_rebase, stp_rebases, stp_block_until; double area_frac; bool wide; };
+struct CallState { int cur; int pending_frames; float background; bool stp; long stp_last_rebase, stp_rebases, stp_block_until; double area_frac; bool wide; long update_clock; };
 CallState save_call_state(const rbs_handle* h)
 {
-    return {h->cur, h->pending_frames, h->background, h->stp, h->stp_last_rebase, h->stp_rebases, h->stp_block_until, h->area_frac, h->wide};
+    return {h->cur, h->pending_frames, h->background, h->stp, h->stp_last_rebase, h->stp_rebases, h->stp_block_until, h->area_frac, h->wide, h->update_clock};
 }
 void restore_call_state(rbs_handle* h, const CallState& c)
 {
-    h->cur = c.cur; h->pending_frames = c.pending_frames; h->background = c.background;
+    h->cur = c.cur; h->pending_frames = c.pending_frames; h->background = c.background; h->update_clock = c.update_clock;
     h->stp = c.stp; h->stp_last_rebase = c.stp_last_rebase; h->stp_rebases = c.stp_rebases; h->stp_block_until = c.stp_block_until;
     h->area_frac = c.area_frac; h->wide = c.wide;
 }
@@ -1022,6 +1167,8 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_bgp[0]);
     (void)hipFree(h->d_bgp[1]);
     (void)hipFree(h->d_bgp_box);
+    (void)hipFree(h->d_ptab);
+    (void)hipFree(h->d_tmp_plane);
     (void)hipFree(h->d_area);
     (void)hipFree(h->d_wide_flags);
     if (h->h_area) (void)hipHostFree(h->h_area);
@@ -1340,6 +1487,8 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("state_layout %d", cfg->state_layout));
     if (cfg->state_slab_px < RBS_SLAB_WHOLE_PLANES)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("state_slab_px %d", cfg->state_slab_px));
+    if (cfg->occlusion_mode < RBS_OCC_DEFAULT || cfg->occlusion_mode > RBS_OCC_REFERENCE)
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("occlusion_mode %d", cfg->occlusion_mode));
 
     DevParams& B = h->base;
     B.rows = h->rows; B.cols = h->cols; B.npx = h->npx;
@@ -1669,6 +1818,37 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         RBS_HIP(h, hipMalloc(&h->d_pbg, plane));
     }
     RBS_HIP(h, hipMalloc(&h->d_render, plane));
+    {   // the occlusion bookkeeping: the caller's choice; left open, the library's (tooling: RBS_OCC=reference|device in the
+        // environment replaces DEFAULT only, never a mode the caller named)
+        int mode = cfg->occlusion_mode;
+        const bool can = h->precision == RBS_PRECISION_F64 && h->windowed;
+        if (mode == RBS_OCC_DEFAULT) {
+            mode = RBS_OCC_LIBRARY_DEFAULT;
+            if (const char* m = std::getenv("RBS_OCC")) mode = !std::strcmp(m, "reference") ? RBS_OCC_REFERENCE : !std::strcmp(m, "device") ? RBS_OCC_DEVICE_RULE : mode;
+            if (mode == RBS_OCC_REFERENCE && !can) mode = RBS_OCC_DEVICE_RULE;
+        } else if (mode == RBS_OCC_REFERENCE && !can) {
+            return fail(h, RBS_ERR_UNSUPPORTED, "occlusion_mode REFERENCE needs the binary64 likelihood (likelihood_precision F64) and the windowed "
+                                                "state layout (cols a multiple of 4)");
+        }
+        h->exact = mode == RBS_OCC_REFERENCE;
+    }
+    if (h->exact) {
+        // the propagation table: entry a = the two terms of oracle orc_propagate that depend on the elapsed time a * delta_time alone
+        const double cc = h->p_oo - h->p_ov, lc = std::log(cc);
+        int K = 0;
+        while (K < 65534 && std::exp(((double)K * h->delta_time) * lc) > kExactTau) ++K;
+        h->age_max = K;
+        h->ptab.resize(2 * (size_t)(K + 1));
+        for (int a = 0; a <= K; ++a) {
+            const double dt = (double)a * h->delta_time;
+            const double pow_c = std::exp(dt * lc);
+            h->ptab[2 * a] = pow_c;
+            h->ptab[2 * a + 1] = (1.0 - h->p_oo) * (pow_c - 1.0) / (cc - 1.0);
+        }
+        RBS_HIP(h, hipMalloc(&h->d_ptab, sizeof(double) * h->ptab.size()));
+        RBS_HIP(h, hipMemcpy(h->d_ptab, h->ptab.data(), sizeof(double) * h->ptab.size(), hipMemcpyHostToDevice));
+        RBS_HIP(h, hipMalloc(&h->d_tmp_plane, plane));
+    }
     // slabs apply to windowed planes only; a slab as large as a plane is a plane
     h->slab_px = 0;
     if (h->windowed && cfg->state_slab_px > 0 && cfg->state_slab_px < h->npx)
@@ -1681,6 +1861,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     }
     if (h->slab_px >= h->npx) h->slab_px = 0;
     h->plane_stride = h->slab_px ? (size_t)h->slab_px : (size_t)h->npx;
+    if (h->exact) h->plane_stride = exact_stride(h->plane_stride);   // (the slots' ages follow their values)
     RBS_HIP(h, hipMalloc(&h->d_occ[0], occ_alloc_bytes(sizeof(float) * h->plane_stride * h->max_particles)));
     RBS_HIP(h, hipMalloc(&h->d_occ[1], occ_alloc_bytes(sizeof(float) * h->plane_stride * h->max_particles)));
     RBS_HIP(h, hipMalloc(&h->d_err, 2 * sizeof(int)));
@@ -1788,13 +1969,22 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<true, true>)};
         for (const void* k : kernels)
             RBS_HIP(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig, false, true)));
+        if (h->exact) {
+            const void* xk[] = {
+#define RBS_X(U, S) reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_exact_f64<U, S, false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_exact_f64<U, S, false, true>), \
+                    reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_exact_f64<U, S, true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_exact_f64<U, S, true, true>)
+                RBS_X(false, false), RBS_X(false, true), RBS_X(true, false), RBS_X(true, true)};
+#undef RBS_X
+            for (const void* k : xk)
+                RBS_HIP(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig, false, true)));
+        }
     }
     RBS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&rbs::rbs_render_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig, false)));
 
     {   // per-item partial sums: sized for the default tiling so no call ever allocates
         const size_t gmul = h->d_groups[0] ? rbs::kMaxGroups : 1;   // every group of bodies tiles its own rectangle
-        size_t need = gmul * (size_t)h->max_particles * tiles_upper_bound(h->cols, h->rows, 256, h->split ? rbs::kDepthTilePx : rbs::kTilePx);
+        size_t need = gmul * (size_t)h->max_particles * tiles_upper_bound(h->cols, h->rows, 256, h->exact ? rbs::kTilePxExact : h->split ? rbs::kDepthTilePx : rbs::kTilePx);
         for (int nn = 1; nn < std::min(h->max_particles, h->raster_blocks); nn *= 2) {
             const int th = std::max(4, rbs::kTilePx / 256 / std::max(1, std::max(h->smalln_target, h->raster_blocks) / nn));
             need = std::max(need, gmul * (size_t)std::min(2 * nn, h->max_particles) * tiles_upper_bound(h->cols, h->rows, 256, 256 * th));
@@ -1878,7 +2068,9 @@ void advance_empty(rbs_handle* h, bool update)
     float alpha, beta;
     occlusion_coeffs(h, h->pending_frames, &alpha, &beta);
     h->background = std::fmaf(alpha, h->background, beta);
+    if (h->exact) h->background = exact_background(h, h->update_clock + h->pending_frames);
     h->cur = 1 - h->cur;
+    h->update_clock += h->pending_frames;
     h->pending_frames = 0;
     // (h->calls stays: it selects the work-item counters, and a raster kernel zeroes the counters of
     // the call that FOLLOWS it -- a skipped call must not change which pair is next)
@@ -2389,6 +2581,7 @@ int32_t rbs_reset(rbs_handle* h)
     h->area_frac = 0.0;
     h->cur = 0;
     h->pending_frames = 0;
+    h->update_clock = 0;
     h->background = (float)h->init_occ;
     {   // windowed: every plane is all background (empty window); dense: full windows for ever
         const int4 w0 = h->windowed ? make_int4(h->cols, h->rows, 0, 0) : make_int4(0, 0, h->cols, h->rows);
@@ -2814,8 +3007,8 @@ int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("get_occlusion: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;
-    if (h->slab_px) {
-        if (int32_t rc = slab_expand(h, slot, h->d_render, h->stream)) return rc;
+    if (h->slab_px || h->exact) {
+        if (int32_t rc = h->exact ? exact_expand(h, slot, h->d_render, h->stream) : slab_expand(h, slot, h->d_render, h->stream)) return rc;
         RBS_HIP(h, hipStreamSynchronize(h->stream));
         RBS_HIP(h, hipMemcpy(out, h->d_render, sizeof(float) * h->npx, hipMemcpyDeviceToHost));
         return RBS_OK;
@@ -2835,9 +3028,9 @@ int32_t rbs_set_occlusion(rbs_handle* h, int32_t slot, const float* plane)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("set_occlusion: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
     if (int32_t rc = drain(h, true)) return rc;
-    if (h->slab_px) {
+    if (h->slab_px || h->exact) {
         RBS_HIP(h, hipMemcpy(h->d_render, plane, sizeof(float) * h->npx, hipMemcpyHostToDevice));
-        return slab_store(h, slot, h->d_render, h->stream);
+        return h->exact ? exact_store(h, slot, h->d_render, h->stream) : slab_store(h, slot, h->d_render, h->stream);
     }
     RBS_HIP(h, hipMemcpy(h->d_occ[h->cur] + (size_t)slot * h->npx, plane, sizeof(float) * h->npx,
                          hipMemcpyHostToDevice));
@@ -2857,6 +3050,7 @@ int32_t rbs_occlusion_device_ptr(rbs_handle* h, int32_t slot, void** out)
     if (slot < 0 || slot >= h->max_particles || !out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("occlusion_device_ptr: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
+    if (h->exact) return fail(h, RBS_ERR_UNSUPPORTED, "occlusion_device_ptr: a slot of stamped planes (occlusion_mode REFERENCE) is not a float plane");
     if (int32_t rc = drain(h, true)) return rc;   // planes complete before the caller touches them
     if (int32_t rc = materialize(h, slot, h->stream)) return rc;   // and dense, whatever the caller does next
     RBS_HIP(h, hipStreamSynchronize(h->stream));
@@ -2872,6 +3066,7 @@ int32_t rbs_occlusion_next_device_ptr(rbs_handle* h, int32_t slot, void** out)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("occlusion_next_device_ptr: bad slot %d", slot));
     RBS_HIP(h, hipSetDevice(h->device));
     if (h->slab_px) return fail(h, RBS_ERR_UNSUPPORTED, "occlusion_next_device_ptr: slots are slabs, not planes (state_slab_px)");
+    if (h->exact) return fail(h, RBS_ERR_UNSUPPORTED, "occlusion_next_device_ptr: a slot of stamped planes (occlusion_mode REFERENCE) is not a float plane");
     if (int32_t rc = drain(h, true)) return rc;   // planes complete before the caller touches them
     *out = h->d_occ[1 - h->cur] + (size_t)slot * h->npx;
     return RBS_OK;
@@ -2886,6 +3081,7 @@ int32_t rbs_export_plane(rbs_handle* h, int32_t slot, void* d_dst, void* stream)
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    if (h->exact) return exact_expand(h, slot, static_cast<float*>(d_dst), s);
     if (h->slab_px) return slab_expand(h, slot, static_cast<float*>(d_dst), s);
     if (int32_t rc = materialize(h, slot, s)) return rc;
     RBS_HIP(h, hipMemcpyAsync(d_dst, h->d_occ[h->cur] + (size_t)slot * h->npx, sizeof(float) * h->npx,
@@ -2902,6 +3098,7 @@ int32_t rbs_import_plane(rbs_handle* h, int32_t slot, const void* d_src, void* s
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    if (h->exact) return exact_store(h, slot, static_cast<const float*>(d_src), s);   // (synchronises)
     if (h->slab_px) return slab_store(h, slot, static_cast<const float*>(d_src), s);   // (synchronises: the box must fit)
     RBS_HIP(h, hipMemcpyAsync(h->d_occ[h->cur] + (size_t)slot * h->npx, d_src, sizeof(float) * h->npx,
                               hipMemcpyDeviceToDevice, s));
@@ -2946,6 +3143,21 @@ int32_t rbs_export_window(rbs_handle* h, int32_t slot, int32_t rect_out[4], void
     RBS_HIP(h, hipSetDevice(h->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (h->join_pending >= 0) RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
+    if (h->exact) {
+        // stamped planes travel as EFFECTIVE values (what the receiver's rbs_import_window takes "as of now"): the slot's plane is
+        // assembled beside the slots and its window cut out of it (shared trail: the whole plane, as below)
+        if (int32_t rc = exact_expand(h, slot, h->d_render, s)) return rc;
+        int box[4] = {0, 0, h->cols, h->rows};
+        if (!h->stp) if (int32_t rc = window_of(h, slot, s, box)) return rc;
+        for (int k = 0; k < 4; ++k) rect_out[k] = box[k];
+        const int w = box[2] - box[0], hh = box[3] - box[1];
+        if (w <= 0 || hh <= 0) return RBS_OK;
+        if ((size_t)w * (size_t)hh > capacity_floats || !d_payload)
+            return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("export_window: the window of slot %d holds %d x %d values, the buffer %zu", slot, w, hh, capacity_floats));
+        RBS_HIP(h, hipMemcpy2DAsync(d_payload, sizeof(float) * (size_t)w, h->d_render + (size_t)box[1] * h->cols + box[0], sizeof(float) * (size_t)h->cols,
+                                    sizeof(float) * (size_t)w, (size_t)hh, hipMemcpyDeviceToDevice, s));
+        return RBS_OK;
+    }
     // (shared trail: outside its window the plane is the handle's background PLANE, which the receiver does not have -- the
     // slot is made dense first and travels whole)
     if (h->stp && h->slab_px) {   // (a slab cannot be made dense in place: the whole plane is assembled beside it and travels from there)
@@ -2995,14 +3207,14 @@ int32_t rbs_import_window(rbs_handle* h, int32_t slot, const int32_t rect[4], co
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("import_window: bad rectangle (%d, %d, %d, %d)", rect[0], rect[1], rect[2], rect[3]));
     const int w = r.z - r.x, hh = r.w - r.y;
     float* dst = h->d_occ[h->cur] + (size_t)slot * h->plane_stride;
-    if (h->stp && h->slab_px) {
+    if ((h->stp && h->slab_px) || h->exact) {
         // the sender's plane = its scalar background outside rect: assembled whole beside the slabs, stored like any plane handed in
         hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(256), dim3(256), 0, s, h->d_render, (size_t)h->npx, h->background);
         RBS_HIP(h, hipGetLastError());
         if (!empty)
             RBS_HIP(h, hipMemcpy2DAsync(h->d_render + (size_t)r.y * h->cols + r.x, sizeof(float) * (size_t)h->cols, d_payload, sizeof(float) * (size_t)w,
                                         sizeof(float) * (size_t)w, (size_t)hh, hipMemcpyDeviceToDevice, s));
-        return slab_store(h, slot, h->d_render, s);
+        return h->exact ? exact_store(h, slot, h->d_render, s) : slab_store(h, slot, h->d_render, s);
     }
     if (!h->windowed || h->stp) {
         // whole planes without windows (or a handle whose implicit background is a plane of its own): the sender's scalar
@@ -3048,7 +3260,7 @@ int32_t rbs_import_window(rbs_handle* h, int32_t slot, const int32_t rect[4], co
 namespace {
 struct IpcBlob {
     uint32_t magic;
-    int32_t device, max_particles, rows, cols, slab_px, windowed, cur;
+    int32_t device, max_particles, rows, cols, slab_px, windowed, cur, exact;
     int64_t plane_stride;
     hipIpcMemHandle_t mem[6];   // occ[0], occ[1], win[0], win[1], reg[0], reg[1] (reg: slabs only)
 };
@@ -3069,7 +3281,7 @@ int32_t rbs_ipc_export(rbs_handle* h, void* blob_out)
     IpcBlob b{};
     b.magic = kIpcMagic;
     b.device = h->device; b.max_particles = h->max_particles; b.rows = h->rows; b.cols = h->cols;
-    b.slab_px = h->slab_px; b.windowed = h->windowed ? 1 : 0; b.cur = h->cur; b.plane_stride = (int64_t)h->plane_stride;
+    b.slab_px = h->slab_px; b.windowed = h->windowed ? 1 : 0; b.cur = h->cur; b.plane_stride = (int64_t)h->plane_stride; b.exact = h->exact ? 1 : 0;
     void* bufs[6] = {h->d_occ[0], h->d_occ[1], h->d_win[0], h->d_win[1], h->d_reg[0], h->d_reg[1]};
     for (int k = 0; k < 6; ++k)
         if (bufs[k]) RBS_HIP(h, hipIpcGetMemHandle(&b.mem[k], bufs[k]));
@@ -3094,7 +3306,7 @@ int32_t rbs_ipc_attach(rbs_handle* h, int32_t rank, int32_t world, const void* b
         std::memcpy(&b, raw + (size_t)k * RBS_IPC_BLOB_BYTES, sizeof(b));
         if (b.magic != kIpcMagic) return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("ipc_attach: blob %d is not an rbs_ipc_export", k));
         if (b.max_particles != h->max_particles || b.rows != h->rows || b.cols != h->cols || b.slab_px != h->slab_px ||
-            b.windowed != (h->windowed ? 1 : 0) || b.plane_stride != (int64_t)h->plane_stride || b.cur != h->cur)
+            b.windowed != (h->windowed ? 1 : 0) || b.plane_stride != (int64_t)h->plane_stride || b.cur != h->cur || b.exact != (h->exact ? 1 : 0))
             return fail(h, RBS_ERR_INVALID_ARGUMENT,
                         fmt("ipc_attach: rank %d's handle differs (max_particles %d, %d x %d, slab %d px, %s planes, buffer %d) from this one "
                             "(%d, %d x %d, %d, %s, %d): every rank must create the same handle and be at the same point of its call sequence",
@@ -3150,6 +3362,7 @@ int32_t rbs_stage_windows(rbs_handle* h, const int32_t* d_src_global, const int3
     DevParams P = h->base;
     P.slots = h->max_particles; P.n_dev = 1; P.shard_cap = h->max_particles;
     P.slab_px = h->slab_px; P.plane_stride = (int)h->plane_stride;
+    P.exact = h->exact ? 1 : 0; P.plane_px = h->slab_px ? h->slab_px : h->npx;
     P.occ_src = h->d_occ[h->cur]; P.win_src = h->d_win[h->cur]; P.reg_src = h->d_reg[h->cur];
     if (h->peer_world > 1) {
         P.n_dev = h->peer_world;

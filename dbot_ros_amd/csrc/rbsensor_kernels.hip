@@ -240,6 +240,19 @@ struct DevParams {
     int depth_items;               // items the buffer holds (an item beyond it is contained: its particle's sum is NaN)
     int* ctrb_this;                // [1] the likelihood kernel's ticket counter of this call ...
     int* ctrb_next;                // ... and the next call's, zeroed by this call's geometry kernel
+    // STAMPED planes (round 6; rbs_config.occlusion_mode = RBS_OCC_REFERENCE: the reference CPU model's own occlusion bookkeeping,
+    // SURVEY A.4 / A.5, oracle mode LAZY).  A slot holds plane_px floats -- the posterior a pixel was last UPDATED to, never
+    // stepped -- followed by plane_px 16-bit AGES: frames between that update and the slot's epoch (the last updating call).
+    // The prior of a pixel at a call `elapsed` frames after the epoch is propagate(value, (age + elapsed) dt) in binary64 from
+    // the table ptab (the oracle's operations in the oracle's order), rounded once to float; an age beyond age_max IS the
+    // background -- a never-covered pixel, prior bg_new = (float)propagate(initial_occlusion_prob, clock dt) -- so a window
+    // still follows the object (c^(age_max dt) <= 2^-40: the value would differ from the background by less than that).
+    // Ages saturate at 0xffff.  Everything above (windows, slabs, shared plane, peers) addresses slots as before.
+    int exact;
+    int plane_px;                  // pixels per slot: npx, or slab_px (the ages of a slot start at its float plane_px)
+    unsigned elapsed2;             // frames since the epoch, saturated to 16 bits, in both halves of a dword (packed adds)
+    int age_max;                   // ages above it are background
+    const double* ptab;            // [age_max + 1][2]: c^(age dt), ((1 - p_oo) (c^(age dt) - 1)) / (c - 1)
 #ifdef RBS_PHASE_TIMING
     unsigned long long* phase;     // [32] accumulated wave-0 cycles per phase and event counts (profiling builds only)
 #endif
@@ -288,6 +301,30 @@ __device__ inline float occ_step(float alpha, float beta, float v, float bg_new)
 {
     const float x = fmaf(alpha, v, beta);
     return fabsf(x - bg_new) <= kSnapTau ? bg_new : x;
+}
+
+// Stamped planes: two 16-bit ages in a dword advanced by the call's elapsed frames, saturating at 0xffff (v_pk_add_u16 clamp).
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+constexpr unsigned kAgeBg2 = 0xffffffffu;    // two background ages
+__device__ inline unsigned age_add2(unsigned packed, unsigned e2)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_add_sat(__builtin_bit_cast(ushort2v, packed), __builtin_bit_cast(ushort2v, e2)));
+}
+// The reference's prior of a pixel (oracle orc_propagate): the stored posterior v, last updated `age` frames ago
+// (this call's elapsed frames included).  pow_c = exp(age dt log c) and the second summand come from the host's table, computed
+// with the oracle's expressions; the three operations left are the oracle's, in its order, individually rounded.
+__device__ inline float exact_prior(const DevParams& P, float v, int age)
+{
+    typedef double doublex2 __attribute__((ext_vector_type(2)));
+    const doublex2 t = reinterpret_cast<const doublex2*>(P.ptab)[min(age, P.age_max)];
+    const double new_visible = t.x * (1.0 - (double)v) + t.y;
+    const float pr = (float)(1.0 - new_visible);
+    return age > P.age_max ? P.bg_new : pr;
+}
+// Does pixel (v, a) of a plane differ from pixel (bv, ba) of the shared background plane?  (Background ages carry no value.)
+__device__ inline bool exact_differs(float v, unsigned a, float bv, unsigned ba, unsigned age_max)
+{
+    return a > age_max ? ba <= age_max : (a != ba || v != bv);
 }
 
 // Where a parent slot's plane and window are: this device's buffers, or a peer's (see DevParams).
@@ -1189,6 +1226,7 @@ struct Smem {
     unsigned* tile; int* big; double* red; int* nbig; int* item; int* evalq;
     double* mtab;   // precision F64: the erfc and log tables of rbs_math.h (kMathTabDoubles doubles)
     unsigned long long* cull;   // MANY: [kCullSteps][2] verdicts of the shared cluster cull (raster_window)
+    int* ageq;                  // stamped planes: per wave kEvalQueue ages of the queued pixels (a fifth plane of the ring, behind everything else)
 };
 __device__ inline Smem carve(unsigned char* smem, int kTilePx, bool math_tables)
 {
@@ -1202,12 +1240,13 @@ __device__ inline Smem carve(unsigned char* smem, int kTilePx, bool math_tables)
     m.mtab = reinterpret_cast<double*>(m.evalq + kQPlanes * (kBlock / 64) * kEvalQueue);   // (16-byte aligned: everything before it is)
     // (last, so that nothing else moves: shifting the rings and the tables by these 448 bytes cost C1 0.6 %)
     m.cull = reinterpret_cast<unsigned long long*>(m.mtab + (math_tables ? kMathTabDoubles : 0));
+    m.ageq = nullptr;
     return m;
 }
 
 // One (particle, tile) work item: rasterize the tile window, evaluate its pixels, return the
 // block-reduced partial log-likelihood (valid in thread 0).
-template <bool UPDATE, int PREC, bool SLAB, bool MANY = false, int PHASE = 0, bool STP = false>
+template <bool UPDATE, int PREC, bool SLAB, bool MANY = false, int PHASE = 0, bool STP = false, bool EXACT = false>
 __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect r, int tile_id,
                                           const Smem& m, unsigned body_mask, bool draw, int& ticket, const unsigned* gtile = nullptr)
 {
@@ -1226,6 +1265,10 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     const float* __restrict__ src = parent_plane(P, parent);
     float* __restrict__ dst = UPDATE ? P.occ_dst + (size_t)particle * P.plane_stride : nullptr;
     const int4 pw = parent_window(P, parent);   // outside it the parent's plane is implicitly bg_old
+    // stamped planes: a slot's ages follow its values
+    const unsigned short* __restrict__ asrc = EXACT ? reinterpret_cast<const unsigned short*>(src + P.plane_px) : nullptr;
+    unsigned short* __restrict__ adst = EXACT && UPDATE ? reinterpret_cast<unsigned short*>(dst + P.plane_px) : nullptr;
+    const unsigned short* __restrict__ abgp = EXACT && STP ? reinterpret_cast<const unsigned short*>(P.bgp_src + P.npx) : nullptr;
 
     RBS_TICK_DECL;
     // a rectangle that is a single tile was sized from the same spheres: nothing to cull
@@ -1245,6 +1288,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     double ll = 0.0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int* q = m.evalq + wave * kQPlanes * kEvalQueue;   // planes: pixel index, depth bits, prior, observation
+    int* aq = EXACT ? m.ageq + wave * kEvalQueue : nullptr;   // stamped planes: plane 2 holds the stored VALUE, this ring its age
     const MathTabs mt = RBS_MATH_LDS ? MathTabs{m.mtab, m.mtab + rbsm::kErfcIntervals * rbsm::kErfcCoefs}
                                      : MathTabs{rbsm::kErfcTab, rbsm::kLogTab};
     int qh = 0, qn = 0;                                // ring: head, count (wave-uniform)
@@ -1254,7 +1298,9 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
         if (lane < (cnt_)) {                                                                            \
             const int at_ = (qh + lane) & (kEvalQueue - 1);                                             \
             const int eg_ = q[at_];                                                                     \
-            const float ed_ = __int_as_float(q[kEvalQueue + at_]), ep_ = __int_as_float(q[2 * kEvalQueue + at_]); \
+            const float ed_ = __int_as_float(q[kEvalQueue + at_]);                                      \
+            float ep_ = __int_as_float(q[2 * kEvalQueue + at_]);                                        \
+            if (EXACT) ep_ = exact_prior(P, ep_, aq[at_]);                                              \
             float post_;                                                                                \
             if (PREC) ll += pixel_loglik_f32(P, ed_, ep_, __int_as_float(q[3 * kEvalQueue + at_]), post_); \
             else ll += pixel_loglik(P, mt, eg_, ed_, ep_, post_);                                       \
@@ -1264,7 +1310,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
         }                                                                                               \
     } while (0)
     // push this lane's pixel if `active`; evaluate 64 queued pixels as soon as there are 64
-#define RBS_PUSH_EVAL(active, gidx, didx, depthbits, prior, obs)                                        \
+#define RBS_PUSH_EVAL(active, gidx, didx, depthbits, prior, obs, age)                                   \
     do {                                                                                                \
         const unsigned long long mask_ = __ballot(active);                                              \
         if (mask_) {                                                                                    \
@@ -1274,6 +1320,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                 q[pos_] = PREC ? (didx) : (gidx);                                                       \
                 q[kEvalQueue + pos_] = (int)(depthbits);                                                \
                 q[2 * kEvalQueue + pos_] = __float_as_int(prior);                                       \
+                if (EXACT) aq[pos_] = (int)(age);                                                       \
                 if (PREC) q[3 * kEvalQueue + pos_] = __float_as_int(obs);                               \
                 else if (SLAB) q[3 * kEvalQueue + pos_] = (didx);                                       \
             }                                                                                           \
@@ -1317,6 +1364,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
         for (int q0 = wave * 64; q0 < nq; q0 += kBlock * kScanUnroll) {
             uint4 d4[kScanUnroll];
             floatx4 s4[kScanUnroll], o4[kScanUnroll];
+            uint2 a4[EXACT ? kScanUnroll : 1];                       // stamped planes: the quad's four ages
             int gb[kScanUnroll], sb[kScanUnroll], db[kScanUnroll];   // offsets into the frame, the parent's plane, the child's
             bool vl[kScanUnroll], ac[kScanUnroll];
 #pragma unroll
@@ -1326,6 +1374,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                 d4[u] = make_uint4(kInfBits, kInfBits, kInfBits, kInfBits);
                 s4[u] = floatx4{P.bg_old, P.bg_old, P.bg_old, P.bg_old};
                 o4[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (EXACT) a4[EXACT ? u : 0] = make_uint2(kAgeBg2, kAgeBg2);
                 gb[u] = 0; sb[u] = 0; db[u] = 0;
                 ac[u] = false;
                 if (vl[u]) {
@@ -1337,8 +1386,13 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                     ac[u] = (d4[u].x & d4[u].y & d4[u].z & d4[u].w) != kInfBits;   // a finite depth lacks an exponent bit
                     const bool stored = gx >= pw.x && gx < pw.z && gy >= pw.y && gy < pw.w;
 #ifndef RBS_EXP_NO_SRCLOAD
-                    if (stored && (UPDATE || ac[u])) s4[u] = *reinterpret_cast<const floatx4*>(src + sb[u]);
-                    else if (STP && (UPDATE || ac[u])) s4[u] = *reinterpret_cast<const floatx4*>(P.bgp_src + gb[u]);   // the shared plane's value
+                    if (stored && (UPDATE || ac[u])) {
+                        s4[u] = *reinterpret_cast<const floatx4*>(src + sb[u]);
+                        if (EXACT) a4[EXACT ? u : 0] = *reinterpret_cast<const uint2*>(asrc + sb[u]);
+                    } else if (STP && (UPDATE || ac[u])) {
+                        s4[u] = *reinterpret_cast<const floatx4*>(P.bgp_src + gb[u]);   // the shared plane's value
+                        if (EXACT) a4[EXACT ? u : 0] = *reinterpret_cast<const uint2*>(abgp + gb[u]);
+                    }
 #endif
                     // (the split launch's likelihood kernel, whose tile read is a memory round trip: requesting the frame's quad WITH it
                     // instead of behind it was measured -- 0.1945 ms either way)
@@ -1350,6 +1404,28 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
 #pragma unroll
             for (int u = 0; u < kScanUnroll; ++u) {
                 if (q0 + u * kBlock >= nq) break;   // wave-uniform
+                if (EXACT) {
+                    // stamped planes: nothing is stepped -- the values travel as they are, the ages advance by the call's elapsed
+                    // frames, and an updated pixel's age restarts (its posterior overwrites the value when its batch is evaluated)
+                    const uint2 ag = make_uint2(age_add2(a4[EXACT ? u : 0].x, P.elapsed2), age_add2(a4[EXACT ? u : 0].y, P.elapsed2));
+                    const bool p0 = d4[u].x != kInfBits && isfinite(o4[u].x), p1 = d4[u].y != kInfBits && isfinite(o4[u].y);
+                    const bool p2 = d4[u].z != kInfBits && isfinite(o4[u].z), p3 = d4[u].w != kInfBits && isfinite(o4[u].w);
+                    if (UPDATE && vl[u]) {
+                        *reinterpret_cast<floatx4*>(dst + db[u]) = s4[u];
+                        uint2 w = ag;
+                        if (p0) w.x &= 0xffff0000u;
+                        if (p1) w.x &= 0x0000ffffu;
+                        if (p2) w.y &= 0xffff0000u;
+                        if (p3) w.y &= 0x0000ffffu;
+                        *reinterpret_cast<uint2*>(adst + db[u]) = w;
+                    }
+                    if (__ballot(ac[u]) == 0) continue;
+                    RBS_PUSH_EVAL(p0, gb[u] + 0, db[u] + 0, d4[u].x, s4[u].x, o4[u].x, ag.x & 0xffffu);
+                    RBS_PUSH_EVAL(p1, gb[u] + 1, db[u] + 1, d4[u].y, s4[u].y, o4[u].y, ag.x >> 16);
+                    RBS_PUSH_EVAL(p2, gb[u] + 2, db[u] + 2, d4[u].z, s4[u].z, o4[u].z, ag.y & 0xffffu);
+                    RBS_PUSH_EVAL(p3, gb[u] + 3, db[u] + 3, d4[u].w, s4[u].w, o4[u].w, ag.y >> 16);
+                    continue;
+                }
                 floatx4 pr;
                 pr.x = occ_step(P.alpha, P.beta, s4[u].x, P.bg_new);
                 pr.y = occ_step(P.alpha, P.beta, s4[u].y, P.bg_new);
@@ -1362,10 +1438,10 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                 continue;
 #endif
                 if (__ballot(ac[u]) == 0) continue;   // wave-uniform: nothing of the object in these 256 pixels
-                RBS_PUSH_EVAL(d4[u].x != kInfBits && isfinite(o4[u].x), gb[u] + 0, db[u] + 0, d4[u].x, pr.x, o4[u].x);
-                RBS_PUSH_EVAL(d4[u].y != kInfBits && isfinite(o4[u].y), gb[u] + 1, db[u] + 1, d4[u].y, pr.y, o4[u].y);
-                RBS_PUSH_EVAL(d4[u].z != kInfBits && isfinite(o4[u].z), gb[u] + 2, db[u] + 2, d4[u].z, pr.z, o4[u].z);
-                RBS_PUSH_EVAL(d4[u].w != kInfBits && isfinite(o4[u].w), gb[u] + 3, db[u] + 3, d4[u].w, pr.w, o4[u].w);
+                RBS_PUSH_EVAL(d4[u].x != kInfBits && isfinite(o4[u].x), gb[u] + 0, db[u] + 0, d4[u].x, pr.x, o4[u].x, 0);
+                RBS_PUSH_EVAL(d4[u].y != kInfBits && isfinite(o4[u].y), gb[u] + 1, db[u] + 1, d4[u].y, pr.y, o4[u].y, 0);
+                RBS_PUSH_EVAL(d4[u].z != kInfBits && isfinite(o4[u].z), gb[u] + 2, db[u] + 2, d4[u].z, pr.z, o4[u].z, 0);
+                RBS_PUSH_EVAL(d4[u].w != kInfBits && isfinite(o4[u].w), gb[u] + 3, db[u] + 3, d4[u].w, pr.w, o4[u].w, 0);
             }
         }
     } else {
@@ -1389,7 +1465,7 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
             const float prior = occ_step(P.alpha, P.beta, sv, P.bg_new);
             const bool active = dbits != kInfBits && isfinite(ov);
             if (UPDATE && valid && !active) dst[gi] = prior;
-            RBS_PUSH_EVAL(active, gi, gi, dbits, prior, ov);   // whole planes only on this path (slabs need cols % 4 == 0)
+            RBS_PUSH_EVAL(active, gi, gi, dbits, prior, ov, 0);   // whole planes only on this path (slabs and stamped planes need cols % 4 == 0)
         }
     }
 #undef RBS_PUSH_EVAL
@@ -1734,11 +1810,13 @@ __global__ __launch_bounds__(64 * kPrepPerBlock) void rbs_frame_prep_kernel(cons
 // Persistent: a fixed number of raster blocks per CU keeps its LDS/VGPR share for the whole
 // launch (never starved by the many small copy blocks) and pulls (particle, tile) items from
 // an atomic queue.
-template <bool UPDATE, int PREC, bool SLAB, bool MANY = false, bool STP = false>
+constexpr size_t smem_bytes(int tile_px, bool math_tables, bool many = false, bool exact = false);
+template <bool UPDATE, int PREC, bool SLAB, bool MANY = false, bool STP = false, bool EXACT = false>
 __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Smem m = carve(smem, P.tile_px, PREC == 0 && RBS_MATH_LDS);
+    Smem m = carve(smem, P.tile_px, PREC == 0 && RBS_MATH_LDS);
+    if (EXACT) m.ageq = reinterpret_cast<int*>(smem + smem_bytes(P.tile_px, PREC == 0 && RBS_MATH_LDS, MANY));
     const int total = P.ctr_this[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr_next[0] = 0; P.ctr_next[1] = 0; }
     if (PREC == 0 && RBS_MATH_LDS) {   // once per persistent block (the first item's tile clear ends in a barrier)
@@ -1777,7 +1855,7 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
         RBS_TICK(15);   // the item's descriptor
 #endif
         if (P.groups == nullptr) {
-            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC, SLAB, MANY, 0, STP>(P, particle, r, item - first, m, 0xffffffffu, draw, ticket);
+            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, PREC, SLAB, MANY, 0, STP, EXACT>(P, particle, r, item - first, m, 0xffffffffu, draw, ticket);
         } else {   // several bodies: the item belongs to one group of bodies with its own rectangle
             const Groups* G = P.groups + particle;
             const int k = item - first, ng = __builtin_amdgcn_readfirstlane(G->n);
@@ -1787,7 +1865,7 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
                 const int4 gq = G->rect[g];
                 const Rect gr = {__builtin_amdgcn_readfirstlane(gq.x), __builtin_amdgcn_readfirstlane(gq.y),
                                  __builtin_amdgcn_readfirstlane(gq.z), __builtin_amdgcn_readfirstlane(gq.w)};
-                part = raster_eval_tile<UPDATE, PREC, SLAB, MANY, 0, STP>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
+                part = raster_eval_tile<UPDATE, PREC, SLAB, MANY, 0, STP, EXACT>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
                                                       (unsigned)__builtin_amdgcn_readfirstlane((int)G->mask[g]), draw, ticket);
             }
         }
@@ -1868,6 +1946,12 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET voi
 {
     raster_kernel_body<UPDATE, 0, SLAB, MANY, true>(P);
 }
+// ... on STAMPED planes (EXACT: the reference's occlusion bookkeeping; binary64; all of SLAB / MANY / STP), kernels of their own again
+template <bool UPDATE, bool SLAB, bool MANY, bool STP>
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_kernel_exact_f64(const DevParams P)
+{
+    raster_kernel_body<UPDATE, 0, SLAB, MANY, STP, true>(P);
+}
 // ... and the same two for object models with a body of more than 256 clusters (MANY: the shared cluster cull).
 template <bool UPDATE, bool SLAB>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) __attribute__((amdgpu_num_vgpr(RBS_RASTER_VGPRS)))
@@ -1936,7 +2020,10 @@ __device__ __forceinline__ void depth_kernel_body(const DevParams& P)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SmemDepth m = carve_depth(smem, P.tile_px);
     const int total = P.ctr_this[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr_next[0] = 0; P.ctr_next[1] = 0; *P.ctrb_next = 0; }
+    // (the likelihood kernel's ticket counter is zeroed for THIS call, which runs behind this kernel on the same stream and is
+    // the only one to use it: a handle mixes the two launch forms call by call, and a one-kernel call in between would leave a
+    // counter that only "the next split call" zeroes holding a stale count -- ADVICE r5)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr_next[0] = 0; P.ctr_next[1] = 0; *P.ctrb_this = 0; *P.ctrb_next = 0; }
     const int grid = (int)gridDim.x;
     int item = (int)blockIdx.x;   // the first round is dealt statically, the rest through the ticket counter (as in the monolith)
     for (;;) {
@@ -2002,11 +2089,12 @@ void rbs_depth_kernel(const DevParams P)
 
 // The likelihood half.  Block per work item (first round dealt statically, then tickets); the particle's sum as in
 // the monolith: its only item's, or the items' partial sums added in item order by whoever finishes last.
-template <bool UPDATE, bool SLAB, bool STP = false>
+template <bool UPDATE, bool SLAB, bool STP = false, bool EXACT = false>
 __global__ __launch_bounds__(kBlock, RBS_EVAL_MINWAVES) void rbs_eval_kernel(const DevParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Smem m = carve(smem, 0, true);
+    Smem m = carve(smem, 0, true);
+    if (EXACT) m.ageq = reinterpret_cast<int*>(smem + smem_bytes(0, true, false));
     const int total = P.ctr_this[0];
     {
         constexpr int ne = rbsm::kErfcIntervals * rbsm::kErfcCoefs, nl = rbsm::kLogIntervals * 2;
@@ -2029,7 +2117,7 @@ __global__ __launch_bounds__(kBlock, RBS_EVAL_MINWAVES) void rbs_eval_kernel(con
         } else if (P.groups == nullptr) {
             const int4 q = reinterpret_cast<const int4*>(P.rects)[particle];
             const Rect r = {q.x, q.y, q.z, q.w};
-            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, 0, SLAB, false, 2, STP>(P, particle, r, item - first, m, 0xffffffffu, false, ticket, gtile);
+            if (r.x1 > r.x0) part = raster_eval_tile<UPDATE, 0, SLAB, false, 2, STP, EXACT>(P, particle, r, item - first, m, 0xffffffffu, false, ticket, gtile);
         } else {
             const Groups* G = P.groups + particle;
             const int k = item - first, ng = __builtin_amdgcn_readfirstlane(G->n);
@@ -2039,7 +2127,7 @@ __global__ __launch_bounds__(kBlock, RBS_EVAL_MINWAVES) void rbs_eval_kernel(con
                 const int4 gq = G->rect[g];
                 const Rect gr = {__builtin_amdgcn_readfirstlane(gq.x), __builtin_amdgcn_readfirstlane(gq.y),
                                  __builtin_amdgcn_readfirstlane(gq.z), __builtin_amdgcn_readfirstlane(gq.w)};
-                part = raster_eval_tile<UPDATE, 0, SLAB, false, 2, STP>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
+                part = raster_eval_tile<UPDATE, 0, SLAB, false, 2, STP, EXACT>(P, particle, gr, k - __builtin_amdgcn_readfirstlane(G->first[g]), m,
                                                                    (unsigned)__builtin_amdgcn_readfirstlane((int)G->mask[g]), false, ticket, gtile);
             }
         }
@@ -2191,12 +2279,17 @@ constexpr int kWinUnroll = RBS_WIN_UNROLL;
 // STP: the shared background PLANE (DevParams.bgp_src / bgp_dst) stands where the scalar background stands -- a cell outside the
 // parent's window holds bgp_src there, and the child's window grows over the cells that differ from bgp_dst.  One cell in flight
 // per lane (its shared-plane values take the registers of the second).
-template <bool SLAB, bool STRIPS, bool STP = false>
+// EXACT: stamped planes (DevParams.exact) -- a cell is four values and four ages; nothing is stepped: the values are copied, the
+// ages advance by the call's elapsed frames, and the child's window grows over the cells that hold an age within age_max (STP:
+// that differ from the shared plane's new cell).
+template <bool SLAB, bool STRIPS, bool STP = false, bool EXACT = false>
 __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
 {
     constexpr int kU = STP ? 1 : kWinUnroll;
     const floatx4* __restrict__ bc4 = reinterpret_cast<const floatx4*>(P.bgp_src);
     const floatx4* __restrict__ bn4 = reinterpret_cast<const floatx4*>(P.bgp_dst);
+    const uint2* __restrict__ bca = EXACT && STP ? reinterpret_cast<const uint2*>(P.bgp_src + P.npx) : nullptr;   // the shared plane's ages
+    const uint2* __restrict__ bna = EXACT && STP ? reinterpret_cast<const uint2*>(P.bgp_dst + P.npx) : nullptr;
     const int particle = (int)blockIdx.y + (int)blockIdx.z * (int)gridDim.y;
     if (particle >= P.n) return;
     const int parent = P.parents[particle];
@@ -2215,6 +2308,20 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
     const int n4 = max(ry1 - ry0, 0) * w4;
     const floatx4* __restrict__ s4 = reinterpret_cast<const floatx4*>(parent_plane(P, parent));
     floatx4* __restrict__ d4 = reinterpret_cast<floatx4*>(P.occ_dst + (size_t)particle * P.plane_stride);
+    const uint2* __restrict__ sa = EXACT ? reinterpret_cast<const uint2*>(reinterpret_cast<const float*>(s4) + P.plane_px) : nullptr;   // the slots' ages,
+    uint2* __restrict__ da = EXACT ? reinterpret_cast<uint2*>(reinterpret_cast<float*>(d4) + P.plane_px) : nullptr;                     // indexed like their float4s
+    const unsigned amax = (unsigned)P.age_max;
+    // one cell of the stamped form: advance the ages, store, report whether the child's window must cover it
+#define RBS_EXACT_CELL(vv, aa, bnv, bnaa, didx)                                                          \
+    ([&]() -> bool {                                                                                    \
+        const uint2 ag_ = make_uint2(age_add2((aa).x, P.elapsed2), age_add2((aa).y, P.elapsed2));       \
+        __builtin_nontemporal_store(vv, &d4[didx]);                                                     \
+        da[didx] = ag_;                                                                                 \
+        const unsigned a0_ = ag_.x & 0xffffu, a1_ = ag_.x >> 16, a2_ = ag_.y & 0xffffu, a3_ = ag_.y >> 16; \
+        if (!STP) return a0_ <= amax || a1_ <= amax || a2_ <= amax || a3_ <= amax;                      \
+        return exact_differs((vv).x, a0_, (bnv).x, (bnaa).x & 0xffffu, amax) || exact_differs((vv).y, a1_, (bnv).y, (bnaa).x >> 16, amax) || \
+               exact_differs((vv).z, a2_, (bnv).z, (bnaa).y & 0xffffu, amax) || exact_differs((vv).w, a3_, (bnv).w, (bnaa).y >> 16, amax);   \
+    }())
     // float4 index of pixel (col, row) in the parent's / the child's plane (whole planes: row W4 + col/4;
     // slabs: relative to the plane's stored region -- the child's region is u itself)
     const PlaneRef sref = SLAB ? parent_ref(P, parent) : PlaneRef{0, 0, P.cols};
@@ -2237,6 +2344,7 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
         const int lo = (int)blockIdx.x * per, hi = min(L, lo + per);
         for (int base = lo; base < hi; base += 64 * kU) {
             floatx4 v[kU], bn[kU];
+            uint2 va[EXACT ? kU : 1], bna_[EXACT && STP ? kU : 1];
             int pk[kU];    // state << 28 | row << 14 | float4 column (rows and columns <= 8 192: create refuses more)
 #pragma unroll
             for (int k = 0; k < kU; ++k) {
@@ -2251,14 +2359,32 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
                 const int col = (ux4 + c4) << 2;
                 const bool stored = live && col >= pw.x && col < pw.z && row >= pw.y && row < pw.w;
                 pk[k] = ((live ? (stored ? 2 : 1) : 0) << 28) | (row << 14) | (ux4 + c4);
-                if (stored) v[k] = __builtin_nontemporal_load(&s4[(row - sy0) * ss4 + (ux4 + c4 - sx4)]);
-                else if (STP && live) v[k] = bc4[row * W4 + (ux4 + c4)];
-                if (STP && live) bn[k] = bn4[row * W4 + (ux4 + c4)];
+                if (EXACT) va[EXACT ? k : 0] = make_uint2(kAgeBg2, kAgeBg2);
+                if (stored) {
+                    v[k] = __builtin_nontemporal_load(&s4[(row - sy0) * ss4 + (ux4 + c4 - sx4)]);
+                    if (EXACT) va[EXACT ? k : 0] = sa[(row - sy0) * ss4 + (ux4 + c4 - sx4)];
+                } else if (STP && live) {
+                    v[k] = bc4[row * W4 + (ux4 + c4)];
+                    if (EXACT) va[EXACT ? k : 0] = bca[row * W4 + (ux4 + c4)];
+                }
+                if (STP && live) {
+                    bn[k] = bn4[row * W4 + (ux4 + c4)];
+                    if (EXACT) bna_[EXACT && STP ? k : 0] = bna[row * W4 + (ux4 + c4)];
+                }
             }
 #pragma unroll
             for (int k = 0; k < kU; ++k) {
                 const int st_ = pk[k] >> 28, row_ = (pk[k] >> 14) & 0x3fff, at_ = pk[k] & 0x3fff;
                 if (!st_) continue;
+                if (EXACT) {
+                    if (st_ != 2 && !STP) v[k] = floatx4{bg_new, bg_new, bg_new, bg_new};
+                    if (RBS_EXACT_CELL(v[k], va[EXACT ? k : 0], bn[k], bna_[EXACT && STP ? k : 0], (row_ - dy0) * ds4 + (at_ - dx4))) {
+                        const int col = at_ << 2;
+                        bx0 = min(bx0, col); bx1 = max(bx1, col + 4);
+                        by0 = min(by0, row_); by1 = max(by1, row_ + 1);
+                    }
+                    continue;
+                }
                 floatx4 w;
                 if (st_ == 2 || STP) {
                     w.x = occ_step(alpha, beta, v[k].x, bg_new);
@@ -2283,6 +2409,7 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
     int c4 = lane - (lane / w4) * w4;
     for (int base = 0; base < n4; base += 64 * kU) {
         floatx4 v[kU], bn[kU];
+        uint2 va[EXACT ? kU : 1], bna_[EXACT && STP ? kU : 1];
         int st[kU], at[kU], rr[kU];
 #pragma unroll
         for (int k = 0; k < kU; ++k) {
@@ -2293,15 +2420,33 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
             st[k] = live ? (stored ? 2 : 1) : 0;
             at[k] = ux4 + c4;
             rr[k] = row;
-            if (stored) v[k] = __builtin_nontemporal_load(&s4[(row - sy0) * ss4 + (at[k] - sx4)]);
-            else if (STP && live) v[k] = bc4[row * W4 + at[k]];
-            if (STP && live) bn[k] = bn4[row * W4 + at[k]];
+            if (EXACT) va[EXACT ? k : 0] = make_uint2(kAgeBg2, kAgeBg2);
+            if (stored) {
+                v[k] = __builtin_nontemporal_load(&s4[(row - sy0) * ss4 + (at[k] - sx4)]);
+                if (EXACT) va[EXACT ? k : 0] = sa[(row - sy0) * ss4 + (at[k] - sx4)];
+            } else if (STP && live) {
+                v[k] = bc4[row * W4 + at[k]];
+                if (EXACT) va[EXACT ? k : 0] = bca[row * W4 + at[k]];
+            }
+            if (STP && live) {
+                bn[k] = bn4[row * W4 + at[k]];
+                if (EXACT) bna_[EXACT && STP ? k : 0] = bna[row * W4 + at[k]];
+            }
             c4 += rstep; row += qstep;
             if (c4 >= w4) { c4 -= w4; ++row; }
         }
 #pragma unroll
         for (int k = 0; k < kU; ++k) {
             if (!st[k]) continue;
+            if (EXACT) {
+                if (st[k] != 2 && !STP) v[k] = floatx4{bg_new, bg_new, bg_new, bg_new};
+                if (RBS_EXACT_CELL(v[k], va[EXACT ? k : 0], bn[k], bna_[EXACT && STP ? k : 0], (rr[k] - dy0) * ds4 + (at[k] - dx4))) {
+                    const int col = at[k] << 2;
+                    bx0 = min(bx0, col); bx1 = max(bx1, col + 4);
+                    by0 = min(by0, rr[k]); by1 = max(by1, rr[k] + 1);
+                }
+                continue;
+            }
             floatx4 w;
             if (st[k] == 2 || STP) {
                 w.x = occ_step(alpha, beta, v[k].x, bg_new);
@@ -2321,6 +2466,7 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
         }
     }
     }
+#undef RBS_EXACT_CELL
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         bx0 = min(bx0, __shfl_xor(bx0, off)); by0 = min(by0, __shfl_xor(by0, off));
@@ -2365,6 +2511,9 @@ __global__ __launch_bounds__(256) void rbs_stage_kernel(const DevParams P, const
         const int r = k / w4, y = y0 + r, x = w.x + ((k - r * w4) << 2);
         const floatx4 v = *reinterpret_cast<const floatx4*>(sp + (size_t)(y - sref.y0) * sref.stride + (x - sref.x0));
         *reinterpret_cast<floatx4*>(dp + (size_t)(y - dy0) * dstride + (x - dx0)) = v;
+        if (P.exact)   // stamped planes: the four ages of the cell travel with it
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dp + P.plane_px) + (size_t)(y - dy0) * dstride + (x - dx0)) =
+                *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(sp + P.plane_px) + (size_t)(y - sref.y0) * sref.stride + (x - sref.x0));
     }
 }
 
@@ -2412,6 +2561,88 @@ __global__ void rbs_bgp_step_kernel(const float* __restrict__ bgp_src, float* __
         }
     }
     bgp_dst[i] = occ_step(alpha, beta, v, bg_new);
+}
+
+// ---- stamped planes (DevParams.exact): the shared plane's step, and the hooks' view of a slot ----
+// The shared plane on stamped planes: values copied, ages advanced (rebase >= 0: re-based on that slot's plane first; -2: all
+// background again).  bgp = [npx floats][npx ages].
+__global__ void rbs_bgp_step_exact_kernel(const float* __restrict__ bgp_src, float* __restrict__ bgp_dst, const float* __restrict__ occ_src,
+                                          const int4* __restrict__ win_src, const int4* __restrict__ reg_src, int plane_stride, int plane_px,
+                                          int rebase, int rows, int cols, unsigned elapsed2, float bg_new)
+{
+    const int npx = rows * cols;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    unsigned short* __restrict__ adst = reinterpret_cast<unsigned short*>(bgp_dst + npx);
+    if (rebase == -2) { bgp_dst[i] = bg_new; adst[i] = 0xffffu; return; }
+    float v = bgp_src[i];
+    unsigned a = reinterpret_cast<const unsigned short*>(bgp_src + npx)[i];
+    if (rebase >= 0) {
+        const int4 w = win_src[rebase];
+        const int y = i / cols, x = i - y * cols;
+        if (x >= w.x && x < w.z && y >= w.y && y < w.w) {
+            const float* slot = occ_src + (size_t)rebase * plane_stride;
+            size_t at = (size_t)i;
+            if (reg_src) { const int4 g = reg_src[rebase]; at = (size_t)(y - g.y) * (g.z - g.x) + (x - g.x); }
+            v = slot[at];
+            a = reinterpret_cast<const unsigned short*>(slot + plane_px)[at];
+        }
+    }
+    bgp_dst[i] = v;
+    adst[i] = (unsigned short)min(a + (elapsed2 & 0xffffu), 0xffffu);
+}
+// A slot as the hooks hand it out: the EFFECTIVE occlusion of every pixel as of the slot's epoch (the last updating call),
+// out[npx] floats -- inside the slot's window propagate(value, age dt) rounded to float (age 0: the value itself), the
+// background level where the age is beyond age_max or outside the window (bgp: the shared plane's pixel there).
+// reg == nullptr: the slot is a whole plane.
+__global__ void rbs_expand_exact_kernel(const float* __restrict__ slot, int plane_px, const int4* __restrict__ reg, const int4* __restrict__ win,
+                                        int rows, int cols, float bg, const float* __restrict__ bgp, DevParams P, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int y = i / cols, x = i - y * cols;
+    float v = bg;
+    unsigned a = 0xffffu;
+    bool have = false;
+    if (win) {
+        const int4 w = *win;
+        if (x >= w.x && x < w.z && y >= w.y && y < w.w) {
+            size_t at = (size_t)i;
+            if (reg) { const int4 r = *reg; at = (size_t)(y - r.y) * (r.z - r.x) + (x - r.x); }
+            v = slot[at];
+            a = reinterpret_cast<const unsigned short*>(slot + plane_px)[at];
+            have = true;
+        }
+    }
+    if (!have && bgp) { v = bgp[i]; a = reinterpret_cast<const unsigned short*>(bgp + rows * cols)[i]; }
+    P.bg_new = bg;
+    out[i] = exact_prior(P, v, (int)a);
+}
+// A whole plane of effective values handed in from outside -> a slot with stored region r (whole planes: r spans the frame and
+// `stride` is cols; slabs: packed, stride = r's width): values as given with age 0 ("as of the epoch", the rule of
+// oracle orc_set_occlusion), background where the value equals the reference (bgref plane, else the scalar bg).
+__global__ void rbs_pack_exact_kernel(const float* __restrict__ full, const float* __restrict__ bgref, float bg, int4 r, int cols,
+                                      int x0, int y0, int stride, float* __restrict__ slot, int plane_px)
+{
+    const int w = r.z - r.x, n = w * (r.w - r.y);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ly = i / w, lx = i - ly * w;
+    const size_t src = (size_t)(r.y + ly) * cols + r.x + lx;
+    const size_t at = (size_t)(r.y + ly - y0) * stride + (r.x + lx - x0);
+    const float v = full[src];
+    slot[at] = v;
+    reinterpret_cast<unsigned short*>(slot + plane_px)[at] = v == (bgref ? bgref[src] : bg) ? 0xffffu : 0u;
+}
+// Bounding box (float4-aligned) of the shared plane's pixels whose age is within age_max (stamped planes).
+__global__ void rbs_bbox_age_kernel(const float* __restrict__ bgp, int rows, int cols, unsigned age_max, int* __restrict__ out4)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    if (reinterpret_cast<const unsigned short*>(bgp + rows * cols)[i] > age_max) return;
+    const int y = i / cols, x = i - y * cols;
+    atomicMin(out4 + 0, x & ~3); atomicMin(out4 + 1, y);
+    atomicMax(out4 + 2, (x & ~3) + 4); atomicMax(out4 + 3, y + 1);
 }
 
 // Make one windowed plane dense in place: pixels outside its window become the background.
@@ -2493,11 +2724,14 @@ __global__ void rbs_fill_kernel(float* __restrict__ p, size_t n, float v)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
-constexpr size_t smem_bytes(int tile_px, bool math_tables, bool many = false)
+constexpr size_t smem_bytes(int tile_px, bool math_tables, bool many, bool exact)
 {
     return sizeof(unsigned) * (size_t)tile_px + sizeof(int) * kBigCap + sizeof(double) * (kBlock / 64) + 16 + (many ? 16 * kCullSteps : 0) +
-           sizeof(int) * kQPlanes * (kBlock / 64) * kEvalQueue + (math_tables ? sizeof(double) * kMathTabDoubles : 0);
+           sizeof(int) * kQPlanes * (kBlock / 64) * kEvalQueue + (math_tables ? sizeof(double) * kMathTabDoubles : 0) +
+           (exact ? sizeof(int) * (kBlock / 64) * kEvalQueue : 0);   // (the stamped planes' age ring sits behind everything else)
 }
+constexpr int kExactRingPx = (kBlock / 64) * kEvalQueue;   // the age ring's size in tile pixels: the stamped kernels' tile is that much smaller
+constexpr int kTilePxExact = kTilePxF64 - kExactRingPx, kTilePxBigExact = kTilePxBigF64 - kExactRingPx;
 static_assert(smem_bytes(kTilePxF64, true) <= smem_bytes(kTilePx, false) && smem_bytes(kTilePxBigF64, true) <= smem_bytes(kTilePxBig, false),
               "the F64 kernel's LDS block must not be larger than the F32 kernel's: the same number of blocks per CU");
 static_assert(3 * ((smem_bytes(kTilePx, false, true) + 1279) / 1280 * 1280) <= 160 * 1024, "three raster blocks per CU: LDS is granted in 1 280-byte steps");

@@ -134,12 +134,14 @@ class RbSensor:
     """dbot RbSensor mirror over the C-ABI handle."""
 
     def __init__(self, object_model, camera_data, params, device_id=0, max_particles=None,
-                 precision=None, state_layout=None, device_ids=None, slab_px=0):
+                 precision=None, state_layout=None, device_ids=None, slab_px=0, occlusion=None):
         """precision: None (library default) | "f64" | "f32" (rbs_config.likelihood_precision);
         state_layout: None | "window" | "dense"; device_ids: several HIP ordinals = particle
         sharding inside the handle (max_particles is then the total); slab_px: floats per
         occlusion slot (rbs_config.state_slab_px; 0 = the library's choice: whole planes up to 8 192 particles per
-        device, growing slabs of rows*cols/8 above; -1 = whole planes always)."""
+        device, growing slabs of rows*cols/8 above; -1 = whole planes always); occlusion: None (library default) |
+        "reference" (rbs_config.occlusion_mode REFERENCE: the reference CPU model's per-pixel time stamps, propagated in
+        binary64 at use -- oracle mode LAZY) | "device" (the float-stepped rule, oracle mode EAGER)."""
         self._lib = _capi.load()
         self._h = C.c_void_p()
         self.n_bodies = object_model.count_parts
@@ -172,6 +174,7 @@ class RbSensor:
         cfg.likelihood_precision = _capi.PRECISIONS[precision]
         cfg.state_layout = _capi.LAYOUTS[state_layout]
         cfg.state_slab_px = int(slab_px)
+        cfg.occlusion_mode = _capi.OCC_MODES[occlusion]
         if device_ids is not None and len(device_ids) >= 1:
             ids = np.ascontiguousarray(device_ids, dtype=np.int32)
             cfg.device_id = int(ids[0])

@@ -80,6 +80,30 @@ enum { RBS_PRECISION_DEFAULT = 0, RBS_PRECISION_F64 = 1, RBS_PRECISION_F32 = 2 }
 enum { RBS_STATE_DEFAULT = 0, RBS_STATE_WINDOWED = 1, RBS_STATE_DENSE = 2 };
 /* rbs_config.state_slab_px: see the field. */
 #define RBS_SLAB_WHOLE_PLANES (-1)
+/* rbs_config.occlusion_mode: how the occlusion process (OcclusionModel propagate, constants at
+ * R:source/dbot_ros/tracker/particle_tracker_node.cpp:176-189) is carried between frames.
+ *   REFERENCE   the reference CPU model's own bookkeeping: a pixel keeps the float posterior it was last UPDATED to and the
+ *               time of that update, and its prior at a later call is propagate(value, elapsed time) evaluated in binary64
+ *               and rounded once -- the oracle's mode LAZY, whose operations the device performs in the oracle's order, so
+ *               priors are bit-identical and log-likelihoods agree to the last digits of the transcendentals (~1e-13
+ *               relative; tests/test_gpu_exact_occlusion.py).  Storage: per pixel of a window the float and a 16-bit AGE
+ *               (frames since the update, counted against the slot's epoch = the last updating call): 6 bytes instead of
+ *               4; nothing is stepped between frames -- the copy kernel copies, ages advance by packed saturating adds.
+ *               A pixel whose age exceeds the frame count at which (p_oo - p_ov)^(age * delta_time) <= 2^-40 (1 628
+ *               frames with the defaults; at most 65 534) is the background again: its value differs from a
+ *               never-covered pixel's by less than that.  Binary64 likelihood and the windowed layout only
+ *               (RBS_ERR_UNSUPPORTED otherwise); every layout option of the windowed form works (slabs, several
+ *               devices, attached ranks, the shared trail).
+ *   DEVICE_RULE the float-stepped rule (oracle mode EAGER): every stored value advanced by one float FMA per updating
+ *               call and snapped onto the background within 2^-18 of it.  Within ~1e-8 of REFERENCE (relative, typical);
+ *               of 30 720 particle-frames one was 1.3e-5 away, and 16 of 600 000 resampled children drew a neighbouring
+ *               parent at 20 000 particles (both gone with REFERENCE).  All precisions and layouts.
+ * The hooks below that hand out or take whole planes (rbs_get/set_occlusion, rbs_export/import_plane/_window) deal in
+ * EFFECTIVE values as of the last updating call in both modes; in REFERENCE mode a plane handed in is taken "as of now"
+ * (ages 0), the rule of the oracle's set_occlusion.  rbs_occlusion_*device_ptr are RBS_ERR_UNSUPPORTED in REFERENCE mode
+ * (a slot is not a float plane).  DEFAULT = RBS_OCC_LIBRARY_DEFAULT. */
+enum { RBS_OCC_DEFAULT = 0, RBS_OCC_DEVICE_RULE = 1, RBS_OCC_REFERENCE = 2 };
+#define RBS_OCC_LIBRARY_DEFAULT RBS_OCC_DEVICE_RULE
 
 typedef struct rbs_handle rbs_handle;
 
@@ -149,7 +173,7 @@ typedef struct rbs_config {
      * several devices and ranks attached with rbs_ipc_attach keep ONE slab size among them: a group grows all its
      * shards together (synchronous calls), attached ranks do not grow. */
     int32_t state_slab_px;
-    int32_t reserved0;
+    int32_t occlusion_mode;         /* RBS_OCC_* (this field was reserved0 = 0 = DEFAULT before round 6: same layout, same ABI version) */
 } rbs_config;
 
 int32_t rbs_abi_version(void);

@@ -1,0 +1,87 @@
+"""rbs_config.occlusion_mode = RBS_OCC_REFERENCE ("stamped planes", round 6): the device keeps the reference CPU model's own
+occlusion bookkeeping -- the float posterior a pixel was last updated to and a per-pixel age -- and propagates in binary64 at
+use with the oracle's operations (oracle/rbsensor_oracle.c orc_propagate; constants at
+R:source/dbot_ros/tracker/particle_tracker_node.cpp:176-189).  Against the LAZY (reference-semantics) oracle the priors are
+then bit-identical, and the bars below are the transcendentals' own: 1e-11 relative on log-likelihoods where the float-stepped
+device rule has 1e-5, planes bit for bit."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scenarios as sc
+from dbot_ros_amd import RbSensor, RbSensorError, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-11   # relative to max(1, |ll|): what is left is the library's exp / erfc / log against libm's (<= 9e-16 per pixel term)
+
+
+def _rel(a, b):
+    return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max())
+
+
+def _planes_equal(g, lazy, slots, allow=0):
+    """Device planes (effective values as of the last updating call) against the LAZY model's "as of now" planes: the same
+    binary64 expression on the same stored floats, so bit for bit -- up to `allow` pixels at one float ulp (a posterior whose
+    float rounding sits within 1e-16 of a boundary: rbs_math against libm)."""
+    bad = 0
+    for s in slots:
+        a, b = g.get_occlusion(s), lazy.get_occlusion(s, now=True)
+        d = a != b
+        if d.any():
+            assert np.abs(a[d] - b[d]).max() <= 1.2e-7, (s, float(np.abs(a[d] - b[d]).max()))
+            bad += int(d.sum())
+    assert bad <= allow, bad
+
+
+@pytest.mark.parametrize("slab_px", [-1, 4096])
+def test_sequence_is_the_lazy_oracle(slab_px):
+    """A resampled sequence, 24 frames: every particle, every frame; then the planes."""
+    n = 96
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    lazy = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
+    frames = sc.make_frames(lazy, 1, 24, seed=3)
+    ref = sc.run_sequence(lazy, frames, n)
+    with RbSensor(om, cam, P, max_particles=n, occlusion="reference", slab_px=slab_px) as g:
+        got = sc.run_sequence(g, frames, n)
+        worst = max(_rel(a, b) for a, b in zip(got, ref))
+        print(f"stamped planes vs LAZY oracle, 24 resampled frames: {worst:.2e}")
+        assert worst <= TOL
+        _planes_equal(g, lazy, range(0, n, 7), allow=2)
+
+
+def test_skipped_frames_and_read_only_calls():
+    """Frames without an updating call in between (the clock runs on), read-only calls at any point: ages, not steps."""
+    n = 48
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    lazy = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
+    frames = sc.make_frames(lazy, 1, 10, seed=5)
+    with RbSensor(om, cam, P, max_particles=n, occlusion="reference") as g:
+        rng = np.random.default_rng(2)
+        for s in (lazy, g):
+            s.reset()
+        idx_o, idx_g = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for k, (truth, frame) in enumerate(frames):
+            for s in (lazy, g):
+                s.set_observation(frame)
+            poses = synth.particle_poses(truth, n, rng, scale=1.0 + 0.3 * k)
+            update = k % 3 != 1          # every third frame is only looked at
+            a = g.loglikes_poses(poses, idx_g, update=update)
+            b = lazy.loglikes_poses(poses, idx_o, update=update)
+            assert _rel(a, b) <= TOL, (k, _rel(a, b))
+            if update:
+                w = np.exp(b - b.max())
+                idx_o = np.sort(rng.choice(n, size=n, p=w / w.sum())).astype(np.int32)
+                idx_g = idx_o.copy()
+            if k == 6:   # two more frames pass unseen
+                for s in (lazy, g):
+                    s.set_observation(frame)
+                    s.set_observation(frame)
+
+
+def test_mode_needs_f64_and_windows():
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=8)
+    with pytest.raises(RbSensorError):
+        RbSensor(om, cam, P, max_particles=8, occlusion="reference", precision="f32")
+    with pytest.raises(RbSensorError):
+        RbSensor(om, cam, P, max_particles=8, occlusion="reference", state_layout="dense")
