@@ -110,6 +110,8 @@ def parse():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"],
                     help="likelihood precision of the headline run (f64 = the library default, the reference CPU model's arithmetic)")
     ap.add_argument("--layout", default="window", choices=["window", "dense"], help="occlusion state layout of the headline run")
+    ap.add_argument("--occlusion", default=None, choices=["reference", "device"],
+                    help="rbs_config.occlusion_mode of the headline run (default: the library's)")
     ap.add_argument("--slab-px", type=int, default=0, help="floats per occlusion slot (rbs_config.state_slab_px; 0 = whole planes)")
     ap.add_argument("--quick", action="store_true", help="headline only: no dense / f64 / host / tracker / cpu / pmc legs")
     ap.add_argument("--no-dense-leg", action="store_true", help="skip the whole-plane (state_layout=dense) comparison run")
@@ -552,11 +554,15 @@ def peer_configs_leg(a, dev, stream, dist, backend, world, rank, names=("c3_slic
     return res
 
 
-def make_sensor(a, om, cam, P, device, precision=None, layout=None, n=None):
+def make_sensor(a, om, cam, P, device, precision=None, layout=None, n=None, occlusion=None):
     from dbot_ros_amd import RbSensor
     lay = layout or a.layout
+    prec = precision or a.precision
+    occ = occlusion or getattr(a, "occlusion", None)
+    if occ == "reference" and (lay != "window" or prec != "f64"):
+        occ = "device"   # (stamped planes: binary64 likelihood on windowed planes only)
     return RbSensor(om, cam, P, device_id=device.index, max_particles=n or a.particles,
-                    precision=precision or a.precision, state_layout=lay, slab_px=a.slab_px if lay == "window" else 0)
+                    precision=prec, state_layout=lay, slab_px=a.slab_px if lay == "window" else 0, occlusion=occ)
 
 
 def prime(sensor, a, W):
@@ -1099,7 +1105,7 @@ def native_tracker_leg(om, cam, P, frames, init, counts, precision):
 
 
 # --------------------------------------------------------------------------------- tracker FPS
-def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30, precision=None, device_ids=None):
+def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30, precision=None, device_ids=None, occlusion=None):
     """Frames/s of the device tracker (rbs_tracker_*: transition, weights, KL, resampling and mean
     on the GPU, device RNG, one host sync per frame; the frame is uploaded from host memory every
     frame) on the 30-frame sequence.  Second half of BASELINE.json's metric."""
@@ -1112,7 +1118,8 @@ def tracker_fps(om, cam, device, counts=(200, 2000, 20000), n_frames=30, precisi
         P = RbSensorBuilder.Parameters(sample_count=n)
         # device_ids: the tracker SHARDED over several devices inside one handle (all states on every device, the sensor
         # call split, one RCCL all-gather of the log-likelihoods per sampling block)
-        with RbSensor(om, cam, P, device_id=device.index, max_particles=max(1, n // nb), precision=precision, device_ids=device_ids) as s:
+        with RbSensor(om, cam, P, device_id=device.index, max_particles=max(1, n // nb), precision=precision, device_ids=device_ids,
+                      occlusion=occlusion) as s:
             if frames is None:
                 rng = np.random.default_rng(0)
                 frames = [synth.make_frame(s.render_depth(synth.truth_pose(nb, frame=k)), cam.rows, cam.cols, rng,

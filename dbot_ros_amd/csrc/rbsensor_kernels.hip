@@ -1106,14 +1106,23 @@ __global__ void frame_aux_kernel(const float* __restrict__ frame, double* __rest
 // agree with the oracle's (libm) except where a term lies within ~1e-15 relative of a rounding
 // boundary -- about one pixel in 1e7 -- which tests/ bound (planes: <= 1e-4 of pixels at 1 ulp;
 // log-likelihoods: 1e-9).
-struct MathTabs { const double* erfc; const double* logt; };
+struct MathTabs { const double* erfc; const double* logt; const double* ages; };
+// Stamped planes: the first kLdsAges entries of the propagation table sit in LDS (a pixel the object covered within the last
+// two seconds -- nearly every evaluated pixel of a tracked object); an older one takes the table in memory.
+#ifndef RBS_EXACT_LDS_AGES
+#define RBS_EXACT_LDS_AGES 64
+#endif
+constexpr int kLdsAges = RBS_EXACT_LDS_AGES;
 
 #ifdef RBS_NOINLINE_EVAL
 #define RBS_EVAL_INLINE __attribute__((noinline))
 #else
 #define RBS_EVAL_INLINE inline
 #endif
-__device__ RBS_EVAL_INLINE double pixel_loglik(const DevParams& P, const MathTabs& M, int gi, float r, float prior, float& posterior)
+// EXACT (stamped planes): `prior` is the pixel's stored VALUE and `age` the frames since its update -- the table entry of that
+// age is requested WITH the frame terms, and the prior is formed once both have arrived (exact_prior's operations).
+template <bool EXACT = false>
+__device__ RBS_EVAL_INLINE double pixel_loglik(const DevParams& P, const MathTabs& M, int gi, float r, float prior, float& posterior, int age = 0)
 {
     // the per-frame terms of this pixel, observation included: one 32-byte entry, one memory round trip
     typedef double doublex2 __attribute__((ext_vector_type(2)));
@@ -1121,6 +1130,15 @@ __device__ RBS_EVAL_INLINE double pixel_loglik(const DevParams& P, const MathTab
     // faster: prefetching the next batch's entries across the scan loop is not worth its registers)
     const doublex2* a4 = reinterpret_cast<const doublex2*>(P.aux + (size_t)AUX_PLANES * gi);
     const doublex2 a01 = a4[0], a23 = a4[1];
+    doublex2 pt = {0.0, 0.0};
+    if (EXACT) {
+        const int ai = age > P.age_max ? 0 : age;   // (a background pixel's prior is bg_new whatever is computed here)
+        // (the LDS pointer in its own address space: left generic, the two loads are merged into ONE flat load through a selected
+        // pointer -- which waits on both memory counters and serialises with the frame-term gather)
+        typedef const doublex2 __attribute__((address_space(3)))* lds_table;
+        if (kLdsAges > 0 && __builtin_expect(__ballot(ai >= kLdsAges) == 0, 1)) pt = ((lds_table)M.ages)[ai];
+        else pt = reinterpret_cast<const doublex2*>(P.ptab)[ai];
+    }
     // what depends on the rendered depth alone runs while that entry travels
     const rbsm::PixelConsts C = {P.lambda, P.tw / kMaxDepth, P.cv0};
     const double rd = (double)r;
@@ -1130,6 +1148,11 @@ __device__ RBS_EVAL_INLINE double pixel_loglik(const DevParams& P, const MathTab
     posterior = prior;
     return a01.x + a01.y + a23.x + a23.y + g;
 #endif
+    if (EXACT) {
+        const double new_visible = pt.x * (1.0 - (double)prior) + pt.y;
+        const float pr = (float)(1.0 - new_visible);
+        prior = age > P.age_max ? P.bg_new : pr;
+    }
     return rbsm::pixel_loglik_f64(C, g, a01.x, a01.y, a23.x, a23.y, rd, prior, M.erfc, M.logt, posterior);
 }
 
@@ -1227,6 +1250,7 @@ struct Smem {
     double* mtab;   // precision F64: the erfc and log tables of rbs_math.h (kMathTabDoubles doubles)
     unsigned long long* cull;   // MANY: [kCullSteps][2] verdicts of the shared cluster cull (raster_window)
     int* ageq;                  // stamped planes: per wave kEvalQueue ages of the queued pixels (a fifth plane of the ring, behind everything else)
+    double* agetab;             // ... and the first kLdsAges entries of the propagation table
 };
 __device__ inline Smem carve(unsigned char* smem, int kTilePx, bool math_tables)
 {
@@ -1241,6 +1265,7 @@ __device__ inline Smem carve(unsigned char* smem, int kTilePx, bool math_tables)
     // (last, so that nothing else moves: shifting the rings and the tables by these 448 bytes cost C1 0.6 %)
     m.cull = reinterpret_cast<unsigned long long*>(m.mtab + (math_tables ? kMathTabDoubles : 0));
     m.ageq = nullptr;
+    m.agetab = nullptr;
     return m;
 }
 
@@ -1289,8 +1314,8 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int* q = m.evalq + wave * kQPlanes * kEvalQueue;   // planes: pixel index, depth bits, prior, observation
     int* aq = EXACT ? m.ageq + wave * kEvalQueue : nullptr;   // stamped planes: plane 2 holds the stored VALUE, this ring its age
-    const MathTabs mt = RBS_MATH_LDS ? MathTabs{m.mtab, m.mtab + rbsm::kErfcIntervals * rbsm::kErfcCoefs}
-                                     : MathTabs{rbsm::kErfcTab, rbsm::kLogTab};
+    const MathTabs mt = RBS_MATH_LDS ? MathTabs{m.mtab, m.mtab + rbsm::kErfcIntervals * rbsm::kErfcCoefs, m.agetab}
+                                     : MathTabs{rbsm::kErfcTab, rbsm::kLogTab, m.agetab};
     int qh = 0, qn = 0;                                // ring: head, count (wave-uniform)
     // evaluate the 64 (or, at the end, `cnt_`) oldest queued pixels
 #define RBS_EVAL_BATCH(cnt_)                                                                            \
@@ -1300,10 +1325,9 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
             const int eg_ = q[at_];                                                                     \
             const float ed_ = __int_as_float(q[kEvalQueue + at_]);                                      \
             float ep_ = __int_as_float(q[2 * kEvalQueue + at_]);                                        \
-            if (EXACT) ep_ = exact_prior(P, ep_, aq[at_]);                                              \
             float post_;                                                                                \
             if (PREC) ll += pixel_loglik_f32(P, ed_, ep_, __int_as_float(q[3 * kEvalQueue + at_]), post_); \
-            else ll += pixel_loglik(P, mt, eg_, ed_, ep_, post_);                                       \
+            else ll += pixel_loglik<EXACT>(P, mt, eg_, ed_, ep_, post_, EXACT ? aq[at_] : 0);           \
             /* plane 0 holds the child-plane offset in precision F32 (which needs no frame index), */   \
             /* plane 3 in F64 */                                                                        \
             if (UPDATE) dst[(PREC || !SLAB) ? eg_ : q[3 * kEvalQueue + at_]] = post_;                   \
@@ -1417,6 +1441,13 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
                         if (p1) w.x &= 0x0000ffffu;
                         if (p2) w.y &= 0xffff0000u;
                         if (p3) w.y &= 0x0000ffffu;
+                        // (These eight bytes per quad are what the mode costs: the ages' lines are as cold as the values' -- a child's slot was
+                        // last written two calls ago -- and the pixel pass is bound by the lines it has in flight.  Measured on C1, raster
+                        // kernel 0.166 ms with the device rule: 0.161 without any age traffic (no stepping to do), + 0.009 for the age
+                        // loads, + 0.022 for these stores, + 0.006 for the binary64 prior.  Tried and no better: the ages interleaved with
+                        // the values in 24-byte cells (0.200: 16-byte accesses at a 24-byte stride), non-temporal stores (0.195 - 0.205),
+                        // the stores deferred to one burst behind the pixel pass through the depth tile (0.197 against 0.197).
+                        // profiles/r06_exact_occlusion_cost.txt)
                         *reinterpret_cast<uint2*>(adst + db[u]) = w;
                     }
                     if (__ballot(ac[u]) == 0) continue;
@@ -1816,7 +1847,11 @@ __device__ __forceinline__ void raster_kernel_body(const DevParams& P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Smem m = carve(smem, P.tile_px, PREC == 0 && RBS_MATH_LDS);
-    if (EXACT) m.ageq = reinterpret_cast<int*>(smem + smem_bytes(P.tile_px, PREC == 0 && RBS_MATH_LDS, MANY));
+    if (EXACT) {
+        m.ageq = reinterpret_cast<int*>(smem + smem_bytes(P.tile_px, PREC == 0 && RBS_MATH_LDS, MANY));
+        m.agetab = reinterpret_cast<double*>(m.ageq + (kBlock / 64) * kEvalQueue);
+        for (int i = threadIdx.x; i < 2 * min(kLdsAges, P.age_max + 1); i += kBlock) m.agetab[i] = P.ptab[i];
+    }
     const int total = P.ctr_this[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) { P.ctr_next[0] = 0; P.ctr_next[1] = 0; }
     if (PREC == 0 && RBS_MATH_LDS) {   // once per persistent block (the first item's tile clear ends in a barrier)
@@ -2094,7 +2129,11 @@ __global__ __launch_bounds__(kBlock, RBS_EVAL_MINWAVES) void rbs_eval_kernel(con
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Smem m = carve(smem, 0, true);
-    if (EXACT) m.ageq = reinterpret_cast<int*>(smem + smem_bytes(0, true, false));
+    if (EXACT) {
+        m.ageq = reinterpret_cast<int*>(smem + smem_bytes(0, true, false));
+        m.agetab = reinterpret_cast<double*>(m.ageq + (kBlock / 64) * kEvalQueue);
+        for (int i = threadIdx.x; i < 2 * min(kLdsAges, P.age_max + 1); i += kBlock) m.agetab[i] = P.ptab[i];
+    }
     const int total = P.ctr_this[0];
     {
         constexpr int ne = rbsm::kErfcIntervals * rbsm::kErfcCoefs, nl = rbsm::kLogIntervals * 2;
@@ -2728,9 +2767,9 @@ constexpr size_t smem_bytes(int tile_px, bool math_tables, bool many, bool exact
 {
     return sizeof(unsigned) * (size_t)tile_px + sizeof(int) * kBigCap + sizeof(double) * (kBlock / 64) + 16 + (many ? 16 * kCullSteps : 0) +
            sizeof(int) * kQPlanes * (kBlock / 64) * kEvalQueue + (math_tables ? sizeof(double) * kMathTabDoubles : 0) +
-           (exact ? sizeof(int) * (kBlock / 64) * kEvalQueue : 0);   // (the stamped planes' age ring sits behind everything else)
+           (exact ? sizeof(int) * (kBlock / 64) * kEvalQueue + 16 * kLdsAges : 0);   // (the stamped planes' age ring and table head sit behind everything else)
 }
-constexpr int kExactRingPx = (kBlock / 64) * kEvalQueue;   // the age ring's size in tile pixels: the stamped kernels' tile is that much smaller
+constexpr int kExactRingPx = (kBlock / 64) * kEvalQueue + 4 * kLdsAges;   // the age ring's size in tile pixels: the stamped kernels' tile is that much smaller
 constexpr int kTilePxExact = kTilePxF64 - kExactRingPx, kTilePxBigExact = kTilePxBigF64 - kExactRingPx;
 static_assert(smem_bytes(kTilePxF64, true) <= smem_bytes(kTilePx, false) && smem_bytes(kTilePxBigF64, true) <= smem_bytes(kTilePxBig, false),
               "the F64 kernel's LDS block must not be larger than the F32 kernel's: the same number of blocks per CU");

@@ -177,18 +177,29 @@ def test_device_tracker_20000_particles_vs_oracle_tracker(gpu_lib, precision, to
         dev.close()
 
 
-@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("precision", ["reference", "f64", "f32"])
 def test_vga_long_sequence_against_reference_semantics(gpu_lib, precision):
-    """120 frames at 640x480 against the LAZY (reference-semantics) oracle: the device's eager
-    occlusion process against per-pixel time stamps, resampling every frame."""
+    """120 frames at 640x480 against the LAZY (reference-semantics) oracle, resampling every frame.
+    "reference": rbs_config.occlusion_mode REFERENCE (round 6) -- the device keeps the reference's per-pixel
+    stamps and propagates in binary64 at use: north_star's bar for EVERY particle, the cancelling sums included (measured
+    ~1e-13; asserted at 1e-9, four orders inside the bar).  "f64": the float-stepped device rule against the same oracle (the
+    bars this test had to take in round 5).  "f32": the opt-in float32 likelihood."""
+    occlusion = "reference" if precision == "reference" else "device"
+    precision = "f64" if precision == "reference" else precision
     n = 256 if precision == "f64" else 8      # (VERDICT r4 #4c: the default precision at n >= 256, resampled every frame)
     om, cam, P = sc.make_scene(("m1",), 640, 480, max_particles=n)
     lazy = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
     frames = sc.make_frames(lazy, 1, 120, seed=13)
     S = []
     ll_l = sc.run_sequence(lazy, frames, n, abs_sums=S)
-    with RbSensor(om, cam, P, max_particles=n, precision=precision) as g:
+    with RbSensor(om, cam, P, max_particles=n, precision=precision, occlusion=occlusion) as g:
         ll_g = sc.run_sequence(g, frames, n)
+    if occlusion == "reference":
+        worst = max(float(rel_err(a, b).max()) for a, b in zip(ll_g, ll_l))
+        print(f"\n120 frames x {n} particles at 640x480, occlusion_mode REFERENCE vs LAZY oracle: worst |d ll| / max(1, |ll|) over "
+              f"EVERY particle = {worst:.3e} (north_star: 1e-5)")
+        assert worst <= 1e-9, worst
+        return
     worst_rel, worst_s, over = 0.0, 0.0, []
     for k, (a, b, s_) in enumerate(zip(ll_g, ll_l, S)):
         if precision == "f64":
