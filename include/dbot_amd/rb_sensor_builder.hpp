@@ -157,6 +157,9 @@ public:
         // particle_filter/gpu/likelihood_precision; the reference has no such keys):
         std::vector<int> devices;            // empty: device_id alone; several: particle sharding inside the handle
         std::string likelihood_precision;    // "" (library default = f64, the reference CPU model's arithmetic) | "f64" | "f32" (opt-in, see rbsensor_mi355x.h)
+        std::string occlusion_mode;          // "" (library default) | "reference" (rbs_config.occlusion_mode REFERENCE: the CPU model's per-pixel time
+                                             // stamps, propagated in binary64 at use) | "device" (the float-stepped rule); rosparam particle_filter/gpu/occlusion_mode
+        bool borrow_frames = false;          // set_observation borrows the image instead of copying it (RbSensor::borrow_observations): off by default
     };
 
     RbSensorBuilder(const std::shared_ptr<ObjectModel>& object_model,
@@ -194,7 +197,8 @@ public:
 
     RbSensor(const ObjectModel& om, const CameraData& cam,
              const typename RbSensorBuilder<State>::Parameters& p, int device_id = 0)
-        : n_bodies_(om.count_parts()), integrated_poses_(om.count_parts())
+        : n_bodies_(om.count_parts()), integrated_poses_(om.count_parts()), max_particles_(static_cast<size_t>(p.sample_count > 0 ? p.sample_count : 0)),
+          borrow_(p.borrow_frames)
     {
         std::vector<Real> verts;
         std::vector<int32_t> tris, vcnt, tcnt;
@@ -225,6 +229,7 @@ public:
         cfg.delta_time = p.delta_time;
         cfg.likelihood_precision = p.likelihood_precision == "f64" ? RBS_PRECISION_F64
                                  : p.likelihood_precision == "f32" ? RBS_PRECISION_F32 : RBS_PRECISION_DEFAULT;
+        cfg.occlusion_mode = p.occlusion_mode == "reference" ? RBS_OCC_REFERENCE : p.occlusion_mode == "device" ? RBS_OCC_DEVICE_RULE : RBS_OCC_DEFAULT;
         std::vector<int32_t> devs(p.devices.begin(), p.devices.end());
         if (devs.size() > 1) {               // max_particles is then the total over the devices
             cfg.device_id = devs[0];
@@ -294,6 +299,8 @@ private:
     {
         const size_t n = deltas.size();
         if (indices.size() != n) throw std::runtime_error("RbSensor::loglikes: indices.size() != deltas.size()");
+        // (the library's pinned staging block holds max_particles states: a larger n is refused before anything is written into it -- ADVICE r5)
+        if (n > max_particles_) throw std::runtime_error("RbSensor::loglikes: more particles than Parameters::sample_count");
         // the filter's arguments go to the library as they are: state deltas + the default ("integrated") poses; the
         // composition R = R(delta) R(default), t = t(delta) + t(default) runs on the device
         // (rbs_loglikes_deltas).  A dbot State is a vector of its own per particle, so the host gathers them into one
@@ -347,8 +354,9 @@ private:
     rbs_handle* handle_ = nullptr;
     int n_bodies_;
     State integrated_poses_;
-    std::vector<Real> poses_, deltas_, defaults_;
+    size_t max_particles_ = 0;
     bool borrow_ = false;
+    std::vector<Real> poses_, deltas_, defaults_;
 };
 
 /// dbot::ObjectTransitionBuilder<State>: parameters of the velocity random walk

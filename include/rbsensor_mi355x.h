@@ -202,7 +202,12 @@ int32_t rbs_set_observation_f32(rbs_handle* h, const float* depth, size_t n);
  * image outlives the filter's set_observation / loglikes pair.  The occlusion clock advances at this call, as for
  * rbs_set_observation.  Handles over several devices, precision F32 and whole-plane handles copy at once (= rbs_set_observation).
  * "Returned" includes returned with an error: a likelihood call that is refused (bad indices, ...) or fails before it staged
- * the frame copies it on its way out -- the frame is the observation from then on, the buffer the caller's again. */
+ * the frame copies it on its way out -- the frame is the observation from then on, the buffer the caller's again.
+ * MEMORY: the two-kernel launch hands its depth tiles from the first kernel to the second through device memory, one tile (44 KB)
+ * per work item, allocated at the first such call for the worst case the call's particle count allows (every rectangle the whole
+ * frame: 36 tiles per particle at 640x480 -- 2.7 GB at 2 000 particles; rbs_tracker_*_f64 below 5 000 evaluations likewise).  The
+ * library takes it only if it is at most 8 GB AND at most half of the device's free memory; otherwise, or if the allocation fails,
+ * the call is launched as one kernel with the frame staged first (= rbs_set_observation), same results. */
 int32_t rbs_set_observation_borrowed(rbs_handle* h, const double* depth, size_t n);
 int32_t rbs_set_observation_borrowed_f32(rbs_handle* h, const float* depth, size_t n);   /* the same for the driver's float pixels */
 
@@ -252,7 +257,10 @@ int32_t rbs_loglikes(rbs_handle* h, const double* poses, int32_t* indices, int32
  * the upload stream, the per-pixel model terms behind it -- the 1.2 MB copy and transfer of a 640x480 frame pass
  * while the raster kernel runs.  The current observation is unchanged.  rbs_set_observation_prefetched then makes
  * that frame the observation at no cost (one frame per call, as rbs_set_observation_f32 does: the model clock
- * advances by delta_time); any other rbs_set_observation* in between abandons it.  Single-device handles. */
+ * advances by delta_time); any other rbs_set_observation* in between abandons it.  One frame may be waiting at a time: a second
+ * rbs_loglikes_prefetch with a next frame before the first has been installed (or abandoned) is RBS_ERR_INVALID_ARGUMENT -- a caller
+ * with several sampling blocks per frame hands the next frame to ONE of them and calls rbs_loglikes for the others.
+ * Single-device handles. */
 int32_t rbs_loglikes_prefetch(rbs_handle* h, const double* poses, int32_t* indices, int32_t n, int32_t update,
                               double* out_loglik, const float* next_depth, size_t next_n);
 int32_t rbs_set_observation_prefetched(rbs_handle* h);

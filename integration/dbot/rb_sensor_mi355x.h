@@ -48,6 +48,14 @@ public:
         std::vector<int> devices;            // empty: device 0; several: particle sharding inside the handle
         int likelihood_precision = RBS_PRECISION_DEFAULT;
         int state_slab_px = 0;               // 0: whole planes
+        int occlusion_mode = RBS_OCC_DEFAULT;    // RBS_OCC_REFERENCE: the CPU model's own per-pixel time stamps, propagated in binary64 at use
+        // set_observation(image) COPIES the image (rbs_set_observation), as dbot's own sensors do -- the default, and the same
+        // default as dbot_amd::RbSensor (include/dbot_amd/rb_sensor_builder.hpp).  borrow_frames = true: the image is only
+        // BORROWED (rbs_set_observation_borrowed) -- it must stay alive and unchanged until the filter's next loglikes() has
+        // RETURNED; that call then converts and sends it while its geometry kernel runs (+20 % on the synchronous step).
+        // Safe only if the caller of set_observation passes the tracker's own `image` through: a temporary (image.cast<...>(),
+        // an expression evaluated into the argument) would dangle.  Opt in where that has been checked against the filter in use.
+        bool borrow_frames = false;
     };
 
     RbSensorMI355X(const std::shared_ptr<ObjectModel>& object_model,
@@ -56,7 +64,8 @@ public:
                    double p_occluded_visible, double p_occluded_occluded, double initial_occlusion_prob,
                    double tail_weight, double model_sigma, double sigma_factor, double delta_time,
                    const Options& options = Options())
-        : Base(object_model->count_parts()), parts_(object_model->count_parts()), defaults_(static_cast<size_t>(6) * object_model->count_parts())
+        : Base(object_model->count_parts()), parts_(object_model->count_parts()), defaults_(static_cast<size_t>(6) * object_model->count_parts()),
+          max_particles_(sample_count), borrow_frames_(options.borrow_frames)
     {
         std::vector<double> vertices;
         std::vector<int32_t> triangles, vertex_counts, triangle_counts;
@@ -89,6 +98,7 @@ public:
         c.delta_time = delta_time;
         c.likelihood_precision = options.likelihood_precision;
         c.state_slab_px = options.state_slab_px;
+        c.occlusion_mode = options.occlusion_mode;
         devices_.assign(options.devices.begin(), options.devices.end());
         if (devices_.size() > 1) { c.device_id = devices_[0]; c.n_devices = static_cast<int32_t>(devices_.size()); c.device_ids = devices_.data(); }
         else if (devices_.size() == 1) c.device_id = devices_[0];
@@ -102,12 +112,11 @@ public:
 
     // image: rows*cols depths, row-major, metres, NaN = no reading (ri::to_eigen_vector,
     // R:source/dbot_ros/util/ros_interface.h:152-168)
-    // The image is BORROWED until the filter's next loglikes() has returned: inside tracker_->track(image) it outlives the
-    // set_observation / loglikes pair, and that loglikes() converts and sends it while its geometry kernel runs (the frame's
-    // 60-100 us hide behind the kernel).  A caller that cannot promise this uses rbs_set_observation (copies at once).
+    // Copied at once (Options::borrow_frames, off by default, borrows it instead: see there for the lifetime it needs).
     void set_observation(const Observation& image) override
     {
-        check(rbs_set_observation_borrowed(handle_, image.data(), static_cast<size_t>(image.size())));
+        if (borrow_frames_) check(rbs_set_observation_borrowed(handle_, image.data(), static_cast<size_t>(image.size())));
+        else check(rbs_set_observation(handle_, image.data(), static_cast<size_t>(image.size())));
     }
 
     // deltas: the particles' states around integrated_poses().  The composition
@@ -119,6 +128,8 @@ public:
     RealArray loglikes(const StateArray& deltas, IntArray& indices, const bool& update = false) override
     {
         const int n = static_cast<int>(deltas.size());
+        // (the library's block holds max_particles states: a larger n is refused before anything is written into it)
+        if (n > max_particles_) throw std::runtime_error("RbSensorMI355X::loglikes: more particles than sample_count");
         double* staging = nullptr;                     // the library's pinned staging block (a handle on one device), else our own
         if (rbs_deltas_buffer(handle_, &staging) != RBS_OK) { deltas_.resize(static_cast<size_t>(6) * n * parts_); staging = deltas_.data(); }
         for (int i = 0; i < n; ++i)
@@ -147,6 +158,8 @@ private:
     }
     rbs_handle* handle_ = nullptr;
     int parts_;
+    int max_particles_;
+    bool borrow_frames_;
     std::vector<double> deltas_, defaults_;
     std::vector<int32_t> devices_;
 };

@@ -17,8 +17,8 @@
 // sensor->set_observation(image) with the image as the reference hands it over -- a vector of rows*cols DOUBLES
 // (R:source/dbot_ros/util/ros_interface.h:152-168, R:source/dbot_ros/object_tracker_ros.hpp:44-49) -- and
 // sensor->loglikes(deltas, indices, update) with the particles' state DELTAS, one State (a heap vector of its own) per
-// particle, around integrated_poses(); synchronous, the frame inside the clock, no look-ahead.  The image is borrowed until
-// loglikes returns, as in the dbot binding (integration/dbot/rb_sensor_mi355x.h); --plugin-copy: copied at set_observation.
+// particle, around integrated_poses(); synchronous, the frame inside the clock, no look-ahead.  --plugin: the image is borrowed until
+// loglikes returns (Options::borrow_frames, opt-in); --plugin-copy: copied at set_observation -- the default of the mirror and of the dbot binding.
 //   host_bench --tracker-plugin <workload.bin> <particles>
 // the device tracker THROUGH THE MIRROR of the reference's builders (dbot_amd::ParticleTrackerBuilder(...).build(), tracker->initialize,
 // tracker->track(image of doubles) / submit + result): what dbot_ros's node would see.
@@ -162,7 +162,7 @@ int main(int argc, char** argv)
         std::shared_ptr<RbSensor<State>> sensor;
         try { sensor = RbSensorBuilder<State>(om, cam, p).build(); }
         catch (const std::exception& e) { std::printf("NO_DEVICE %s\n", e.what()); return 0; }
-        sensor->borrow_observations(!plugin_copy);   // (--plugin: as the dbot binding does -- the image outlives the set_observation / loglikes pair)
+        sensor->borrow_observations(!plugin_copy);   // (--plugin: the opt-in borrowed frames; --plugin-copy: the default)
         // the images as the reference's tracker receives them: doubles
         std::vector<std::vector<double>> images(F, std::vector<double>(npx));
         for (int k = 0; k < F; ++k) for (size_t q = 0; q < npx; ++q) images[k][q] = (double)frames[npx * k + q];
