@@ -371,7 +371,8 @@ def setup_peer_run(a, om, cam, P, W, dev, stream, dist, backend, world):
     # the same arithmetic as ~45 tensor kernels (dist.global_resample + dist.plan_shard), for comparison
     fused = os.environ.get("RBS_BENCH_TENSOR_RESAMPLE") != "1"
     pstep = rdist.PeerShardedStep(sensor, n, 2 * n, device=dev, min_share=2, stream=stream.cuda_stream, all_gather=gather,
-                                  temperature=a.resample_temperature, fused=fused)
+                                  temperature=a.resample_temperature, fused=fused,
+                                  shared_trail=os.environ.get("RBS_BENCH_PEER_SHARED_TRAIL", "1") != "0")   # (agreed by one all-reduce every 32 steps)
     gen = torch.Generator().manual_seed(1234)        # the same uniforms on every rank
     uniforms = [torch.rand(n * world, dtype=torch.float64, generator=gen) for _ in range(16)]
     if fused:
@@ -610,6 +611,58 @@ def configs_leg(a, dev, stream, names=("c1_readonly", "c2", "c3_slice", "c4_slic
     return res
 
 
+def sweep_truths(n_frames):
+    """The travelling object of the sweep legs: along the diagonal of the visible volume at 0.7 m and back, 2 mm per frame."""
+    from dbot_ros_amd import synth
+    p0, p1 = np.array([-0.30, -0.21, 0.7]), np.array([0.30, 0.21, 0.7])
+    length = float(np.linalg.norm(p1 - p0))
+    truths = []
+    for k in range(n_frames):
+        s_ = (0.002 * k) % (2.0 * length)
+        s_ = s_ if s_ <= length else 2.0 * length - s_           # there and back
+        t = synth.truth_pose(1, frame=k % 360).copy()
+        t[0, 9:12] = p0 + (p1 - p0) * (s_ / length)
+        truths.append(t)
+    return truths
+
+
+def sweep_tracker_run(make, om, frames, truths, n, tail, shared_trail):
+    """The device tracker (its own KL-triggered resampling) following the sweep's object, frame by frame from host memory: rate over the
+    last `tail` frames, stored window fraction at the end.  make() -> the sensor (a context manager); shared_trail: RBS_SHARED_TRAIL."""
+    from dbot_ros_amd import pose
+    from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
+    n_frames = len(frames)
+    init = np.zeros(12)
+    Rt = truths[0][0]
+    init[3:6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
+    init[0:3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0]
+    old_env = os.environ.get("RBS_SHARED_TRAIL")
+    os.environ["RBS_SHARED_TRAIL"] = "1" if shared_trail else "0"
+    try:
+        with make() as s:
+            trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=1)).build()
+            tr = DeviceParticleTracker(trans, s, om, ParticleTrackerBuilder.Parameters(evaluation_count=n), device_rng=True, seed=3)
+            tr.initialize([init])
+            errs = []
+            for k in range(1, n_frames - tail):
+                tr.track(frames[k])
+            t0 = time.perf_counter()
+            for k in range(n_frames - tail, n_frames):
+                est = tr.track(frames[k])
+                errs.append(float(np.linalg.norm(est[0:3] - (truths[k][0, 9:12] - truths[k][0, :9].reshape(3, 3) @ om.centers[0]))))
+            el = time.perf_counter() - t0
+            w = np.array([s.get_window(q) for q in range(0, n, max(1, n // 64))])
+            fr = float(np.mean(np.maximum(0, w[:, 2] - w[:, 0]) * np.maximum(0, w[:, 3] - w[:, 1]))) / (s.rows * s.cols)
+            active, rebases = s.shared_trail_state()
+            tr.close()
+    finally:
+        if old_env is None:
+            os.environ.pop("RBS_SHARED_TRAIL", None)
+        else:
+            os.environ["RBS_SHARED_TRAIL"] = old_env
+    return {"fps": tail / el, "value": n * tail / el, "window_fraction": fr, "position_error_max_m": max(errs), "rebasings": rebases}
+
+
 def sweep_leg(a, dev, stream, n_frames=1000, tail=200, table=(0.03, 0.10, 0.25, 0.50)):
     """What the windowed state layout sustains when the object MOVES ACROSS THE IMAGE: a pixel stays in a
     particle's window until its occlusion value has relaxed to within 2^-18 of the background, ~730 frames (24 s) after the
@@ -628,16 +681,7 @@ def sweep_leg(a, dev, stream, n_frames=1000, tail=200, table=(0.03, 0.10, 0.25, 
     res = {}
     rng = np.random.default_rng(7)
     prng = np.random.default_rng(8)
-    # the diagonal of the visible volume at 0.7 m (fx = 570: +-0.39 m x +-0.29 m), a margin of the object's size kept
-    p0, p1 = np.array([-0.30, -0.21, 0.7]), np.array([0.30, 0.21, 0.7])
-    length = float(np.linalg.norm(p1 - p0))
-    truths = []
-    for k in range(n_frames):
-        s_ = (0.002 * k) % (2.0 * length)
-        s_ = s_ if s_ <= length else 2.0 * length - s_           # there and back
-        t = synth.truth_pose(1, frame=k % 360).copy()
-        t[0, 9:12] = p0 + (p1 - p0) * (s_ / length)
-        truths.append(t)
+    truths = sweep_truths(n_frames)
     with RbSensor(om, cam, P, device_id=dev.index, max_particles=1) as r:
         frames = np.stack([synth.make_frame(r.render_depth(t), b.rows, b.cols, rng) for t in truths]).astype(np.float32)
     # the particles of a tracker that follows the object: a cloud around the truth, one fixed set of offsets (the transition's spread)
@@ -688,39 +732,9 @@ def sweep_leg(a, dev, stream, n_frames=1000, tail=200, table=(0.03, 0.10, 0.25, 
     # filter's own genealogy -- children share parents, so the trail is common to the particles -- with the shared background
     # plane (the library's default once windows have grown) and without it (RBS_SHARED_TRAIL=0)
     try:
-        from dbot_ros_amd import pose
-        from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
-        init = np.zeros(12)
-        Rt = truths[0][0]
-        init[3:6] = pose.matrix_to_rotvec(Rt[:9].reshape(3, 3))
-        init[0:3] = Rt[9:] - Rt[:9].reshape(3, 3) @ om.centers[0]
-        for tag, env in (("sweep_tracker", "1"), ("sweep_tracker_scalar_background", "0")):
-            old_env = os.environ.get("RBS_SHARED_TRAIL")
-            os.environ["RBS_SHARED_TRAIL"] = env
-            try:
-                with make_sensor(b, om, cam, P, dev) as s:
-                    trans = ObjectTransitionBuilder(ObjectTransitionBuilder.Parameters(part_count=1)).build()
-                    tr = DeviceParticleTracker(trans, s, om, ParticleTrackerBuilder.Parameters(evaluation_count=n), device_rng=True, seed=3)
-                    tr.initialize([init])
-                    errs = []
-                    for k in range(1, n_frames - tail):
-                        tr.track(frames[k])
-                    t0 = time.perf_counter()
-                    for k in range(n_frames - tail, n_frames):
-                        est = tr.track(frames[k])
-                        errs.append(float(np.linalg.norm(est[0:3] - (truths[k][0, 9:12] - truths[k][0, :9].reshape(3, 3) @ om.centers[0]))))
-                    el = time.perf_counter() - t0
-                    w = np.array([s.get_window(q) for q in range(0, n, max(1, n // 64))])
-                    fr = float(np.mean(np.maximum(0, w[:, 2] - w[:, 0]) * np.maximum(0, w[:, 3] - w[:, 1]))) / (b.rows * b.cols)
-                    active, rebases = s.shared_trail_state()
-                    tr.close()
-                res.update({tag + "_fps": tail / el, tag + "_value": n * tail / el, tag + "_window_fraction": fr,
-                            tag + "_position_error_max_m": max(errs), tag + "_rebasings": rebases})
-            finally:
-                if old_env is None:
-                    os.environ.pop("RBS_SHARED_TRAIL", None)
-                else:
-                    os.environ["RBS_SHARED_TRAIL"] = old_env
+        for tag, env in (("sweep_tracker", True), ("sweep_tracker_scalar_background", False)):
+            r_ = sweep_tracker_run(lambda: make_sensor(b, om, cam, P, dev), om, frames, truths, n, tail, env)
+            res.update({tag + "_" + k_: v_ for k_, v_ in r_.items()})
         res["sweep_tracker_note"] = ("the same travelling object followed by the device tracker (%d particles, frame by frame from host memory, "
                                      "its own KL-triggered resampling): frames/s and particle-likelihoods/s over the last %d of %d frames, stored window "
                                      "fraction at the end; sweep_tracker_*: planes stored against the shared background plane once windows have grown "
@@ -1301,9 +1315,28 @@ def sharded_tracker_child(a):
     fps = tracker_fps(om, cam, dev, precision=a.precision, device_ids=ids)
     fps.pop("_native", None)
     print("SHARDED_TRACKER " + json.dumps({str(k): {"fps": v["fps"], "fps_pipelined": v["fps_pipelined"]} for k, v in fps.items()}), flush=True)
+    # the travelling object under the tracker sharded over the job's devices: the shared trail on a handle over several devices
+    # (one decision per call for all shards, every device its own copy of the shared plane -- round 6)
+    try:
+        from dbot_ros_amd import RbSensor, RbSensorBuilder, synth
+        n, n_frames, tail = 2000 * len(ids), 600, 150
+        truths = sweep_truths(n_frames)
+        rng = np.random.default_rng(7)
+        Pn = RbSensorBuilder.Parameters(sample_count=n)
+        with RbSensor(om, cam, Pn, device_id=ids[0], max_particles=1) as r:
+            frames = np.stack([synth.make_frame(r.render_depth(t), cam.rows, cam.cols, rng) for t in truths]).astype(np.float32)
+        out = {}
+        for tag, env in (("sweep_tracker_sharded", True), ("sweep_tracker_sharded_scalar_background", False)):
+            r_ = sweep_tracker_run(lambda: RbSensor(om, cam, Pn, max_particles=n, precision=a.precision, device_ids=ids), om, frames, truths, n, tail, env)
+            out.update({tag + "_" + k_: v_ for k_, v_ in r_.items()})
+        out["sweep_tracker_sharded_note"] = (f"the sweep legs' travelling object followed by the device tracker over ONE handle on devices {ids}, {n} particles, "
+                                             f"rate over the last {tail} of {n_frames} frames; *_scalar_background_*: RBS_SHARED_TRAIL=0")
+        print("SHARDED_SWEEP " + json.dumps(out), flush=True)
+    except Exception as e:   # noqa: BLE001
+        print("SHARDED_SWEEP " + json.dumps({"sweep_tracker_sharded_note": f"failed: {e!r}"}), flush=True)
 
 
-def sharded_tracker_leg(a, ids, timeout=420):
+def sharded_tracker_leg(a, ids, timeout=600):
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
                         "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE")}
@@ -1329,6 +1362,9 @@ def sharded_tracker_leg(a, ids, timeout=420):
                                                "particle states, the sensor call is sharded, RCCL all-gather of the log-likelihoods per sampling "
                                                "block; frame uploaded from host memory every frame; a process of its own started by rank 0 while "
                                                "the ranks wait")
+            for line2 in r.stdout.splitlines():
+                if line2.startswith("SHARDED_SWEEP "):
+                    out.update(json.loads(line2[len("SHARDED_SWEEP "):]))
             return out
     return dict(chk, in_handle_rccl_ok=False, tracker_fps_sharded_note="sharded tracker leg failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
 

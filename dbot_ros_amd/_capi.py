@@ -33,6 +33,7 @@ EXPORTS = (
     "rbs_set_observation_native_f32", "rbs_set_observation_device", "rbs_get_observation", "rbs_loglikes",
     "rbs_acquire_frame_buffer", "rbs_commit_frame_buffer", "rbs_loglikes_prefetch", "rbs_set_observation_prefetched",
     "rbs_loglikes_deltas", "rbs_get_poses", "rbs_deltas_buffer", "rbs_set_observation_borrowed", "rbs_set_observation_borrowed_f32", "rbs_shared_trail_state",
+    "rbs_shared_trail_rebase", "rbs_window_fraction",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_export_plane", "rbs_import_plane",
     "rbs_export_window", "rbs_import_window", "rbs_stream_join", "rbs_ipc_export", "rbs_ipc_attach", "rbs_stage_windows", "rbs_peer_resample",
@@ -161,6 +162,10 @@ def load():
     lib.rbs_get_window.argtypes = [H, C.c_int32, C.POINTER(C.c_int32)]
     lib.rbs_shared_trail_state.restype = C.c_int32
     lib.rbs_shared_trail_state.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.rbs_shared_trail_rebase.restype = C.c_int32
+    lib.rbs_shared_trail_rebase.argtypes = [H, C.c_int32]
+    lib.rbs_window_fraction.restype = C.c_int32
+    lib.rbs_window_fraction.argtypes = [H, C.POINTER(C.c_double)]
     lib.rbs_get_background.restype = C.c_int32
     lib.rbs_get_background.argtypes = [H, C.POINTER(C.c_float)]
     lib.rbs_raster_kernel_ms.restype = C.c_int32

@@ -134,6 +134,17 @@ struct rbs_handle {
     long stp_last_rebase = -1000000;
     long stp_rebases = 0;
     long stp_block_until = 0;               // re-basing did not shrink the windows (particles that share no ancestor): not again before this call
+    // Round 6: the shared trail on handles whose planes OTHERS read in place.  The planes of every shard of a group (every rank of
+    // an attached job) are stored against ONE shared plane, of which every device keeps its own identical copy: it starts as the
+    // scalar level everywhere, steps with the same operations on every device, and is re-based by all of them in the SAME call on
+    // the SAME global slot (a shard reads that slot's plane from its owner, in place) -- so "outside its window" means the same
+    // values whichever device asks.  A group takes ONE decision per call for all its shards (group_begin_call, from the largest
+    // window fraction any shard has sampled); attached ranks are told by their caller (rbs_shared_trail_rebase: the same call on
+    // every rank before the same step), who has the collective to agree on it.
+    struct StpNow { int rebase = -1; bool entering = false; } stp_now;   // group: this call's directive to the shards
+    bool stp_leave_pending = false;         // group: the call in flight leaves the shared trail (the group's own state follows at the next call)
+    int stp_request = -1;                   // rbs_shared_trail_rebase: >= 0 re-base on that GLOBAL slot at the next updating call (entering if need be), -2: leave
+    bool ipc_exported = false;              // other processes may map this handle's planes (rbs_ipc_export): it no longer switches on its own
     int4* d_bgp_box = nullptr;              // [1] bounding box of the shared plane's values that differ from the scalar background
     bool split = false;
     unsigned* d_depth = nullptr;    // [depth_items][kDepthTilePx]
@@ -426,6 +437,44 @@ void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size
 
 int32_t stage_borrowed(rbs_handle* h);
 
+// The shared plane's own step on stream s: bgp[1 - cur] = step(bgp[cur]), re-based first on local slot `rebase` of the planes
+// (occ, win, reg) -- its owner's, wherever they live -- or (-2) reset to the scalar level.
+int32_t launch_bgp_step(rbs_handle* h, const DevParams& P, const float* occ, const int4* win, const int4* reg, int rebase, hipStream_t s)
+{
+    if (h->exact)
+        hipLaunchKernelGGL(rbs::rbs_bgp_step_exact_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, h->d_bgp[h->cur], h->d_bgp[1 - h->cur],
+                           occ, win, reg, P.plane_stride, P.plane_px, rebase, h->rows, h->cols, P.elapsed2, P.bg_new);
+    else
+        hipLaunchKernelGGL(rbs::rbs_bgp_step_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, h->d_bgp[h->cur], h->d_bgp[1 - h->cur],
+                           occ, win, reg, P.plane_stride, rebase, h->rows, h->cols, P.alpha, P.beta, P.bg_new);
+    RBS_HIP(h, hipGetLastError());
+    return RBS_OK;
+}
+
+// The shared trail's policy (rbs_handle::stp), one decision per call: `o` owns the state -- a handle of its own, or the GROUP for
+// all its shards.  Returns this call's directive: rebase >= 0 (re-base on that slot's plane; entering: the shared plane starts as
+// the scalar level first), -2 (back to the scalar background), -1 (nothing).
+rbs_handle::StpNow stp_decide(rbs_handle* o, bool update, double area_frac)
+{
+    rbs_handle::StpNow d;
+    const long since = o->calls - o->stp_last_rebase;
+    if (update && o->stp && area_frac > o->wide_enter && since >= 16 && since < o->stp_every) {
+        // re-basing did not help: the windows are still most of the frame a sample or two later -- the particles share no
+        // ancestor (a synthetic permutation of parents; a filter that never resamples).  Back to the scalar background and
+        // the whole-plane machinery that serves such windows best: this call re-measures every child against the scalar
+        // level over the bounding box of the shared plane's own values.
+        d.rebase = -2;
+    } else if (update && !o->stp && area_frac > o->stp_enter && o->calls > 0 && o->calls >= o->stp_block_until) {
+        d.entering = true;
+        d.rebase = 0;
+        o->stp = true;
+    } else if (update && o->stp && area_frac > o->stp_enter && since >= o->stp_every) {
+        d.rebase = 0;
+    }
+    if (o->stp && d.rebase >= 0) { o->stp_last_rebase = o->calls; o->stp_rebases += 1; }
+    return d;
+}
+
 int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indices, int n,
                          bool update, double* d_out, hipStream_t s, const double* host_poses = nullptr, const double* host_deltas = nullptr)
 {
@@ -508,27 +557,32 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         h->area_pending = false;
     }
     // shared trail: enter once the windows have grown, re-base while they stay large (see rbs_handle::stp)
-    int rebase = -1;          // >= 0: re-base on that slot's plane; -2: back to the scalar background
+    int rebase = -1;          // >= 0: re-base on that (global) slot's plane; -2: back to the scalar background
     bool stp_leaving = false;
     P.bgp_src = nullptr; P.bgp_dst = nullptr; P.rebase_box = nullptr;
-    if (h->windowed && !h->group && h->peer_world <= 1 && h->precision == RBS_PRECISION_F64 && h->stp_allowed) {
-        const long since = h->calls - h->stp_last_rebase;
-        if (update && h->stp && h->area_frac > h->wide_enter && since >= 16 && since < h->stp_every) {
-            // re-basing did not help: the windows are still most of the frame a sample or two later -- the particles share no
-            // ancestor (a synthetic permutation of parents; a filter that never resamples).  Back to the scalar background and
-            // the whole-plane machinery that serves such windows best: this call re-measures every child against the scalar
-            // level over the bounding box of the shared plane's own values.
-            hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_bgp_box, 1, make_int4(h->cols, h->rows, 0, 0));
-            if (h->exact)
-                hipLaunchKernelGGL(rbs::rbs_bbox_age_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, h->d_bgp[h->cur], h->rows, h->cols,
-                                   (unsigned)h->age_max, reinterpret_cast<int*>(h->d_bgp_box));
-            else
-            hipLaunchKernelGGL(rbs::rbs_bbox_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, h->d_bgp[h->cur], h->rows, h->cols,
-                               h->background, reinterpret_cast<int*>(h->d_bgp_box));
-            RBS_HIP(h, hipGetLastError());
-            rebase = -2;
-            stp_leaving = true;
-        } else if (update && !h->stp && h->area_frac > h->stp_enter && h->calls > 0 && h->calls >= h->stp_block_until) {
+    rbs_handle* const so = h->group ? h->group : h;   // who owns the shared trail's state: the group for all its shards
+    if (h->windowed && h->precision == RBS_PRECISION_F64 && so->stp_allowed) {
+        rbs_handle::StpNow d;
+        if (h->group) {
+            d = so->stp_now;                               // (decided once for every shard: group_begin_call)
+        } else if (h->peer_world > 1 || h->ipc_exported || h->stp_request != -1) {   // the caller's directive (rbs_shared_trail_rebase): attached ranks always
+            if (update && h->stp_request != -1) {
+                if (h->stp_request >= 0) {
+                    d.rebase = h->stp_request;
+                    d.entering = !h->stp;
+                    h->stp_last_rebase = h->calls;
+                    h->stp_rebases += 1;
+                } else if (h->stp) {
+                    d.rebase = -2;
+                }
+                h->stp_request = -1;
+            }
+        } else {
+            d = stp_decide(h, update, h->area_frac);
+        }
+        rebase = d.rebase;
+        stp_leaving = rebase == -2;
+        if (d.entering || (h->group && so->stp && !h->stp && !stp_leaving)) {   // this device's copy of the shared plane: the scalar level everywhere
             for (int k = 0; k < 2; ++k)
                 if (!h->d_bgp[k]) RBS_HIP(h, hipMalloc(&h->d_bgp[k], sizeof(float) * (h->exact ? exact_stride((size_t)h->npx) : (size_t)h->npx)));
             if (!h->d_bgp_box) RBS_HIP(h, hipMalloc(&h->d_bgp_box, sizeof(int4)));
@@ -538,16 +592,24 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
                 RBS_HIP(h, hipMemsetAsync(h->d_bgp[h->cur] + h->npx, 0xff, sizeof(unsigned short) * (size_t)h->npx, s));
             h->stp = true;
             h->wide = false;
-            rebase = 0;
-        } else if (update && h->stp && h->area_frac > h->stp_enter && h->calls - h->stp_last_rebase >= h->stp_every) {
-            rebase = 0;
+        }
+        if (stp_leaving && h->stp) {
+            hipLaunchKernelGGL(rbs::rbs_set_window_kernel, dim3(1), dim3(64), 0, s, h->d_bgp_box, 1, make_int4(h->cols, h->rows, 0, 0));
+            if (h->exact)
+                hipLaunchKernelGGL(rbs::rbs_bbox_age_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, h->d_bgp[h->cur], h->rows, h->cols,
+                                   (unsigned)h->age_max, reinterpret_cast<int*>(h->d_bgp_box));
+            else
+            hipLaunchKernelGGL(rbs::rbs_bbox_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, h->d_bgp[h->cur], h->rows, h->cols,
+                               h->background, reinterpret_cast<int*>(h->d_bgp_box));
+            RBS_HIP(h, hipGetLastError());
         }
         if (h->stp) {
             P.bgp_src = h->d_bgp[h->cur];
             P.bgp_dst = h->d_bgp[1 - h->cur];
-            P.rebase_box = rebase >= 0 ? P.win_src + rebase : rebase == -2 ? h->d_bgp_box : nullptr;
             h->wide = false;   // (the whole-plane machinery knows the scalar background only)
-            if (rebase >= 0) { h->stp_last_rebase = h->calls; h->stp_rebases += 1; h->area_frac = 0.0; }   // (judged again from the next sample)
+            if (rebase >= 0) h->area_frac = 0.0;   // (judged again from the next sample)
+        } else {
+            rebase = -1; stp_leaving = false;
         }
     }
     // the whole-plane layout always runs two raster blocks per CU and can afford the larger LDS
@@ -657,18 +719,17 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipStreamWaitEvent(s, h->ev_join[h->join_pending], 0));
         h->join_pending = -1;
     }
-    if (P.bgp_src && update && h->exact) {
-        hipLaunchKernelGGL(rbs::rbs_bgp_step_exact_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, P.bgp_src, h->d_bgp[1 - h->cur],
-                           P.occ_src, P.win_src, h->slab_px ? P.reg_src : (const int4*)nullptr, P.plane_stride, P.plane_px, rebase, h->rows, h->cols,
-                           P.elapsed2, P.bg_new);
-        RBS_HIP(h, hipGetLastError());
-    } else
-    if (P.bgp_src && update) {   // the shared plane's own step (and re-basing): reads the current planes, complete after the join above
-        hipLaunchKernelGGL(rbs::rbs_bgp_step_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, s, P.bgp_src, h->d_bgp[1 - h->cur],
-                           P.occ_src, P.win_src, h->slab_px ? P.reg_src : (const int4*)nullptr, P.plane_stride, rebase, h->rows, h->cols,
-                           P.alpha, P.beta, P.bg_new);
-        RBS_HIP(h, hipGetLastError());
+    // the plane the shared plane is re-based on: GLOBAL slot `rebase`, wherever it lives (a shard / an attached rank reads it from its owner)
+    const float* rb_occ = P.occ_src; const int4* rb_win = P.win_src; const int4* rb_reg = h->slab_px ? P.reg_src : (const int4*)nullptr;
+    int rb_local = rebase;
+    if (rebase >= 0 && P.n_dev > 1) {
+        const int owner = rebase / P.shard_cap;
+        rb_local = rebase - owner * P.shard_cap;
+        rb_occ = P.occ_src_dev[owner]; rb_win = P.win_src_dev[owner]; rb_reg = h->slab_px ? P.reg_src_dev[owner] : (const int4*)nullptr;
     }
+    if (P.bgp_src) P.rebase_box = rebase >= 0 ? rb_win + rb_local : rebase == -2 ? h->d_bgp_box : nullptr;
+    if (P.bgp_src && update)   // the shared plane's own step (and re-basing): reads the current planes, complete after the join above
+        if (int32_t rc = launch_bgp_step(h, P, rb_occ, rb_win, rb_reg, rebase >= 0 ? rb_local : rebase, s)) return rc;
     bool sample_area = false;
     if (h->windowed && update) {
         sample_area = timed && !h->area_pending;
@@ -2071,9 +2132,25 @@ int32_t poison(rbs_handle* h, int32_t rc)
 // the other shards' current planes (complete only when their previous updating call is) and
 // overwrites the buffer the other shards' previous call was still reading.  All waits are
 // issued before any shard enqueues (an event waited on is the one last recorded).
-int32_t group_begin_call(rbs_handle* g, hipStream_t const* streams)
+int32_t group_begin_call(rbs_handle* g, hipStream_t const* streams, bool update)
 {
     const int nd = (int)g->shards.size();
+    // the shared trail: ONE decision for every shard of this call (rbs_handle::stp_now), from the largest window fraction any
+    // shard has sampled so far
+    if (g->stp_leave_pending) {   // the previous call left the shared trail
+        g->stp = false;
+        g->stp_block_until = g->calls + 4000;
+        g->stp_leave_pending = false;
+    }
+    g->stp_now = rbs_handle::StpNow();
+    if (g->windowed && g->precision == RBS_PRECISION_F64 && g->stp_allowed) {
+        double frac = 0.0;
+        for (rbs_handle* h : g->shards) frac = std::max(frac, h->area_frac);
+        g->stp_now = stp_decide(g, update, frac);
+        if (g->stp_now.rebase >= 0) for (rbs_handle* h : g->shards) h->area_frac = 0.0;
+        if (g->stp_now.rebase == -2) { g->stp_leave_pending = true; for (rbs_handle* h : g->shards) h->area_frac = 1.0; }
+    }
+    g->calls += 1;
     for (int k = 0; k < nd; ++k) {
         g->snap_occ[k] = g->shards[k]->d_occ[g->shards[k]->cur];
         g->snap_win[k] = g->shards[k]->d_win[g->shards[k]->cur];
@@ -2088,19 +2165,52 @@ int32_t group_begin_call(rbs_handle* g, hipStream_t const* streams)
     return RBS_OK;
 }
 
-// A shard that evaluates no particle in an updating call still moves its state on with the group.
-void advance_empty(rbs_handle* h, bool update)
+// A shard that evaluates no particle in an updating call still moves its state on with the group -- its copy of the shared
+// plane included (entering, stepping, re-basing, leaving: every device's copy stays the same plane).
+int32_t advance_empty(rbs_handle* h, bool update)
 {
-    if (!update) return;
+    if (!update) return RBS_OK;
     float alpha, beta;
     occlusion_coeffs(h, h->pending_frames, &alpha, &beta);
-    h->background = std::fmaf(alpha, h->background, beta);
-    if (h->exact) h->background = exact_background(h, h->update_clock + h->pending_frames);
+    const float bg_new = h->exact ? exact_background(h, h->update_clock + h->pending_frames) : std::fmaf(alpha, h->background, beta);
+    rbs_handle* g = h->group;
+    if (g && h->windowed && h->precision == RBS_PRECISION_F64 && g->stp_allowed) {
+        const rbs_handle::StpNow d = g->stp_now;
+        if (d.entering || (g->stp && !h->stp && d.rebase != -2)) {
+            for (int k = 0; k < 2; ++k)
+                if (!h->d_bgp[k]) RBS_HIP(h, hipMalloc(&h->d_bgp[k], sizeof(float) * (h->exact ? exact_stride((size_t)h->npx) : (size_t)h->npx)));
+            if (!h->d_bgp_box) RBS_HIP(h, hipMalloc(&h->d_bgp_box, sizeof(int4)));
+            hipLaunchKernelGGL(rbs::rbs_fill_kernel, dim3(256), dim3(256), 0, h->stream, h->d_bgp[h->cur], (size_t)h->npx, h->background);
+            RBS_HIP(h, hipGetLastError());
+            if (h->exact) RBS_HIP(h, hipMemsetAsync(h->d_bgp[h->cur] + h->npx, 0xff, sizeof(unsigned short) * (size_t)h->npx, h->stream));
+            h->stp = true;
+            h->wide = false;
+        }
+        if (h->stp) {
+            DevParams P = h->base;
+            P.alpha = alpha; P.beta = beta; P.bg_new = bg_new;
+            P.plane_stride = (int)h->plane_stride;
+            P.plane_px = h->slab_px ? h->slab_px : h->npx;
+            const unsigned e = (unsigned)std::min(h->pending_frames, 0xffff);
+            P.elapsed2 = e | (e << 16);
+            int rb = d.rebase;
+            const float* occ = nullptr; const int4* win = nullptr; const int4* reg = nullptr;
+            if (rb >= 0) {
+                const int owner = rb / g->shard_cap;
+                occ = g->snap_occ[owner]; win = g->snap_win[owner]; reg = h->slab_px ? g->snap_reg[owner] : (const int4*)nullptr;
+                rb -= owner * g->shard_cap;
+            }
+            if (int32_t rc = launch_bgp_step(h, P, occ, win, reg, rb, h->stream)) return rc;
+            if (d.rebase == -2) { h->stp = false; h->area_frac = 1.0; }
+        }
+    }
+    h->background = bg_new;
     h->cur = 1 - h->cur;
     h->update_clock += h->pending_frames;
     h->pending_frames = 0;
     // (h->calls stays: it selects the work-item counters, and a raster kernel zeroes the counters of
     // the call that FOLLOWS it -- a skipped call must not change which pair is next)
+    return RBS_OK;
 }
 
 int32_t group_load_rccl(rbs_handle* g, const std::vector<int>& devs)
@@ -2197,6 +2307,10 @@ int32_t create_group(const rbs_config* cfg, rbs_handle* g)
     }
     g->windowed = g->shards[0]->windowed;
     g->precision = g->shards[0]->precision;
+    g->stp_allowed = g->shards[0]->stp_allowed;      // (the shared trail's policy is the group's: one decision per call for every shard)
+    g->stp_enter = g->shards[0]->stp_enter;
+    g->stp_every = g->shards[0]->stp_every;
+    g->wide_enter = g->shards[0]->wide_enter;
 #ifdef RBS_TEST_HOOKS   // (librbsensor_mi355x_hooks.so, `make hooks`: the release library carries no fault injection -- ADVICE r3)
     if (const char* f = std::getenv("RBS_TEST_FAULT")) {
         int a = -1; long c = -1;
@@ -2355,17 +2469,19 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
             return fail(g, RBS_ERR_INVALID_ARGUMENT, fmt("loglikes: indices[%d] = %d outside 0..%d", i, indices[i], nd * cap - 1));
     std::vector<CallState> before;
     for (rbs_handle* h : g->shards) before.push_back(save_call_state(h));
+    const CallState gbefore = save_call_state(g);      // (the shared trail's state is the group's)
+    const bool gleave = g->stp_leave_pending;
     const size_t stride = (size_t)12 * g->n_bodies;
     bool stale_overflow = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         // from here on a failure leaves some shards advanced and others not: the group is poisoned
-        if (int32_t rc = group_begin_call(g, nullptr)) return poison(g, rc);
+        if (int32_t rc = group_begin_call(g, nullptr, update != 0)) return poison(g, rc);
         for (int k = 0; k < nd; ++k) {
             rbs_handle* h = g->shards[k];
             const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
             if (hipSetDevice(h->device) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, fmt("hipSetDevice(%d) failed", h->device)));
             if (cnt <= 0) {
-                advance_empty(h, update != 0);
+                if (int32_t rc = advance_empty(h, update != 0)) return poison(g, gfail(g, h, rc));
                 if (hipEventRecord(h->ev_done, h->stream) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, "hipEventRecord failed"));
                 continue;
             }
@@ -2400,6 +2516,8 @@ int32_t group_loglikes(rbs_handle* g, const double* poses, int32_t* indices, int
         // (the planes it read are intact), every shard's slabs are enlarged alike -- a shard reads
         // its neighbours' planes with its own stride -- and the call runs again
         if (int32_t rc = group_grow_slabs(g, &before)) return poison(g, rc);
+        restore_call_state(g, gbefore);
+        g->stp_leave_pending = gleave;
     }
     if (update)
         for (int32_t i = 0; i < n; ++i) indices[i] = i;
@@ -2456,14 +2574,14 @@ int32_t group_loglikes_device(rbs_handle* g, const double* d_poses, const int32_
         RBS_HIP(g, hipStreamWaitEvent(g->shards[k]->stream, s0->ev_reader, 0));
     }
     // from here on a failure leaves some shards advanced and others not: the group is poisoned
-    if (int32_t rc = group_begin_call(g, nullptr)) return poison(g, rc);
+    if (int32_t rc = group_begin_call(g, nullptr, update != 0)) return poison(g, rc);
     const size_t stride = (size_t)12 * g->n_bodies;
     for (int k = 0; k < nd; ++k) {
         rbs_handle* h = g->shards[k];
         const int lo = std::min(n, k * cap), cnt = std::min(n, (k + 1) * cap) - lo;
         if (hipSetDevice(h->device) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, fmt("hipSetDevice(%d) failed", h->device)));
         if (cnt <= 0) {
-            advance_empty(h, update != 0);
+            if (int32_t rc = advance_empty(h, update != 0)) return poison(g, gfail(g, h, rc));
             if (hipEventRecord(h->ev_done, h->stream) != hipSuccess) return poison(g, fail(g, RBS_ERR_HIP, "hipEventRecord failed"));
             continue;
         }
@@ -2590,6 +2708,12 @@ int32_t rbs_reset(rbs_handle* h)
         }
         h->poisoned = false;
         h->frame_acquired = false;
+        h->stp = false;
+        h->stp_leave_pending = false;
+        h->stp_now = rbs_handle::StpNow();
+        h->stp_last_rebase = -1000000;
+        h->stp_block_until = 0;
+        h->calls = 0;
         return RBS_OK;
     }
     RBS_HIP(h, hipSetDevice(h->device));
@@ -2603,6 +2727,7 @@ int32_t rbs_reset(rbs_handle* h)
     h->borrowed = nullptr;
     h->borrowed_f32 = nullptr;
     h->stp = false;            // (every plane is all background again: the scalar says it all)
+    h->stp_request = -1;
     h->stp_last_rebase = -1000000;
     h->stp_block_until = 0;
     h->area_frac = 0.0;
@@ -3302,7 +3427,8 @@ int32_t rbs_ipc_export(rbs_handle* h, void* blob_out)
     RBS_HIP(h, hipSetDevice(h->device));
     if (h->stp) return fail(h, RBS_ERR_UNSUPPORTED, "ipc_export: the handle already stores its planes against a shared background plane of its own "
                                                     "(windows grew past the shared-trail threshold): rbs_reset first, then export");
-    h->stp_allowed = false;   // (other ranks read these planes in place: the implicit background must be the scalar they all have)
+    h->ipc_exported = true;   // (other ranks read these planes in place: from now on the shared trail is entered / re-based / left only when the
+                              //  caller says so, on every rank alike -- rbs_shared_trail_rebase)
     if (int32_t rc = drain(h, true)) return rc;
     std::memset(blob_out, 0, RBS_IPC_BLOB_BYTES);
     IpcBlob b{};
@@ -3323,6 +3449,7 @@ int32_t rbs_ipc_attach(rbs_handle* h, int32_t rank, int32_t world, const void* b
     if (world < 1 || world > rbs::kMaxDevices || rank < 0 || rank >= world)
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("ipc_attach: rank %d of %d (at most %d ranks)", rank, world, rbs::kMaxDevices));
     if (h->peer_world > 1) return fail(h, RBS_ERR_INVALID_ARGUMENT, "ipc_attach: already attached");
+    if (h->stp) return fail(h, RBS_ERR_UNSUPPORTED, "ipc_attach: the handle stores its planes against a shared background plane already: rbs_reset first");
 #ifdef RBS_TEST_HOOKS   // (librbsensor_mi355x_hooks.so only) RBS_TEST_ATTACH_HANG=1: the call never returns -- what hipIpcOpenMemHandle was
                         // seen to do for some buffer sizes; tests/test_gpu_fullsize.py checks that bench.py --gpus N still prints its line
     if (const char* e = std::getenv("RBS_TEST_ATTACH_HANG"))
@@ -3585,10 +3712,32 @@ int32_t rbs_get_window(rbs_handle* h, int32_t slot, int32_t out[4])
     return RBS_OK;
 }
 
+int32_t rbs_window_fraction(rbs_handle* h, double* out)
+{
+    if (!h || !out) return RBS_ERR_INVALID_ARGUMENT;
+    double f = h->area_frac;
+    for (rbs_handle* sh : h->shards) f = std::max(f, sh->area_frac);
+    *out = f;
+    return RBS_OK;
+}
+
+int32_t rbs_shared_trail_rebase(rbs_handle* h, int32_t global_slot)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!h->shards.empty()) return fail(h, RBS_ERR_UNSUPPORTED, "shared_trail_rebase: a handle over several devices decides for its shards itself");
+    if (!h->windowed || h->precision != RBS_PRECISION_F64)
+        return fail(h, RBS_ERR_UNSUPPORTED, "shared_trail_rebase: windowed planes and the binary64 likelihood only");
+    const int slots = std::max(1, h->peer_world) * h->max_particles;
+    if (global_slot != -2 && (global_slot < 0 || global_slot >= slots))
+        return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("shared_trail_rebase: slot %d outside 0..%d (or -2: leave)", global_slot, slots - 1));
+    h->stp_request = global_slot;
+    return RBS_OK;
+}
+
 int32_t rbs_shared_trail_state(rbs_handle* h, int32_t* active, int32_t* rebases)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
-    RBS_GROUP_FIRST(h, rbs_shared_trail_state(sh_, active, rebases));
+    // (a handle over several devices: the group's own state -- one decision for all shards)
     if (active) *active = h->stp ? 1 : 0;
     if (rebases) *rebases = (int32_t)h->stp_rebases;
     return RBS_OK;
@@ -3901,7 +4050,7 @@ int32_t group_tracker_track(rbs_tracker* t, const float* frame, const double* no
                 hipLaunchKernelGGL(rbt::shard_gather_kernel, dim3((unsigned)((cnt + 255) / 256)), b256, 0, streams[k], r->T, lo, cnt);
             RBT_HIP(t, hipGetLastError());
         }
-        if (int32_t rc = group_begin_call(g, nullptr)) return rc;
+        if (int32_t rc = group_begin_call(g, nullptr, last)) return rc;
         for (int k = 0; k < nd; ++k) {
             rbs_tracker* r = t->reps[k];
             rbs_handle* h = r->s;
@@ -3911,7 +4060,7 @@ int32_t group_tracker_track(rbs_tracker* t, const float* frame, const double* no
                 if (int32_t rc = enqueue_loglikes(h, r->T.poses_sorted, r->T.idx_sorted, cnt, last, r->T.ll_sorted + lo, h->stream))
                     return gfail(g, h, rc);
             } else {
-                advance_empty(h, last);
+                if (int32_t rc = advance_empty(h, last)) return gfail(g, h, rc);
                 RBT_HIP(t, hipEventRecord(h->ev_done, h->stream));
             }
         }

@@ -375,10 +375,16 @@ class PeerShardedStep:
     operations (the CPU tests drive the oracle through them; the one-GPU test gathers through gloo).
     fused=True: global_resample + plan_shard as ONE library kernel (rbs_peer_resample) instead of ~45 tensor
     kernels; the step's uniforms must then be SORTED ascending (children are exchangeable: the parents come out
-    sorted either way, and they are the same parents), step() returns this rank's slice of the sorted parents."""
+    sorted either way, and they are the same parents), step() returns this rank's slice of the sorted parents.
+    shared_trail=True (round 6): the ranks' planes are stored against ONE shared background plane once windows have grown
+    (include/rbsensor_mi355x.h, rbs_shared_trail_rebase): every trail_every steps each rank looks at the window fraction its
+    handle sampled last (no synchronisation), the ranks agree by ONE all-reduce (max) of that flag -- `agree(flag) -> bool`
+    replaces it -- and, if any rank's windows exceed trail_threshold of the frame, every rank tells its handle to re-base on
+    global slot 0 at the step that follows.  Values do not change by a bit; stored windows shrink to what the particles do not
+    share with their common ancestor."""
 
     def __init__(self, sensor, n, cap, group=None, device=None, min_share=2, stream=None, evaluate=None, stage=None, all_gather=None,
-                 temperature=1.0, fused=False, world=None, rank=None):
+                 temperature=1.0, fused=False, world=None, rank=None, shared_trail=False, trail_every=32, trail_threshold=0.10, agree=None):
         self.sensor, self.n, self.cap, self.group, self.device, self.min_share = sensor, n, cap, group, device, min_share
         self.temperature = temperature
         self.fused = fused
@@ -404,6 +410,8 @@ class PeerShardedStep:
         self._all_gather = all_gather or ((lambda out, inp: out.copy_(inp)) if self.world == 1 and world is not None
                                           else (lambda out, inp: dist.all_gather_into_tensor(out, inp, group=group)))
         self._keep = None
+        self.shared_trail, self.trail_every, self.trail_threshold, self._steps = shared_trail, max(1, int(trail_every)), trail_threshold, 0
+        self._agree = agree or self._agree_all_reduce
         if fused:   # two sets of plan buffers: a step's plan is read by kernels enqueued behind the next step's
             self._plans = [tuple(torch.full((n,), -1, dtype=torch.int32, device=device) for _ in range(4)) for _ in range(2)]
             self._flip = 0
@@ -412,10 +420,23 @@ class PeerShardedStep:
         self.sensor.loglikes_device(poses.data_ptr(), parent_idx.data_ptr(), self.n, True, out.data_ptr(), self.stream)
         self.sensor.stream_join(self.stream)
 
+    def _agree_all_reduce(self, flag):
+        """True on every rank if `flag` is true on any: one all-reduce (max) of one number (the backend's device)."""
+        if self.world == 1:
+            return bool(flag)
+        on_device = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([1.0 if flag else 0.0], device=self.device if on_device else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(t.item() > 0.5)
+
     def step(self, poses, uniforms):
         """One updating call + exchange + resampling.  poses: this rank's [n, 12 bodies] tensor; `uniforms` [N]
         identical on every rank (fused: ascending).  Returns the sorted global parents (indices into the gathered
         vector) -- fused: this rank's n of them."""
+        if self.shared_trail and self._steps > 0 and self._steps % self.trail_every == 0:
+            if self._agree(self.sensor.window_fraction() > self.trail_threshold):
+                self.sensor.shared_trail_rebase(0)      # (every rank, the same slot, before the same step)
+        self._steps += 1
         self._evaluate(poses, self.parent_idx, self.d_out)
         self._all_gather(self.d_all, self.d_out)
         if self.fused:

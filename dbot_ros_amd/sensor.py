@@ -375,6 +375,17 @@ class RbSensor:
         self._check(self._lib.rbs_shared_trail_state(self._h, C.byref(a), C.byref(r)))
         return bool(a.value), int(r.value)
 
+    def shared_trail_rebase(self, global_slot):
+        """rbs_shared_trail_rebase: at the next updating call enter the shared-trail representation (if need be) and re-base the shared
+        plane on that GLOBAL slot's plane; -2: back to the scalar background.  Attached ranks: the same call on every rank."""
+        self._check(self._lib.rbs_shared_trail_rebase(self._h, int(global_slot)))
+
+    def window_fraction(self):
+        """The window area the handle sampled last, as a fraction of the frame (what the shared trail's policy looks at)."""
+        v = C.c_double()
+        self._check(self._lib.rbs_window_fraction(self._h, C.byref(v)))
+        return float(v.value)
+
     def get_background(self):
         v = C.c_float()
         self._check(self._lib.rbs_get_background(self._h, C.byref(v)))

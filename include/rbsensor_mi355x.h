@@ -356,9 +356,23 @@ int32_t rbs_get_window(rbs_handle* h, int32_t slot, int32_t out[4]);
  * re-measured against it, so that what the particles share from a common ancestor is stored once (after a resampling that is
  * nearly all of it).  Stored VALUES do not change by a bit -- the shared plane steps with the float operations of any stored
  * value -- and every entry point sees whole planes as before (rbs_get_occlusion, rbs_export_window: the slot is made dense first).
- * RBS_SHARED_TRAIL=0 in the environment disables it; handles whose planes other ranks read in place (rbs_ipc_export) never use it.
+ * RBS_SHARED_TRAIL=0 in the environment disables it; handles over several devices and attached ranks: see rbs_shared_trail_rebase below.
  * Inspection: *active = the handle has switched, *rebases = how often it re-based so far. */
 int32_t rbs_shared_trail_state(rbs_handle* h, int32_t* active, int32_t* rebases);
+/* Round 6: the shared trail where OTHERS read a handle's planes in place.  A handle over several devices (rbs_config.n_devices) takes
+ * ONE decision per call for all its shards -- every device keeps its own, identical copy of the shared plane, stepped alike and
+ * re-based in the same call on the same global slot, whose plane the other devices read from its owner -- and needs nothing from the
+ * caller.  Handles of one process per GPU (rbs_ipc_export / rbs_ipc_attach) cannot agree among themselves: the CALLER, who owns the
+ * collective, tells every rank before the SAME updating call -- rbs_shared_trail_rebase(h, global_slot): at the next updating call the
+ * handle enters the shared-trail representation if it has not yet and re-bases its shared plane on that global slot's plane (any
+ * rank's; read in place); global_slot = -2: it returns to the scalar background at that call.  Same slot, same call, every rank --
+ * dbot_ros_amd/dist.py PeerShardedStep does it (shared_trail=True: every 32 steps while any rank's windows exceed a tenth of the
+ * frame, agreed by one all-reduce of a flag).  On a handle of its own the call forces a re-basing on one of its slots (tests).
+ * Values are unchanged by a bit, as for a single handle; an exported handle never switches by itself. */
+int32_t rbs_shared_trail_rebase(rbs_handle* h, int32_t global_slot);
+/* The window area the handle sampled last (mean over its particles of the region an updating call stored, as a fraction of the
+ * frame; sampled every 8th updating call, read back without blocking): what the shared trail's policy looks at. */
+int32_t rbs_window_fraction(rbs_handle* h, double* out);
 int32_t rbs_get_background(rbs_handle* h, float* out);
 /* Stored occlusion plane of a slot -> host float[rows*cols]. */
 int32_t rbs_get_occlusion(rbs_handle* h, int32_t slot, float* out);

@@ -76,3 +76,71 @@ def test_two_bodies_borrowed_sequence():
             ig, ip = parents[k].copy(), parents[k].copy()
         for q in range(0, n, 173):
             assert np.array_equal(g.get_occlusion(q), plain.get_occlusion(q)), q
+
+
+# ---- the shared trail where others read a handle's planes in place ----
+TOL_EAGER = 1e-9
+
+
+@pytest.mark.parametrize("occlusion,slab", [("device", 0), ("device", 16384), ("reference", 0)])
+def test_shared_trail_on_two_shards_stores_the_same_planes(monkeypatch, occlusion, slab):
+    """One handle over two shards (device_ids = [0, 0]): the group takes ONE decision per call for both shards, each keeps its own
+    identical copy of the shared plane, re-based in the same call on the same global slot (read from its owner).  Against the same
+    handle with the shared trail disabled: log-likelihoods and planes bit for bit, read-only calls included; windows smaller."""
+    n, cols, rows = 128, 640, 480
+    om, cam, P = sc.make_scene(("m1",), cols, rows, max_particles=n)
+    o = ob.Oracle(om, cam, P, max_particles=n, mode=ob.EAGER if occlusion == "device" else ob.LAZY)
+    rng = np.random.default_rng(31)
+    frames = []
+    for k in range(26):
+        t = synth.truth_pose(1, frame=k)
+        t[:, 9] += -0.12 + 0.01 * k
+        t[:, 10] += -0.06 + 0.005 * k
+        frames.append((t, synth.make_frame(o.render_depth(t), rows, cols, rng)))
+    poses = [synth.particle_poses(t, n, rng, scale=1.0) for t, _ in frames]
+    parents = [np.sort(rng.choice(n, size=n, p=(lambda w: w / w.sum())(rng.random(n) ** 8))).astype(np.int32) for _ in frames]
+    monkeypatch.setenv("RBS_SHARED_TRAIL", "0")
+    with RbSensor(om, cam, P, max_particles=n, device_ids=[0, 0], occlusion=occlusion, slab_px=slab) as plain:
+        monkeypatch.setenv("RBS_SHARED_TRAIL", "1")
+        monkeypatch.setenv("RBS_STP_ENTER", "0.0")
+        monkeypatch.setenv("RBS_STP_EVERY", "3")
+        with RbSensor(om, cam, P, max_particles=n, device_ids=[0, 0], occlusion=occlusion, slab_px=slab) as g:
+            g.set_timing_every(1); plain.set_timing_every(1)
+            for s_ in (g, plain, o):
+                s_.reset()
+            ig, ip, io = (np.zeros(n, np.int32) for _ in range(3))
+            for k, (_, frame) in enumerate(frames):
+                for s_ in (g, plain, o):
+                    s_.set_observation(frame)
+                if k % 5 == 4:
+                    ra, rb = g.loglikes_poses(poses[k - 1], ig.copy(), update=False), plain.loglikes_poses(poses[k - 1], ip.copy(), update=False)
+                    assert np.array_equal(ra, rb), (k, np.abs(ra - rb).max())
+                la, lb = g.loglikes_poses(poses[k], ig, update=True), plain.loglikes_poses(poses[k], ip, update=True)
+                lo = o.loglikes_poses(poses[k], io, update=True)
+                assert np.array_equal(la, lb), (k, np.abs(la - lb).max())
+                assert (np.abs(la - lo) / np.maximum(1.0, np.abs(lo))).max() <= TOL_EAGER
+                ig, ip, io = parents[k].copy(), parents[k].copy(), parents[k].copy()
+            active, rebases = g.shared_trail_state()
+            assert active and rebases >= 3, (active, rebases)
+            assert plain.shared_trail_state() == (False, 0)
+            area = lambda w: max(0, w[2] - w[0]) * max(0, w[3] - w[1])
+            slots = list(range(0, n, max(1, n // 16)))
+            a_g, a_p = np.mean([area(g.get_window(q)) for q in slots]), np.mean([area(plain.get_window(q)) for q in slots])
+            print(f"\ntwo shards, occlusion {occlusion}, slab {slab}: mean window: shared trail {a_g:.0f} px, scalar background {a_p:.0f} px ({rebases} re-basings)")
+            assert a_g < 0.75 * a_p
+            for q in slots:
+                assert np.array_equal(g.get_occlusion(q), plain.get_occlusion(q)), q
+
+
+def test_shared_trail_across_processes():
+    """tests/peer_trail_worker.py: two processes on cuda:0, handles attached over HIP IPC, dist.PeerShardedStep with
+    shared_trail=True (rbs_shared_trail_rebase on every rank before the same step) against the same job without it."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "peer_trail_worker.py")
+    port = 27100 + os.getpid() % 800
+    r = subprocess.run([sys.executable, script, str(port)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "TRAIL_OK" in r.stdout, r.stdout[-2000:]
+    print(r.stdout[-900:])
