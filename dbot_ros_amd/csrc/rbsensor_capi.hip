@@ -164,6 +164,7 @@ struct rbs_handle {
     int precision = RBS_PRECISION_F64;
     // Stamped planes (rbs_config.occlusion_mode = RBS_OCC_REFERENCE; DevParams::exact): a slot is plane_px floats + plane_px
     // 16-bit ages, plane_stride floats in all.
+    bool one_body_kernel = true;    // single-body models take rbs_raster_kernel_one_f64 (RBS_ONE_BODY=0, tooling: the general kernel)
     bool exact = false;
     int age_max = 0;            // ages beyond it are background
     double* d_ptab = nullptr;   // [age_max + 1][2] the propagation table
@@ -411,6 +412,15 @@ void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size
             case 5: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<true, false, true>), grid, block, smem, s, P); break;
             case 6: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<true, true, false>), grid, block, smem, s, P); break;
             default: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<true, true, true>), grid, block, smem, s, P); break;
+        }
+        return;
+    }
+    if (h->one_body_kernel && !h->many_clusters && h->precision == RBS_PRECISION_F64 && h->n_bodies == 1 && !P.groups) {
+        switch ((update ? 2 : 0) | (h->slab_px ? 1 : 0)) {
+            case 0: hipLaunchKernelGGL((rbs::rbs_raster_kernel_one_f64<false, false>), grid, block, smem, s, P); break;
+            case 1: hipLaunchKernelGGL((rbs::rbs_raster_kernel_one_f64<false, true>), grid, block, smem, s, P); break;
+            case 2: hipLaunchKernelGGL((rbs::rbs_raster_kernel_one_f64<true, false>), grid, block, smem, s, P); break;
+            default: hipLaunchKernelGGL((rbs::rbs_raster_kernel_one_f64<true, true>), grid, block, smem, s, P); break;
         }
         return;
     }
@@ -1862,6 +1872,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         // tuning overrides (defaults are the measured best on MI355X)
         if (const char* m = std::getenv("RBS_RASTER_BLOCKS")) h->raster_blocks = std::max(1, std::atoi(m));
         if (const char* m = std::getenv("RBS_SHARED_TRAIL")) h->stp_allowed = std::atoi(m) != 0;
+        if (const char* m = std::getenv("RBS_ONE_BODY")) h->one_body_kernel = std::atoi(m) != 0;
         if (const char* m = std::getenv("RBS_STP_ENTER")) h->stp_enter = std::atof(m);
         if (const char* m = std::getenv("RBS_STP_EVERY")) h->stp_every = std::max(1, std::atoi(m));
         h->split = RBS_SPLIT_DEFAULT != 0;
@@ -2054,7 +2065,9 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f64<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f64<false, true>),
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<false, true>),
             reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f64<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f64<true, true>),
-            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<true, true>)};
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_many_f32<true, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_one_f64<false, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_one_f64<false, true>),
+            reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_one_f64<true, false>), reinterpret_cast<const void*>(&rbs::rbs_raster_kernel_one_f64<true, true>)};
         for (const void* k : kernels)
             RBS_HIP(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbs::smem_bytes(rbs::kTilePxBig, false, true)));
         if (h->exact) {
