@@ -64,6 +64,8 @@ struct rbs_handle {
     int* d_rects[2] = {nullptr, nullptr};  // [max_particles][4], alternating per call: the previous
                                 // call's copy kernel may still be reading its rectangles
     rbs::Groups* d_groups[2] = {nullptr, nullptr};   // [max_particles] per-group rectangles (several bodies), alternating like d_rects
+    rbs::Strips* d_strips[2] = {nullptr, nullptr};   // [max_particles] the copy kernel's cells outside the groups' rectangles (windowed planes), alternating alike
+    bool copy_walk = false;                          // RBS_COPY_WALK=1 (tooling / A-B): several bodies take the walk over the whole region instead
     int* d_parents[2] = {nullptr, nullptr};   // [max_particles] snapshot of the caller's indices, alternating like d_rects
     int4* d_win[2] = {nullptr, nullptr};   // [max_particles] window of each plane, per buffer
     int4* d_win_used = nullptr; // [max_particles] region the copy kernel writes this call
@@ -708,6 +710,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     int* const d_rects = h->d_rects[h->calls & 1];
     P.rects = d_rects;
     P.groups = h->d_groups[h->calls & 1];
+    P.strips = update && h->windowed && !h->copy_walk ? h->d_strips[h->calls & 1] : nullptr;
     P.parents = h->d_parents[h->calls & 1];
     P.item_range = h->d_item_range;
     P.item_particle = h->d_item_particle;
@@ -816,31 +819,23 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
         RBS_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_fork, 0));
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_start[tslot], h->copy_stream));
         const int ny = std::min(n, 32768);
-        const dim3 wg((unsigned)(P.groups || !RBS_COPY_STRIPS ? h->win_chunks : h->win_chunks_single), (unsigned)ny, (unsigned)((n + ny - 1) / ny));
-        const bool strips = RBS_COPY_STRIPS && !P.groups;
-        if (h->exact) {
-#define RBS_X(S, T, B) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<S, T, B, true>), wg, dim3(64), 0, h->copy_stream, P); break
-            switch ((h->slab_px ? 4 : 0) | (strips ? 2 : 0) | (P.bgp_src ? 1 : 0)) {
-                case 0: RBS_X(false, false, false);  case 1: RBS_X(false, false, true);
-                case 2: RBS_X(false, true, false);   case 3: RBS_X(false, true, true);
-                case 4: RBS_X(true, false, false);   case 5: RBS_X(true, false, true);
-                case 6: RBS_X(true, true, false);    default: RBS_X(true, true, true);
-            }
-#undef RBS_X
-        } else
-        if (P.bgp_src && h->slab_px) {
-            if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, true, true>), wg, dim3(64), 0, h->copy_stream, P);
-            else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, false, true>), wg, dim3(64), 0, h->copy_stream, P);
-        } else if (P.bgp_src) {
-            if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, true, true>), wg, dim3(64), 0, h->copy_stream, P);
-            else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, false, true>), wg, dim3(64), 0, h->copy_stream, P);
-        } else if (h->slab_px) {
-            if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, true>), wg, dim3(64), 0, h->copy_stream, P);
-            else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<true, false>), wg, dim3(64), 0, h->copy_stream, P);
-        } else {
-            if (strips) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, true>), wg, dim3(64), 0, h->copy_stream, P);
-            else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<false, false>), wg, dim3(64), 0, h->copy_stream, P);
+        // one body: only the cells outside its rectangle are enumerated (1); several bodies: the strip list the rectangles kernel
+        // made (2: round 6); RBS_COPY_STRIPS=0 builds / RBS_COPY_WALK=1: the walk over the whole region (0)
+        const int strips = !RBS_COPY_STRIPS ? 0 : !P.groups ? 1 : (P.strips ? 2 : 0);
+        const dim3 wg((unsigned)(strips == 1 ? h->win_chunks_single : h->win_chunks), (unsigned)ny, (unsigned)((n + ny - 1) / ny));
+#define RBS_X3(S, B, E)                                                                                                             \
+        do {                                                                                                                        \
+            if (strips == 2) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<S, 2, B, E>), wg, dim3(64), 0, h->copy_stream, P);      \
+            else if (strips == 1) hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<S, 1, B, E>), wg, dim3(64), 0, h->copy_stream, P); \
+            else hipLaunchKernelGGL((rbs::rbs_copy_window_kernel<S, 0, B, E>), wg, dim3(64), 0, h->copy_stream, P);                  \
+        } while (0)
+        switch ((h->exact ? 4 : 0) | (h->slab_px ? 2 : 0) | (P.bgp_src ? 1 : 0)) {
+            case 0: RBS_X3(false, false, false); break;  case 1: RBS_X3(false, true, false); break;
+            case 2: RBS_X3(true, false, false); break;   case 3: RBS_X3(true, true, false); break;
+            case 4: RBS_X3(false, false, true); break;   case 5: RBS_X3(false, true, true); break;
+            case 6: RBS_X3(true, false, true); break;    default: RBS_X3(true, true, true); break;
         }
+#undef RBS_X3
         RBS_HIP(h, hipGetLastError());
         if (timed) RBS_HIP(h, hipEventRecord(h->ev_copy_stop[tslot], h->copy_stream));
         RBS_HIP(h, hipEventRecord(h->ev_join[slot], h->copy_stream));
@@ -1243,6 +1238,8 @@ void release(rbs_handle* h)
     (void)hipFree(h->d_rects[1]);
     (void)hipFree(h->d_groups[0]);
     (void)hipFree(h->d_groups[1]);
+    (void)hipFree(h->d_strips[0]);
+    (void)hipFree(h->d_strips[1]);
     (void)hipFree(h->d_parents[0]);
     (void)hipFree(h->d_parents[1]);
     (void)hipFree(h->d_win[0]);
@@ -1980,6 +1977,9 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     if (h->n_bodies > 1 && !(std::getenv("RBS_NO_GROUPS") && std::atoi(std::getenv("RBS_NO_GROUPS")))) {
         RBS_HIP(h, hipMalloc(&h->d_groups[0], sizeof(rbs::Groups) * (size_t)h->max_particles));
         RBS_HIP(h, hipMalloc(&h->d_groups[1], sizeof(rbs::Groups) * (size_t)h->max_particles));
+        if (const char* e = std::getenv("RBS_COPY_WALK")) h->copy_walk = std::atoi(e) != 0;
+        if (h->windowed)
+            for (int k = 0; k < 2; ++k) RBS_HIP(h, hipMalloc(&h->d_strips[k], sizeof(rbs::Strips) * (size_t)h->max_particles));
     }
     RBS_HIP(h, hipMalloc(&h->d_parents[0], sizeof(int) * (size_t)h->max_particles));
     RBS_HIP(h, hipMalloc(&h->d_parents[1], sizeof(int) * (size_t)h->max_particles));

@@ -146,6 +146,17 @@ struct Groups {
     unsigned mask[kMaxGroups];    // bodies of the group
 };
 
+// Several bodies, windowed planes: what the copy kernel writes of a particle's region is the region MINUS its groups' rectangles.
+// The rectangles kernel cuts that into STRIPS -- bands between the rectangles' top and bottom edges, within a band the intervals no
+// rectangle covers -- so that the copy kernel enumerates the cells it writes instead of walking the whole region and skipping the
+// rectangles' share (C2: 55 % of the cells).  At most (2 kMaxGroups + 1) bands of (kMaxGroups + 1) intervals.
+constexpr int kMaxStrips = (2 * kMaxGroups + 1) * (kMaxGroups + 1);
+struct Strips {
+    int n, pad0, pad1, pad2;
+    int first[kMaxStrips + 1];       // first cell (float4) of each strip in the particle's enumeration; [n] = their number
+    ushort4 box[kMaxStrips];         // x0 / 4, x1 / 4, y0, y1 (columns and rows <= 8 192)
+};
+
 struct DevParams {
     int rows, cols, npx;
     int n_bodies;
@@ -219,6 +230,7 @@ struct DevParams {
     int bands, band_rows;          // copy blocks per particle, rows per band
     const int* rects;              // [n][4] screen rectangles (rbs_prep_kernel): the union over the bodies
     Groups* groups;                // [n] per-group rectangles, several bodies only (null for one body)
+    Strips* strips;                // [n] the copy kernel's cells, several bodies on windowed planes (null otherwise)
     int2* item_range;              // [n] (first work item, number of work items) of each particle
     int* item_particle;            // [items] owner of each work item
     int* ctr_this;                 // [2] this call's (items allotted, items taken) counters ...
@@ -1662,6 +1674,7 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
     __shared__ int4 gr_s[kPrepPerBlock][kMaxBodies];
     __shared__ unsigned gm_s[kPrepPerBlock][kMaxBodies];
     __shared__ Groups G_s[kPrepPerBlock];
+    __shared__ int ys_s[kPrepPerBlock][2 * kMaxGroups + 4];   // (the strips' band edges: run-time indexed, so not a local array)
     int4* const gr = gr_s[w];
     unsigned* const gm = gm_s[w];
     Groups& G = G_s[w];
@@ -1804,6 +1817,50 @@ __device__ inline void prep_particles(const DevParams& P, int block, int* __rest
         }
         P.win_used[i] = u;
         P.win_dst[i] = seed;
+        if (P.strips && P.groups) {   // (lane 0 of the particle's wave: at most kMaxGroups rectangles, a few dozen scalar steps)
+            Strips* S = P.strips + i;
+            int* ys = ys_s[w];
+            int ny = 0, ns = 0, total = 0;
+            const int ng_ = G.n;
+            if (u.z > u.x && u.w > u.y) {
+                ys[ny++] = u.y;
+                for (int g = 0; g < ng_; ++g) {
+                    const int4 R = G.rect[g];
+                    for (int e = 0; e < 2; ++e) {
+                        const int y = min(max(e ? R.w : R.y, u.y), u.w);
+                        int k = ny;                      // insert sorted, drop duplicates
+                        while (k > 0 && ys[k - 1] > y) --k;
+                        if (k > 0 && ys[k - 1] == y) continue;
+                        for (int m = ny; m > k; --m) ys[m] = ys[m - 1];
+                        ys[k] = y; ++ny;
+                    }
+                }
+                if (ys[ny - 1] != u.w) ys[ny++] = u.w;
+                for (int bnd = 0; bnd + 1 < ny; ++bnd) {
+                    const int ya = ys[bnd], yb = ys[bnd + 1];
+                    int cur = u.x;
+                    for (;;) {     // the rectangles that span this band, left to right (they do not overlap: overlapping ones were merged)
+                        int best = -1, bx = u.z;
+                        for (int g = 0; g < ng_; ++g) {
+                            const int4 R = G.rect[g];
+                            if (R.z > R.x && R.y <= ya && R.w >= yb && R.z > cur && max(R.x, u.x) < bx) { best = g; bx = max(R.x, u.x); }
+                        }
+                        const int x1 = best < 0 ? u.z : bx;
+                        if (x1 > cur) {
+                            S->first[ns] = total;
+                            S->box[ns] = make_ushort4((unsigned short)(cur >> 2), (unsigned short)(x1 >> 2), (unsigned short)ya, (unsigned short)yb);
+                            total += ((x1 - cur) >> 2) * (yb - ya);
+                            ++ns;
+                        }
+                        if (best < 0) break;
+                        cur = max(cur, min(G.rect[best].z, u.z));
+                        if (cur >= u.z) break;
+                    }
+                }
+            }
+            S->first[ns] = total;
+            S->n = ns;
+        }
         // (every 8th particle: the sum only feeds an estimate of the stored fraction of a plane, and one atomic per
         // particle on one address serialises at ~12 ns each -- 24 us of a sampled call's rectangles kernel at 2 000
         // particles, 250 us at 20 000)
@@ -2341,7 +2398,8 @@ constexpr int kWinUnroll = RBS_WIN_UNROLL;
 // EXACT: stamped planes (DevParams.exact) -- a cell is four values and four ages; nothing is stepped: the values are copied, the
 // ages advance by the call's elapsed frames, and the child's window grows over the cells that hold an age within age_max (STP:
 // that differ from the shared plane's new cell).
-template <bool SLAB, bool STRIPS, bool STP = false, bool EXACT = false>
+// STRIPS == 2 (round 6): several bodies -- the cells come from the strip list the rectangles kernel made (DevParams::strips).
+template <bool SLAB, int STRIPS, bool STP = false, bool EXACT = false>
 __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
 {
     constexpr int kU = STP ? 1 : kWinUnroll;
@@ -2398,7 +2456,10 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
         const int ty1 = has ? q.y : u.w, tby0 = has ? q.w : u.w;
         const int left4 = has ? (q.x - u.x) >> 2 : 0, right4 = has ? (u.z - q.z) >> 2 : 0, m = left4 + right4;
         const int rjump = has ? (q.z - u.x) >> 2 : 0;
-        const int n_top = (ty1 - u.y) * w4, n_mid = (tby0 - ty1) * m, L = n_top + n_mid + (u.w - tby0) * w4;
+        const Strips* __restrict__ SL = STRIPS == 2 ? P.strips + particle : nullptr;
+        const int ns = STRIPS == 2 ? SL->n : 0;
+        int sc = 0;                                      // (STRIPS == 2: this lane's cursor into the strip list: its cells only go forward)
+        const int n_top = (ty1 - u.y) * w4, n_mid = (tby0 - ty1) * m, L = STRIPS == 2 ? SL->first[ns] : n_top + n_mid + (u.w - tby0) * w4;
         const int per = (L + (int)gridDim.x - 1) / (int)gridDim.x;
         const int lo = (int)blockIdx.x * per, hi = min(L, lo + per);
         for (int base = lo; base < hi; base += 64 * kU) {
@@ -2410,6 +2471,15 @@ __global__ __launch_bounds__(64) void rbs_copy_window_kernel(const DevParams P)
                 const int idx = base + k * 64 + lane;
                 const bool live = idx < hi;
                 int row, c4;
+                if (STRIPS == 2) {
+                    row = u.y; c4 = 0;
+                    if (live) {
+                        while (idx >= SL->first[sc + 1]) ++sc;
+                        const ushort4 B = SL->box[sc];
+                        const int j = idx - SL->first[sc], sw = (int)B.y - (int)B.x, r = j / sw;
+                        row = (int)B.z + r; c4 = (int)B.x + (j - r * sw) - ux4;
+                    }
+                } else
                 if (idx < n_top) { const int r = idx / w4; row = u.y + r; c4 = idx - r * w4; }
                 else if (idx < n_top + n_mid) {
                     const int j = idx - n_top, r = j / max(m, 1), kk = j - r * m;
