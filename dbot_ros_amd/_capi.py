@@ -24,6 +24,7 @@ RBS_STATE_DEFAULT, RBS_STATE_WINDOWED, RBS_STATE_DENSE = 0, 1, 2
 PRECISIONS = {None: 0, "default": 0, "f64": 1, "f32": 2}
 LAYOUTS = {None: 0, "default": 0, "window": 1, "windowed": 1, "dense": 2}
 RBS_OCC_DEFAULT, RBS_OCC_DEVICE_RULE, RBS_OCC_REFERENCE = 0, 1, 2
+OPTIONS = {"shared_trail": 1, "shared_trail_enter": 2, "shared_trail_every": 3, "tracker_split_max": 4, "timing_every": 5}
 OCC_MODES = {None: 0, "default": 0, "device": 1, "eager": 1, "reference": 2, "lazy": 2, "exact": 2}
 
 # every symbol include/rbsensor_mi355x.h declares
@@ -33,7 +34,7 @@ EXPORTS = (
     "rbs_set_observation_native_f32", "rbs_set_observation_device", "rbs_get_observation", "rbs_loglikes",
     "rbs_acquire_frame_buffer", "rbs_commit_frame_buffer", "rbs_loglikes_prefetch", "rbs_set_observation_prefetched",
     "rbs_loglikes_deltas", "rbs_get_poses", "rbs_deltas_buffer", "rbs_set_observation_borrowed", "rbs_set_observation_borrowed_f32", "rbs_shared_trail_state",
-    "rbs_shared_trail_rebase", "rbs_window_fraction",
+    "rbs_shared_trail_rebase", "rbs_window_fraction", "rbs_set_option",
     "rbs_loglikes_device", "rbs_synchronize", "rbs_get_occlusion", "rbs_set_occlusion",
     "rbs_occlusion_device_ptr", "rbs_occlusion_next_device_ptr", "rbs_export_plane", "rbs_import_plane",
     "rbs_export_window", "rbs_import_window", "rbs_stream_join", "rbs_ipc_export", "rbs_ipc_attach", "rbs_stage_windows", "rbs_peer_resample",
@@ -164,6 +165,8 @@ def load():
     lib.rbs_shared_trail_state.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.rbs_shared_trail_rebase.restype = C.c_int32
     lib.rbs_shared_trail_rebase.argtypes = [H, C.c_int32]
+    lib.rbs_set_option.restype = C.c_int32
+    lib.rbs_set_option.argtypes = [H, C.c_int32, C.c_double]
     lib.rbs_window_fraction.restype = C.c_int32
     lib.rbs_window_fraction.argtypes = [H, C.POINTER(C.c_double)]
     lib.rbs_get_background.restype = C.c_int32

@@ -40,6 +40,10 @@ static_assert(sizeof(rbs_config) == 216 && offsetof(rbs_config, state_slab_px) =
                   offsetof(rbs_config, device_ids) == 200,
               "rbs_config layout (ABI 2) is mirrored by dbot_ros_amd/_capi.py and tests/test_capi_cpu.py");
 
+#ifndef RBS_TRACKER_SPLIT_MAX_DEFAULT
+#define RBS_TRACKER_SPLIT_MAX_DEFAULT 5000   // (measured, tests/cpp/host_bench --tracker: frame by frame +12-16 % at 1 000-2 000 particles, +6-10 % at 4 000, nothing from 6 000 up)
+#endif
+
 struct rbs_handle {
     int device = 0;
     int rows = 0, cols = 0, npx = 0;
@@ -65,6 +69,7 @@ struct rbs_handle {
                                 // call's copy kernel may still be reading its rectangles
     rbs::Groups* d_groups[2] = {nullptr, nullptr};   // [max_particles] per-group rectangles (several bodies), alternating like d_rects
     rbs::Strips* d_strips[2] = {nullptr, nullptr};   // [max_particles] the copy kernel's cells outside the groups' rectangles (windowed planes), alternating alike
+    int tracker_split_max = RBS_TRACKER_SPLIT_MAX_DEFAULT;   // rbs_tracker_*: see RBS_OPT_TRACKER_SPLIT_MAX
     bool copy_walk = false;                          // RBS_COPY_WALK=1 (tooling / A-B): several bodies take the walk over the whole region instead
     int* d_parents[2] = {nullptr, nullptr};   // [max_particles] snapshot of the caller's indices, alternating like d_rects
     int4* d_win[2] = {nullptr, nullptr};   // [max_particles] window of each plane, per buffer
@@ -1870,6 +1875,7 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
         if (const char* m = std::getenv("RBS_RASTER_BLOCKS")) h->raster_blocks = std::max(1, std::atoi(m));
         if (const char* m = std::getenv("RBS_SHARED_TRAIL")) h->stp_allowed = std::atoi(m) != 0;
         if (const char* m = std::getenv("RBS_ONE_BODY")) h->one_body_kernel = std::atoi(m) != 0;
+        if (const char* m = std::getenv("RBS_TRACKER_SPLIT_MAX")) h->tracker_split_max = std::atoi(m);
         if (const char* m = std::getenv("RBS_STP_ENTER")) h->stp_enter = std::atof(m);
         if (const char* m = std::getenv("RBS_STP_EVERY")) h->stp_every = std::max(1, std::atoi(m));
         h->split = RBS_SPLIT_DEFAULT != 0;
@@ -3725,6 +3731,33 @@ int32_t rbs_get_window(rbs_handle* h, int32_t slot, int32_t out[4])
     return RBS_OK;
 }
 
+int32_t rbs_set_option(rbs_handle* h, int32_t option, double value)
+{
+    if (!h) return RBS_ERR_INVALID_ARGUMENT;
+    if (!std::isfinite(value)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_option: the value is not finite");
+    std::vector<rbs_handle*> all(h->shards.begin(), h->shards.end());
+    all.push_back(h);      // (a group keeps the shared trail's policy itself; its shards the rest)
+    for (rbs_handle* x : all) {
+        switch (option) {
+            case RBS_OPT_SHARED_TRAIL: x->stp_allowed = value != 0.0; break;
+            case RBS_OPT_SHARED_TRAIL_ENTER:
+                if (!(value > 0.0 && value <= 1.0)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_option: RBS_OPT_SHARED_TRAIL_ENTER must be in (0, 1]");
+                x->stp_enter = value; break;
+            case RBS_OPT_SHARED_TRAIL_EVERY:
+                if (!(value >= 1.0)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_option: RBS_OPT_SHARED_TRAIL_EVERY must be >= 1");
+                x->stp_every = (int)value; break;
+            case RBS_OPT_TRACKER_SPLIT_MAX:
+                if (!(value >= 0.0)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_option: RBS_OPT_TRACKER_SPLIT_MAX must be >= 0");
+                x->tracker_split_max = (int)std::min(value, 2e9); break;
+            case RBS_OPT_TIMING_EVERY:
+                if (!(value >= 1.0)) return fail(h, RBS_ERR_INVALID_ARGUMENT, "set_option: RBS_OPT_TIMING_EVERY must be >= 1");
+                x->timing_every = (int)std::min(value, 1e9); break;
+            default: return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("set_option: unknown option %d", option));
+        }
+    }
+    return RBS_OK;
+}
+
 int32_t rbs_window_fraction(rbs_handle* h, double* out)
 {
     if (!h || !out) return RBS_ERR_INVALID_ARGUMENT;
@@ -4218,7 +4251,7 @@ static int32_t tracker_submit_impl(rbs_tracker* t, const float* frame, const dou
             // GEOMETRY kernel does not need it -- the frame is handed to the sensor as a borrowed one and staged by enqueue_loglikes
             // between the two kernels of the split launch (inside this call: the caller's buffer is free on return as before).  Above
             // kTrackerSplitMax evaluations the one-kernel launch's shorter kernel time wins (RBS_TRACKER_SPLIT_MAX, 0: never).
-            static const int split_max = [] { const char* e = std::getenv("RBS_TRACKER_SPLIT_MAX"); return e ? std::atoi(e) : RBS_TRACKER_SPLIT_MAX_DEFAULT; }();
+            const int split_max = h->tracker_split_max;
             const bool idle = t->submitted == t->collected;   // (a frame already in flight -- look-ahead -- hides the journey by itself, and the one-kernel launch is the shorter)
             if (idle && T.n * T.parts <= split_max && h->precision == RBS_PRECISION_F64 && h->windowed && !h->frame_ingest && !h->group) {
                 RBS_REFUSE_POISONED(h);

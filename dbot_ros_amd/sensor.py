@@ -375,6 +375,11 @@ class RbSensor:
         self._check(self._lib.rbs_shared_trail_state(self._h, C.byref(a), C.byref(r)))
         return bool(a.value), int(r.value)
 
+    def set_option(self, name, value):
+        """rbs_set_option: "shared_trail" (0 / 1), "shared_trail_enter" (window fraction), "shared_trail_every" (calls),
+        "tracker_split_max" (evaluations), "timing_every"."""
+        self._check(self._lib.rbs_set_option(self._h, _capi.OPTIONS[name], float(value)))
+
     def shared_trail_rebase(self, global_slot):
         """rbs_shared_trail_rebase: at the next updating call enter the shared-trail representation (if need be) and re-base the shared
         plane on that GLOBAL slot's plane; -2: back to the scalar background.  Attached ranks: the same call on every rank."""

@@ -370,6 +370,19 @@ int32_t rbs_shared_trail_state(rbs_handle* h, int32_t* active, int32_t* rebases)
  * frame, agreed by one all-reduce of a flag).  On a handle of its own the call forces a re-basing on one of its slots (tests).
  * Values are unchanged by a bit, as for a single handle; an exported handle never switches by itself. */
 int32_t rbs_shared_trail_rebase(rbs_handle* h, int32_t global_slot);
+/* Behaviour switches a caller may need, as an API (round 6; the environment variables of the same meaning are tooling and are read
+ * once at rbs_create -- INTEGRATION.md section 6 lists them).  Values take effect from the next call on; results never depend on them
+ * (they choose what is stored and how a call is launched).
+ *   RBS_OPT_SHARED_TRAIL        0 / 1   may the handle store its planes against a shared background plane (default 1; a handle that
+ *                                       has already switched stays so until rbs_reset)
+ *   RBS_OPT_SHARED_TRAIL_ENTER  (0, 1]  sampled window fraction of the frame above which it switches / keeps re-basing (default 0.10)
+ *   RBS_OPT_SHARED_TRAIL_EVERY  >= 1    updating calls between re-basings while windows stay large (default 32)
+ *   RBS_OPT_TRACKER_SPLIT_MAX   >= 0    rbs_tracker_*: evaluations per frame up to which a frame handed over frame by frame travels
+ *                                       behind the geometry kernel (two-kernel launch; default 5 000, 0 = never)
+ *   RBS_OPT_TIMING_EVERY        >= 1    = rbs_set_timing_every
+ * A handle over several devices applies them to all its shards. */
+enum { RBS_OPT_SHARED_TRAIL = 1, RBS_OPT_SHARED_TRAIL_ENTER = 2, RBS_OPT_SHARED_TRAIL_EVERY = 3, RBS_OPT_TRACKER_SPLIT_MAX = 4, RBS_OPT_TIMING_EVERY = 5 };
+int32_t rbs_set_option(rbs_handle* h, int32_t option, double value);
 /* The window area the handle sampled last (mean over its particles of the region an updating call stored, as a fraction of the
  * frame; sampled every 8th updating call, read back without blocking): what the shared trail's policy looks at. */
 int32_t rbs_window_fraction(rbs_handle* h, double* out);
