@@ -424,3 +424,63 @@ def test_attach_peers_fails_on_every_rank_alike(fail):
         assert all(g[1] == "ok" and g[2] == [0, 1, 2] for g in got), got
     else:
         assert all(g[1] == "raised" and "rank 1" in g[2] and "refused" in g[2] for g in got), got
+
+
+class _TrailSensor:
+    """What PeerShardedStep's shared-trail policy needs of a sensor: the window fraction this rank sampled, and a record of the
+    re-basings it was told to do."""
+
+    def __init__(self, fractions):
+        self.fractions, self.k, self.rebased = fractions, 0, []
+
+    def window_fraction(self):
+        return self.fractions[min(self.k, len(self.fractions) - 1)]
+
+    def shared_trail_rebase(self, slot):
+        self.rebased.append((self.k, slot))
+
+
+def _trail_worker(rank, world, port, q):
+    import torch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, cap, steps = 8, 16, 13
+        # rank 1's windows grow past the threshold from step 6 on, rank 0's never do: BOTH must re-base, at the same steps
+        s = _TrailSensor([0.02] * steps if rank == 0 else [0.02] * 6 + [0.4] * (steps - 6))
+
+        def evaluate(poses, parent_idx, out):
+            out.copy_(torch.arange(n, dtype=torch.float64) * 0.01 + rank)
+
+        def all_gather(out, inp):
+            parts = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(parts, inp)
+            out.copy_(torch.cat(parts))
+
+        step = rdist.PeerShardedStep(s, n, cap, min_share=2, evaluate=evaluate, stage=lambda src, dst: None, all_gather=all_gather,
+                                     temperature=1.0, shared_trail=True, trail_every=4, trail_threshold=0.10)
+        g = torch.Generator().manual_seed(3)
+        for k in range(steps):
+            s.k = k
+            step.step(torch.zeros(n, 12), torch.rand(n * world, dtype=torch.float64, generator=g))
+        q.put((rank, s.rebased))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_step_shared_trail_is_agreed_by_all_ranks():
+    """dist.PeerShardedStep(shared_trail=True) on two gloo ranks: every trail_every steps the ranks all-reduce "my windows exceed the
+    threshold"; when ANY rank's do, EVERY rank tells its handle to re-base on global slot 0 before the same step
+    (rbs_shared_trail_rebase: the handles' shared planes stay identical only if all of them re-base in the same call)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 26300 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_trail_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == [(8, 0), (12, 0)], got      # steps 4 (nobody above the threshold): nothing; 8 and 12: both ranks

@@ -144,3 +144,43 @@ def test_shared_trail_across_processes():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "TRAIL_OK" in r.stdout, r.stdout[-2000:]
     print(r.stdout[-900:])
+
+
+def test_set_option_switches_the_shared_trail_and_refuses_nonsense():
+    """rbs_set_option: the switches a caller may need as an API (the environment variables of the same meaning are tooling).  The
+    shared trail switched off by option never activates on a sequence that activates it otherwise; values are the same bits."""
+    from dbot_ros_amd import RbSensorError
+    n, cols, rows = 64, 320, 240
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    frames = []
+    o = ob.Oracle(om, cam, P, max_particles=1, mode=ob.EAGER)
+    rng = np.random.default_rng(2)
+    for k in range(20):
+        t = synth.truth_pose(1, frame=k)
+        t[:, 9] += -0.10 + 0.012 * k
+        frames.append((t, synth.make_frame(o.render_depth(t), rows, cols, rng)))
+    o.close()
+    poses = [synth.particle_poses(t, n, rng, scale=1.0) for t, _ in frames]
+    parents = [np.sort(rng.choice(n, size=n, p=(lambda w: w / w.sum())(rng.random(n) ** 8))).astype(np.int32) for _ in frames]
+    with RbSensor(om, cam, P, max_particles=n) as a, RbSensor(om, cam, P, max_particles=n) as b:
+        for s_ in (a, b):
+            s_.set_option("timing_every", 1)
+            s_.set_option("shared_trail_enter", 0.02)
+            s_.set_option("shared_trail_every", 3)
+        b.set_option("shared_trail", 0)
+        a.reset(); b.reset()
+        ia, ib = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for k, (_, frame) in enumerate(frames):
+            a.set_observation(frame); b.set_observation(frame)
+            la, lb = a.loglikes_poses(poses[k], ia, update=True), b.loglikes_poses(poses[k], ib, update=True)
+            assert np.array_equal(la, lb), k
+            ia, ib = parents[k].copy(), parents[k].copy()
+        assert a.shared_trail_state()[0] and a.shared_trail_state()[1] >= 2
+        assert b.shared_trail_state() == (False, 0)
+        for q in range(0, n, 7):
+            assert np.array_equal(a.get_occlusion(q), b.get_occlusion(q))
+        for name, bad in (("shared_trail_enter", 0.0), ("shared_trail_every", 0), ("tracker_split_max", -1), ("timing_every", 0)):
+            with pytest.raises(RbSensorError):
+                a.set_option(name, bad)
+        with pytest.raises(RbSensorError):
+            a._check(a._lib.rbs_set_option(a._h, 99, 1.0))
