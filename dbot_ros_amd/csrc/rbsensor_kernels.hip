@@ -2749,7 +2749,7 @@ __global__ void rbs_expand_exact_kernel(const float* __restrict__ slot, int plan
 }
 // A whole plane of effective values handed in from outside -> a slot with stored region r (whole planes: r spans the frame and
 // `stride` is cols; slabs: packed, stride = r's width): values as given with age 0 ("as of the epoch", the rule of
-// oracle orc_set_occlusion), background where the value equals the reference (bgref plane, else the scalar bg).
+// oracle orc_set_occlusion), background where the value equals the scalar background level.
 __global__ void rbs_pack_exact_kernel(const float* __restrict__ full, const float* __restrict__ bgref, float bg, int4 r, int cols,
                                       int x0, int y0, int stride, float* __restrict__ slot, int plane_px)
 {
@@ -2761,7 +2761,10 @@ __global__ void rbs_pack_exact_kernel(const float* __restrict__ full, const floa
     const size_t at = (size_t)(r.y + ly - y0) * stride + (r.x + lx - x0);
     const float v = full[src];
     slot[at] = v;
-    reinterpret_cast<unsigned short*>(slot + plane_px)[at] = v == (bgref ? bgref[src] : bg) ? 0xffffu : 0u;
+    // (inside a window an age beyond age_max means the SCALAR background, shared plane or not: a value that merely equals the shared
+    // plane's is stored like any other -- bgref only decided the window's extent)
+    (void)bgref;
+    reinterpret_cast<unsigned short*>(slot + plane_px)[at] = v == bg ? 0xffffu : 0u;
 }
 // Bounding box (float4-aligned) of the shared plane's pixels whose age is within age_max (stamped planes).
 __global__ void rbs_bbox_age_kernel(const float* __restrict__ bgp, int rows, int cols, unsigned age_max, int* __restrict__ out4)

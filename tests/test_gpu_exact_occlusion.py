@@ -85,3 +85,45 @@ def test_mode_needs_f64_and_windows():
         RbSensor(om, cam, P, max_particles=8, occlusion="reference", precision="f32")
     with pytest.raises(RbSensorError):
         RbSensor(om, cam, P, max_particles=8, occlusion="reference", state_layout="dense")
+
+
+@pytest.mark.parametrize("slab_px", [0, 16384])
+def test_plane_transport_against_a_shared_plane(monkeypatch, slab_px):
+    """Stamped planes stored against the shared background plane: a plane sent with rbs_export_window and taken in by
+    rbs_import_window is the same plane -- also where it merely EQUALS the shared plane's values inside the window (found by running
+    the whole suite with RBS_OCC=reference: such pixels had been marked "background", which inside a window means the scalar level)."""
+    import torch
+    monkeypatch.setenv("RBS_SHARED_TRAIL", "1")
+    monkeypatch.setenv("RBS_STP_ENTER", "0.0")
+    monkeypatch.setenv("RBS_STP_EVERY", "3")
+    n, cols, rows = 48, 320, 240
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    lazy = ob.Oracle(om, cam, P, max_particles=1, mode=ob.LAZY)
+    rng = np.random.default_rng(31)
+    frames = []
+    for k in range(14):
+        t = synth.truth_pose(1, frame=k)
+        t[:, 9] += -0.08 + 0.012 * k
+        frames.append((t, synth.make_frame(lazy.render_depth(t), rows, cols, rng)))
+    poses = [synth.particle_poses(t, n, rng, scale=1.0) for t, _ in frames]
+    parents = [np.sort(rng.choice(n, size=n, p=(lambda w: w / w.sum())(rng.random(n) ** 8))).astype(np.int32) for _ in frames]
+    with RbSensor(om, cam, P, max_particles=n, occlusion="reference", slab_px=slab_px) as g:
+        g.set_timing_every(1)
+        g.reset()
+        idx = np.zeros(n, np.int32)
+        for k, (_, frame) in enumerate(frames):
+            g.set_observation(frame)
+            g.loglikes_poses(poses[k], idx, update=True)
+            idx = parents[k].copy()
+        assert g.shared_trail_state()[0]
+        buf = torch.empty(cols * rows, dtype=torch.float32, device="cuda:0")
+        for src in (3, 17):
+            before = g.get_occlusion(src)
+            rect = g.export_window(src, buf.data_ptr(), buf.numel())
+            assert rect == (0, 0, cols, rows)                      # against a shared plane the plane travels whole
+            assert np.array_equal(buf.cpu().numpy(), before)
+            g.import_window(n - 1, rect, buf.data_ptr())
+            g.synchronize()
+            assert np.array_equal(g.get_occlusion(n - 1), before), src
+            g.set_occlusion(n - 2, before)
+            assert np.array_equal(g.get_occlusion(n - 2), before), src
