@@ -146,6 +146,33 @@ int main(int argc, char** argv)
             std::printf("\n");
         }
     }
+    // ---- Parameters::occlusion_mode = "reference" (rbs_config.occlusion_mode REFERENCE): the CPU model's own occlusion bookkeeping;
+    // three frames, the children of the second and third inheriting reversed slots: compared with the LAZY oracle on the pytest side
+    {
+        SensorBuilder::Parameters pr = params_obsrv;
+        pr.occlusion_mode = "reference";
+        auto rs = SensorBuilder(object_model, camera_data, pr).build();
+        rs->integrated_poses() = def;
+        rs->reset();
+        std::vector<int32_t> idx(n, 0);
+        for (int k = 0; k < 3; ++k) {
+            rs->set_observation(frame);
+            auto ll = rs->loglikes(deltas, idx, true);
+            std::printf("REF%d", k);
+            for (double v : ll) std::printf(" %.17g", v);
+            std::printf("\n");
+            for (int i = 0; i < n; ++i) idx[i] = n - 1 - i;
+        }
+        // more particles than Parameters::sample_count: refused before anything is written into the pinned staging block
+        std::vector<State> many(static_cast<size_t>(n) + 1, State(parts));
+        std::vector<int32_t> idx2(static_cast<size_t>(n) + 1, 0);
+        try {
+            rs->loglikes(many, idx2, false);
+            std::printf("ERR2 missing\n");
+        } catch (const std::runtime_error&) {
+            std::printf("ERR2 ok\n");
+        }
+    }
     // error path: wrong observation size must surface as std::runtime_error
     try {
         sensor->set_observation(std::vector<double>(3));

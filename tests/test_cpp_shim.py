@@ -158,6 +158,19 @@ def test_cpp_shim_matches_oracle(tmp_path, gpu_lib, monkeypatch, precision):
     for got, ref in ((ll1, r1), (ll2, r2), (ll3, r3)):
         # F32: north_star's tolerance (these sums are well conditioned)
         assert (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max() <= (1e-9 if precision == "f64" else 1e-5)
+    if precision == "f64":
+        # Parameters::occlusion_mode = "reference": three frames against the LAZY (reference-semantics) oracle at the transcendentals' accuracy
+        om_ = ObjectModel([synth.mesh_m1(level=2)[0], synth.mesh_box12()[0]], [synth.mesh_m1(level=2)[1], synth.mesh_box12()[1]], center=True)
+        lazy = ob.Oracle(om_, CameraData(synth.camera_matrix(80, 60), 60, 80), RbSensorBuilder.Parameters(sample_count=n), max_particles=n, mode=ob.LAZY)
+        lazy.reset()
+        idx = np.zeros(n, np.int32)
+        for k in range(3):
+            lazy.set_observation(frame)
+            ref = lazy.loglikes_poses(poses, idx, update=True)
+            got = np.array(lines[f"REF{k}"], dtype=np.float64)
+            assert (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max() <= 1e-10, k      # (the poses are composed on the device: an entry may differ from the host composition in its last bit)
+            idx = np.arange(n - 1, -1, -1, dtype=np.int32)
+        assert lines["ERR2"] == ["ok"]
     # the C++ tracker mirror against the Python device tracker: same device RNG key -> same states
     from dbot_ros_amd import RbSensor
     from dbot_ros_amd.tracker import DeviceParticleTracker, ObjectTransitionBuilder, ParticleTrackerBuilder
