@@ -127,3 +127,24 @@ def test_plane_transport_against_a_shared_plane(monkeypatch, slab_px):
             assert np.array_equal(g.get_occlusion(n - 1), before), src
             g.set_occlusion(n - 2, before)
             assert np.array_equal(g.get_occlusion(n - 2), before), src
+
+
+def test_the_parity_suite_in_reference_mode():
+    """tests/test_gpu_parity.py's windowed cases once more with the LIBRARY in occlusion_mode REFERENCE and the tests' device-rule
+    oracles replaced by the reference-semantics one (RBS_OCC=reference: the library takes it where the caller leaves the mode
+    open, tests/oracle_binding.py switches the oracle): sequences, several bodies, read-only calls, skipped frames, NaN / inf frames,
+    off-screen particles, bad parent slots, many tiles, varying particle counts and call patterns, threads, borrowed frames -- at
+    those tests' own bars (1e-9 on log-likelihoods, planes bit for bit up to 1e-4 of pixels at one ulp).  Left out: the cases that test
+    the device rule itself (goldens generated by it, its background snap, the wide-window route) or compare with dense planes."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, RBS_OCC="reference")
+    sel = "window and not golden and not windows_follow and not wide_windows and not layouts_hold and not 322 and not eager_background"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k", sel,
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=1200, env=env, cwd=os.path.dirname(here))
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    print("\ntest_gpu_parity.py (windowed cases) with RBS_OCC=reference: " + tail)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+    assert " passed" in tail and "failed" not in tail
