@@ -1050,6 +1050,13 @@ def native_host_leg(a, om, cam, P, W, steps):
                         "host_api_native_borrowed_checksum_equal": tb[6] == tok[6] if len(tb) > 6 and len(tok) > 6 else None,
                         "host_api_native_borrowed_note": "the same synchronous step with the frame BORROWED until rbs_loglikes returns (rbs_set_observation_borrowed_f32): "
                                                          "staged behind the geometry kernel of the two-kernel launch"})
+        rl = subprocess.run([exe, "--loglikes-only", path, str(steps), "10"], capture_output=True, text=True, timeout=300, env=env)
+        linel = next((l for l in rl.stdout.splitlines() if l.startswith("host_bench ")), None)
+        if linel:
+            tl_ = linel.split()
+            res.update({"host_api_native_loglikes_only_value": float(tl_[2]), "host_api_native_loglikes_only_ms_per_step": float(tl_[4]),
+                        "host_api_native_loglikes_only_note": "SURVEY 8(d)'s metric to the letter from C++: rbs_loglikes alone, synchronous -- poses and parent slots from host "
+                                                              "memory, log-likelihoods back to host memory, the frame resident (host_api_loglikes_only_value: the same through ctypes)"})
         r2 = subprocess.run([exe, "--prefetch", path, str(steps), "10"], capture_output=True, text=True, timeout=300, env=env)
         line2 = next((l for l in r2.stdout.splitlines() if l.startswith("host_bench ")), None)
         if line2:
@@ -1846,7 +1853,8 @@ def main():
                 "dense_hbm_frac": out["roofline"].get("dense_frac"), "sweep_value": out.get("sweep_value"), "sweep_hbm_frac": out.get("sweep_hbm_frac"),
                 "roofline_frac": out["roofline"].get("frac"),
                 "note": "particle-likelihoods/s on C1, one GPU.  resident_value = `value` (device-pointer API, inputs in HBM: the bench contract's clock); "
-                        "host_pointer_value = SURVEY 8(d)'s metric to the letter (rbs_loglikes from host memory: poses up, log-likelihoods down, synchronous); "
+                        "host_pointer_value = SURVEY 8(d)'s metric to the letter (rbs_loglikes from host memory: poses up, log-likelihoods down, synchronous; called from "
+                        "C++ as the reference's filter would -- host_api_loglikes_only_value is the same through ctypes); "
                         "plugin_api_value = the reference's own call sequence from C++ (set_observation of a double image, copied, + loglikes(deltas, indices, "
                         "update)); exact_occlusion_value = resident_value with rbs_config.occlusion_mode = REFERENCE; dense / sweep: where SURVEY 8(d)'s "
                         "bytes really move, as fractions of 8 TB/s; roofline_frac: the dominant kernel against the guide's VALU issue peak"}

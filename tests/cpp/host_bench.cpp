@@ -1,7 +1,7 @@
 // host_bench.cpp -- the host-pointer step (rbs_set_observation_f32 + rbs_loglikes) driven from
 // C++ through the C-ABI, the way the reference's own (C++) filter would call it; bench.py's
 // host_api_* leg goes through Python/ctypes and pays the interpreter per call.
-//   host_bench [--prefetch] <workload.bin> <steps> [warmup]
+//   host_bench [--prefetch | --borrowed | --loglikes-only] <workload.bin> <steps> [warmup]     (--loglikes-only: rbs_loglikes alone, the frame resident: SURVEY 8(d)'s metric to the letter)
 //   (--prefetch: rbs_loglikes_prefetch + rbs_set_observation_prefetched, the next frame uploaded behind each call's kernels;
 //    --borrowed: rbs_set_observation_borrowed_f32, the frame staged by rbs_loglikes behind its geometry kernel)
 // workload.bin (written by bench.py, native endianness):
@@ -47,10 +47,11 @@ int main(int argc, char** argv)
     const bool tracker_plugin = argc > 1 && !std::strcmp(argv[1], "--tracker-plugin");   // the tracker through dbot_amd::ParticleTrackerBuilder, images of doubles
     const bool tracker_mode = tracker_plugin || (argc > 1 && !std::strcmp(argv[1], "--tracker"));
     const bool prefetch_mode = argc > 1 && !std::strcmp(argv[1], "--prefetch");   // the next frame travels behind each call's kernels
+    const bool loglikes_only = argc > 1 && !std::strcmp(argv[1], "--loglikes-only");   // SURVEY 8(d)'s metric to the letter: rbs_loglikes alone (poses up, log-likelihoods down), the frame resident
     const bool borrowed_mode = argc > 1 && !std::strcmp(argv[1], "--borrowed");   // rbs_set_observation_borrowed_f32: staged behind the geometry kernel
     const bool plugin_copy = argc > 1 && !std::strcmp(argv[1], "--plugin-copy");  // ... set_observation copying at once, as dbot's own sensors do
     const bool plugin_mode = plugin_copy || (argc > 1 && !std::strcmp(argv[1], "--plugin"));   // through dbot_amd::RbSensor (double frame, state deltas)
-    if (tracker_mode || prefetch_mode || plugin_mode || borrowed_mode) { --argc; ++argv; }
+    if (tracker_mode || prefetch_mode || plugin_mode || borrowed_mode || loglikes_only) { --argc; ++argv; }
     if (argc < 3) { std::fprintf(stderr, "usage: host_bench workload.bin steps [warmup] | host_bench --tracker workload.bin particles\n"); return 2; }
     std::FILE* f = std::fopen(argv[1], "rb");
     if (!f) { std::perror(argv[1]); return 2; }
@@ -271,6 +272,7 @@ int main(int argc, char** argv)
     }
     auto step = [&](int i) -> int32_t {
         const int k = i % F;
+        if (loglikes_only) { idx = parents; return rbs_loglikes(h, poses.data() + stride * k, idx.data(), n, update, out.data()); }
         if (int32_t rc = borrowed_mode ? rbs_set_observation_borrowed_f32(h, frames.data() + npx * k, npx) : rbs_set_observation_f32(h, frames.data() + npx * k, npx)) return rc;
         idx = parents;
         return rbs_loglikes(h, poses.data() + stride * k, idx.data(), n, update, out.data());
@@ -282,7 +284,7 @@ int main(int argc, char** argv)
         if (int32_t rc = rbs_loglikes_prefetch(h, poses.data() + stride * k, idx.data(), n, update, out.data(), frames.data() + npx * k1, npx)) return rc;
         return rbs_set_observation_prefetched(h);
     };
-    if (prefetch_mode && rbs_set_observation_f32(h, frames.data(), npx)) { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; }
+    if ((prefetch_mode || loglikes_only) && rbs_set_observation_f32(h, frames.data(), npx)) { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; }
     for (int i = 0; i < warmup; ++i)
         if (prefetch_mode ? step_ahead(i) : step(i)) { std::printf("ERROR %s\n", rbs_last_error(h)); return 1; }
     const auto t0 = std::chrono::steady_clock::now();
