@@ -96,6 +96,11 @@ class RbSensorBuilder:
         vertex_shader_file: str = ""
         fragment_shader_file: str = ""
         geometry_shader_file: str = ""
+        # extension keys next to particle_filter/gpu/sample_count (the same fields as
+        # dbot_amd::RbSensorBuilder<State>::Parameters in include/dbot_amd/rb_sensor_builder.hpp), "" / None: the library's choice
+        likelihood_precision: str = ""        # "f64" | "f32"
+        occlusion_mode: str = ""              # "reference" | "device"
+        devices: "list | None" = None         # HIP ordinals: particle sharding inside the handle
 
         @classmethod
         def from_rosparam(cls, tree):
@@ -116,6 +121,14 @@ class RbSensorBuilder:
             p.vertex_shader_file = str(g.get("vertex_shader_file", ""))
             p.fragment_shader_file = str(g.get("fragment_shader_file", ""))
             p.geometry_shader_file = str(g.get("geometry_shader_file", ""))
+            p.likelihood_precision = str(g.get("likelihood_precision", "") or "")
+            p.occlusion_mode = str(g.get("occlusion_mode", "") or "")
+            for key, val, known in (("likelihood_precision", p.likelihood_precision, _capi.PRECISIONS),
+                                    ("occlusion_mode", p.occlusion_mode, _capi.OCC_MODES)):
+                if val and val not in known:
+                    raise ValueError(f"particle_filter/gpu/{key}: {val!r} (one of {sorted(k for k in known if k)})")
+            dev = g.get("devices")
+            p.devices = [int(d) for d in dev] if dev else None
             return p
 
     def __init__(self, object_model, camera_data, params, device_id=0):
@@ -127,7 +140,9 @@ class RbSensorBuilder:
             raise RbSensorError(_capi.RBS_ERR_UNSUPPORTED,
                                 "use_gpu:false selects dbot's CPU model; this package only "
                                 "provides the MI355X implementation (no CPU fallback)")
-        return RbSensor(self.object_model, self.camera_data, self.params, self.device_id)
+        p = self.params
+        return RbSensor(self.object_model, self.camera_data, p, self.device_id, precision=p.likelihood_precision or None,
+                        occlusion=p.occlusion_mode or None, device_ids=p.devices)
 
 
 class RbSensor:

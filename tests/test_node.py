@@ -69,6 +69,21 @@ def test_rosparam_tree_and_subsampling(tmp_path):
     assert sub.shape == (60 * 80,) and sub[1] == img[0, 8] and sub[80] == img[8, 0]
 
 
+def test_extension_keys_next_to_sample_count(tmp_path):
+    """particle_filter/gpu/{likelihood_precision, occlusion_mode, devices}: optional -- the reference's files
+    have none of them and give the library's choices -- read into the same fields as dbot_amd::RbSensorBuilder<State>::Parameters."""
+    from dbot_ros_amd import RbSensorBuilder
+    tree = node.load_rosparams(*_write(tmp_path))
+    p = RbSensorBuilder.Parameters.from_rosparam(tree)
+    assert (p.likelihood_precision, p.occlusion_mode, p.devices) == ("", "", None)
+    tree["particle_filter"]["gpu"].update(likelihood_precision="f64", occlusion_mode="reference", devices=[0, 1])
+    p = RbSensorBuilder.Parameters.from_rosparam(tree)
+    assert (p.likelihood_precision, p.occlusion_mode, p.devices) == ("f64", "reference", [0, 1])
+    tree["particle_filter"]["gpu"]["occlusion_mode"] = "exactly"
+    with pytest.raises(ValueError):
+        RbSensorBuilder.Parameters.from_rosparam(tree)
+
+
 REFERENCE_CONFIG = "/root/reference/config"
 
 
@@ -135,6 +150,41 @@ def test_node_assembly_tracks_at_the_reference_operating_point(tmp_path, gpu_lib
     assert max(errs[-5:]) < 0.025, errs   # 80x60: one pixel is 8.8 mm at 0.7 m -> a few pixels
     tracker.close()
     sensor.close()
+
+
+@pytest.mark.gpu
+def test_node_assembly_in_occlusion_mode_reference(tmp_path, gpu_lib):
+    """particle_filter/gpu/occlusion_mode: reference in the node's YAML -> the sensor the assembly builds keeps the reference's own
+    occlusion bookkeeping (its slots are stamped planes: no raw float plane to hand out) and tracks like the default."""
+    from dbot_ros_amd import CameraData, RbSensor, RbSensorBuilder, RbSensorError
+    paths = _write(tmp_path)
+    K = synth.camera_matrix(640, 480)
+    ests = {}
+    for mode in ("reference", "device"):
+        tree = node.load_rosparams(*paths)
+        tree["particle_filter"]["gpu"]["occlusion_mode"] = mode
+        tracker, om, cam, _ = node.build_particle_tracker(tree, K, str(tmp_path), seed=3)
+        sensor = tracker.sensor
+        if mode == "reference":
+            with pytest.raises(RbSensorError):
+                sensor.occlusion_device_ptr(0)
+        else:
+            assert sensor.occlusion_device_ptr(0)
+        full = RbSensor(om, CameraData(K, 480, 640), RbSensorBuilder.Parameters(sample_count=1), max_particles=1)
+        rng = np.random.default_rng(0)
+        Rt0 = synth.truth_pose(1, frame=0)[0]
+        s0 = np.zeros(12)
+        s0[3:6] = pose.matrix_to_rotvec(Rt0[:9].reshape(3, 3))
+        s0[0:3] = Rt0[9:] - Rt0[:9].reshape(3, 3) @ om.centers[0]
+        tracker.initialize([s0])
+        out = []
+        for k in range(1, 9):
+            native = synth.make_frame(full.render_depth(synth.truth_pose(1, frame=k)), 480, 640, rng, occluder=False)
+            out.append(tracker.track(node.to_eigen_vector(native.reshape(480, 640), tree["downsampling_factor"])))
+        ests[mode] = np.array(out)
+        full.close(); tracker.close(); sensor.close()
+    # the two bookkeepings differ by ~1e-8 in a log-likelihood: the same track (a resampling draw on the edge may pick a neighbour)
+    assert np.abs(ests["reference"][:, 0:3] - ests["device"][:, 0:3]).max() < 5e-3
 
 
 @pytest.mark.gpu
