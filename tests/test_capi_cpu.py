@@ -141,9 +141,16 @@ def test_register_budgets_the_kernels_overlap_depends_on():
         # the budget is stated (amdgpu_num_vgpr); inside it the compiler may park a kernel-lifetime
         # value or two in scratch (stored once, reloaded per work item): fine; spills in the loops are not
         assert vgprs <= 160 and spills <= 4, (name, vgprs, spills)
-    for name in ("rbs_copy_window_kernelILb0E", "rbs_copy_window_kernelILb1E"):
-        vgprs, spills = usage(name)
-        assert vgprs <= 32 and spills == 0, (name, vgprs, spills)
+    # EVERY variant of the windowed copy kernel <SLAB, STRIPS, STP, EXACT> (round 6 found the stamped-plane ones outside the check: two
+    # registers over, the kernel ran BEHIND the raster kernel instead of beside it, 0.097 -> 0.201 ms).  Known and accepted: slabs + one
+    # rectangle + shared background plane + stamped planes holds a cell, its ages and the shared plane's cell and ages: 34.
+    over_budget_ok = {"ILb1ELi1ELb1ELb1E": 34}
+    seen = 0
+    for m in re.finditer(r"Function Name: \S*rbs_copy_window_kernel(ILb[01]ELi[012]ELb[01]ELb[01]E)\S*.*?VGPRs: (\d+).*?VGPRs Spill: (\d+)", txt, re.S):
+        variant, vgprs, spills = m.group(1), int(m.group(2)), int(m.group(3))
+        assert vgprs <= over_budget_ok.get(variant, 32) and spills == 0, (variant, vgprs, spills)
+        seen += 1
+    assert seen == 24, seen
     for name in ("rbs_raster_kernel_f64ILb1ELb0EE", "rbs_raster_kernel_f64ILb0ELb0EE", "rbs_raster_kernel_f64ILb1ELb1EE",
                  "rbs_raster_kernel_f64ILb0ELb1EE"):
         vgprs, spills = usage(name)        # precision F64 (the default): the same budget; a kernel-lifetime value or two
