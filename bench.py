@@ -1449,6 +1449,7 @@ def headline(a, world, n, n_tri, elapsed, regions, peer):
 
 
 def main():
+    t_main = time.perf_counter()
     if os.environ.get("RBS_BENCH_WATCHDOG"):    # diagnostics: dump every thread's stack and exit after that many seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["RBS_BENCH_WATCHDOG"]), exit=True)
@@ -1859,6 +1860,7 @@ def main():
                         "update)); exact_occlusion_value = resident_value with rbs_config.occlusion_mode = REFERENCE; dense / sweep: where SURVEY 8(d)'s "
                         "bytes really move, as fractions of 8 TB/s; roofline_frac: the dominant kernel against the guide's VALU issue peak"}
         out = {**{k: out[k] for k in ("metric", "value", "unit")}, "survey_8d": lead, **{k: v for k, v in out.items() if k not in ("metric", "value", "unit")}}
+    out["bench_wall_s"] = round(time.perf_counter() - t_main, 1)   # the whole run, every leg (the timed region is ms_per_step x steps)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -104,3 +104,49 @@ def test_exposure_of_the_unpinned_rules():
         assert r["max_rel_loglik_diff"] > 1e-5 and r["covered_pixels_that_differ"] > 0
     for r in table["inf_evaluated"].values():      # an evaluated +inf poisons the sum: there is no finite "other answer"
         assert r["particles_with_nan"] > 0
+
+
+def test_pixel_centre_sampling_is_a_shift_of_the_principal_point():
+    """The one consequential open rule (cov_centres above) needs no rebuild should upstream turn out to use it: the renderer meets pixel
+    coordinates only as sample points against the projected triangles, so samples at (col + 0.5, row + 0.5) under K are samples at
+    (col, row) under K with the principal point moved by (-0.5, -0.5).  The variant oracle with K against the oracle of record with the
+    shifted K: the same coverage (but for samples on an edge to rounding) and the same depths to float rounding; log-likelihoods
+    agree to 1e-6 -- against 8 % / 240 % between the conventions themselves.  INTEGRATION.md section 5 states the remedy."""
+    import copy
+    for cols, rows, n in ((640, 480, 24), (80, 60, 96)):
+        om, cam, P = sc.make_scene(("m1",), cols, rows, max_particles=n)
+        cam_shift = copy.deepcopy(cam)
+        cam_shift.camera_matrix = np.array(cam.camera_matrix, dtype=np.float64).copy()
+        cam_shift.camera_matrix[0, 2] -= 0.5
+        cam_shift.camera_matrix[1, 2] -= 0.5
+        centres = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY, variant="cov_centres")
+        shifted = ob.Oracle(om, cam_shift, P, max_particles=n, mode=ob.LAZY)
+        threads = sc.usable_threads()
+        centres.reset(threads=threads); shifted.reset(threads=threads)
+        rng = np.random.default_rng(7)
+        flips = covered = 0
+        worst_depth = worst_ll = 0.0
+        idx = [np.zeros(n, np.int32), np.zeros(n, np.int32)]
+        for k in range(6):
+            truth = synth.truth_pose(1, frame=k)
+            da, db = centres.render_depth(truth), shifted.render_depth(truth)
+            fa, fb = np.isfinite(da), np.isfinite(db)
+            flips += int((fa != fb).sum()); covered += int(fa.sum())
+            both = fa & fb
+            worst_depth = max(worst_depth, float((np.abs(da[both] - db[both]) / da[both]).max()))
+            frame = synth.make_frame(da, rows, cols, rng)
+            centres.set_observation(frame); shifted.set_observation(frame)
+            poses = synth.particle_poses(truth, n, rng, scale=1.0)
+            la = centres.loglikes_poses(poses, idx[0], update=True, threads=threads)
+            lb = shifted.loglikes_poses(poses, idx[1], update=True, threads=threads)
+            worst_ll = max(worst_ll, float((np.abs(la - lb) / np.maximum(1.0, np.abs(la))).max()))
+            p = np.sort(rng.choice(n, size=n)).astype(np.int32)
+            idx = [p.copy(), p.copy()]
+        record = ob.Oracle(om, cam, P, max_particles=1, mode=ob.LAZY)      # (not vacuous: under the SAME K the two conventions differ)
+        d0 = record.render_depth(synth.truth_pose(1, frame=0))
+        assert (np.isfinite(d0) != np.isfinite(centres.render_depth(synth.truth_pose(1, frame=0)))).sum() > 0
+        record.close()
+        centres.close(); shifted.close()
+        print(f"\n{cols}x{rows}: pixel centres under K vs integer samples under K - (0.5, 0.5): {flips} of {covered} covered px flip, "
+              f"depth {worst_depth:.1e}, log-likelihood {worst_ll:.1e}")
+        assert flips <= max(2, covered // 20000) and worst_depth <= 1e-6 and worst_ll <= 1e-6
