@@ -184,3 +184,33 @@ def test_set_option_switches_the_shared_trail_and_refuses_nonsense():
                 a.set_option(name, bad)
         with pytest.raises(RbSensorError):
             a._check(a._lib.rbs_set_option(a._h, 99, 1.0))
+
+
+def test_pixel_centre_convention_through_a_shifted_principal_point():
+    """DESIGN.md section 2 / INTEGRATION.md section 3: were upstream's renderer to sample at pixel centres, the binding hands K over with
+    (cx - 0.5, cy - 0.5).  The DEVICE with the shifted K against the oracle VARIANT that samples at centres under the unshifted K:
+    rendered depth bit for bit, a resampled sequence's log-likelihoods at the usual bar."""
+    import copy
+    n, cols, rows = 64, 320, 240
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    cam_shift = copy.deepcopy(cam)
+    cam_shift.camera_matrix = np.array(cam.camera_matrix, dtype=np.float64).copy()
+    cam_shift.camera_matrix[0, 2] -= 0.5
+    cam_shift.camera_matrix[1, 2] -= 0.5
+    centres = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY, variant="cov_centres")
+    rng = np.random.default_rng(12)
+    with RbSensor(om, cam_shift, P, max_particles=n, occlusion="reference") as g:
+        g.reset(); centres.reset()
+        idx_g, idx_o = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for k in range(8):
+            truth = synth.truth_pose(1, frame=k)
+            d_o, d_g = centres.render_depth(truth), g.render_depth(truth)
+            assert np.array_equal(d_o, d_g, equal_nan=True), k
+            frame = synth.make_frame(d_o, rows, cols, rng)
+            g.set_observation(frame); centres.set_observation(frame)
+            poses = synth.particle_poses(truth, n, rng, scale=1.0)
+            a, b = g.loglikes_poses(poses, idx_g, update=True), centres.loglikes_poses(poses, idx_o, update=True)
+            assert (np.abs(a - b) / np.maximum(1.0, np.abs(b))).max() <= 1e-10, k
+            p = np.sort(rng.choice(n, size=n)).astype(np.int32)
+            idx_g, idx_o = p.copy(), p.copy()
+    centres.close()
