@@ -194,7 +194,7 @@ def test_20000_particles_parents_vs_lazy_oracle(gpu_lib):
     assert worst_plane <= PLANE_TOL, worst_plane
 
 
-def _two_frames(meshes, cols, rows, n, k_oracle, blocks_readonly, chunk, z=0.7):
+def _two_frames(meshes, cols, rows, n, k_oracle, blocks_readonly, chunk, z=0.7, occlusion=None, tol=None):
     """test_gpu_fullsize._full_size_case's two-frame run with the LAZY oracle as the checker."""
     nb = len(meshes)
     om, cam, P = sc.make_scene(meshes, cols, rows, max_particles=n)
@@ -204,7 +204,7 @@ def _two_frames(meshes, cols, rows, n, k_oracle, blocks_readonly, chunk, z=0.7):
     frame = synth.make_frame(render.render_depth(truth), rows, cols, rng)
     render.close()
     poses = synth.particle_poses(truth, n, rng, scale=2.0)
-    with RbSensor(om, cam, P, max_particles=n) as g:
+    with RbSensor(om, cam, P, max_particles=n, occlusion=occlusion) as g:
         g.reset()
         g.set_observation(frame)
         idx = np.zeros(n, np.int32)
@@ -229,7 +229,7 @@ def _two_frames(meshes, cols, rows, n, k_oracle, blocks_readonly, chunk, z=0.7):
         orc.close()
         for x, y in zip(out, r):
             e = rel_err(x[part], y)
-            assert e.max() <= TOL_LAZY, float(e.max())
+            assert e.max() <= (TOL_LAZY if tol is None else tol), float(e.max())
             worst = max(worst, float(e.max()))
     return worst
 
@@ -239,18 +239,21 @@ def test_c1_full_size_every_particle_vs_lazy_oracle(gpu_lib):
     print(f"\nC1, all 2 000 particles vs LAZY oracle: {worst:.3e}")
 
 
-def test_c2_full_size_random_1000_vs_lazy_oracle(gpu_lib):
+@pytest.mark.parametrize("occlusion", ["device", "reference"])
+def test_c2_full_size_random_1000_vs_lazy_oracle(gpu_lib, occlusion):
     """BASELINE C2: 6 666 particles x meshes [M1, M2, M3] (R:config/object.yaml:3-5 lists several meshes),
     two read-only blocks and the updating one per frame; a random 1 000 against the LAZY oracle."""
-    worst = _two_frames(("m1", "m2", "m3"), 640, 480, 6666, 1000, 2, 500)
-    print(f"\nC2, a random 1 000 particles vs LAZY oracle: {worst:.3e}")
+    worst = _two_frames(("m1", "m2", "m3"), 640, 480, 6666, 1000, 2, 500, occlusion=occlusion, tol=TOL_EXACT if occlusion == "reference" else None)
+    print(f"\nC2, a random 1 000 particles vs LAZY oracle, occlusion {occlusion}: {worst:.3e}")
 
 
-def test_c4_geometry_vs_lazy_oracle(gpu_lib):
+@pytest.mark.parametrize("occlusion", ["device", "reference"])
+def test_c4_geometry_vs_lazy_oracle(gpu_lib, occlusion):
     """BASELINE C4's geometry -- M4 (50 880 triangles) at 1280x960, the object at 0.5 m (8 work items per particle,
-    the shared cluster cull of the many-cluster kernels) -- 256 particles, two frames, against the LAZY oracle (VERDICT r4 #4a)."""
-    worst = _two_frames(("m4",), 1280, 960, 256, 256, 0, 128, z=0.5)
-    print(f"\nC4 geometry (M4, 1280x960), 256 particles vs LAZY oracle: {worst:.3e}")
+    the shared cluster cull of the many-cluster kernels) -- 256 particles, two frames, against the LAZY oracle (VERDICT r4 #4a);
+    occlusion reference: the stamped-plane form of those kernels (rbs_raster_kernel_exact_f64<.., MANY = true, ..>) at its own bar."""
+    worst = _two_frames(("m4",), 1280, 960, 256, 256, 0, 128, z=0.5, occlusion=occlusion, tol=TOL_EXACT if occlusion == "reference" else None)
+    print(f"\nC4 geometry (M4, 1280x960), 256 particles vs LAZY oracle, occlusion {occlusion}: {worst:.3e}")
 
 
 def test_c2_sequence_three_bodies_three_blocks_vs_lazy_oracle(gpu_lib):
