@@ -33,7 +33,7 @@ def _check_against_oracle(ll, ref, S, precision):
         assert (d <= 1e-6 * np.maximum(1.0, S)).all(), (d / np.maximum(1.0, S)).max()
 
 
-def _oracle_for_subset(om, cam, P, frame, poses, sel, blocks_readonly, chunk, threads):
+def _oracle_for_subset(om, cam, P, frame, poses, sel, blocks_readonly, chunk, threads, mode=None):
     """The device's two-frame run restricted to the particles `sel`, on the CPU oracle: frame 1
     (every particle inherits slot 0: blocks_readonly read-only calls, then the updating one), frame
     2 (particle i inherits its own slot i).  Slots are private to a particle in this run, so any
@@ -42,7 +42,7 @@ def _oracle_for_subset(om, cam, P, frame, poses, sel, blocks_readonly, chunk, th
     for lo in range(0, len(sel), chunk):
         part = sel[lo:lo + chunk]
         k = len(part)
-        orc = ob.Oracle(om, cam, P, max_particles=k, mode=ob.EAGER)
+        orc = ob.Oracle(om, cam, P, max_particles=k, mode=ob.EAGER if mode is None else mode)
         orc.reset(threads=threads)
         orc.set_observation(frame)
         io = np.zeros(k, np.int32)
@@ -88,7 +88,8 @@ def _full_size_case(meshes, cols, rows, n, k_oracle, precision, blocks_readonly=
         for x, y in zip(a, c):
             assert np.array_equal(x[perm], y)                             # permutation equivariance
     sel = np.arange(n) if k_oracle >= n else np.sort(rng.choice(n, size=k_oracle, replace=False))
-    refs, S = _oracle_for_subset(om, cam, P, frame, poses, sel, blocks_readonly, chunk, sc.usable_threads())
+    refs, S = _oracle_for_subset(om, cam, P, frame, poses, sel, blocks_readonly, chunk, sc.usable_threads(),
+                                 mode=ob.LAZY if sensor_kw.get("occlusion") == "reference" else None)   # (the oracle of the handle's own bookkeeping)
     for j, (x, r) in enumerate(zip(a, refs)):
         _check_against_oracle(x[sel], r, S[min(max(j - blocks_readonly, 0), 1)], precision)
 
@@ -127,6 +128,12 @@ def test_c3_all_200000_particles_on_one_gpu_in_eight_shards(gpu_lib):
     occlusion state; whole planes would be 492 GB).  A random 1 000 particles against the oracle,
     determinism and permutation equivariance over all 200 000."""
     _full_size_case(("m1",), 640, 480, 200000, 1000, "f64", device_ids=[0] * 8, slab_px=640 * 480 // 8)
+
+
+def test_c3_all_200000_particles_in_occlusion_mode_reference(gpu_lib):
+    """The same 200 000 particles in eight shards with rbs_config.occlusion_mode = REFERENCE (stamped planes in slabs: 92 GB of
+    occlusion state), a random 1 000 against the reference-semantics (LAZY) oracle."""
+    _full_size_case(("m1",), 640, 480, 200000, 1000, "f64", device_ids=[0] * 8, slab_px=640 * 480 // 8, occlusion="reference")
 
 
 def test_c4_all_50000_particles_on_one_gpu_in_eight_shards(gpu_lib):
