@@ -148,3 +148,37 @@ def test_the_parity_suite_in_reference_mode():
     print("\ntest_gpu_parity.py (windowed cases) with RBS_OCC=reference: " + tail)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
     assert " passed" in tail and "failed" not in tail
+
+
+@pytest.mark.parametrize("slab_px", [-1, 0])
+def test_large_windows_without_the_shared_trail(slab_px):
+    """An object that crosses the image with the shared trail switched off (rbs_set_option): the windows grow to most of the plane -- the
+    regime where the device rule changes to its whole-plane machinery, which stamped planes do not have (their windowed kernels carry
+    on) -- and shrink again behind the object only as ages pass age_max.  Every particle, every frame against the LAZY oracle."""
+    n, cols, rows = 64, 160, 120
+    om, cam, P = sc.make_scene(("m1_l2",), cols, rows, max_particles=n)
+    lazy = ob.Oracle(om, cam, P, max_particles=n, mode=ob.LAZY)
+    rng = np.random.default_rng(41)
+    with RbSensor(om, cam, P, max_particles=n, occlusion="reference", slab_px=slab_px) as g:
+        g.set_option("shared_trail", 0)
+        g.set_option("timing_every", 1)
+        g.reset(); lazy.reset()
+        idx_g, idx_o = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        frac = 0.0
+        for k in range(48):
+            t = synth.truth_pose(1, frame=k)
+            t[:, 9] += -0.27 + 0.0115 * k           # corner to corner across the image
+            t[:, 10] += -0.19 + 0.0082 * k
+            frame = synth.make_frame(lazy.render_depth(t), rows, cols, rng)
+            g.set_observation(frame); lazy.set_observation(frame)
+            poses = synth.particle_poses(t, n, rng, scale=1.0)
+            a, b = g.loglikes_poses(poses, idx_g, update=True), lazy.loglikes_poses(poses, idx_o, update=True)
+            assert _rel(a, b) <= TOL, (k, _rel(a, b))
+            p = np.sort(rng.choice(n, size=n, p=(lambda w: w / w.sum())(rng.random(n) ** 6))).astype(np.int32)
+            idx_g, idx_o = p.copy(), p.copy()
+            frac = max(frac, g.window_fraction())
+        assert not g.shared_trail_state()[0]
+        area = np.mean([max(0, w[2] - w[0]) * max(0, w[3] - w[1]) for w in (g.get_window(q) for q in range(0, n, 5))]) / (rows * cols)
+        print(f"\nslab_px {slab_px}: stored window at the end {area:.2f} of the plane (sampled fraction {frac:.2f})")
+        assert area > 0.5
+        _planes_equal(g, lazy, range(0, n, 9), allow=2)
