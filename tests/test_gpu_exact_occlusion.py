@@ -150,7 +150,7 @@ def test_the_parity_suite_in_reference_mode():
     assert " passed" in tail and "failed" not in tail
 
 
-@pytest.mark.parametrize("slab_px", [-1, 0])
+@pytest.mark.parametrize("slab_px", [-1, 0, 2048])      # (2 048: slabs that must grow several times on the way -- values AND ages move)
 def test_large_windows_without_the_shared_trail(slab_px):
     """An object that crosses the image with the shared trail switched off (rbs_set_option): the windows grow to most of the plane -- the
     regime where the device rule changes to its whole-plane machinery, which stamped planes do not have (their windowed kernels carry
