@@ -2236,9 +2236,14 @@ int32_t group_load_rccl(rbs_handle* g, const std::vector<int>& devs)
 {
     Rccl* r = new Rccl;
     g->rccl = r;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r->lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // a copy the process has loaded already (PyTorch ships its own librccl) before a second one from the ROCm tree
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        r->lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
         if (r->lib) break;
+    }
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        if (r->lib) break;
+        r->lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!r->lib) return fail(g, RBS_ERR_UNSUPPORTED, fmt("several devices need RCCL: dlopen(librccl.so.1) failed: %s", dlerror()));
     r->CommInitAll = reinterpret_cast<decltype(r->CommInitAll)>(dlsym(r->lib, "ncclCommInitAll"));
@@ -2352,8 +2357,27 @@ int32_t create_group(const rbs_config* cfg, rbs_handle* g)
             (void)hipGetLastError();
         }
     }
-    if (distinct)
-        if (int32_t rc = group_load_rccl(g, devs)) return rc;
+    bool want_rccl = distinct;
+#ifdef RBS_TEST_HOOKS   // (hooks library only) RBS_TEST_FORCE_RCCL=1: take the RCCL branch on a one-GPU box too -- ncclCommInitAll refuses a
+                        // device that appears twice, which is the failure the fall-back below exists for
+    if (const char* e = std::getenv("RBS_TEST_FORCE_RCCL")) want_rccl = want_rccl || std::atoi(e) != 0;
+#endif
+    if (want_rccl) {
+        if (int32_t rc = group_load_rccl(g, devs)) {
+            // First contact with a node must not end at the communicator: the exchange is n doubles per block, and the devices can
+            // read each other (checked above) -- the peer-copy form of group_allgather does the same job.  RBS_REQUIRE_RCCL=1: fatal.
+            const char* req = std::getenv("RBS_REQUIRE_RCCL");
+            if (req && std::atoi(req) != 0) return rc;
+            std::fprintf(stderr, "[rbsensor_mi355x] RCCL is not used for this handle (%s): log-likelihoods are exchanged by peer copies\n", g->err.c_str());
+            if (g->rccl) {
+                for (auto c : g->rccl->comms)
+                    if (c) (void)g->rccl->CommDestroy(c);
+                delete g->rccl;
+                g->rccl = nullptr;
+            }
+            g->err.clear();
+        }
+    }
     return RBS_OK;
 }
 

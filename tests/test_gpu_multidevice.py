@@ -383,3 +383,38 @@ def test_a_fan_out_that_fails_half_way_poisons_the_handle_until_reset(gpu_lib, m
                 idx = rng.integers(0, n, n).astype(np.int32)
             for s_ in (0, n - 1):
                 assert np.array_equal(grp.get_occlusion(s_), one.get_occlusion(s_))
+
+
+def test_a_communicator_that_cannot_be_made_falls_back_to_peer_copies(gpu_lib, monkeypatch):
+    """First contact with a multi-GPU node must not end at ncclCommInitAll: a handle over several devices whose RCCL communicator cannot
+    be made exchanges its log-likelihoods by peer copies instead (the devices can read each other: checked at create) and says so on
+    stderr; RBS_REQUIRE_RCCL=1 makes it an error.  Provoked on one GPU with the hooks library: RBS_TEST_FORCE_RCCL takes the RCCL branch
+    for device_ids = [0, 0], which ncclCommInitAll refuses."""
+    import os
+    import subprocess
+    import sys
+    from dbot_ros_amd import _capi
+    from dbot_ros_amd.sensor import RbSensorError
+    hooks = os.path.join(os.path.dirname(_capi.LIB_PATH), "librbsensor_mi355x_hooks.so")
+    if os.path.abspath(_capi.LIB_PATH) != os.path.abspath(hooks):
+        assert os.path.exists(hooks), "build() makes librbsensor_mi355x_hooks.so"
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-s",
+                            __file__ + "::test_a_communicator_that_cannot_be_made_falls_back_to_peer_copies"],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, RBS_LIB_PATH=hooks))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert "RCCL is not used for this handle" in r.stderr + r.stdout
+        return
+    n, nb = 64, 1
+    om, cam, P = sc.make_scene(("m1_l2",), 160, 120, max_particles=n)
+    rng = np.random.default_rng(3)
+    with RbSensor(om, cam, P, max_particles=1) as r:
+        frames = [synth.make_frame(r.render_depth(synth.truth_pose(nb, frame=k)), 120, 160, rng, occluder=False).astype(np.float32)
+                  for k in range(1, 5)]
+    randomness = [(rng.standard_normal((nb, n, 6)), rng.random((nb, n))) for _ in frames]
+    e1, _, r1 = _run_tracker(om, cam, P, n, nb, frames, None, randomness)
+    monkeypatch.setenv("RBS_TEST_FORCE_RCCL", "1")
+    e2, _, r2 = _run_tracker(om, cam, P, n, nb, frames, [0, 0], randomness)      # the communicator fails, the tracker runs
+    assert r1 == r2 and np.abs(e1 - e2).max() <= 1e-9
+    monkeypatch.setenv("RBS_REQUIRE_RCCL", "1")
+    with pytest.raises(RbSensorError, match="ncclCommInitAll"):
+        RbSensor(om, cam, P, max_particles=n, device_ids=[0, 0])
