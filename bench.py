@@ -59,6 +59,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_COPY_MEASURED_GBPS = 6290.0
 # VALU issue ceilings of this chip in G wave64-instructions/s, chip-wide (1 024 SIMDs).
 # MEASURED (tools/valu_bench.hip, profiles/r04_valu_issue_microbench.txt: kernels of 6-55 ms, every block's
 # start / end and cycle count logged, 1..8 waves per SIMD; wall-clock rates cross-checked against the chip's own
@@ -1693,6 +1694,7 @@ def main():
         out["dense_ms_per_step"] = td / dsteps * 1e3
         out["roofline"].update({"dense_bound": "hbm", "dense_kernel": "rbs_copy_rows_kernel", "dense_kernel_ms": d_copy_ms,
                                 "dense_achieved_GBps": dach, "dense_frac": dach / HBM_PEAK_GBPS,
+                                "dense_frac_of_measured_copy": dach / HBM_COPY_MEASURED_GBPS,   # (what a float4 copy reaches on this part: the guide)
                                 "dense_traffic": dtraffic,
                                 "dense_traffic_over_algorithmic": (dtraffic / alg_bytes) if dtraffic else None,
                                 "dense_kernel_launches_averaged": d_used, "dense_raster_kernel_ms": d_raster_ms})
