@@ -1923,7 +1923,14 @@ int32_t create_impl(const rbs_config* cfg, rbs_handle* h)
     {   // the occlusion bookkeeping: the caller's choice; left open, the library's (tooling: RBS_OCC=reference|device in the
         // environment replaces DEFAULT only, never a mode the caller named)
         int mode = cfg->occlusion_mode;
-        const bool can = h->precision == RBS_PRECISION_F64 && h->windowed;
+        // (a pixel's age must fit 16 bits: c^(65 534 delta_time) <= 2^-40, i.e. the process forgets within the counter's range -- with the
+        // reference's constants after 1 628 frames; a process that nearly never forgets, c = p_oo - p_ov above ~0.987 at 30 frames/s, cannot
+        // be kept exactly this way)
+        const bool ages_fit = std::exp((65534.0 * h->delta_time) * std::log(h->p_oo - h->p_ov)) <= kExactTau;
+        const bool can = h->precision == RBS_PRECISION_F64 && h->windowed && ages_fit;
+        if (mode == RBS_OCC_REFERENCE && h->precision == RBS_PRECISION_F64 && h->windowed && !ages_fit)
+            return fail(h, RBS_ERR_UNSUPPORTED, fmt("occlusion_mode REFERENCE keeps a 16-bit age per pixel: with p_occluded_occluded - p_occluded_visible = %.6g and "
+                                                    "delta_time = %.6g a value has not decayed to 2^-40 of itself after 65 534 frames", h->p_oo - h->p_ov, h->delta_time));
         if (mode == RBS_OCC_DEFAULT) {
             mode = RBS_OCC_LIBRARY_DEFAULT;
             if (const char* m = std::getenv("RBS_OCC")) mode = !std::strcmp(m, "reference") ? RBS_OCC_REFERENCE : !std::strcmp(m, "device") ? RBS_OCC_DEVICE_RULE : mode;

@@ -90,10 +90,11 @@ enum { RBS_STATE_DEFAULT = 0, RBS_STATE_WINDOWED = 1, RBS_STATE_DENSE = 2 };
  *               (frames since the update, counted against the slot's epoch = the last updating call): 6 bytes instead of
  *               4; nothing is stepped between frames -- the copy kernel copies, ages advance by packed saturating adds.
  *               A pixel whose age exceeds the frame count at which (p_oo - p_ov)^(age * delta_time) <= 2^-40 (1 628
- *               frames with the defaults; at most 65 534) is the background again: its value differs from a
- *               never-covered pixel's by less than that.  Binary64 likelihood and the windowed layout only
- *               (RBS_ERR_UNSUPPORTED otherwise); every layout option of the windowed form works (slabs, several
- *               devices, attached ranks, the shared trail).
+ *               frames with the defaults) is the background again: its value differs from a never-covered pixel's by
+ *               less than that.  That count must fit the age: parameters with which a value has not decayed so far
+ *               within 65 534 frames (p_oo - p_ov above ~0.987 at 30 frames/s) are RBS_ERR_UNSUPPORTED in this mode.
+ *               Binary64 likelihood and the windowed layout only (RBS_ERR_UNSUPPORTED otherwise); every layout option
+ *               of the windowed form works (slabs, several devices, attached ranks, the shared trail).
  *   DEVICE_RULE the float-stepped rule (oracle mode EAGER): every stored value advanced by one float FMA per updating
  *               call and snapped onto the background within 2^-18 of it.  Within ~1e-8 of REFERENCE (relative, typical);
  *               of 30 720 particle-frames one was 1.3e-5 away, and 16 of 600 000 resampled children drew a neighbouring

@@ -85,6 +85,14 @@ def test_mode_needs_f64_and_windows():
         RbSensor(om, cam, P, max_particles=8, occlusion="reference", precision="f32")
     with pytest.raises(RbSensorError):
         RbSensor(om, cam, P, max_particles=8, occlusion="reference", state_layout="dense")
+    # ... and a process that forgets within the 16-bit age counter's range (the reference's constants: within 1 628 frames)
+    import copy
+    slow = copy.deepcopy(P)
+    slow.occlusion.p_occluded_occluded, slow.occlusion.p_occluded_visible = 0.9995, 0.0005
+    with pytest.raises(RbSensorError, match="16-bit age"):
+        RbSensor(om, cam, slow, max_particles=8, occlusion="reference")
+    with RbSensor(om, cam, slow, max_particles=8, occlusion="device"):
+        pass
 
 
 @pytest.mark.parametrize("slab_px", [0, 16384])
