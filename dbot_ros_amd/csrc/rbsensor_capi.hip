@@ -409,6 +409,17 @@ void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size
 #undef RBS_X
         return;
     }
+    if (P.bgp_src && h->precision == RBS_PRECISION_F32) {   // the shared background plane, float32 likelihood
+#define RBS_X(U, S, M) hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f32<U, S, M>), grid, block, smem, s, P); break
+        switch ((update ? 4 : 0) | (h->slab_px ? 2 : 0) | (h->many_clusters ? 1 : 0)) {
+            case 0: RBS_X(false, false, false);  case 1: RBS_X(false, false, true);
+            case 2: RBS_X(false, true, false);   case 3: RBS_X(false, true, true);
+            case 4: RBS_X(true, false, false);   case 5: RBS_X(true, false, true);
+            case 6: RBS_X(true, true, false);    default: RBS_X(true, true, true);
+        }
+#undef RBS_X
+        return;
+    }
     if (P.bgp_src) {   // the shared background plane (binary64)
         switch ((update ? 4 : 0) | (h->slab_px ? 2 : 0) | (h->many_clusters ? 1 : 0)) {
             case 0: hipLaunchKernelGGL((rbs::rbs_raster_kernel_stp_f64<false, false, false>), grid, block, smem, s, P); break;
@@ -578,7 +589,7 @@ int32_t enqueue_loglikes(rbs_handle* h, const double* d_poses, const int* d_indi
     bool stp_leaving = false;
     P.bgp_src = nullptr; P.bgp_dst = nullptr; P.rebase_box = nullptr;
     rbs_handle* const so = h->group ? h->group : h;   // who owns the shared trail's state: the group for all its shards
-    if (h->windowed && h->precision == RBS_PRECISION_F64 && so->stp_allowed) {
+    if (h->windowed && so->stp_allowed) {
         rbs_handle::StpNow d;
         if (h->group) {
             d = so->stp_now;                               // (decided once for every shard: group_begin_call)
@@ -2169,7 +2180,7 @@ int32_t group_begin_call(rbs_handle* g, hipStream_t const* streams, bool update)
         g->stp_leave_pending = false;
     }
     g->stp_now = rbs_handle::StpNow();
-    if (g->windowed && g->precision == RBS_PRECISION_F64 && g->stp_allowed) {
+    if (g->windowed && g->stp_allowed) {
         double frac = 0.0;
         for (rbs_handle* h : g->shards) frac = std::max(frac, h->area_frac);
         g->stp_now = stp_decide(g, update, frac);
@@ -2200,7 +2211,7 @@ int32_t advance_empty(rbs_handle* h, bool update)
     occlusion_coeffs(h, h->pending_frames, &alpha, &beta);
     const float bg_new = h->exact ? exact_background(h, h->update_clock + h->pending_frames) : std::fmaf(alpha, h->background, beta);
     rbs_handle* g = h->group;
-    if (g && h->windowed && h->precision == RBS_PRECISION_F64 && g->stp_allowed) {
+    if (g && h->windowed && g->stp_allowed) {
         const rbs_handle::StpNow d = g->stp_now;
         if (d.entering || (g->stp && !h->stp && d.rebase != -2)) {
             for (int k = 0; k < 2; ++k)
@@ -3802,8 +3813,7 @@ int32_t rbs_shared_trail_rebase(rbs_handle* h, int32_t global_slot)
 {
     if (!h) return RBS_ERR_INVALID_ARGUMENT;
     if (!h->shards.empty()) return fail(h, RBS_ERR_UNSUPPORTED, "shared_trail_rebase: a handle over several devices decides for its shards itself");
-    if (!h->windowed || h->precision != RBS_PRECISION_F64)
-        return fail(h, RBS_ERR_UNSUPPORTED, "shared_trail_rebase: windowed planes and the binary64 likelihood only");
+    if (!h->windowed) return fail(h, RBS_ERR_UNSUPPORTED, "shared_trail_rebase: windowed planes only");
     const int slots = std::max(1, h->peer_world) * h->max_particles;
     if (global_slot != -2 && (global_slot < 0 || global_slot >= slots))
         return fail(h, RBS_ERR_INVALID_ARGUMENT, fmt("shared_trail_rebase: slot %d outside 0..%d (or -2: leave)", global_slot, slots - 1));

@@ -2058,6 +2058,13 @@ __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET voi
 {
     raster_kernel_body<UPDATE, 0, SLAB, MANY, true>(P);
 }
+// ... the same for the float32 likelihood (round 6: the shared trail no longer needs the binary64 likelihood)
+template <bool UPDATE, bool SLAB, bool MANY>
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES) __attribute__((amdgpu_num_vgpr(RBS_RASTER_VGPRS)))
+void rbs_raster_kernel_stp_f32(const DevParams P)
+{
+    raster_kernel_body<UPDATE, 1, SLAB, MANY, true>(P);
+}
 // ... on STAMPED planes (EXACT: the reference's occlusion bookkeeping; binary64; all of SLAB / MANY / STP), kernels of their own again
 template <bool UPDATE, bool SLAB, bool MANY, bool STP>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_kernel_exact_f64(const DevParams P)

@@ -352,8 +352,8 @@ int32_t rbs_get_window(rbs_handle* h, int32_t slot, int32_t out[4]);
 /* Shared trail (round 5).  With a scalar background a pixel stays in a window until its value has relaxed to within 2^-18 of
  * that level, ~730 frames after the object left it, and every child inherits the whole trail from its parent: an object that
  * moves across the image leaves windows of most of the frame, stored, read and stepped once per particle per frame.  Once the
- * sampled window area exceeds a tenth of the frame, a single-device handle (whole planes or slabs, binary64 likelihood) stores its
- * planes against a handle-wide background PLANE instead: the plane is re-based on one particle's plane and every child is
+ * sampled window area exceeds a tenth of the frame, a handle on windowed planes (whole planes or slabs; either likelihood precision,
+ * round 6) stores its planes against a handle-wide background PLANE instead: the plane is re-based on one particle's plane and every child is
  * re-measured against it, so that what the particles share from a common ancestor is stored once (after a resampling that is
  * nearly all of it).  Stored VALUES do not change by a bit -- the shared plane steps with the float operations of any stored
  * value -- and every entry point sees whole planes as before (rbs_get_occlusion, rbs_export_window: the slot is made dense first).

@@ -325,7 +325,8 @@ def test_borrowed_frame_gives_the_same_bits(gpu_lib):
 
 @pytest.mark.parametrize("meshes,cols,rows,n,slab", [(("m1",), 640, 480, 128, 0), (("m1_l2", "box12"), 320, 240, 96, 0), (("m1",), 640, 480, 96, 16384),
                                                        (("m4",), 640, 480, 32, 0), (("m4",), 640, 480, 32, 16384)])   # (m4: the many-cluster kernels)
-def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols, rows, n, slab):
+@pytest.mark.parametrize("precision", ["f64", "f32"])      # (f32: round 6 -- the float32 likelihood's kernels take the shared plane too)
+def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols, rows, n, slab, precision):
     """The shared background plane (rbsensor_mi355x.h "shared trail") changes what is STORED, not a bit of what is computed: a
     handle forced into it (RBS_STP_ENTER=0: at the first sampled window area; re-based every 3rd updating call) against a handle
     that never uses it, on a tracked sequence whose object travels across the image with resampling (children share parents):
@@ -343,11 +344,11 @@ def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols,
     poses = [synth.particle_poses(t, n, rng, scale=1.0) for t, _ in frames]
     parents = [np.sort(rng.choice(n, size=n, p=(lambda w: w / w.sum())(rng.random(n) ** 8))).astype(np.int32) for _ in frames]   # few survivors
     monkeypatch.setenv("RBS_SHARED_TRAIL", "0")
-    with RbSensor(om, cam, P, max_particles=n, precision="f64") as plain:      # (whole planes, scalar background: the reference run)
+    with RbSensor(om, cam, P, max_particles=n, precision=precision) as plain:      # (whole planes, scalar background: the reference run)
         monkeypatch.setenv("RBS_SHARED_TRAIL", "1")
         monkeypatch.setenv("RBS_STP_ENTER", "0.0")
         monkeypatch.setenv("RBS_STP_EVERY", "3")
-        with RbSensor(om, cam, P, max_particles=n, precision="f64", slab_px=slab) as g:      # (slab > 0: window-sized slabs, which grow on the way)
+        with RbSensor(om, cam, P, max_particles=n, precision=precision, slab_px=slab) as g:      # (slab > 0: window-sized slabs, which grow on the way)
             g.set_timing_every(1); plain.set_timing_every(1)      # (the window area is sampled on timed calls)
             for s_ in (g, plain):
                 s_.reset()
@@ -362,7 +363,7 @@ def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols,
                 la, lb = g.loglikes_poses(poses[k], ig, update=True), plain.loglikes_poses(poses[k], ip, update=True)
                 lo = o.loglikes_poses(poses[k], io, update=True)
                 assert np.array_equal(la, lb), (k, np.abs(la - lb).max())
-                assert rel_err(la, lo).max() <= TOL_EAGER
+                assert rel_err(la, lo).max() <= (TOL_EAGER if precision == "f64" else 1e-3)   # (f32: float32-level agreement, tests/test_gpu_f32.py)
                 ig, ip, io = parents[k].copy(), parents[k].copy(), parents[k].copy()
             active, rebases = g.shared_trail_state()
             assert active and rebases >= 3, (active, rebases)
@@ -382,7 +383,8 @@ def test_shared_trail_stores_the_same_planes(gpu_lib, monkeypatch, meshes, cols,
                 assert np.array_equal(g.get_occlusion(n - 1), g.get_occlusion(slots[1]))
             for q in slots:
                 assert np.array_equal(g.get_occlusion(q), plain.get_occlusion(q)), q
-                assert np.array_equal(g.get_occlusion(q), o.get_occlusion(q)) or (g.get_occlusion(q) != o.get_occlusion(q)).mean() <= 1e-4
+                if precision == "f64":
+                    assert np.array_equal(g.get_occlusion(q), o.get_occlusion(q)) or (g.get_occlusion(q) != o.get_occlusion(q)).mean() <= 1e-4
 
 
 @pytest.mark.parametrize("slab", [0, 2048])
