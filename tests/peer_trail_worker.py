@@ -41,7 +41,7 @@ def inputs():
     return om, cam, P, frames, poses, uniforms
 
 
-def worker(rank, world, port, slab_px, occlusion, shared, q):
+def worker(rank, world, port, slab_px, occlusion, shared, q, precision=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -51,7 +51,7 @@ def worker(rank, world, port, slab_px, occlusion, shared, q):
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(stream)
         n, cap = PN, 2 * PN
-        with RbSensor(om, cam, P, max_particles=cap, slab_px=slab_px, occlusion=occlusion) as s:
+        with RbSensor(om, cam, P, max_particles=cap, slab_px=slab_px, occlusion=occlusion, precision=precision) as s:
             s.reset()
             rdist.attach_peers(s)
 
@@ -79,10 +79,10 @@ def worker(rank, world, port, slab_px, occlusion, shared, q):
         dist.destroy_process_group()
 
 
-def run(port, slab_px, occlusion, shared):
+def run(port, slab_px, occlusion, shared, precision=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, WORLD, port, slab_px, occlusion, shared, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=worker, args=(r, WORLD, port, slab_px, occlusion, shared, q, precision)) for r in range(WORLD)]
     for p in procs:
         p.start()
     got = sorted([q.get(timeout=300) for _ in procs], key=lambda g: g[0])
@@ -94,9 +94,10 @@ def run(port, slab_px, occlusion, shared):
 
 def main():
     port = int(sys.argv[1])
-    for slab_px, occlusion in ((0, "device"), (49152, "device"), (0, "reference")):   # (attached ranks: slabs do not grow -- sized for the trail)
-        plain = run(port, slab_px, occlusion, False)
-        trail = run(port + 3, slab_px, occlusion, True)
+    # (attached ranks: slabs do not grow -- sized for the trail; the last case: the float32 likelihood)
+    for slab_px, occlusion, precision in ((0, "device", None), (49152, "device", None), (0, "reference", None), (0, "device", "f32")):
+        plain = run(port, slab_px, occlusion, False, precision)
+        trail = run(port + 3, slab_px, occlusion, True, precision)
         port += 7
         for a, b in zip(plain, trail):
             assert a[4] == (False, 0) and b[4][0] and b[4][1] >= 4, (a[4], b[4])
@@ -105,7 +106,7 @@ def main():
                 assert np.array_equal(psa, psb), k
             for pa, pb in zip(a[2], b[2]):
                 assert np.array_equal(pa, pb)
-        print(f"slab_px={slab_px} occlusion={occlusion}: mean stored window, ranks 0/1: scalar background {plain[0][3]:.0f}/{plain[1][3]:.0f} px, "
+        print(f"slab_px={slab_px} occlusion={occlusion} precision={precision or 'f64'}: mean stored window, ranks 0/1: scalar background {plain[0][3]:.0f}/{plain[1][3]:.0f} px, "
               f"shared trail {trail[0][3]:.0f}/{trail[1][3]:.0f} px; re-basings {trail[0][4][1]}")
         assert trail[0][3] < 0.8 * plain[0][3] and trail[1][3] < 0.8 * plain[1][3]
     print("TRAIL_OK")
