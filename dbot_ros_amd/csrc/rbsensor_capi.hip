@@ -394,6 +394,17 @@ int32_t flush_lazy_frame(rbs_handle* h, hipStream_t then)
 // whole planes or slabs, and the same eight again for object models with a body of many clusters.
 void launch_raster(const rbs_handle* h, bool update, dim3 grid, dim3 block, size_t smem, hipStream_t s, const DevParams& P)
 {
+    if (h->exact && h->one_body_kernel && !h->many_clusters && h->n_bodies == 1 && !P.groups) {   // stamped planes, one body
+#define RBS_X(U, S, T) hipLaunchKernelGGL((rbs::rbs_raster_kernel_exact_one_f64<U, S, T>), grid, block, smem, s, P); break
+        switch ((update ? 4 : 0) | (h->slab_px ? 2 : 0) | (P.bgp_src ? 1 : 0)) {
+            case 0: RBS_X(false, false, false);  case 1: RBS_X(false, false, true);
+            case 2: RBS_X(false, true, false);   case 3: RBS_X(false, true, true);
+            case 4: RBS_X(true, false, false);   case 5: RBS_X(true, false, true);
+            case 6: RBS_X(true, true, false);    default: RBS_X(true, true, true);
+        }
+#undef RBS_X
+        return;
+    }
     if (h->exact) {   // stamped planes (binary64): updating or not, whole planes or slabs, many clusters, shared background plane
 #define RBS_X(U, S, M, T) hipLaunchKernelGGL((rbs::rbs_raster_kernel_exact_f64<U, S, M, T>), grid, block, smem, s, P); break
         switch ((update ? 8 : 0) | (h->slab_px ? 4 : 0) | (h->many_clusters ? 2 : 0) | (P.bgp_src ? 1 : 0)) {

@@ -1405,8 +1405,11 @@ __device__ inline double raster_eval_tile(const DevParams& P, int particle, Rect
 #ifndef RBS_SCAN_UNROLL_EXACT
 #define RBS_SCAN_UNROLL_EXACT RBS_SCAN_UNROLL_F64
 #endif
-        constexpr int kScanUnroll = PHASE == 2 ? RBS_SCAN_UNROLL_EVAL : PREC ? RBS_SCAN_UNROLL : ONE ? RBS_SCAN_UNROLL_ONE
-                                    : EXACT ? RBS_SCAN_UNROLL_EXACT : RBS_SCAN_UNROLL_F64;
+#ifndef RBS_SCAN_UNROLL_EXACT_ONE
+#define RBS_SCAN_UNROLL_EXACT_ONE RBS_SCAN_UNROLL_EXACT
+#endif
+        constexpr int kScanUnroll = PHASE == 2 ? RBS_SCAN_UNROLL_EVAL : PREC ? RBS_SCAN_UNROLL : EXACT ? (ONE ? RBS_SCAN_UNROLL_EXACT_ONE : RBS_SCAN_UNROLL_EXACT)
+                                    : ONE ? RBS_SCAN_UNROLL_ONE : RBS_SCAN_UNROLL_F64;
         for (int q0 = wave * 64; q0 < nq; q0 += kBlock * kScanUnroll) {
             uint4 d4[kScanUnroll];
             floatx4 s4[kScanUnroll], o4[kScanUnroll];
@@ -2070,6 +2073,12 @@ template <bool UPDATE, bool SLAB, bool MANY, bool STP>
 __global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_kernel_exact_f64(const DevParams P)
 {
     raster_kernel_body<UPDATE, 0, SLAB, MANY, STP, true>(P);
+}
+// ... stamped planes, object model of ONE body (the specialisation of rbs_raster_kernel_one_f64)
+template <bool UPDATE, bool SLAB, bool STP>
+__global__ __launch_bounds__(kBlock, RBS_RASTER_MINWAVES_F64) RBS_F64_BUDGET void rbs_raster_kernel_exact_one_f64(const DevParams P)
+{
+    raster_kernel_body<UPDATE, 0, SLAB, false, STP, true, true>(P);
 }
 // ... and the same two for object models with a body of more than 256 clusters (MANY: the shared cluster cull).
 template <bool UPDATE, bool SLAB>
