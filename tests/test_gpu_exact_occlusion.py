@@ -190,3 +190,22 @@ def test_large_windows_without_the_shared_trail(slab_px):
         print(f"\nslab_px {slab_px}: stored window at the end {area:.2f} of the plane (sampled fraction {frac:.2f})")
         assert area > 0.5
         _planes_equal(g, lazy, range(0, n, 9), allow=2)
+
+
+def test_the_layout_suites_in_reference_mode():
+    """... and the suites of the storage layouts and of the handles that read each other's planes -- slabs (tests/test_gpu_slabs.py), several
+    devices in one handle (test_gpu_multidevice.py), attached processes (test_gpu_peers.py), the shared trail and the host routes of round 5
+    (test_gpu_round5.py) -- once more with the library in occlusion_mode REFERENCE and the reference-semantics oracle as the checker
+    (RBS_OCC=reference, as above).  Left out: whole-plane (dense) cases, which the mode does not have."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, RBS_OCC="reference")
+    files = [os.path.join(here, f) for f in ("test_gpu_slabs.py", "test_gpu_multidevice.py", "test_gpu_peers.py", "test_gpu_round5.py")]
+    r = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-q", "-x", "-m", "gpu", "-k", "not dense", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=2400, env=env, cwd=os.path.dirname(here))
+    tail = [l for l in r.stdout.strip().splitlines() if " passed" in l or " failed" in l]
+    print("\nslabs / multi-device / peers / round-5 suites with RBS_OCC=reference: " + (tail[-1] if tail else ""))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+    assert tail and "failed" not in tail[-1]
